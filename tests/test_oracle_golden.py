@@ -1,0 +1,221 @@
+"""The oracle against the reference's own outputs (tests/golden/*.npz).
+
+Every fixture was produced by running the reference's saltelli.py / scale.py in
+the build container (tests/golden/make_golden.py).  Same numpy calls in the same
+order => the oracle must reproduce them BIT FOR BIT, except where libm (sin,
+pow) could differ between hosts (tolerance written at the assertion).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import saltelli_oracle as orc
+
+A6 = [0, 0.5, 3, 9, 99, 99]
+FIELDS = ("E_2", "var_y", "U_j", "U_nj", "sens", "sens_t", "sens_2", "sens_2n")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def same(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(a, b, equal_nan=True)
+
+
+def run(k, n, scaling, rows_func, raw=None):
+    S = orc.build_sample(k, n, scaling, raw=raw)
+    F = orc.evaluate_rows(rows_func, *S)
+    return S, F, orc.compute_varsens(*F, n)
+
+
+@pytest.mark.parametrize("name,n", [("g1_gfunc_k6_n1024", 1024), ("g2_gfunc_k6_n51200", 51200)])
+def test_gfunction(golden, name, n):
+    g = golden(name)
+    S, F, R = run(6, n, None, lambda X: orc.g_function_rows(X, A6))
+    same(S[0][:8], g["M_1_head"]); same(S[1][:8], g["M_2_head"])
+    assert sha(orc.flat_sample(*S)) == str(g["flat_sha"])
+    # the reference multiplies the six factors with numpy.prod on a 6-list: same
+    # left-to-right order as the oracle => identical bits
+    assert sha(orc.flat_objective(*F)) == str(g["fvals_sha"])
+    for f in FIELDS:
+        same(R[f], g[f])
+
+
+def test_gfunction_known_answers(golden):
+    """varsens/tests/test_g_function.py:52-73, places=2, on the reference's n=51200 output."""
+    g = golden("g2_gfunc_k6_n51200")
+    V = orc.g_partial_variances(A6)
+    total, S, ST = orc.product_form_indices(V)
+    assert abs(total - g["var_y"][0]) < 0.005 and abs(1.0 - g["E_2"][0]) < 0.005
+    assert np.all(np.abs(g["sens"][:, 0] * g["var_y"][0] - V) < 0.005)
+    assert np.all(np.abs(g["sens_t"][:, 0] * g["var_y"][0] - ST * total) < 0.005)
+    for i in range(6):
+        for j in range(i + 1, 6):
+            assert abs(g["sens_2"][i, 0, j, 0] * g["var_y"][0] - (V[i] + V[j] + V[i] * V[j])) < 0.005
+            rest = np.delete(V, [i, j])
+            assert abs(g["sens_2n"][i, 0, j, 0] * g["var_y"][0] - (np.prod(1 + rest) - 1)) < 0.005
+
+
+def test_two_outputs(golden):
+    g = golden("g3_gfunc2_k6_n1024")
+    rows = lambda X: np.stack([orc.g_function_rows(X, A6), orc.g_function_rows(X, A6[::-1])], axis=-1)
+    S, F, R = run(6, 1024, None, rows)
+    assert F[0].shape == (1024, 2) and F[2].shape == (6, 1024, 2)
+    assert sha(orc.flat_objective(*F)) == str(g["fvals_sha"])
+    for f in FIELDS:
+        same(R[f], g[f])
+    assert R["sens_2"].shape == (6, 2, 6, 2)
+
+
+def test_ishigami(golden):
+    g = golden("g4_ishigami_k3_n4096")
+    lo, hi = g["lower"], g["upper"]
+    S, F, R = run(3, 4096, lambda x: orc.scale_linear(x, lo, hi), orc.ishigami_rows)
+    same(S[0][:8], g["M_1_head"]); same(S[1][:8], g["M_2_head"])
+    # reference objective: sin(x0) + 7*sin(x1)**2 + 0.1*x2**4*sin(x0); the oracle's
+    # device-ordered expression groups the products differently -> few-ulp differences
+    np.testing.assert_allclose(F[0][:8], g["fM_1_head"], rtol=4e-15, atol=1e-15)
+    for f in FIELDS:
+        np.testing.assert_allclose(R[f], g[f], rtol=1e-11, atol=1e-13)
+
+
+def test_linear_k32(golden):
+    g = golden("g5_linear_k32_n4096")
+    S, F, R = run(32, 4096, None, lambda X: orc.linear_rows(X, g["c"]))
+    # reference used numpy.dot (blocked/pairwise order): values agree to rounding only
+    np.testing.assert_allclose(F[0][:8], g["fM_1_head"], rtol=1e-14)
+    for f in FIELDS:
+        np.testing.assert_allclose(R[f], g[f], rtol=2e-10, atol=1e-12)
+
+
+def test_polynomial_k16(golden):
+    g = golden("g5b_poly_k16_n2048")
+    S, F, R = run(16, 2048, None, lambda X: orc.polynomial_rows(X, g["beta"]))
+    np.testing.assert_allclose(F[0][:8], g["fM_1_head"], rtol=1e-14)
+    for f in FIELDS:
+        np.testing.assert_allclose(R[f], g[f], rtol=2e-10, atol=1e-12)
+
+
+def test_nan_trim(golden):
+    g = golden("g6_nantrim_k5_n64_l2")
+    k, n = int(g["k"]), int(g["n"])
+    fM_1, fM_2, fN_j, fN_nj, dropped = orc.load_objective(g["vals"], k, n)
+    assert dropped == 3 and fM_1.shape[0] == int(g["kept"]) == 61
+    same(fM_1, g["fM_1"]); same(fN_nj, g["fN_nj"])
+    R = orc.compute_varsens(fM_1, fM_2, fN_j, fN_nj, n)   # divisor stays n=64
+    for f in FIELDS:
+        same(R[f], g[f])
+    assert np.isnan(R["sens"][:, 1]).all() and np.isfinite(R["sens"][:, 0]).all()
+
+
+def test_seed1_permutation(golden):
+    g = golden("g7_seed1_perm")
+    for n in (1, 2, 5, 13, 1024, 100003):
+        p = orc.seed1_permutation(n)
+        assert sha(p) == str(g["sha_n%d" % n])
+        ref = g["n%d" % n]
+        same(p if n <= 1024 else np.concatenate([p[:64], p[-64:]]), ref)
+    same(orc.seed1_permutation(1024)[:6], [830, 795, 495, 822, 859, 104])
+
+
+def test_flat_power(golden):
+    g = golden("g8_flat_power_k5_n13")
+    S = orc.build_sample(5, 13, lambda x: orc.scale_power(x, g["lower"], g["upper"]), raw=g["raw"])
+    for got, name in zip(S, ("M_1", "M_2", "N_j", "N_nj")):
+        np.testing.assert_allclose(got, g[name], rtol=4e-16)  # libm pow, same host => normally identical
+    flat = orc.flat_sample(*S)
+    assert flat.shape == (13 * 12, 5)
+    np.testing.assert_allclose(flat, g["flat"], rtol=4e-16)
+    # varsens/tests/test_sample.py:74-75
+    assert flat[0].sum() == S[0][0].sum() and flat[-1].sum() == S[3][4][-1].sum()
+
+
+def test_scale_known_answers(golden):
+    g = golden("g9_scale")
+    pts = g["pts"]
+    same(orc.scale_linear(pts, np.array([-100.0] * 5), np.array([100.0] * 5)), g["linear"])
+    np.testing.assert_allclose(orc.scale_power(pts, np.ones(5), np.full(5, 100.0)), g["power"], rtol=4e-16)
+    same(orc.scale_percentage(pts, np.array([-10.0, -1, 0, 1, 20]), 33.0), g["percentage"])
+    np.testing.assert_allclose(orc.scale_magnitude(pts, np.array([1, 10, 100, 1000, 1e4])), g["magnitude"], rtol=4e-16)
+    # literal answers of varsens/tests/test_scaling.py:9,31,53,61 (7 places)
+    np.testing.assert_allclose(g["linear"], [-100, -50, 0, 50, 100], atol=1e-7)
+    np.testing.assert_allclose(g["power"], [1, 10 * np.sqrt(.1), 10, 100 * np.sqrt(.1), 100], atol=1e-7)
+    np.testing.assert_allclose(g["percentage"], [-6.7, -0.835, 0.0, 1.165, 26.6], atol=1e-7)
+    np.testing.assert_allclose(g["magnitude"], [1e-3, np.sqrt(.1), 100, np.sqrt(.1) * 1e5, 1e7], rtol=1e-9)
+    # doctests varsens/scale.py:28-29,57-58,85-86,116-117
+    np.testing.assert_allclose(g["doc_linear"], [0, 5, 1500])
+    # third doctest value is 1414.2 only under Python 2's INTEGER 2500/1000 == 2; float inputs
+    # (and Python 3) give 1000*sqrt(2.5)
+    np.testing.assert_allclose(g["doc_power"], [100, 141.42135624, 1000 * np.sqrt(2.5)], rtol=1e-9)
+    np.testing.assert_allclose(g["doc_percentage"], [0.833, 8.33, 833.0])
+    np.testing.assert_allclose(g["doc_magnitude"], [0.09954054, 0.99540542, 99.54054174], rtol=1e-7)
+
+
+def test_percentage_magnitude_samples(golden):
+    g = golden("g10_pct_mag_k4_n7")
+    refp = g["reference"]
+    S = orc.build_sample(4, 7, lambda x: orc.scale_percentage(x, refp, 20.0), raw=g["raw"])
+    for got, name in zip(S, ("pct_M_1", "pct_M_2", "pct_N_j", "pct_N_nj")):
+        same(got, g[name])
+    S = orc.build_sample(4, 7, lambda x: orc.scale_magnitude(x, np.abs(refp), 2.0, 10.0), raw=g["raw"])
+    np.testing.assert_allclose(S[0], g["mag_M_1"], rtol=4e-16)
+    np.testing.assert_allclose(orc.flat_sample(*S), g["mag_flat"], rtol=4e-16)
+
+
+def test_vector_objective_invert(golden):
+    """varsens/tests/test_objective.py:18-42."""
+    g = golden("g11_invert_k8_n23")
+    S = orc.build_sample(8, 23)
+    same(S[0], g["M_1"]); same(S[1], g["M_2"])
+    F = orc.evaluate_callable(lambda x: 1.0 - x, *S)
+    for got, name in zip(F, ("fM_1", "fM_2", "fN_j", "fN_nj")):
+        same(got, g[name])
+    same(orc.flat_objective(*F), g["flat_obj"])
+    assert F[0].shape == (23, 8) and F[2].shape == (8, 23, 8)
+    R = orc.compute_varsens(*F, 23)
+    for f in FIELDS:
+        same(R[f], g[f])
+    F2 = orc.evaluate_rows(lambda X: 1.0 - X, *S)
+    for a, b in zip(F, F2):
+        same(a, b)
+
+
+@pytest.mark.parametrize("name", ["g12_vals_k7_n50_l1", "g12_vals_k7_n50_l3", "g12_vals_k7_n50_l3_div4"])
+def test_precomputed_values(golden, name):
+    g = golden(name)
+    k, n = int(g["k"]), int(g["n"])
+    div = float(g["divide"]) if "divide" in g.files else 1.0
+    F = orc.load_objective(g["vals"], k, n, scaling=div)
+    assert F[4] == 0
+    R = orc.compute_varsens(*F[:4], n)
+    for f in FIELDS:
+        same(R[f], g[f])
+    l = int(g["l"])
+    assert R["E_2"].shape == (l,) and R["sens"].shape == (k, l) and R["sens_2n"].shape == (k, l, k, l)
+
+
+def test_discard(golden):
+    g = golden("g13_discard37_k3_n16")
+    S = orc.build_sample(3, 16, discard=37)
+    same(S[0], g["M_1"]); same(S[1], g["M_2"])
+    same(S[0][0], orc.halton(3, 1 + 60 + 37, 1)[0])
+
+
+def test_exact_accumulators_reproduce_reference_within_rounding(golden):
+    """The correctly-rounded sums (what the GPU is compared with) vs the
+    reference's own floating-point order: the gap IS the reference's rounding noise."""
+    g = golden("g1_gfunc_k6_n1024")
+    S = orc.build_sample(6, 1024)
+    F = orc.evaluate_rows(lambda X: orc.g_function_rows(X, A6), *S)
+    R = orc.indices_from_accumulators(orc.exact_accumulators(*F), 1024)
+    for f in ("E_2", "var_y", "U_j", "U_nj"):
+        np.testing.assert_allclose(R[f], g[f], rtol=5e-15)
+    for f in ("sens", "sens_t"):
+        np.testing.assert_allclose(R[f], g[f], rtol=1e-10, atol=1e-14)
+    s2, s2n = orc.exact_second_order(F[2], F[3], R["E_2"], R["var_y"], 1024)
+    np.testing.assert_allclose(s2, g["sens_2"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(s2n, g["sens_2n"], rtol=1e-10, atol=1e-13)
