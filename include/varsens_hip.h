@@ -1,0 +1,238 @@
+/*
+ * varsens_hip.h -- C ABI of libvarsens_hip.so, the MI355X (gfx950) engine behind
+ * the Saltelli hot path of LoLab-MSM/varsens.
+ *
+ * The reference has no FFI boundary of its own: the path lives behind three
+ * Python classes in varsens/saltelli.py.  Each entry point below names the
+ * reference code it replaces (paths relative to the reference checkout); the
+ * Python shim in varsens_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *   - plain C symbols; every function returns 0 on success, a negative
+ *     vs_status on failure; vs_last_error() returns the message of the calling
+ *     thread's last failure.  No C++ exception crosses the boundary.
+ *   - host buffers are caller-owned, contiguous, and never retained after the
+ *     call returns unless the function says "uploaded" (then they are copied).
+ *   - device buffers are raw HIP device pointers (void*) owned by a context:
+ *     vs_alloc / vs_free.  A context binds one GPU and one HIP stream; it is not
+ *     thread-safe.  One process drives one GPU (one context per rank); ranks
+ *     meet only in vs_comm_allreduce (RCCL).
+ *   - there is NO host fallback: without a usable gfx950 device
+ *     vs_context_create fails and nothing else can be called.
+ *   - all floating point data is IEEE binary64.
+ */
+#ifndef VARSENS_HIP_H
+#define VARSENS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_ABI_VERSION 1
+
+typedef enum vs_status {
+    VS_OK = 0,
+    VS_ERR_ARG = -1,      /* bad argument (shape, null pointer, unsupported size) */
+    VS_ERR_HIP = -2,      /* a HIP runtime call failed */
+    VS_ERR_NODEVICE = -3, /* no usable GPU */
+    VS_ERR_COMM = -4,     /* RCCL failure */
+    VS_ERR_STATE = -5,    /* call sequence error (e.g. comm not initialised) */
+    VS_ERR_COMPILE = -6   /* hiprtc compilation of a user objective failed */
+} vs_status;
+
+typedef struct vs_context vs_context;     /* one GPU + one stream */
+typedef struct vs_design vs_design;       /* a Saltelli design resident on the GPU */
+typedef struct vs_objective vs_objective; /* an objective function resident on the GPU */
+
+/* ------------------------------------------------------------------ basics */
+
+int vs_abi_version(void);
+const char* vs_last_error(void);
+int vs_device_count(int* count);
+
+typedef struct vs_device_info {
+    char name[128];
+    char arch[64];
+    int32_t compute_units;
+    int32_t wavefront_size;
+    int32_t lds_bytes_per_cu;
+    int32_t clock_mhz;
+    uint64_t hbm_bytes;
+} vs_device_info;
+
+int vs_context_create(int device, vs_context** out);
+int vs_context_destroy(vs_context* ctx);
+int vs_context_info(vs_context* ctx, vs_device_info* out);
+int vs_sync(vs_context* ctx);
+
+int vs_alloc(vs_context* ctx, size_t bytes, void** dptr);
+int vs_free(vs_context* ctx, void* dptr);
+int vs_upload(vs_context* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int vs_download(vs_context* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int vs_memset(vs_context* ctx, void* dst_dev, int byte, size_t bytes);
+
+/* Per-launch timing.  Between begin and end every kernel launched through
+ * this context is bracketed by HIP events on the context's stream (no host
+ * synchronisation is added).  vs_profile_end synchronises, then fills up to
+ * `capacity` records in launch order and returns the number written in *count.
+ * kernel_id values: VS_KERNEL_* below. */
+typedef struct vs_profile_record {
+    int32_t kernel_id;
+    float ms;
+} vs_profile_record;
+
+enum {
+    VS_KERNEL_HALTON_FILL = 1,
+    VS_KERNEL_SOBOL_FILL = 2,
+    VS_KERNEL_SAMPLE_FLAT = 3,
+    VS_KERNEL_EVAL = 4,
+    VS_KERNEL_REDUCE_FIRST = 5,  /* the sens/sens_t streaming reduction */
+    VS_KERNEL_FOLD = 6,
+    VS_KERNEL_FINISH = 7,
+    VS_KERNEL_NAN_MASK = 8,
+    VS_KERNEL_SECOND_ORDER = 9,
+    VS_KERNEL_SECOND_FOLD = 10,
+    VS_KERNEL_FUSED = 11
+};
+
+int vs_profile_begin(vs_context* ctx, int capacity);
+int vs_profile_end(vs_context* ctx, vs_profile_record* out, int capacity, int* count);
+
+/* ------------------------------------------------ a1: low-discrepancy points
+ * Replaces ghalton.Halton(k).get(m) (varsens/saltelli.py:82-84): rows are the
+ * Halton points of indices start .. start+count-1 (first point of the stream
+ * has index 1), bases = first k primes, row-major (count,k) into device memory.
+ * Requires (start+count) * prime_k < 2^53. */
+int vs_halton_fill(vs_context* ctx, int k, uint64_t start, uint64_t count, double* out_dev);
+
+/* Capability counterpart of quantlib/sobolGen.cpp:47-60.  `directions` is a
+ * host (k,32) table of left-justified 32-bit direction integers (Joe-Kuo;
+ * varsens_amd ships one).  Index 0 is the origin.  start+count <= 2^32. */
+int vs_sobol_fill(vs_context* ctx, int k, const uint32_t* directions, uint64_t start,
+                  uint64_t count, double* out_dev);
+
+/* -------------------------------------------- a1-a5: the design (class Sample)
+ * Describes M_1, M_2 and, implicitly, N_j / N_nj (varsens/saltelli.py:62-125)
+ * without materialising them. */
+enum { VS_GEN_HALTON = 0, VS_GEN_SOBOL = 1, VS_GEN_RAW = 2 };
+enum { VS_SCALE_IDENTITY = 0, VS_SCALE_LINEAR = 1, VS_SCALE_POWER = 2 };
+
+typedef struct vs_design_desc {
+    int32_t generator;     /* VS_GEN_* */
+    int32_t k;             /* parameters */
+    uint64_t n;            /* draws (global n, before any sharding) */
+    uint64_t first_index;  /* sequence index that becomes row 0 of M_1; row r of the
+                              un-shuffled second half is first_index + n + r
+                              (saltelli.py:83-84,92,95).  Ignored for VS_GEN_RAW. */
+    int32_t scale_mode;    /* VS_SCALE_*: scale.py:33 (linear), :62 (power) */
+    int32_t reserved;
+    const double* lower;   /* host, k entries (LINEAR/POWER) */
+    const double* upper;   /* host, k entries (LINEAR/POWER) */
+    const uint32_t* perm;  /* host, n entries: M_2[r] = second_half[perm[r]]
+                              (the seed-1 shuffle, saltelli.py:100-101); NULL = identity */
+    const double* raw;     /* host (2n,k) unit-cube points for VS_GEN_RAW
+                              (Sample(raw=...), saltelli.py:69-73), uploaded */
+    const uint32_t* sobol_directions; /* host (k,32) for VS_GEN_SOBOL, uploaded */
+} vs_design_desc;
+
+int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_design** out);
+int vs_design_destroy(vs_context* ctx, vs_design* design);
+
+/* Rows [row_begin, row_begin+row_count) of Sample.flat() (saltelli.py:127-160):
+ * global row order [M_1; M_2; N_j[0..k); N_nj[0..k)], 2n(k+1) rows of k values,
+ * written row-major to out_dev.  Serves Sample.M_1/M_2/N_j/N_nj and export. */
+int vs_sample_flat(vs_context* ctx, const vs_design* design, uint64_t row_begin,
+                   uint64_t row_count, double* out_dev);
+
+/* ----------------------------------------- a6: objectives (class Objective)
+ * Built-in objectives evaluated on the GPU.  l = outputs per evaluation.
+ *   G_FUNCTION  params = a[l][k]      f_o = prod_i (|4x_i-2|+a_oi)/(1+a_oi)
+ *   ISHIGAMI    params = {a, b}       k must be 3, l = 1
+ *   LINEAR      params = c[l][k]      f_o = sum_i c_oi x_i
+ *   POLYNOMIAL  params = beta[l][k]   f_o = prod_i (1 + beta_oi (x_i - 1/2))
+ *   INVERT      no params             f_o = 1 - x_o, l = k (varsens/tests/test_objective.py:5)
+ * Operation order is fixed and documented in DESIGN.md (the oracle follows it). */
+enum {
+    VS_OBJ_G_FUNCTION = 1,
+    VS_OBJ_ISHIGAMI = 2,
+    VS_OBJ_LINEAR = 3,
+    VS_OBJ_POLYNOMIAL = 4,
+    VS_OBJ_INVERT = 5
+};
+
+int vs_objective_create(vs_context* ctx, int kind, int k, int l, const double* params,
+                        size_t nparams, vs_objective** out);
+int vs_objective_destroy(vs_context* ctx, vs_objective* obj);
+
+/* Replaces the four evaluation loops of Objective.__init__ (saltelli.py:329-355)
+ * for design rows [row_begin, row_begin+row_count) (a shard of r in [0,n)).
+ * Output: f_dev[(block*row_count + (r-row_begin))*l + o], block order
+ * [fM_1, fM_2, fN_j[0..k), fN_nj[0..k)] -- Objective.flat() of the shard
+ * (saltelli.py:357-391); 2(k+1)*row_count*l doubles. */
+int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,
+            uint64_t row_begin, uint64_t row_count, double* f_dev);
+
+/* ------------------------------ a7-a11: the estimators (Varsens.compute_varsens)
+ * Accumulator record produced per GPU and summed across GPUs.  All doubles.
+ *   [0] rows_kept   [1] rows_dropped (NaN-trimmed)   [2] ranks   [3] reserved
+ *   then for each output o (stride VS_ACC_PER_OUTPUT(k)):
+ *     sab, sa, sb, ac[k], bd[k], ad[k], bc[k]
+ *   then `max_ranks` slots of (count, mean[l], m2[l]) -- each rank fills its own
+ *   slot, so the sum-all-reduce doubles as the all-gather the variance merge needs.
+ */
+#define VS_ACC_HEADER 4
+#define VS_ACC_PER_OUTPUT(k) (3 + 4 * (size_t)(k))
+#define VS_ACC_SLOT(l) (1 + 2 * (size_t)(l))
+#define VS_ACC_LEN(k, l, max_ranks) \
+    (VS_ACC_HEADER + (size_t)(l) * VS_ACC_PER_OUTPUT(k) + (size_t)(max_ranks) * VS_ACC_SLOT(l))
+
+enum { VS_REDUCE_NAN_TRIM = 1 };
+
+/* The sens/sens_t streaming reduction over a shard's f-values (layout of
+ * vs_eval).  One pass over HBM; replaces saltelli.py:577 (E_2 sum), :583
+ * (variance sums) and :591-596 (the 4k dot products).  With VS_REDUCE_NAN_TRIM,
+ * rows holding a NaN in output 0 of any block are left out of every sum
+ * (saltelli.py:474-492).  Writes this rank's record (slot `rank` of
+ * `max_ranks`) to acc_dev (VS_ACC_LEN doubles, device). */
+int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
+                          int flags, int rank, int max_ranks, double* acc_dev);
+
+/* Finished indices from a (summed) record; divisors use the REQUESTED global n
+ * even when rows were trimmed (saltelli.py:576-577,591).  out_dev layout
+ * (doubles): E_2[l], var_y[l], U_j[k][l], U_nj[k][l], sens[k][l], sens_t[k][l]
+ * = (2 + 4k) * l values (saltelli.py:577-609). */
+#define VS_FIRST_ORDER_LEN(k, l) ((2 + 4 * (size_t)(k)) * (size_t)(l))
+int vs_finish_first_order(vs_context* ctx, const double* acc_dev, uint64_t n, int k, int l,
+                          int max_ranks, double* out_dev);
+
+/* a12: second-order Gram sums over a shard (saltelli.py:612-619).  With
+ * C = fN_j, D = fN_nj viewed as (k*l, rows): gram_dev receives three row-major
+ * (k*l, k*l) matrices DC = D C^T, DD = D D^T, CC = C C^T (3 (kl)^2 doubles),
+ * NaN-trimmed like the first-order pass when VS_REDUCE_NAN_TRIM is set. */
+int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
+                           int flags, double* gram_dev);
+
+/* sens_2, sens_2n (each (k,l,k,l) row-major) from summed Gram matrices and the
+ * finished first-order block (E_2, var_y) (saltelli.py:612-622). */
+int vs_finish_second_order(vs_context* ctx, const double* gram_dev, const double* first_dev,
+                           uint64_t n, int k, int l, double* sens2_dev, double* sens2n_dev);
+
+/* ------------------------------------------------------- multi-GPU exchange
+ * One rank per process/GPU.  Rank 0 calls vs_comm_unique_id and ships the 128
+ * bytes to the others by any host channel; then every rank calls vs_comm_init.
+ * vs_comm_allreduce sums `count` doubles in place over xGMI (ncclAllReduce on
+ * the context's stream).  The reference has no counterpart (its only scale-out
+ * is PBS array jobs over text files, varsens/cluster/accre-job.sh:13). */
+#define VS_COMM_ID_BYTES 128
+int vs_comm_unique_id(void* id_out);
+int vs_comm_init(vs_context* ctx, const void* id, int nranks, int rank);
+int vs_comm_allreduce(vs_context* ctx, double* buf_dev, size_t count);
+int vs_comm_destroy(vs_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VARSENS_HIP_H */

@@ -1,0 +1,294 @@
+"""Parity of the HIP kernels with the oracle, through the C ABI (ctypes).  GPU only."""
+import numpy as np
+import pytest
+
+from oracle import saltelli_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+A6 = [0, 0.5, 3, 9, 99, 99]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from varsens_amd import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def same(a, b):
+    assert a.shape == b.shape
+    assert np.array_equal(a, b, equal_nan=True), "max |d| = %g" % np.nanmax(np.abs(a - b))
+
+
+# ------------------------------------------------------------------ generators
+
+@pytest.mark.parametrize("k,start,count", [(1, 1, 1), (7, 1, 513), (40, 801, 5000), (128, 2561, 3000),
+                                           (3, 2 ** 32 - 100, 300)])
+def test_halton_fill_bit_exact(ctx, k, start, count):
+    buf = ctx.halton_fill(k, start, count)
+    got = ctx.download(buf, (count, k))
+    same(got, orc.halton(k, start, count))
+    assert got.min() > 0.0 and got.max() < 1.0   # varsens/tests/test_sample.py:23-42
+
+
+def test_halton_range_guard(ctx):
+    from varsens_amd._native import VarsensHipError
+    with pytest.raises(VarsensHipError):
+        ctx.halton_fill(128, 2 ** 50, 10)
+
+
+def test_sobol_fill_bit_exact(ctx):
+    from varsens_amd.saltelli import sobol_directions
+    d = sobol_directions(64)
+    buf = ctx.sobol_fill(64, d, 4096, 5000)
+    same(ctx.download(buf, (5000, 64)), orc.sobol(64, 4096, 5000, d))
+
+
+def make_design(ctx, k, n, mode=0, lo=None, hi=None, raw=None, discard=0, perm=True):
+    from varsens_amd import _native
+    p = orc.seed1_permutation(n).astype(np.uint32) if perm else None
+    if raw is None:
+        return ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k, discard), mode, lo, hi, p)
+    return ctx.design_create(_native.GEN_RAW, k, n, 0, mode, lo, hi, p, raw)
+
+
+@pytest.mark.parametrize("k,n", [(5, 13), (3, 5), (11, 13), (17, 1024)])
+def test_sample_flat_identity(ctx, k, n):
+    d = make_design(ctx, k, n)
+    rows = 2 * n * (k + 1)
+    buf = ctx.alloc(8 * rows * k)
+    ctx.sample_flat(d, 0, rows, buf)
+    same(ctx.download(buf, (rows, k)), orc.flat_sample(*orc.build_sample(k, n)))
+
+
+def test_sample_flat_linear_and_window(ctx):
+    k, n = 6, 200
+    lo = np.linspace(-3, 2, k); hi = lo + np.arange(1, k + 1)
+    d = make_design(ctx, k, n, 1, lo, hi)
+    want = orc.flat_sample(*orc.build_sample(k, n, lambda x: orc.scale_linear(x, lo, hi)))
+    buf = ctx.alloc(8 * 777 * k)
+    ctx.sample_flat(d, 1234, 777, buf)
+    same(ctx.download(buf, (777, k)), want[1234:1234 + 777])
+
+
+def test_sample_flat_power_raw(ctx, golden):
+    g = golden("g8_flat_power_k5_n13")
+    d = make_design(ctx, 5, 13, 2, g["lower"], g["upper"], raw=g["raw"])
+    buf = ctx.alloc(8 * 156 * 5)
+    ctx.sample_flat(d, 0, 156, buf)
+    # device pow vs libm pow: a few ulp
+    np.testing.assert_allclose(ctx.download(buf, (156, 5)), g["flat"], rtol=1e-14)
+
+
+# ------------------------------------------------------------------ fused evaluation
+
+def eval_dev(ctx, design, kind, k, l, params, n, begin=0, count=None):
+    count = n if count is None else count
+    obj = ctx.objective_create(kind, k, l, params)
+    f = ctx.alloc(8 * 2 * (k + 1) * count * l)
+    ctx.eval(design, obj, begin, count, f)
+    return f, ctx.download(f, (2 * k + 2, count, l))
+
+
+def oracle_blocks(F):
+    fM_1, fM_2, fN_j, fN_nj = F
+    return np.concatenate([fM_1[None], fM_2[None], fN_j, fN_nj], axis=0)
+
+
+@pytest.mark.parametrize("k,n,l", [(6, 1024, 1), (6, 1024, 2), (1, 7, 1), (33, 300, 1), (70, 129, 1)])
+def test_eval_gfunction_bit_exact(ctx, k, n, l):
+    from varsens_amd import _native
+    rng = np.random.RandomState(k)
+    a = np.array(A6, dtype=float) if k == 6 else rng.rand(k) * 10
+    A = np.stack([a, a[::-1]])[:l]
+    d = make_design(ctx, k, n)
+    _, got = eval_dev(ctx, d, _native.OBJ_G_FUNCTION, k, l, A, n)
+    S = orc.build_sample(k, n)
+    F = orc.evaluate_rows(lambda X: np.stack([orc.g_function_rows(X, A[o]) for o in range(l)], axis=-1), *S)
+    same(got, oracle_blocks(F))
+
+
+def test_eval_linear_polynomial_bit_exact(ctx):
+    from varsens_amd import _native
+    k, n = 32, 500
+    d = make_design(ctx, k, n)
+    S = orc.build_sample(k, n)
+    c = np.arange(1, k + 1, dtype=float)
+    _, got = eval_dev(ctx, d, _native.OBJ_LINEAR, k, 1, c, n)
+    same(got, oracle_blocks(orc.evaluate_rows(lambda X: orc.linear_rows(X, c), *S)))
+    beta = 1.0 / (1.0 + np.arange(k) / 8.0)
+    _, got = eval_dev(ctx, d, _native.OBJ_POLYNOMIAL, k, 1, beta, n)
+    same(got, oracle_blocks(orc.evaluate_rows(lambda X: orc.polynomial_rows(X, beta), *S)))
+
+
+def test_eval_ishigami(ctx):
+    from varsens_amd import _native
+    n = 4096
+    lo = np.full(3, -np.pi); hi = np.full(3, np.pi)
+    d = make_design(ctx, 3, n, 1, lo, hi)
+    _, got = eval_dev(ctx, d, _native.OBJ_ISHIGAMI, 3, 1, [7.0, 0.1], n)
+    S = orc.build_sample(3, n, lambda x: orc.scale_linear(x, lo, hi))
+    want = oracle_blocks(orc.evaluate_rows(orc.ishigami_rows, *S))
+    # device sin vs libm sin: <= 2 ulp of values up to ~18
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-14)
+
+
+def test_eval_invert_and_shard(ctx, golden):
+    from varsens_amd import _native
+    g = golden("g11_invert_k8_n23")
+    d = make_design(ctx, 8, 23)
+    _, got = eval_dev(ctx, d, _native.OBJ_INVERT, 8, 8, None, 23)
+    same(got[0], g["fM_1"]); same(got[1], g["fM_2"]); same(got[2:10], g["fN_j"]); same(got[10:], g["fN_nj"])
+    # a shard of rows evaluates to the same values (multi-GPU row split)
+    _, part = eval_dev(ctx, d, _native.OBJ_INVERT, 8, 8, None, 23, begin=5, count=11)
+    same(part, got[:, 5:16])
+
+
+# ------------------------------------------------------------------ first-order reduction
+
+def reduce_dev(ctx, blocks, n, flags=0, rank=0, world=1):
+    from varsens_amd import _native
+    nb, rows, l = blocks.shape
+    k = (nb - 2) // 2
+    f = ctx.upload(blocks)
+    acc = ctx.alloc(8 * _native.acc_len(k, l, world))
+    ctx.reduce_first_order(f, rows, k, l, acc, flags, rank, world)
+    out = ctx.alloc(8 * _native.first_order_len(k, l))
+    ctx.finish_first_order(acc, n, k, l, out, world)
+    rec = ctx.download(acc, (_native.acc_len(k, l, world),))
+    fin = ctx.download(out, (2 + 4 * k, l))
+    return rec, fin
+
+
+def unpack(rec, k, l):
+    from varsens_amd import _native
+    per = _native.acc_per_output(k)
+    body = rec[4:4 + l * per].reshape(l, per)
+    return dict(rows=rec[0], dropped=rec[1], sab=body[:, 0], sa=body[:, 1], sb=body[:, 2],
+                ac=body[:, 3:3 + k].T, bd=body[:, 3 + k:3 + 2 * k].T, ad=body[:, 3 + 2 * k:3 + 3 * k].T,
+                bc=body[:, 3 + 3 * k:3 + 4 * k].T, slots=rec[4 + l * per:])
+
+
+def check_against_exact(rec, fin, blocks, n, rtol_acc=1e-13):
+    nb, rows, l = blocks.shape
+    k = (nb - 2) // 2
+    ex = orc.exact_accumulators(blocks[0], blocks[1], blocks[2:2 + k], blocks[2 + k:])
+    got = unpack(rec, k, l)
+    assert got["rows"] == rows
+    for name in ("sab", "sa", "sb", "ac", "bd", "ad", "bc"):
+        scale = np.abs(ex[name]).max() + 1e-300
+        np.testing.assert_allclose(got[name], ex[name], rtol=rtol_acc, atol=rtol_acc * scale, err_msg=name)
+    want = orc.indices_from_accumulators(ex, n)
+    np.testing.assert_allclose(fin[0], want["E_2"], rtol=1e-13)
+    np.testing.assert_allclose(fin[1], want["var_y"], rtol=1e-12)
+    np.testing.assert_allclose(fin[2:2 + k], want["U_j"], rtol=1e-13)
+    np.testing.assert_allclose(fin[2 + k:2 + 2 * k], want["U_nj"], rtol=1e-13)
+    return want
+
+
+@pytest.mark.parametrize("k,rows,l", [(6, 1024, 1), (6, 1023, 1), (3, 1, 1), (3, 2, 1), (5, 7, 2), (7, 50, 3),
+                                      (32, 4096, 1), (32, 20000, 1), (2, 70001, 1), (130, 600, 1), (4, 3000, 5)])
+def test_reduce_random_values(ctx, k, rows, l):
+    rng = np.random.RandomState(1000 * k + rows + l)
+    blocks = 2.0 + rng.randn(2 * k + 2, rows, l)
+    rec, fin = reduce_dev(ctx, blocks, max(rows, 2))
+    check_against_exact(rec, fin, blocks, max(rows, 2))
+
+
+def test_reduce_large_offset_variance(ctx):
+    """var_y must survive a mean that dwarfs the spread (shifted sums, not raw moments)."""
+    rng = np.random.RandomState(5)
+    blocks = 1e6 + rng.randn(2 * 4 + 2, 30000, 1)
+    rec, fin = reduce_dev(ctx, blocks, 30000)
+    want = np.var(np.concatenate([blocks[0], blocks[1]]), axis=0, ddof=1)
+    np.testing.assert_allclose(fin[1], want, rtol=1e-10)
+
+
+def test_reduce_gfunction_matches_reference_golden(ctx, golden):
+    """Config 1: device evaluation + device reduction against the reference's own numbers."""
+    from varsens_amd import _native
+    g = golden("g1_gfunc_k6_n1024")
+    d = make_design(ctx, 6, 1024)
+    f, blocks = eval_dev(ctx, d, _native.OBJ_G_FUNCTION, 6, 1, A6, 1024)
+    rec, fin = reduce_dev(ctx, blocks, 1024)
+    check_against_exact(rec, fin, blocks, 1024)
+    k = 6
+    # raw estimates: 5e-15 is the reference's own distance to correctly rounded sums at n=1024
+    np.testing.assert_allclose(fin[0], g["E_2"], rtol=5e-15)
+    np.testing.assert_allclose(fin[1], g["var_y"], rtol=5e-15)
+    np.testing.assert_allclose(fin[2:2 + k], g["U_j"], rtol=5e-15)
+    np.testing.assert_allclose(fin[2 + k:2 + 2 * k], g["U_nj"], rtol=5e-15)
+    # indices: north-star tolerance 1e-10 relative
+    np.testing.assert_allclose(fin[2 + 2 * k:2 + 3 * k], g["sens"], rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(fin[2 + 3 * k:2 + 4 * k], g["sens_t"], rtol=1e-10, atol=1e-14)
+
+
+def test_reduce_nan_trim_golden(ctx, golden):
+    from varsens_amd import _native
+    g = golden("g6_nantrim_k5_n64_l2")
+    k, n, l = 5, 64, 2
+    blocks = g["vals"].reshape(2 * k + 2, n, l)
+    rec, fin = reduce_dev(ctx, blocks, n, flags=_native.REDUCE_NAN_TRIM)
+    assert rec[0] == 61 and rec[1] == 3
+    # output 0 is finite and equals the reference (divisor stays n = 64); output 1 keeps its NaNs
+    np.testing.assert_allclose(fin[0][0], g["E_2"][0], rtol=1e-14)
+    np.testing.assert_allclose(fin[1][0], g["var_y"][0], rtol=1e-13)
+    np.testing.assert_allclose(fin[2 + 2 * k:2 + 3 * k, 0], g["sens"][:, 0], rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(fin[2 + 3 * k:2 + 4 * k, 0], g["sens_t"][:, 0], rtol=1e-10, atol=1e-14)
+    assert np.isnan(fin[2 + 2 * k:2 + 3 * k, 1]).all()
+    # without the flag the NaNs poison everything, as on the reference's live-evaluation route
+    rec2, fin2 = reduce_dev(ctx, blocks, n)
+    assert np.isnan(fin2[0]).all()
+
+
+def test_reduce_nan_trim_big_fast_path(ctx):
+    from varsens_amd import _native
+    rng = np.random.RandomState(77)
+    k, rows = 9, 20000
+    blocks = 1.0 + rng.rand(2 * k + 2, rows, 1)
+    bad = rng.choice(rows, 37, replace=False)
+    blocks[rng.randint(0, 2 * k + 2, 37), bad, 0] = np.nan
+    blocks[0, 0, 0] = np.nan   # the row the un-masked pass takes its shift from
+    rec, fin = reduce_dev(ctx, blocks, rows, flags=_native.REDUCE_NAN_TRIM)
+    keep = ~np.isnan(blocks[:, :, 0]).any(axis=0)
+    kept = blocks[:, keep]
+    assert rec[0] == keep.sum() and rec[1] == rows - keep.sum()
+    ex = orc.exact_accumulators(kept[0], kept[1], kept[2:2 + k], kept[2 + k:])
+    got = unpack(rec, k, 1)
+    for name in ("sab", "ac", "bd", "ad", "bc"):
+        np.testing.assert_allclose(got[name], ex[name], rtol=1e-13)
+    want = orc.indices_from_accumulators(ex, rows)
+    np.testing.assert_allclose(fin[1], want["var_y"], rtol=1e-12)
+
+
+def test_reduce_is_bit_reproducible(ctx):
+    rng = np.random.RandomState(3)
+    blocks = rng.randn(2 * 16 + 2, 50000, 1)
+    r1, _ = reduce_dev(ctx, blocks, 50000)
+    r2, _ = reduce_dev(ctx, blocks, 50000)
+    same(r1, r2)
+
+
+def test_reduce_shards_merge_like_one_pass(ctx):
+    """Two ranks' records summed (what the all-reduce does) finish to the single-GPU result."""
+    from varsens_amd import _native
+    rng = np.random.RandomState(11)
+    k, rows, l = 6, 9000, 2
+    blocks = 5.0 + rng.randn(2 * k + 2, rows, l)
+    blocks[:, :4000] += 3.0   # make the shard means differ
+    rec, fin = reduce_dev(ctx, blocks, rows)
+    world = 2
+    recs = []
+    for rank, (b, e) in enumerate([(0, 4000), (4000, rows)]):
+        f = ctx.upload(np.ascontiguousarray(blocks[:, b:e]))
+        acc = ctx.alloc(8 * _native.acc_len(k, l, world))
+        ctx.reduce_first_order(f, e - b, k, l, acc, 0, rank, world)
+        recs.append(ctx.download(acc, (_native.acc_len(k, l, world),)))
+    summed = ctx.upload(recs[0] + recs[1])
+    out = ctx.alloc(8 * _native.first_order_len(k, l))
+    ctx.finish_first_order(summed, rows, k, l, out, world)
+    fin2 = ctx.download(out, (2 + 4 * k, l))
+    np.testing.assert_allclose(fin2, fin, rtol=1e-12)
+    np.testing.assert_allclose(fin2[1], np.var(np.concatenate([blocks[0], blocks[1]]), axis=0, ddof=1), rtol=1e-12)

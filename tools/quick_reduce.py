@@ -1,0 +1,48 @@
+"""Quick on-GPU timing sweep of the eval and first-order reduction kernels (tuning aid)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from varsens_amd import _native  # noqa: E402
+from varsens_amd.saltelli import seed1_permutation  # noqa: E402
+
+k = int(os.environ.get("K", 32))
+n = 1 << int(os.environ.get("LOG2N", 22))
+ctx = _native.Context(0)
+print(ctx.info(), flush=True)
+t0 = time.time()
+perm = seed1_permutation(n)
+print("perm %.3fs" % (time.time() - t0), flush=True)
+design = ctx.design_create(_native.GEN_HALTON, k, n, 1 + 20 * k, 0, None, None, perm)
+obj = ctx.objective_create(_native.OBJ_LINEAR, k, 1, np.arange(1, k + 1, dtype=float))
+N = 2 * (k + 1) * n
+f = ctx.alloc(8 * N)
+acc = ctx.alloc(8 * _native.acc_len(k, 1, 1))
+
+
+def timed(fn, reps=10):
+    fn(); ctx.sync()
+    ctx.profile_begin(1024)
+    for _ in range(reps):
+        fn()
+    recs = ctx.profile_end()
+    out = {}
+    for name, ms in recs:
+        out.setdefault(name, []).append(ms)
+    return {kk: (np.median(v), np.min(v)) for kk, v in out.items()}
+
+
+r = timed(lambda: ctx.eval(design, obj, 0, n, f), 5)
+ms = r["eval"][0]
+print("eval: %.3f ms  -> %.1f G evals/s, write %.1f GB/s" % (ms, N / ms / 1e6, 8 * N / ms / 1e6), flush=True)
+for nv in (2, 4, 8):
+    for wpc in (2, 4, 8, 16):
+        os.environ["VS_REDUCE_NV"] = str(nv)
+        os.environ["VS_REDUCE_WGS_PER_CU"] = str(wpc)
+        r = timed(lambda: ctx.reduce_first_order(f, n, k, 1, acc))
+        ms = r["reduce_first"][0]
+        print("reduce nv=%d wgs/cu=%2d: %.3f ms (min %.3f) -> %.0f GB/s = %.1f GSamples/s ; fold %.3f ms" %
+              (nv, wpc, ms, r["reduce_first"][1], 8 * N / ms / 1e6, N / ms / 1e6, r["fold"][0]), flush=True)

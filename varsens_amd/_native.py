@@ -1,0 +1,355 @@
+"""ctypes binding of libvarsens_hip.so (C ABI: include/varsens_hip.h).
+
+This is the only door between the Python host code and the GPU.  There is no
+CPU implementation behind it: if the shared library is missing, or no gfx950
+device is usable, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvarsens_hip.so")
+
+ABI_VERSION = 1
+COMM_ID_BYTES = 128
+
+GEN_HALTON, GEN_SOBOL, GEN_RAW = 0, 1, 2
+SCALE_IDENTITY, SCALE_LINEAR, SCALE_POWER = 0, 1, 2
+OBJ_G_FUNCTION, OBJ_ISHIGAMI, OBJ_LINEAR, OBJ_POLYNOMIAL, OBJ_INVERT = 1, 2, 3, 4, 5
+REDUCE_NAN_TRIM = 1
+
+KERNEL_NAMES = {
+    1: "halton_fill", 2: "sobol_fill", 3: "sample_flat", 4: "eval", 5: "reduce_first",
+    6: "fold", 7: "finish", 8: "nan_mask", 9: "second_order", 10: "second_fold", 11: "fused",
+}
+
+ACC_HEADER = 4
+
+
+def acc_per_output(k):
+    return 3 + 4 * k
+
+
+def acc_slot(l):
+    return 1 + 2 * l
+
+
+def acc_len(k, l, max_ranks):
+    return ACC_HEADER + l * acc_per_output(k) + max_ranks * acc_slot(l)
+
+
+def first_order_len(k, l):
+    return (2 + 4 * k) * l
+
+
+class VarsensHipError(RuntimeError):
+    """A call into libvarsens_hip.so failed."""
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64), ("compute_units", C.c_int32),
+                ("wavefront_size", C.c_int32), ("lds_bytes_per_cu", C.c_int32), ("clock_mhz", C.c_int32),
+                ("hbm_bytes", C.c_uint64)]
+
+
+class ProfileRecord(C.Structure):
+    _fields_ = [("kernel_id", C.c_int32), ("ms", C.c_float)]
+
+
+class DesignDesc(C.Structure):
+    _fields_ = [("generator", C.c_int32), ("k", C.c_int32), ("n", C.c_uint64), ("first_index", C.c_uint64),
+                ("scale_mode", C.c_int32), ("reserved", C.c_int32),
+                ("lower", C.c_void_p), ("upper", C.c_void_p), ("perm", C.c_void_p), ("raw", C.c_void_p),
+                ("sobol_directions", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/varsens_hip.h declares
+SIGNATURES = {
+    "vs_abi_version": (C.c_int, []),
+    "vs_last_error": (C.c_char_p, []),
+    "vs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "vs_context_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "vs_context_destroy": (C.c_int, [C.c_void_p]),
+    "vs_context_info": (C.c_int, [C.c_void_p, C.POINTER(DeviceInfo)]),
+    "vs_sync": (C.c_int, [C.c_void_p]),
+    "vs_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vs_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vs_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vs_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vs_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "vs_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "vs_profile_end": (C.c_int, [C.c_void_p, C.POINTER(ProfileRecord), C.c_int, C.POINTER(C.c_int)]),
+    "vs_halton_fill": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "vs_sobol_fill": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "vs_design_create": (C.c_int, [C.c_void_p, C.POINTER(DesignDesc), C.POINTER(C.c_void_p)]),
+    "vs_design_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vs_sample_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "vs_objective_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_void_p)]),
+    "vs_objective_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vs_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "vs_reduce_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p]),
+    "vs_finish_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p]),
+    "vs_reduce_second_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p]),
+    "vs_finish_second_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p]),
+    "vs_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "vs_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "vs_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vs_comm_destroy": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the engine and bind every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.isfile(p):
+        raise VarsensHipError(
+            "libvarsens_hip.so not found at %s -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)" % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vs_abi_version() != ABI_VERSION:
+        raise VarsensHipError("libvarsens_hip.so has ABI %d, binding expects %d" %
+                              (lib.vs_abi_version(), ABI_VERSION))
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise VarsensHipError("%s (status %d)" % (load_library().vs_last_error().decode("utf-8", "replace"), rc))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load_library().vs_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _host(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuffer(object):
+    """A block of HBM owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _check(ctx.lib.vs_alloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def at(self, byte_offset):
+        return C.c_void_p(self.ptr + int(byte_offset))
+
+    def free(self):
+        if self.ptr and self.ctx.handle:
+            _check(self.ctx.lib.vs_free(self.ctx.handle, C.c_void_p(self.ptr)))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context(object):
+    """One GPU + one HIP stream (vs_context)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.handle = None
+        h = C.c_void_p()
+        _check(self.lib.vs_context_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+        self._designs = []
+
+    # -- plumbing
+    def close(self):
+        if self.handle:
+            self.lib.vs_context_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        d = DeviceInfo()
+        _check(self.lib.vs_context_info(self.handle, C.byref(d)))
+        return dict(name=d.name.decode(), arch=d.arch.decode(), compute_units=d.compute_units,
+                    wavefront_size=d.wavefront_size, lds_bytes_per_cu=d.lds_bytes_per_cu,
+                    clock_mhz=d.clock_mhz, hbm_bytes=d.hbm_bytes)
+
+    def sync(self):
+        _check(self.lib.vs_sync(self.handle))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, array, dtype=np.float64):
+        a, p = _host(array, dtype)
+        buf = DeviceBuffer(self, a.nbytes)
+        _check(self.lib.vs_upload(self.handle, C.c_void_p(buf.ptr), p, a.nbytes))
+        return buf
+
+    def upload_into(self, buf, array, dtype=np.float64, byte_offset=0):
+        a, p = _host(array, dtype)
+        if byte_offset + a.nbytes > buf.nbytes:
+            raise VarsensHipError("upload exceeds the device buffer")
+        _check(self.lib.vs_upload(self.handle, buf.at(byte_offset), p, a.nbytes))
+
+    def download(self, buf, shape, dtype=np.float64, byte_offset=0):
+        out = np.empty(shape, dtype=dtype)
+        if byte_offset + out.nbytes > buf.nbytes:
+            raise VarsensHipError("download exceeds the device buffer")
+        _check(self.lib.vs_download(self.handle, out.ctypes.data_as(C.c_void_p), buf.at(byte_offset), out.nbytes))
+        return out
+
+    def memset(self, buf, byte=0):
+        _check(self.lib.vs_memset(self.handle, C.c_void_p(buf.ptr), int(byte), buf.nbytes))
+
+    def profile_begin(self, capacity=4096):
+        self._prof_capacity = int(capacity)
+        _check(self.lib.vs_profile_begin(self.handle, self._prof_capacity))
+
+    def profile_end(self):
+        recs = (ProfileRecord * self._prof_capacity)()
+        n = C.c_int(0)
+        _check(self.lib.vs_profile_end(self.handle, recs, self._prof_capacity, C.byref(n)))
+        return [(KERNEL_NAMES.get(recs[i].kernel_id, str(recs[i].kernel_id)), float(recs[i].ms))
+                for i in range(n.value)]
+
+    # -- generators
+    def halton_fill(self, k, start, count):
+        buf = DeviceBuffer(self, 8 * int(count) * int(k))
+        _check(self.lib.vs_halton_fill(self.handle, int(k), int(start), int(count), C.c_void_p(buf.ptr)))
+        return buf
+
+    def sobol_fill(self, k, directions, start, count):
+        d, dp = _host(directions, np.uint32)
+        if d.shape != (k, 32):
+            raise VarsensHipError("direction table must have shape (k, 32)")
+        buf = DeviceBuffer(self, 8 * int(count) * int(k))
+        _check(self.lib.vs_sobol_fill(self.handle, int(k), dp, int(start), int(count), C.c_void_p(buf.ptr)))
+        return buf
+
+    # -- design / objective handles
+    def design_create(self, generator, k, n, first_index=0, scale_mode=SCALE_IDENTITY, lower=None, upper=None,
+                      perm=None, raw=None, sobol_directions=None):
+        keep = []
+
+        def ptr(a, dtype, shape=None):
+            if a is None:
+                return None
+            arr, p = _host(a, dtype)
+            if shape is not None and arr.shape != shape:
+                raise VarsensHipError("array of shape %s expected, got %s" % (shape, arr.shape))
+            keep.append(arr)
+            return p
+        desc = DesignDesc()
+        desc.generator = int(generator)
+        desc.k = int(k)
+        desc.n = int(n)
+        desc.first_index = int(first_index)
+        desc.scale_mode = int(scale_mode)
+        desc.lower = ptr(lower, np.float64, (k,))
+        desc.upper = ptr(upper, np.float64, (k,))
+        desc.perm = ptr(perm, np.uint32, (n,))
+        desc.raw = ptr(raw, np.float64, (2 * n, k))
+        desc.sobol_directions = ptr(sobol_directions, np.uint32, (k, 32))
+        h = C.c_void_p()
+        _check(self.lib.vs_design_create(self.handle, C.byref(desc), C.byref(h)))
+        return Handle(self, h, self.lib.vs_design_destroy)
+
+    def objective_create(self, kind, k, l, params=None):
+        if params is None or len(params) == 0:
+            p, n = None, 0
+        else:
+            arr, p = _host(np.asarray(params, dtype=np.float64).ravel(), np.float64)
+            n = arr.size
+        h = C.c_void_p()
+        _check(self.lib.vs_objective_create(self.handle, int(kind), int(k), int(l), p, n, C.byref(h)))
+        return Handle(self, h, self.lib.vs_objective_destroy)
+
+    # -- compute
+    def sample_flat(self, design, row_begin, row_count, out_buf):
+        _check(self.lib.vs_sample_flat(self.handle, design.h, int(row_begin), int(row_count),
+                                       C.c_void_p(out_buf.ptr)))
+
+    def eval(self, design, objective, row_begin, row_count, f_buf):
+        _check(self.lib.vs_eval(self.handle, design.h, objective.h, int(row_begin), int(row_count),
+                                C.c_void_p(f_buf.ptr)))
+
+    def reduce_first_order(self, f_buf, rows, k, l, acc_buf, flags=0, rank=0, max_ranks=1):
+        _check(self.lib.vs_reduce_first_order(self.handle, C.c_void_p(f_buf.ptr), int(rows), int(k), int(l),
+                                              int(flags), int(rank), int(max_ranks), C.c_void_p(acc_buf.ptr)))
+
+    def finish_first_order(self, acc_buf, n, k, l, out_buf, max_ranks=1):
+        _check(self.lib.vs_finish_first_order(self.handle, C.c_void_p(acc_buf.ptr), int(n), int(k), int(l),
+                                              int(max_ranks), C.c_void_p(out_buf.ptr)))
+
+    def reduce_second_order(self, f_buf, rows, k, l, gram_buf, flags=0):
+        _check(self.lib.vs_reduce_second_order(self.handle, C.c_void_p(f_buf.ptr), int(rows), int(k), int(l),
+                                               int(flags), C.c_void_p(gram_buf.ptr)))
+
+    def finish_second_order(self, gram_buf, first_buf, n, k, l, s2_buf, s2n_buf):
+        _check(self.lib.vs_finish_second_order(self.handle, C.c_void_p(gram_buf.ptr), C.c_void_p(first_buf.ptr),
+                                               int(n), int(k), int(l), C.c_void_p(s2_buf.ptr),
+                                               C.c_void_p(s2n_buf.ptr)))
+
+    # -- multi-GPU
+    def comm_unique_id(self):
+        raw = C.create_string_buffer(COMM_ID_BYTES)
+        _check(self.lib.vs_comm_unique_id(raw))
+        return raw.raw
+
+    def comm_init(self, unique_id, nranks, rank):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise VarsensHipError("unique id must be %d bytes" % COMM_ID_BYTES)
+        _check(self.lib.vs_comm_init(self.handle, C.c_char_p(unique_id), int(nranks), int(rank)))
+
+    def comm_allreduce(self, buf, count):
+        _check(self.lib.vs_comm_allreduce(self.handle, C.c_void_p(buf.ptr), int(count)))
+
+    def comm_destroy(self):
+        _check(self.lib.vs_comm_destroy(self.handle))
+
+
+class Handle(object):
+    """A vs_design / vs_objective owned by a Context."""
+
+    def __init__(self, ctx, h, destroy):
+        self.ctx, self.h, self._destroy = ctx, h, destroy
+
+    def free(self):
+        if self.h and self.ctx.handle:
+            self._destroy(self.ctx.handle, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

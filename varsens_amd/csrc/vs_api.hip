@@ -1,0 +1,214 @@
+// Context, memory, error and profiling plumbing of libvarsens_hip.so.
+#include "vs_common.h"
+
+static thread_local char g_err[1024] = "";
+
+int vs_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" int vs_abi_version(void) { return VS_ABI_VERSION; }
+extern "C" const char* vs_last_error(void) { return g_err; }
+
+extern "C" int vs_device_count(int* count) {
+    VS_REQUIRE(count, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return vs_fail(VS_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return VS_OK;
+}
+
+extern "C" int vs_context_create(int device, vs_context** out) {
+    VS_REQUIRE(out, "out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return vs_fail(VS_ERR_NODEVICE, "no HIP device available (%s); libvarsens_hip has no host fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    VS_REQUIRE(device >= 0 && device < n, "device %d out of range [0,%d)", device, n);
+    VS_HIP(hipSetDevice(device));
+    vs_context* ctx = new vs_context();
+    ctx->device = device;
+    hipError_t pe = hipGetDeviceProperties(&ctx->prop, device);
+    if (pe != hipSuccess) {
+        delete ctx;
+        return vs_fail(VS_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(pe));
+    }
+    if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        char arch[64];
+        snprintf(arch, sizeof(arch), "%s", ctx->prop.gcnArchName);
+        delete ctx;
+        return vs_fail(VS_ERR_NODEVICE, "device %d is %s; this library holds gfx950 code only", device, arch);
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return vs_fail(VS_ERR_HIP, "hipStreamCreate failed");
+    }
+    if (hipMalloc(&ctx->counters, 64 * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc(&ctx->counters_host, 64 * sizeof(uint32_t)) != hipSuccess) {
+        delete ctx;
+        return vs_fail(VS_ERR_HIP, "counter allocation failed");
+    }
+    *out = ctx;
+    return VS_OK;
+}
+
+extern "C" int vs_context_destroy(vs_context* ctx) {
+    if (!ctx) return VS_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->comm) vs_comm_destroy(ctx);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->prof_pool) {
+        hipEventDestroy(s.start);
+        hipEventDestroy(s.stop);
+    }
+    if (ctx->partials) hipFree(ctx->partials);
+    if (ctx->keep) hipFree(ctx->keep);
+    if (ctx->counters) hipFree(ctx->counters);
+    if (ctx->counters_host) hipHostFree(ctx->counters_host);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VS_OK;
+}
+
+extern "C" int vs_context_info(vs_context* ctx, vs_device_info* out) {
+    VS_REQUIRE(ctx && out, "null argument");
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", ctx->prop.name);
+    snprintf(out->arch, sizeof(out->arch), "%s", ctx->prop.gcnArchName);
+    out->compute_units = ctx->prop.multiProcessorCount;
+    out->wavefront_size = ctx->prop.warpSize;
+    out->lds_bytes_per_cu = (int32_t)ctx->prop.maxSharedMemoryPerMultiProcessor;
+    out->clock_mhz = ctx->prop.clockRate / 1000;
+    out->hbm_bytes = ctx->prop.totalGlobalMem;
+    return VS_OK;
+}
+
+extern "C" int vs_sync(vs_context* ctx) {
+    VS_REQUIRE(ctx, "ctx is null");
+    VS_HIP(hipStreamSynchronize(ctx->stream));
+    return VS_OK;
+}
+
+extern "C" int vs_alloc(vs_context* ctx, size_t bytes, void** dptr) {
+    VS_REQUIRE(ctx && dptr, "null argument");
+    *dptr = nullptr;
+    if (bytes == 0) bytes = 8;
+    VS_HIP(hipSetDevice(ctx->device));
+    VS_HIP(hipMalloc(dptr, bytes));
+    return VS_OK;
+}
+
+extern "C" int vs_free(vs_context* ctx, void* dptr) {
+    VS_REQUIRE(ctx, "ctx is null");
+    if (!dptr) return VS_OK;
+    VS_HIP(hipStreamSynchronize(ctx->stream));
+    VS_HIP(hipFree(dptr));
+    return VS_OK;
+}
+
+extern "C" int vs_upload(vs_context* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    VS_REQUIRE(ctx && (bytes == 0 || (dst_dev && src_host)), "null argument");
+    if (!bytes) return VS_OK;
+    VS_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VS_HIP(hipStreamSynchronize(ctx->stream));  // the host buffer is not retained
+    return VS_OK;
+}
+
+extern "C" int vs_download(vs_context* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    VS_REQUIRE(ctx && (bytes == 0 || (dst_host && src_dev)), "null argument");
+    if (!bytes) return VS_OK;
+    VS_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VS_HIP(hipStreamSynchronize(ctx->stream));
+    return VS_OK;
+}
+
+extern "C" int vs_memset(vs_context* ctx, void* dst_dev, int byte, size_t bytes) {
+    VS_REQUIRE(ctx && (bytes == 0 || dst_dev), "null argument");
+    if (!bytes) return VS_OK;
+    VS_HIP(hipMemsetAsync(dst_dev, byte, bytes, ctx->stream));
+    return VS_OK;
+}
+
+int vs_workspace_partials(vs_context* ctx, size_t bytes) {
+    if (bytes <= ctx->partials_bytes) return VS_OK;
+    if (ctx->partials) {
+        VS_HIP(hipStreamSynchronize(ctx->stream));
+        VS_HIP(hipFree(ctx->partials));
+        ctx->partials = nullptr;
+        ctx->partials_bytes = 0;
+    }
+    VS_HIP(hipMalloc(&ctx->partials, bytes));
+    ctx->partials_bytes = bytes;
+    return VS_OK;
+}
+
+int vs_workspace_keep(vs_context* ctx, size_t bytes) {
+    if (bytes <= ctx->keep_bytes) return VS_OK;
+    if (ctx->keep) {
+        VS_HIP(hipStreamSynchronize(ctx->stream));
+        VS_HIP(hipFree(ctx->keep));
+        ctx->keep = nullptr;
+        ctx->keep_bytes = 0;
+    }
+    VS_HIP(hipMalloc(&ctx->keep, bytes));
+    ctx->keep_bytes = bytes;
+    return VS_OK;
+}
+
+// ---- profiling --------------------------------------------------------------
+
+extern "C" int vs_profile_begin(vs_context* ctx, int capacity) {
+    VS_REQUIRE(ctx && capacity > 0, "bad argument");
+    while (ctx->prof_pool.size() < (size_t)capacity) {
+        vs_prof_slot s;
+        s.kernel_id = 0;
+        VS_HIP(hipEventCreate(&s.start));
+        VS_HIP(hipEventCreate(&s.stop));
+        ctx->prof_pool.push_back(s);
+    }
+    ctx->prof.clear();
+    ctx->prof_capacity = (size_t)capacity;
+    ctx->profiling = true;
+    return VS_OK;
+}
+
+extern "C" int vs_profile_end(vs_context* ctx, vs_profile_record* out, int capacity, int* count) {
+    VS_REQUIRE(ctx && count, "null argument");
+    ctx->profiling = false;
+    VS_HIP(hipStreamSynchronize(ctx->stream));
+    int n = 0;
+    for (auto& s : ctx->prof) {
+        if (n >= capacity || !out) break;
+        float ms = 0.f;
+        VS_HIP(hipEventElapsedTime(&ms, s.start, s.stop));
+        out[n].kernel_id = s.kernel_id;
+        out[n].ms = ms;
+        ++n;
+    }
+    *count = n;
+    ctx->prof.clear();
+    return VS_OK;
+}
+
+vs_launch_scope::vs_launch_scope(vs_context* c, int kernel_id) : ctx(c) {
+    if (!ctx->profiling || ctx->prof.size() >= ctx->prof_capacity) return;
+    slot = (int)ctx->prof.size();
+    vs_prof_slot s = ctx->prof_pool[slot];
+    s.kernel_id = kernel_id;
+    ctx->prof.push_back(s);
+    hipEventRecord(s.start, ctx->stream);
+}
+
+vs_launch_scope::~vs_launch_scope() {
+    if (slot >= 0) hipEventRecord(ctx->prof[slot].stop, ctx->stream);
+}

@@ -1,0 +1,94 @@
+// Internal declarations shared by the translation units of libvarsens_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "varsens_hip.h"
+
+struct vs_prof_slot {
+    int kernel_id;
+    hipEvent_t start, stop;
+};
+
+struct vs_context {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    // partial-sum workspace of the reductions (grown on demand, never shrunk)
+    double* partials = nullptr;
+    size_t partials_bytes = 0;
+    // NaN-trim keep mask workspace (one byte per row)
+    uint8_t* keep = nullptr;
+    size_t keep_bytes = 0;
+    uint32_t* counters = nullptr;  // 64 x u32 scratch counters (device)
+    uint32_t* counters_host = nullptr;  // pinned mirror
+    // profiling
+    bool profiling = false;
+    std::vector<vs_prof_slot> prof;
+    std::vector<vs_prof_slot> prof_pool;
+    size_t prof_capacity = 0;
+    // RCCL
+    void* comm = nullptr;
+    int comm_ranks = 0;
+    int comm_rank = -1;
+};
+
+struct vs_design {
+    vs_design_desc d;          // host copy (pointers below replace the host ones)
+    double* lower = nullptr;   // device, k (POWER: lower; LINEAR: lower)
+    double* width = nullptr;   // device, k (LINEAR: upper-lower; POWER: upper/lower)
+    uint32_t* perm = nullptr;  // device, n or null
+    double* raw = nullptr;     // device (2n,k) or null
+    uint32_t* dirs = nullptr;  // device (k,32) or null
+    uint32_t* bases = nullptr; // device, k x {base, magic, shift, pad}
+};
+
+struct vs_objective {
+    int kind = 0;
+    int k = 0;
+    int l = 1;
+    double* params = nullptr;  // device
+    size_t nparams = 0;
+};
+
+int vs_fail(int code, const char* fmt, ...);
+
+#define VS_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return vs_fail(VS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                           __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define VS_REQUIRE(cond, ...)                        \
+    do {                                             \
+        if (!(cond)) return vs_fail(VS_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+// Brackets a launch with profiling events when enabled.
+struct vs_launch_scope {
+    vs_context* ctx;
+    int slot = -1;
+    vs_launch_scope(vs_context* c, int kernel_id);
+    ~vs_launch_scope();
+};
+
+int vs_workspace_partials(vs_context* ctx, size_t bytes);
+int vs_workspace_keep(vs_context* ctx, size_t bytes);
+
+// ---- device helpers -------------------------------------------------------
+#ifdef __HIPCC__
+// Sum over the 64 lanes of a wavefront; result valid in every lane.
+__device__ __forceinline__ double vs_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+#endif

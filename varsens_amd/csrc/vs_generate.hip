@@ -1,0 +1,606 @@
+// Low-discrepancy generators, the implicit Saltelli design and the fused
+// generate -> scale -> column-swap -> evaluate kernel.
+//
+// Reference counterparts (paths relative to the reference checkout):
+//   ghalton.Halton(k).get(..)          varsens/saltelli.py:82-84
+//   scaling(x[0:n]), scaling(x[n:2n])  varsens/saltelli.py:92,95 + varsens/scale.py:33,62
+//   seed-1 row shuffle of M_2          varsens/saltelli.py:100-101 (perm computed on host)
+//   generate_N_j                       varsens/saltelli.py:112-125 (never materialised here)
+//   Sample.flat                        varsens/saltelli.py:127-160
+//   Objective evaluation loops         varsens/saltelli.py:329-355
+//
+// Built with -ffp-contract=off: every multiply/add below rounds separately
+// unless written as fma(), so the arithmetic matches numpy's operation for
+// operation.
+#include "vs_common.h"
+
+// ---------------------------------------------------------------------------
+// Halton radical inverse
+// ---------------------------------------------------------------------------
+
+struct vs_base {
+    uint32_t b;      // prime base
+    uint32_t magic;  // round-up magic multiplier for q / b, q < 2^32
+    uint32_t shift;  // ceil(log2 b) - 1
+    uint32_t pad;
+};
+
+__device__ __forceinline__ uint32_t vs_div_magic(uint32_t q, uint32_t magic, uint32_t shift) {
+    uint32_t t = __umulhi(q, magic);
+    return (t + ((q - t) >> 1)) >> shift;
+}
+
+// Digit-reversed integer of i over b^digits, one correctly rounded division.
+// num and den stay exact integers in fp64 (i * b < 2^53 is checked on the host).
+__device__ __forceinline__ double vs_radical_inverse(uint64_t i, vs_base B) {
+    double num = 0.0, den = 1.0;
+    const double bd = (double)B.b;
+    while (i >> 32) {  // rare: indices beyond 2^32
+        uint64_t q = i / B.b;
+        uint32_t d = (uint32_t)(i - q * B.b);
+        num = fma(num, bd, (double)d);
+        den = den * bd;
+        i = q;
+    }
+    uint32_t j = (uint32_t)i;
+    while (j) {
+        uint32_t q = vs_div_magic(j, B.magic, B.shift);
+        uint32_t d = j - q * B.b;
+        num = fma(num, bd, (double)d);
+        den = den * bd;
+        j = q;
+    }
+    return num / den;
+}
+
+__device__ __forceinline__ double vs_sobol_point(uint64_t i, const uint32_t* __restrict__ dir) {
+    uint32_t g = (uint32_t)(i ^ (i >> 1));
+    uint32_t x = 0;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) x ^= ((g >> j) & 1u) ? dir[j] : 0u;
+    return (double)x * (1.0 / 4294967296.0);
+}
+
+struct vs_design_dev {
+    int generator, k, scale_mode;
+    uint64_t n, first_index;
+    const double* lower;
+    const double* width;
+    const uint32_t* perm;
+    const double* raw;
+    const uint32_t* dirs;
+    const vs_base* bases;
+};
+
+// Unit-cube coordinate c of sequence row `seq_row` (0..2n-1: first half feeds
+// M_1, second half M_2 before the shuffle).
+__device__ __forceinline__ double vs_unit_point(const vs_design_dev& D, uint64_t seq_row, int c) {
+    if (D.generator == VS_GEN_HALTON) return vs_radical_inverse(D.first_index + seq_row, D.bases[c]);
+    if (D.generator == VS_GEN_SOBOL) return vs_sobol_point(D.first_index + seq_row, D.dirs + 32 * c);
+    return D.raw[seq_row * (uint64_t)D.k + c];
+}
+
+__device__ __forceinline__ double vs_apply_scale(const vs_design_dev& D, double p, int c) {
+    if (D.scale_mode == VS_SCALE_LINEAR) return p * D.width[c] + D.lower[c];   // scale.py:33
+    if (D.scale_mode == VS_SCALE_POWER) return D.lower[c] * pow(D.width[c], p); // scale.py:62
+    return p;
+}
+
+// M_1[r][c] / M_2[r][c] (M_2 after the shuffle)
+__device__ __forceinline__ double vs_m1(const vs_design_dev& D, uint64_t r, int c) {
+    return vs_apply_scale(D, vs_unit_point(D, r, c), c);
+}
+__device__ __forceinline__ double vs_m2(const vs_design_dev& D, uint64_t r, int c) {
+    uint64_t src = D.perm ? (uint64_t)D.perm[r] : r;
+    return vs_apply_scale(D, vs_unit_point(D, D.n + src, c), c);
+}
+
+static vs_design_dev to_dev(const vs_design* g) {
+    vs_design_dev D;
+    D.generator = g->d.generator;
+    D.k = g->d.k;
+    D.scale_mode = g->d.scale_mode;
+    D.n = g->d.n;
+    D.first_index = g->d.first_index;
+    D.lower = g->lower;
+    D.width = g->width;
+    D.perm = g->perm;
+    D.raw = g->raw;
+    D.dirs = g->dirs;
+    D.bases = (const vs_base*)g->bases;
+    return D;
+}
+
+// ---------------------------------------------------------------------------
+// host-side tables
+// ---------------------------------------------------------------------------
+
+static std::vector<uint32_t> first_primes(int k) {
+    std::vector<uint32_t> p;
+    for (uint32_t c = 2; (int)p.size() < k; ++c) {
+        bool prime = true;
+        for (uint32_t q : p) {
+            if ((uint64_t)q * q > c) break;
+            if (c % q == 0) { prime = false; break; }
+        }
+        if (prime) p.push_back(c);
+    }
+    return p;
+}
+
+static vs_base make_base(uint32_t b) {
+    vs_base B;
+    B.b = b;
+    uint32_t L = 0;
+    while ((1ull << L) < b) ++L;  // ceil(log2 b), b >= 2 -> L >= 1
+    B.magic = (uint32_t)(((1ull << 32) * ((1ull << L) - b)) / b + 1);
+    B.shift = L - 1;
+    B.pad = 0;
+    return B;
+}
+
+static int upload_bases(vs_context* ctx, int k, uint32_t** out_dev, uint32_t* largest) {
+    std::vector<uint32_t> p = first_primes(k);
+    std::vector<vs_base> tab(k);
+    for (int c = 0; c < k; ++c) tab[c] = make_base(p[c]);
+    *largest = p[k - 1];
+    VS_HIP(hipMalloc(out_dev, sizeof(vs_base) * k));
+    VS_HIP(hipMemcpyAsync(*out_dev, tab.data(), sizeof(vs_base) * k, hipMemcpyHostToDevice, ctx->stream));
+    VS_HIP(hipStreamSynchronize(ctx->stream));
+    return VS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// vs_halton_fill / vs_sobol_fill
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+halton_fill_kernel(const vs_base* __restrict__ bases, int k, uint64_t start, uint64_t total,
+                   double* __restrict__ out) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; e < total; e += stride) {
+        uint64_t row = e / (uint32_t)k;
+        int c = (int)(e - row * (uint32_t)k);
+        out[e] = vs_radical_inverse(start + row, bases[c]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sobol_fill_kernel(const uint32_t* __restrict__ dirs, int k, uint64_t start, uint64_t total,
+                  double* __restrict__ out) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; e < total; e += stride) {
+        uint64_t row = e / (uint32_t)k;
+        int c = (int)(e - row * (uint32_t)k);
+        out[e] = vs_sobol_point(start + row, dirs + 32 * c);
+    }
+}
+
+static unsigned grid_for(uint64_t total, unsigned block, unsigned cap) {
+    uint64_t g = (total + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+extern "C" int vs_halton_fill(vs_context* ctx, int k, uint64_t start, uint64_t count, double* out_dev) {
+    VS_REQUIRE(ctx, "ctx is null");
+    VS_REQUIRE(k >= 1 && k <= 65536, "k=%d out of range", k);
+    if (count == 0) return VS_OK;
+    VS_REQUIRE(out_dev, "out_dev is null");
+    uint32_t* bases = nullptr;
+    uint32_t largest = 0;
+    int rc = upload_bases(ctx, k, &bases, &largest);
+    if (rc) return rc;
+    if ((long double)(start + count) * largest >= 9007199254740992.0L) {
+        hipFree(bases);
+        return vs_fail(VS_ERR_ARG, "Halton index range too large for exact fp64 (index*base >= 2^53)");
+    }
+    uint64_t total = count * (uint64_t)k;
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_HALTON_FILL);
+        hipLaunchKernelGGL(halton_fill_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ctx->stream,
+                           (const vs_base*)bases, k, start, total, out_dev);
+    }
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipStreamSynchronize(ctx->stream));
+    VS_HIP(hipFree(bases));
+    return VS_OK;
+}
+
+extern "C" int vs_sobol_fill(vs_context* ctx, int k, const uint32_t* directions, uint64_t start,
+                             uint64_t count, double* out_dev) {
+    VS_REQUIRE(ctx && directions, "null argument");
+    VS_REQUIRE(k >= 1, "k=%d out of range", k);
+    VS_REQUIRE(start + count <= (1ull << 32), "Sobol indices must stay below 2^32");
+    if (count == 0) return VS_OK;
+    VS_REQUIRE(out_dev, "out_dev is null");
+    uint32_t* dirs = nullptr;
+    VS_HIP(hipMalloc(&dirs, sizeof(uint32_t) * 32 * k));
+    VS_HIP(hipMemcpyAsync(dirs, directions, sizeof(uint32_t) * 32 * k, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t total = count * (uint64_t)k;
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_SOBOL_FILL);
+        hipLaunchKernelGGL(sobol_fill_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)dirs, k, start, total, out_dev);
+    }
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipStreamSynchronize(ctx->stream));
+    VS_HIP(hipFree(dirs));
+    return VS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// design objects
+// ---------------------------------------------------------------------------
+
+extern "C" int vs_design_destroy(vs_context* ctx, vs_design* g) {
+    if (!g) return VS_OK;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (g->lower) hipFree(g->lower);
+    if (g->width) hipFree(g->width);
+    if (g->perm) hipFree(g->perm);
+    if (g->raw) hipFree(g->raw);
+    if (g->dirs) hipFree(g->dirs);
+    if (g->bases) hipFree(g->bases);
+    delete g;
+    return VS_OK;
+}
+
+extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_design** out) {
+    VS_REQUIRE(ctx && desc && out, "null argument");
+    *out = nullptr;
+    const int k = desc->k;
+    const uint64_t n = desc->n;
+    VS_REQUIRE(k >= 1 && k <= 4096, "k=%d out of range [1,4096]", k);
+    VS_REQUIRE(n >= 1 && n <= 0xffffffffull, "n=%llu out of range [1,2^32)", (unsigned long long)n);
+    VS_REQUIRE(desc->generator >= VS_GEN_HALTON && desc->generator <= VS_GEN_RAW, "unknown generator %d",
+               desc->generator);
+    VS_REQUIRE(desc->scale_mode >= VS_SCALE_IDENTITY && desc->scale_mode <= VS_SCALE_POWER,
+               "unknown scale mode %d", desc->scale_mode);
+    if (desc->scale_mode != VS_SCALE_IDENTITY)
+        VS_REQUIRE(desc->lower && desc->upper, "lower/upper bounds are required for this scale mode");
+    if (desc->generator == VS_GEN_RAW) VS_REQUIRE(desc->raw, "raw points are required for VS_GEN_RAW");
+    if (desc->generator == VS_GEN_SOBOL) {
+        VS_REQUIRE(desc->sobol_directions, "direction numbers are required for VS_GEN_SOBOL");
+        VS_REQUIRE(desc->first_index + 2 * n <= (1ull << 32), "Sobol indices must stay below 2^32");
+    }
+    if (desc->perm)
+        for (uint64_t r = 0; r < n; ++r)
+            VS_REQUIRE(desc->perm[r] < n, "perm[%llu]=%u is not a row of the second half",
+                       (unsigned long long)r, desc->perm[r]);
+
+    vs_design* g = new vs_design();
+    g->d = *desc;
+    int rc = VS_OK;
+    auto bail = [&](int code) {
+        vs_design_destroy(ctx, g);
+        return code;
+    };
+#define VS_TRY(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return bail(vs_fail(VS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)));     \
+    } while (0)
+
+    if (desc->scale_mode != VS_SCALE_IDENTITY) {
+        std::vector<double> lo(desc->lower, desc->lower + k), w(k);
+        for (int c = 0; c < k; ++c)
+            w[c] = desc->scale_mode == VS_SCALE_LINEAR ? desc->upper[c] - desc->lower[c]   // scale.py:33
+                                                       : desc->upper[c] / desc->lower[c];  // scale.py:62
+        VS_TRY(hipMalloc(&g->lower, sizeof(double) * k));
+        VS_TRY(hipMalloc(&g->width, sizeof(double) * k));
+        VS_TRY(hipMemcpyAsync(g->lower, lo.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+        VS_TRY(hipMemcpyAsync(g->width, w.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+        VS_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (desc->perm) {
+        VS_TRY(hipMalloc(&g->perm, sizeof(uint32_t) * n));
+        VS_TRY(hipMemcpyAsync(g->perm, desc->perm, sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (desc->generator == VS_GEN_RAW) {
+        size_t bytes = sizeof(double) * 2 * n * (size_t)k;
+        VS_TRY(hipMalloc(&g->raw, bytes));
+        VS_TRY(hipMemcpyAsync(g->raw, desc->raw, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (desc->generator == VS_GEN_SOBOL) {
+        VS_TRY(hipMalloc(&g->dirs, sizeof(uint32_t) * 32 * k));
+        VS_TRY(hipMemcpyAsync(g->dirs, desc->sobol_directions, sizeof(uint32_t) * 32 * k,
+                              hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (desc->generator == VS_GEN_HALTON) {
+        uint32_t largest = 0;
+        rc = upload_bases(ctx, k, &g->bases, &largest);
+        if (rc) return bail(rc);
+        if ((long double)(desc->first_index + 2 * n) * largest >= 9007199254740992.0L)
+            return bail(vs_fail(VS_ERR_ARG, "Halton index range too large for exact fp64 (index*base >= 2^53)"));
+    }
+    VS_TRY(hipStreamSynchronize(ctx->stream));
+#undef VS_TRY
+    g->d.lower = g->d.upper = nullptr;
+    g->d.perm = nullptr;
+    g->d.raw = nullptr;
+    g->d.sobol_directions = nullptr;
+    *out = g;
+    return VS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// vs_sample_flat: rows of Sample.flat()
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256)
+sample_flat_kernel(vs_design_dev D, uint64_t row_begin, uint64_t total, double* __restrict__ out) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t k = (uint32_t)D.k;
+    for (; e < total; e += stride) {
+        uint64_t lr = e / k;
+        int c = (int)(e - lr * k);
+        uint64_t fr = row_begin + lr;
+        uint64_t block = fr / D.n;
+        uint64_t r = fr - block * D.n;
+        // block 0: M_1, 1: M_2, 2+i: N_j[i] (M_2, column i from M_1), 2+k+i: N_nj[i]
+        bool from_m1;
+        if (block == 0) from_m1 = true;
+        else if (block == 1) from_m1 = false;
+        else if (block < 2 + k) from_m1 = ((uint64_t)c == block - 2);
+        else from_m1 = ((uint64_t)c != block - 2 - k);
+        out[e] = from_m1 ? vs_m1(D, r, c) : vs_m2(D, r, c);
+    }
+}
+
+extern "C" int vs_sample_flat(vs_context* ctx, const vs_design* design, uint64_t row_begin,
+                              uint64_t row_count, double* out_dev) {
+    VS_REQUIRE(ctx && design, "null argument");
+    const uint64_t rows_total = 2 * design->d.n * ((uint64_t)design->d.k + 1);
+    VS_REQUIRE(row_begin <= rows_total && row_count <= rows_total - row_begin,
+               "flat rows [%llu,+%llu) exceed 2n(k+1)=%llu", (unsigned long long)row_begin,
+               (unsigned long long)row_count, (unsigned long long)rows_total);
+    if (row_count == 0) return VS_OK;
+    VS_REQUIRE(out_dev, "out_dev is null");
+    uint64_t total = row_count * (uint64_t)design->d.k;
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_SAMPLE_FLAT);
+        hipLaunchKernelGGL(sample_flat_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, ctx->stream,
+                           to_dev(design), row_begin, total, out_dev);
+    }
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// objectives
+// ---------------------------------------------------------------------------
+
+extern "C" int vs_objective_destroy(vs_context* ctx, vs_objective* obj) {
+    if (!obj) return VS_OK;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (obj->params) hipFree(obj->params);
+    delete obj;
+    return VS_OK;
+}
+
+extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, const double* params,
+                                   size_t nparams, vs_objective** out) {
+    VS_REQUIRE(ctx && out, "null argument");
+    *out = nullptr;
+    VS_REQUIRE(k >= 1 && l >= 1, "k and l must be positive");
+    switch (kind) {
+        case VS_OBJ_G_FUNCTION:
+        case VS_OBJ_LINEAR:
+        case VS_OBJ_POLYNOMIAL:
+            VS_REQUIRE(nparams == (size_t)k * l, "objective %d needs l*k=%d parameters, got %zu", kind, k * l,
+                       nparams);
+            break;
+        case VS_OBJ_ISHIGAMI:
+            VS_REQUIRE(k == 3 && l == 1 && nparams == 2, "Ishigami needs k=3, l=1 and parameters {a,b}");
+            break;
+        case VS_OBJ_INVERT:
+            VS_REQUIRE(l == k && nparams == 0, "invert has l=k outputs and no parameters");
+            break;
+        default:
+            return vs_fail(VS_ERR_ARG, "unknown objective kind %d", kind);
+    }
+    VS_REQUIRE(nparams == 0 || params, "params is null");
+    vs_objective* o = new vs_objective();
+    o->kind = kind;
+    o->k = k;
+    o->l = l;
+    o->nparams = nparams;
+    if (nparams) {
+        if (hipMalloc(&o->params, sizeof(double) * nparams) != hipSuccess ||
+            hipMemcpyAsync(o->params, params, sizeof(double) * nparams, hipMemcpyHostToDevice, ctx->stream) !=
+                hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            vs_objective_destroy(ctx, o);
+            return vs_fail(VS_ERR_HIP, "uploading objective parameters failed");
+        }
+    }
+    *out = o;
+    return VS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the fused evaluation kernel
+// ---------------------------------------------------------------------------
+//
+// One thread owns one design row r.  It generates (or gathers) the 2k scaled
+// coordinates M_1[r][:], M_2[r][:] into its private column of an LDS tile
+// ([coordinate][thread], conflict-free), then produces all 2k+2 objective values
+// of that row: f(M_1[r]), f(M_2[r]), f(N_j[i][r]), f(N_nj[i][r]).  N_j / N_nj
+// are never built: point (i) is a column select between the two LDS columns.
+//
+// Separable objectives (g-function, polynomial: product of per-coordinate
+// terms; linear: sum of per-coordinate terms) are folded strictly left to
+// right, so the first i terms of N_j[i] are exactly the running prefix over
+// M_2's terms: cost k^2/2 per family instead of k^2, bit-identical to folding
+// each point on its own.
+//
+// Output index: f[(block*rows + (r-row_begin))*l + o].
+
+struct vs_eval_args {
+    vs_design_dev D;
+    int kind, l;
+    const double* params;
+    uint64_t row_begin, rows;
+    double* f;
+};
+
+template <int KIND>
+__device__ __forceinline__ double vs_term(double x, double p) {
+    if (KIND == VS_OBJ_G_FUNCTION) return (fabs(4.0 * x - 2.0) + p) / (1.0 + p);
+    if (KIND == VS_OBJ_POLYNOMIAL) return 1.0 + p * (x - 0.5);
+    return p * x;  // VS_OBJ_LINEAR
+}
+
+template <int KIND>
+__device__ __forceinline__ double vs_fold(double acc, double t) {
+    return KIND == VS_OBJ_LINEAR ? acc + t : acc * t;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+eval_kernel(vs_eval_args A) {
+    extern __shared__ double lds[];
+    const int T = blockDim.x;
+    const int k = A.D.k;
+    const int tid = threadIdx.x;
+    double* X1 = lds + tid;                 // X1[c*T]
+    double* X2 = lds + (size_t)k * T + tid; // X2[c*T]
+    const uint64_t lr = (uint64_t)blockIdx.x * T + tid;
+    if (lr >= A.rows) return;  // no barrier is used below
+    const uint64_t r = A.row_begin + lr;
+
+    for (int c = 0; c < k; ++c) {
+        X1[(size_t)c * T] = vs_m1(A.D, r, c);
+        X2[(size_t)c * T] = vs_m2(A.D, r, c);
+    }
+
+    const uint64_t rows = A.rows;
+    const int l = A.l;
+    double* f = A.f;
+#define VS_OUT(block, o) f[((uint64_t)(block) * rows + lr) * l + (o)]
+
+    if (KIND == VS_OBJ_G_FUNCTION || KIND == VS_OBJ_POLYNOMIAL || KIND == VS_OBJ_LINEAR) {
+        double* F1 = X1;
+        double* F2 = X2;
+        if (l > 1) {  // keep the coordinates; terms go to a second pair of tiles
+            F1 = lds + 2 * (size_t)k * T + tid;
+            F2 = lds + 3 * (size_t)k * T + tid;
+        }
+        const double ident = KIND == VS_OBJ_LINEAR ? 0.0 : 1.0;
+        for (int o = 0; o < l; ++o) {
+            const double* p = A.params + (size_t)o * k;
+            for (int c = 0; c < k; ++c) {
+                F1[(size_t)c * T] = vs_term<KIND>(X1[(size_t)c * T], p[c]);
+                F2[(size_t)c * T] = vs_term<KIND>(X2[(size_t)c * T], p[c]);
+            }
+            double pa = ident, pb = ident;  // folds of M_1 / M_2 terms over columns < i
+            for (int i = 0; i < k; ++i) {
+                const double ta = F1[(size_t)i * T], tb = F2[(size_t)i * T];
+                double cj = vs_fold<KIND>(pb, ta);  // N_j[i]: M_2 with column i from M_1
+                double dj = vs_fold<KIND>(pa, tb);  // N_nj[i]: M_1 with column i from M_2
+                for (int c = i + 1; c < k; ++c) {
+                    cj = vs_fold<KIND>(cj, F2[(size_t)c * T]);
+                    dj = vs_fold<KIND>(dj, F1[(size_t)c * T]);
+                }
+                VS_OUT(2 + i, o) = cj;
+                VS_OUT(2 + k + i, o) = dj;
+                pa = vs_fold<KIND>(pa, ta);
+                pb = vs_fold<KIND>(pb, tb);
+            }
+            VS_OUT(0, o) = pa;
+            VS_OUT(1, o) = pb;
+        }
+    } else if (KIND == VS_OBJ_ISHIGAMI) {
+        const double a = A.params[0], b = A.params[1];
+        double s[2][2], q[2];  // [which sample][coordinate]
+        s[0][0] = sin(X1[0]);
+        s[1][0] = sin(X2[0]);
+        s[0][1] = sin(X1[(size_t)T]);
+        s[1][1] = sin(X2[(size_t)T]);
+        double x3a = X1[2 * (size_t)T], x3b = X2[2 * (size_t)T];
+        q[0] = (x3a * x3a) * (x3a * x3a);
+        q[1] = (x3b * x3b) * (x3b * x3b);
+        // value with coordinate c taken from sample u_c in {0 = M_1, 1 = M_2}
+        auto val = [&](int u0, int u1, int u2) {
+            double s1 = s[u0][0], s2 = s[u1][1];
+            return (s1 + a * (s2 * s2)) + (b * q[u2]) * s1;
+        };
+        VS_OUT(0, 0) = val(0, 0, 0);
+        VS_OUT(1, 0) = val(1, 1, 1);
+        VS_OUT(2, 0) = val(0, 1, 1);  // N_j[i]: M_2 except column i
+        VS_OUT(3, 0) = val(1, 0, 1);
+        VS_OUT(4, 0) = val(1, 1, 0);
+        VS_OUT(5, 0) = val(1, 0, 0);  // N_nj[i]: M_1 except column i
+        VS_OUT(6, 0) = val(0, 1, 0);
+        VS_OUT(7, 0) = val(0, 0, 1);
+    } else if (KIND == VS_OBJ_INVERT) {
+        for (int o = 0; o < k; ++o) {
+            const double ia = 1.0 - X1[(size_t)o * T], ib = 1.0 - X2[(size_t)o * T];
+            VS_OUT(0, o) = ia;
+            VS_OUT(1, o) = ib;
+            for (int i = 0; i < k; ++i) {
+                VS_OUT(2 + i, o) = (i == o) ? ia : ib;
+                VS_OUT(2 + k + i, o) = (i == o) ? ib : ia;
+            }
+        }
+    }
+#undef VS_OUT
+}
+
+template <int KIND>
+static int launch_eval(vs_context* ctx, const vs_eval_args& A, int tiles) {
+    const int k = A.D.k;
+    // threads per block: as many as keep the LDS tile within budget
+    const size_t per_thread = sizeof(double) * (size_t)tiles * k;
+    const size_t budget = 64 * 1024;   // two blocks per CU of up to 64 KiB each
+    int T = 256;
+    while (T > 64 && per_thread * T > budget) T >>= 1;
+    size_t lds = per_thread * T;
+    VS_REQUIRE(lds <= 160 * 1024, "k=%d (x%d tiles) needs %zu bytes of LDS per 64 rows; limit is 160 KiB", k,
+               tiles, lds);
+    if (lds > 64 * 1024)
+        VS_HIP(hipFuncSetAttribute((const void*)eval_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    uint64_t blocks = (A.rows + T - 1) / T;
+    VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_EVAL);
+        hipLaunchKernelGGL(eval_kernel<KIND>, dim3((unsigned)blocks), dim3(T), lds, ctx->stream, A);
+    }
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,
+                       uint64_t row_begin, uint64_t row_count, double* f_dev) {
+    VS_REQUIRE(ctx && design && obj, "null argument");
+    VS_REQUIRE(obj->k == design->d.k, "objective has k=%d, design has k=%d", obj->k, design->d.k);
+    VS_REQUIRE(row_begin <= design->d.n && row_count <= design->d.n - row_begin,
+               "rows [%llu,+%llu) exceed n=%llu", (unsigned long long)row_begin,
+               (unsigned long long)row_count, (unsigned long long)design->d.n);
+    if (row_count == 0) return VS_OK;
+    VS_REQUIRE(f_dev, "f_dev is null");
+    vs_eval_args A;
+    A.D = to_dev(design);
+    A.kind = obj->kind;
+    A.l = obj->l;
+    A.params = obj->params;
+    A.row_begin = row_begin;
+    A.rows = row_count;
+    A.f = f_dev;
+    const int sep_tiles = obj->l > 1 ? 4 : 2;
+    switch (obj->kind) {
+        case VS_OBJ_G_FUNCTION: return launch_eval<VS_OBJ_G_FUNCTION>(ctx, A, sep_tiles);
+        case VS_OBJ_POLYNOMIAL: return launch_eval<VS_OBJ_POLYNOMIAL>(ctx, A, sep_tiles);
+        case VS_OBJ_LINEAR: return launch_eval<VS_OBJ_LINEAR>(ctx, A, sep_tiles);
+        case VS_OBJ_ISHIGAMI: return launch_eval<VS_OBJ_ISHIGAMI>(ctx, A, 2);
+        case VS_OBJ_INVERT: return launch_eval<VS_OBJ_INVERT>(ctx, A, 2);
+    }
+    return vs_fail(VS_ERR_ARG, "unknown objective kind %d", obj->kind);
+}

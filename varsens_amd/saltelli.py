@@ -1,0 +1,498 @@
+"""Host-side mirror of the reference's three classes, executing on the GPU.
+
+``Sample``, ``Objective`` and ``Varsens`` keep the constructor signatures,
+attribute names, result shapes and error behaviour of varsens/saltelli.py
+(:62, :287, :545 of the reference) so that ``import varsens_amd as varsens`` is
+a drop-in.  What differs is where the work happens:
+
+* ``Sample`` holds a *design* on the GPU (vs_design): generator, index range,
+  scaling spec and the seed-1 permutation.  M_1, M_2, N_j, N_nj are never
+  stored; the attributes of those names materialise rows on demand through
+  vs_sample_flat.
+* ``Objective`` holds the 2n(k+1) objective values in HBM in the reference's
+  flat block order, written by the fused generate->evaluate kernel (device
+  objectives), or uploaded (opaque callables, pre-computed values, files).
+* ``Varsens.compute_varsens`` is two kernel passes (first-order streaming
+  reduction, second-order Gram sums) plus small finishing kernels; with a
+  communicator the accumulator record is summed over ranks in between.
+
+The one-shot constructor ``Varsens(f, scaling, k, n, verbose=False)`` works as
+the reference's docstring intends; at the reference's HEAD it raises TypeError
+because ``verbose`` is passed positionally into ``discard``/``objective_vals``
+(varsens/saltelli.py:555,567).
+"""
+import os
+
+import numpy
+
+from . import _native
+from . import objectives as _objectives
+from . import scale as _scale
+
+_default_ctx = {}
+
+# largest array an attribute such as Sample.N_j may materialise on the host
+HOST_MATERIALISE_LIMIT = int(os.environ.get("VARSENS_HOST_LIMIT_BYTES", 8 << 30))
+# rows handed to an opaque Python objective per chunk
+_HOST_CHUNK_ROWS = 1 << 16
+
+
+def default_context(device=None):
+    """The process-wide GPU context (one GPU per process)."""
+    if device is None:
+        device = int(os.environ.get("VARSENS_DEVICE", os.environ.get("LOCAL_RANK", 0)))
+    if device not in _default_ctx:
+        _default_ctx[device] = _native.Context(device)
+    return _default_ctx[device]
+
+
+def seed1_permutation(n):
+    """Row order the reference's ``numpy.random.seed(1); numpy.random.shuffle(M_2)``
+    produces (varsens/saltelli.py:100-101): shuffled[r] = original[perm[r]].
+    A private legacy RandomState(1) draws the same MT19937 stream; numpy's global
+    RNG is left alone (the reference reseeds it as a side effect)."""
+    order = numpy.arange(n, dtype=numpy.uint32)
+    numpy.random.RandomState(1).shuffle(order)
+    return order
+
+
+def sobol_directions(k):
+    table = numpy.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data",
+                                    "sobol_joe_kuo_1024x32.npy"))
+    if k > table.shape[0]:
+        raise Exception("the shipped Sobol table covers %d dimensions, k=%d asked" % (table.shape[0], k))
+    return numpy.ascontiguousarray(table[:k])
+
+
+def _shard_rows(n, shard):
+    if shard is None:
+        return 0, n
+    begin, count = int(shard[0]), int(shard[1])
+    if begin < 0 or count < 0 or begin + count > n:
+        raise Exception("shard rows [%d,%d) are outside [0,%d)" % (begin, begin + count, n))
+    return begin, count
+
+
+class Sample(object):
+    """The Saltelli design: M_1, M_2 and the column-swapped N_j, N_nj.
+
+    Parameters are those of the reference (varsens/saltelli.py:62):
+    ``Sample(k, n, scaling=None, discard=0, verbose=True, raw=None, **loadArgs)``
+    plus keyword-only extras: ``generator`` ('halton' default, 'sobol'),
+    ``context`` (a _native.Context).
+
+    ``scaling`` may be a ``scale.Linear/Power/Percentage/Magnitude/Identity``
+    spec (applied on the GPU) or any callable on an (n,k) block (applied on the
+    host to the two halves, as the reference does at :92,95).
+    """
+
+    def __init__(self, k, n, scaling=None, discard=0, verbose=True, raw=None, **loadArgs):
+        generator = loadArgs.pop('generator', 'halton')
+        self._ctx = loadArgs.pop('context', None) or default_context()
+        self.k = int(k)
+        self.n = int(n)
+        self.scaling = scaling
+        self.verbose = verbose
+        self._host = {}       # name -> host array, for samples loaded from a flat file
+        self._design = None
+        k, n = self.k, self.n
+
+        unit = None  # host (2n,k) unit-cube points, when they come from outside
+        if raw is not None:
+            if self.verbose: print("Using provided raw sample")
+            unit = numpy.asarray(raw)
+            if unit.shape != (2 * n, k):
+                raise Exception("Raw sample dimensions do not match specified dimensions")
+        elif loadArgs:
+            if self.verbose: print("Loading Sample from loadArgs")
+            unit = self.load(**loadArgs)
+            if unit.shape == (2 * n * (1 + k), k):
+                return
+        else:
+            if self.verbose: print("Generating Low Discrepancy Sequence")
+            if not self.scaling:
+                raise Exception("Generating a fresh sample space requires that a 'scaling' function be defined.")
+            if generator not in ('halton', 'sobol'):
+                raise Exception("generator must be 'halton' or 'sobol'")
+
+        if scaling is None:
+            if self.verbose: print("Defaulting to identity scaling of parameter space")
+            self.scaling = _scale.Identity()
+
+        if self.verbose: print("Eliminating correlations")
+        perm = seed1_permutation(n)
+
+        if generator == 'halton':
+            gen, first = _native.GEN_HALTON, 1 + 20 * k + int(discard)   # saltelli.py:83: skip 20k + discard
+        else:
+            gen, first = _native.GEN_SOBOL, 4096 + int(discard)          # quantlib/sobolGen.cpp:50 skipTo(4096)
+        dirs = sobol_directions(k) if (unit is None and generator == 'sobol') else None
+
+        if isinstance(self.scaling, _scale.DeviceScale):
+            mode, lo, hi = self.scaling.device_spec(k)
+            if unit is None:
+                self._design = self._ctx.design_create(gen, k, n, first, mode, lo, hi, perm, None, dirs)
+            else:
+                self._design = self._ctx.design_create(_native.GEN_RAW, k, n, 0, mode, lo, hi, perm, unit)
+        else:
+            # opaque callable: its own Python code has to see the two (n,k) halves (saltelli.py:92,95)
+            if unit is None:
+                if gen == _native.GEN_HALTON:
+                    buf = self._ctx.halton_fill(k, first, 2 * n)
+                else:
+                    buf = self._ctx.sobol_fill(k, dirs, first, 2 * n)
+                unit = self._ctx.download(buf, (2 * n, k))
+                buf.free()
+            if self.verbose: print("Generating M_1")
+            m1 = numpy.asarray(self.scaling(unit[0:n, ...]), dtype=numpy.float64)
+            if self.verbose: print("Generating M_2")
+            m2 = numpy.asarray(self.scaling(unit[n:2 * n, ...]), dtype=numpy.float64)
+            if m1.shape != (n, k) or m2.shape != (n, k):
+                raise Exception("scaling must map an (n,k) block to an (n,k) block")
+            self._design = self._ctx.design_create(_native.GEN_RAW, k, n, 0, _native.SCALE_IDENTITY, None, None,
+                                                   perm, numpy.concatenate([m1, m2], axis=0))
+        if self.verbose: print("...Sample Created.")
+
+    # -- materialisation on demand --------------------------------------------------------
+    def _rows(self, begin, count):
+        """Rows [begin, begin+count) of the flat sample as a host (count,k) array."""
+        if count * self.k * 8 > HOST_MATERIALISE_LIMIT:
+            raise Exception("refusing to materialise %d x %d sample rows on the host (limit %d bytes, "
+                            "VARSENS_HOST_LIMIT_BYTES); evaluate on the device instead" %
+                            (count, self.k, HOST_MATERIALISE_LIMIT))
+        if 'flat' in self._host:
+            return self._host['flat'][begin:begin + count]
+        buf = self._ctx.alloc(8 * count * self.k)
+        self._ctx.sample_flat(self._design, begin, count, buf)
+        out = self._ctx.download(buf, (count, self.k))
+        buf.free()
+        return out
+
+    @property
+    def M_1(self):
+        return self._rows(0, self.n)
+
+    @property
+    def M_2(self):
+        return self._rows(self.n, self.n)
+
+    @property
+    def N_j(self):
+        return self._rows(2 * self.n, self.k * self.n).reshape(self.k, self.n, self.k)
+
+    @property
+    def N_nj(self):
+        return self._rows((2 + self.k) * self.n, self.k * self.n).reshape(self.k, self.n, self.k)
+
+    def generate_N_j(self, M_1, M_2):
+        """k copies of M_2, copy i carrying column i of M_1 (varsens/saltelli.py:112-125).
+        Host helper kept for API parity; the kernels never build these arrays."""
+        M_1 = numpy.asarray(M_1)
+        M_2 = numpy.asarray(M_2)
+        out = numpy.repeat(M_2[numpy.newaxis, ...], self.k, axis=0)
+        cols = numpy.arange(self.k)
+        out[cols, :, cols] = M_1.T
+        return out
+
+    def flat(self):
+        """(2n(k+1), k) array in the order [M_1; M_2; N_j[0..k); N_nj[0..k)] (varsens/saltelli.py:127-160)."""
+        if self.verbose: print("Flattening sample space...")
+        return self._rows(0, 2 * self.n * (self.k + 1))
+
+    # -- text files (varsens/saltelli.py:173-250) -------------------------------------------
+    def export(self, outdir=os.getcwd(), prefix="sample", postfix=".txt", blocksize=float("inf"), delimiter="\t"):
+        total = 2 * self.n * (self.k + 1)
+        blocksize = total if blocksize > total else int(blocksize)
+        prefix = "_".join(str(prefix).split())
+        if prefix[-1] == "_": prefix = prefix[:-1]
+        prefix = os.path.join(outdir, prefix)
+        nFiles = int(numpy.ceil(float(total) / blocksize))
+        for b in range(nFiles):
+            name = "%s%s" % (prefix, postfix) if nFiles == 1 else "%s_%d%s" % (prefix, b + 1, postfix)
+            if self.verbose: print("Writing to %s ..." % name)
+            rows = self._rows(b * blocksize, min(blocksize, total - b * blocksize))
+            numpy.savetxt(name, rows, delimiter=delimiter)
+
+    def load(self, indir='', loadFile=None, prefix=None, postfix='.txt', nFiles=None, offset=1, delimiter='\t'):
+        files = _file_list("sample", indir, loadFile, prefix, postfix, nFiles, offset)
+        parts = []
+        for name in files:
+            if not os.path.isfile(name):
+                raise Exception("Cannot find input file " + name)
+            if self.verbose: print("Reading " + name + " ...")
+            parts.append(numpy.loadtxt(name, delimiter=delimiter, ndmin=2))
+        x = numpy.vstack(parts)
+        n, k = self.n, self.k
+        if x.shape == (2 * n, k):
+            if not self.scaling:
+                raise Exception("Loading a pre-generated, unscaled sample space requires that a 'scaling' "
+                                "function be defined.")
+        elif x.shape == (2 * n * (1 + k), k):
+            if self.verbose: print("Flattened sample detected")
+            # already scaled and shuffled: the design is M_1, M_2 as they stand
+            self._host['flat'] = x
+            self._design = self._ctx.design_create(_native.GEN_RAW, k, n, 0, _native.SCALE_IDENTITY, None, None,
+                                                   None, x[0:2 * n])
+        else:
+            raise Exception("Loaded sample has shape " + str(x.shape) + ". Must have shape (%d,%d) or (%d,%d)." %
+                            (2 * n, k, 2 * n * (1 + k), k))
+        return x
+
+
+def _file_list(what, indir, loadFile, prefix, postfix, nFiles, offset):
+    if loadFile:
+        return [os.path.join(indir, loadFile)]
+    if not prefix:
+        raise Exception("Either 'loadFile' or 'prefix' are required to load %s from file." %
+                        ("a sample" if what == "sample" else "an objective"))
+    if not nFiles:
+        raise Exception("Loading %s files with 'prefix' requires defining 'nFiles'." % what)
+    if prefix[-1] != "_": prefix += "_"
+    return [os.path.join(indir, prefix) + str(i) + postfix for i in range(offset, offset + nFiles)]
+
+
+class Objective(object):
+    """The 2n(k+1) objective values, resident in HBM.
+
+    ``Objective(k, n, sample=None, objective_func=None, objective_vals=[], verbose=True, **loadArgs)``
+    as varsens/saltelli.py:287.  ``objective_func`` may be a device objective
+    (``varsens_amd.objectives``) or any Python callable on one sample row.
+    Keyword-only extras: ``shard=(row_begin, row_count)`` restricts a rank to a
+    slice of the n draws (multi-GPU), ``context``.
+    """
+
+    def __init__(self, k, n, sample=None, objective_func=None, objective_vals=[], verbose=True, **loadArgs):
+        self._ctx = loadArgs.pop('context', None) or (sample._ctx if sample is not None else default_context())
+        shard = loadArgs.pop('shard', None)
+        self.k = k
+        self.n = n
+        self.sample = sample
+        self.objective_func = objective_func
+        self.verbose = verbose
+        self._row_begin, self._rows = _shard_rows(int(n), shard)
+        self._f = None          # device buffer, [2k+2][rows][l]
+        self._l = None
+        self._nan_trim = False  # only values that come through load() are trimmed (saltelli.py:474-495)
+        self._host_cache = None
+
+        if self.verbose: print("Generating Objective Values.")
+        if len(objective_vals) > 0:
+            self.load(objective_vals)
+        elif loadArgs:
+            self.load(**loadArgs)
+        else:
+            if not self.sample:
+                raise Exception("Generating a fresh objective requires that a 'sample' be defined.")
+            elif not self.objective_func:
+                raise Exception("Generating a fresh objective requires that an 'objective_func' be defined.")
+            if isinstance(objective_func, _objectives.DeviceObjective):
+                self._evaluate_on_device()
+            else:
+                self._evaluate_on_host()
+
+    # -- evaluation -----------------------------------------------------------------------
+    def _evaluate_on_device(self):
+        k = int(self.k)
+        spec = self.objective_func
+        self._l = int(spec.outputs(k))
+        handle = self._ctx.objective_create(spec.kind, k, self._l, spec.params(k))
+        self._f = self._ctx.alloc(8 * 2 * (k + 1) * self._rows * self._l)
+        self._ctx.eval(self.sample._design, handle, self._row_begin, self._rows, self._f)
+        self._ctx.sync()
+        handle.free()
+
+    def _evaluate_on_host(self):
+        """An opaque Python objective: rows come from the GPU in chunks, the calls happen
+        here one row at a time as in varsens/saltelli.py:329-355, the values go back to HBM."""
+        k, n = int(self.k), int(self.n)
+        func = self.objective_func
+        test = func(self.sample._rows(self._row_begin, 1)[0])
+        try:
+            l = len(test)
+        except TypeError:
+            l = 1
+        self._l = l
+        rows = self._rows
+        vals = numpy.zeros((2 * k + 2, rows, l))
+        total, step = (2 * k + 2) * rows, 0
+        report = max(1, int(0.01 * total))
+        for block in range(2 * k + 2):
+            for c0 in range(0, rows, _HOST_CHUNK_ROWS):
+                c1 = min(rows, c0 + _HOST_CHUNK_ROWS)
+                pts = self.sample._rows(block * n + self._row_begin + c0, c1 - c0)
+                for i in range(c1 - c0):
+                    vals[block, c0 + i] = func(pts[i])
+                    step += 1
+                    if self.verbose and step % report == 0: print(str(int(round(100. * step / total))) + "%")
+        self._f = self._ctx.upload(vals)
+
+    # -- access ---------------------------------------------------------------------------
+    def _blocks(self):
+        """Host copy [2k+2][rows][l] with NaN rows removed when the values came through load()."""
+        if self._host_cache is None:
+            k = int(self.k)
+            if 8 * (2 * k + 2) * self._rows * self._l > HOST_MATERIALISE_LIMIT:
+                raise Exception("refusing to copy the objective values to the host (VARSENS_HOST_LIMIT_BYTES)")
+            v = self._ctx.download(self._f, (2 * k + 2, self._rows, self._l))
+            if self._nan_trim:
+                drop = numpy.isnan(v[:, :, 0]).any(axis=0)     # first output only (saltelli.py:482)
+                v = v[:, ~drop]
+            self._host_cache = v
+        return self._host_cache
+
+    @property
+    def fM_1(self):
+        return self._blocks()[0]
+
+    @property
+    def fM_2(self):
+        return self._blocks()[1]
+
+    @property
+    def fN_j(self):
+        return self._blocks()[2:2 + int(self.k)]
+
+    @property
+    def fN_nj(self):
+        return self._blocks()[2 + int(self.k):]
+
+    def flat(self):
+        """(rows*2(k+1), l) values in block order (varsens/saltelli.py:357-391)."""
+        if self.verbose: print("Flattening objectives...")
+        v = self._blocks()
+        return v.reshape(-1, v.shape[2])
+
+    # -- text files (varsens/saltelli.py:393-472) --------------------------------------------
+    def export(self, outdir=os.getcwd(), prefix="objective", postfix=".txt", blocksize=float("inf")):
+        f = self.flat()
+        blocksize = len(f) if blocksize > len(f) else int(blocksize)
+        prefix = "_".join(str(prefix).split())
+        if prefix[-1] == "_": prefix = prefix[:-1]
+        prefix = os.path.join(outdir, prefix)
+        nFiles = int(numpy.ceil(float(len(f)) / blocksize))
+        for b in range(nFiles):
+            name = "%s%s" % (prefix, postfix) if nFiles == 1 else "%s_%d%s" % (prefix, b + 1, postfix)
+            if self.verbose: print("Writing to %s ..." % name)
+            numpy.savetxt(name, f[b * blocksize:(b + 1) * blocksize])
+
+    def load(self, obj_vals=[], indir='', loadFile=None, prefix=None, postfix='.txt', nFiles=None, offset=1,
+             scaling=1.0):
+        k, n = int(self.k), int(self.n)
+        if len(obj_vals) > 0:
+            x = numpy.asarray(obj_vals, dtype=numpy.float64)
+        else:
+            files = _file_list("objective", indir, loadFile, prefix, postfix, nFiles, offset)
+            parts = []
+            for name in files:
+                if not os.path.isfile(name):
+                    raise Exception("Cannot find input file " + name)
+                if self.verbose: print("Reading " + name + " ...")
+                parts.append(numpy.loadtxt(name))
+            # one observable: a list of 1-D arrays; several: 2-D arrays (saltelli.py:443-446)
+            x = numpy.hstack(parts) if parts[0].ndim == 1 else numpy.vstack(parts)
+        if len(x) != 2 * n * (1 + k):
+            raise Exception("Loaded objective has length " + str(len(x)) + ". Must have length %d." %
+                            (2 * n * (1 + k)))
+        if x.ndim == 1:
+            x = x[:, numpy.newaxis]
+        if scaling != 1.0:
+            x = x / scaling                                   # saltelli.py:451-468
+        self._l = x.shape[1]
+        blocks = x.reshape(2 * k + 2, n, self._l)
+        if (self._row_begin, self._rows) != (0, n):
+            blocks = blocks[:, self._row_begin:self._row_begin + self._rows]
+        self._f = self._ctx.upload(blocks)
+        self._nan_trim = True
+        self._host_cache = None
+        first = blocks[:, :, 0]
+        lost = int(numpy.isnan(first).any(axis=0).sum())
+        if lost > 0:
+            print("WARNING: %d of %d objectives were NaN, %f%% loss" %
+                  (lost, 2 * n * (1 + k), 100.0 * lost / (2 * n * (1 + k))))
+
+
+class Varsens(object):
+    """Variance-based sensitivity by the method of Saltelli (2002).
+
+    ``Varsens(objective, scaling_func=None, k=None, n=None, sample=None, verbose=True)``
+    (varsens/saltelli.py:545).  Results: ``E_2``, ``var_y`` of shape (l,); ``U_j``,
+    ``U_nj``, ``sens``, ``sens_t`` (k,l); ``sens_2``, ``sens_2n`` (k,l,k,l).
+    Keyword-only extras: ``second_order`` (default True), ``comm`` (an object with
+    ``world``, ``rank`` and ``allreduce(buffer, count)`` -- see varsens_amd.dist),
+    ``context``.
+
+        >>> import varsens_amd as varsens                                  # doctest: +SKIP
+        >>> v = varsens.Varsens(varsens.objectives.GFunction([0, .5, 3, 9, 99, 99]),
+        ...                     varsens.scale.Identity(), 6, 1024, verbose=False)  # doctest: +SKIP
+    """
+
+    def __init__(self, objective, scaling_func=None, k=None, n=None, sample=None, verbose=True, **extra):
+        self.verbose = verbose
+        self._second_order = extra.pop('second_order', True)
+        self._comm = extra.pop('comm', None)
+        ctx = extra.pop('context', None)
+        shard = extra.pop('shard', None)
+        if extra:
+            raise TypeError("unexpected keyword arguments: %s" % sorted(extra))
+        if isinstance(sample, Sample):
+            self.sample = sample
+            self.k = sample.k
+            self.n = sample.n
+        elif k is not None and n is not None and scaling_func is not None:
+            self.k = k
+            self.n = n
+            kw = dict(context=ctx) if ctx is not None else {}
+            self.sample = Sample(k, n, scaling_func, verbose=verbose, **kw)
+        elif not isinstance(objective, Objective):
+            raise ValueError("Must specify sample, (k,n,scaling_func), or Objective object")
+
+        if isinstance(objective, Objective):
+            self.objective = objective
+            self.k = objective.k
+            self.n = objective.n
+        else:
+            kw = dict(shard=shard) if shard is not None else {}
+            self.objective = Objective(self.k, self.n, self.sample, objective, verbose=verbose, **kw)
+        self._ctx = self.objective._ctx
+        self.compute_varsens()
+
+    def compute_varsens(self):
+        """E_2, var_y, U_j, U_nj, sens, sens_t, sens_2, sens_2n (varsens/saltelli.py:572-622)."""
+        if self.verbose: print("Final sensitivity calculation")
+        ctx, obj = self._ctx, self.objective
+        k, n, l = int(self.k), int(self.n), int(obj._l)
+        world = self._comm.world if self._comm is not None else 1
+        rank = self._comm.rank if self._comm is not None else 0
+        flags = _native.REDUCE_NAN_TRIM if obj._nan_trim else 0
+
+        nacc = _native.acc_len(k, l, world)
+        acc = ctx.alloc(8 * nacc)
+        ctx.reduce_first_order(obj._f, obj._rows, k, l, acc, flags, rank, world)
+        if world > 1:
+            self._comm.allreduce(acc, nacc)
+        first = ctx.alloc(8 * _native.first_order_len(k, l))
+        ctx.finish_first_order(acc, n, k, l, first, world)
+        r = ctx.download(first, (2 + 4 * k, l))
+        self.accumulators = ctx.download(acc, (nacc,))
+        self.E_2 = r[0].copy()
+        self.var_y = r[1].copy()
+        self.U_j = r[2:2 + k].copy()
+        self.U_nj = r[2 + k:2 + 2 * k].copy()
+        self.sens = r[2 + 2 * k:2 + 3 * k].copy()
+        self.sens_t = r[2 + 3 * k:2 + 4 * k].copy()
+
+        if self._second_order:
+            K = k * l
+            gram = ctx.alloc(8 * 3 * K * K)
+            ctx.reduce_second_order(obj._f, obj._rows, k, l, gram, flags)
+            if world > 1:
+                self._comm.allreduce(gram, 3 * K * K)
+            s2 = ctx.alloc(8 * K * K)
+            s2n = ctx.alloc(8 * K * K)
+            ctx.finish_second_order(gram, first, n, k, l, s2, s2n)
+            self.sens_2 = ctx.download(s2, (k, l, k, l))
+            self.sens_2n = ctx.download(s2n, (k, l, k, l))
+            for b in (gram, s2, s2n):
+                b.free()
+        acc.free()
+        first.free()
