@@ -1,0 +1,305 @@
+"""The reference's own test-suite, restated against varsens_amd on the GPU, plus the
+golden outputs of the reference.  Reads like varsens/tests/*.py on purpose."""
+import itertools
+import shutil
+import tempfile
+
+import numpy
+import pytest
+
+from oracle import saltelli_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+model = [0, 0.5, 3, 9, 99, 99]
+
+
+@pytest.fixture(scope="module")
+def vs():
+    import varsens_amd
+    return varsens_amd
+
+
+# ---------------------------------------------------------------- varsens/tests/test_sample.py
+
+def test_dimensionality(vs):
+    k, n = 11, 13
+    x = vs.Sample(k, n, lambda x: x, verbose=False)
+    assert (x.k, x.n) == (k, n)
+    assert x.M_1.shape == (n, k) and x.M_2.shape == (n, k)
+    assert x.N_j.shape == (k, n, k) and x.N_nj.shape == (k, n, k)
+
+
+def test_range(vs):
+    x = vs.Sample(7, 11, lambda x: x, verbose=False)
+    for a in (x.M_1, x.M_2, x.N_j, x.N_nj):
+        assert a.min() >= 0.0 and a.max() <= 1.0
+
+
+@pytest.mark.parametrize("scaling", ["lambda", "spec"])
+def test_resampling(vs, scaling):
+    k, n = 3, 5
+    x = vs.Sample(k, n, (lambda x: x) if scaling == "lambda" else vs.scale.Identity(), verbose=False)
+    for i in range(k):
+        assert numpy.array_equal(x.M_1.T[i], x.N_j[i].T[i])
+        assert numpy.array_equal(x.M_2.T[i], x.N_nj[i].T[i])
+        for j in range(k):
+            if j != i:
+                assert numpy.array_equal(x.M_1.T[j], x.N_nj[i].T[j])
+                assert numpy.array_equal(x.M_2.T[j], x.N_j[i].T[j])
+
+
+def test_expected(vs):
+    k, n = 17, 1024
+    x = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
+    assert abs(numpy.sum(x.M_1) / n / k - 0.5) < 0.005
+    assert abs(numpy.sum(x.M_2) / n / k - 0.5) < 0.005
+    assert abs(numpy.sum(x.N_j) / n / k / k - 0.5) < 0.005
+    assert abs(numpy.sum(x.N_nj) / n / k / k - 0.5) < 0.005
+
+
+def test_flat(vs):
+    k, n = 5, 13
+    s = vs.Sample(k, n, lambda x: x, verbose=False)
+    assert s.flat().shape == (n * (2 * k + 2), k)
+    assert numpy.sum(s.M_1[0]) == numpy.sum(s.flat()[0])
+    assert numpy.sum(s.N_nj[k - 1][-1]) == numpy.sum(s.flat()[-1])
+    assert numpy.array_equal(s.flat(), orc.flat_sample(*orc.build_sample(k, n)))
+    assert numpy.array_equal(s.generate_N_j(s.M_1, s.M_2), s.N_j)
+
+
+def test_sample_errors(vs):
+    with pytest.raises(Exception, match="requires that a 'scaling' function"):
+        vs.Sample(3, 5, verbose=False)
+    with pytest.raises(Exception, match="Raw sample dimensions"):
+        vs.Sample(3, 5, lambda x: x, verbose=False, raw=numpy.zeros((9, 3)))
+
+
+def test_sample_scaling_specs_match_reference(vs, golden):
+    g = golden("g8_flat_power_k5_n13")
+    s = vs.Sample(5, 13, vs.scale.Power(g["lower"], g["upper"]), verbose=False, raw=g["raw"])
+    numpy.testing.assert_allclose(s.flat(), g["flat"], rtol=1e-14)           # device pow
+    s = vs.Sample(5, 13, lambda x: vs.scale.power(x, g["lower"], g["upper"]), verbose=False, raw=g["raw"])
+    numpy.testing.assert_allclose(s.flat(), g["flat"], rtol=4e-16)           # host pow (user lambda)
+    g = golden("g10_pct_mag_k4_n7")
+    s = vs.Sample(4, 7, vs.scale.Percentage(g["reference"], 20.0), verbose=False, raw=g["raw"])
+    assert numpy.array_equal(s.M_1, g["pct_M_1"]) and numpy.array_equal(s.N_nj, g["pct_N_nj"])
+    s = vs.Sample(4, 7, vs.scale.Magnitude(numpy.abs(g["reference"]), 2.0, 10.0), verbose=False, raw=g["raw"])
+    numpy.testing.assert_allclose(s.flat(), g["mag_flat"], rtol=1e-14)
+    g = golden("g13_discard37_k3_n16")
+    s = vs.Sample(3, 16, vs.scale.Identity(), 37, verbose=False)
+    assert numpy.array_equal(s.M_1, g["M_1"]) and numpy.array_equal(s.M_2, g["M_2"])
+
+
+def test_sobol_generator(vs):
+    from scipy.stats import qmc
+    k, n = 9, 64
+    s = vs.Sample(k, n, vs.scale.Identity(), verbose=False, generator='sobol')
+    eng = qmc.Sobol(d=k, scramble=False, bits=30)
+    eng.fast_forward(4096)
+    pts = eng.random(2 * n)
+    assert numpy.array_equal(s.M_1, pts[:n])
+    assert numpy.array_equal(s.M_2, pts[n:][orc.seed1_permutation(n)])
+
+
+# ---------------------------------------------------------------- varsens/tests/test_objective.py
+
+def invert(x): return 1.0 - x
+
+
+@pytest.mark.parametrize("func", ["callable", "device"])
+def test_invert(vs, func, golden):
+    k, n = 8, 23
+    s = vs.Sample(k, n, lambda x: x, verbose=False)
+    o = vs.Objective(k, n, s, invert if func == "callable" else vs.objectives.Invert(), verbose=False)
+    assert abs(numpy.sum(1.0 - o.fM_1 - s.M_1)) < 1e-12
+    assert abs(numpy.sum(1.0 - o.fM_2 - s.M_2)) < 1e-12
+    assert abs(numpy.sum(1.0 - o.fN_j - s.N_j)) < 1e-12
+    assert abs(numpy.sum(1.0 - o.fN_nj - s.N_nj)) < 1e-12
+    assert o.fM_1.shape == (n, k) and o.fM_2.shape == (n, k)
+    assert o.fN_j.shape == (k, n, k) and o.fN_nj.shape == (k, n, k)
+    g = golden("g11_invert_k8_n23")
+    assert numpy.array_equal(o.flat(), g["flat_obj"])
+    v = vs.Varsens(o, verbose=False)
+    numpy.testing.assert_allclose(v.sens, g["sens"], rtol=1e-9, atol=1e-12)
+    numpy.testing.assert_allclose(v.sens_2n, g["sens_2n"], rtol=1e-9, atol=1e-12)
+
+
+def test_objective_errors(vs):
+    s = vs.Sample(8, 23, lambda x: x, verbose=False)
+    with pytest.raises(Exception, match="requires that an 'objective_func'"):
+        vs.Objective(8, 23, s, None, verbose=False)
+    with pytest.raises(Exception, match="requires that a 'sample'"):
+        vs.Objective(8, 23, None, invert, verbose=False)
+    with pytest.raises(Exception, match="Must have length"):
+        vs.Objective(8, 23, objective_vals=numpy.zeros((7, 1)), verbose=False)
+    with pytest.raises(ValueError, match="Must specify sample"):
+        vs.Varsens(invert)
+
+
+# ---------------------------------------------------------------- varsens/tests/test_g_function.py
+
+def gi_function(xi, ai): return (numpy.abs(4.0 * xi - 2.0) + ai) / (1.0 + ai)
+
+
+def g_function(x, a): return numpy.prod([gi_function(xi, a[i]) for i, xi in enumerate(x)])
+
+
+def g_objective(x): return g_function(x, model)
+
+
+def g_truth(model): return 1.0 / (3.0 * ((numpy.array(model) + 1.0) ** 2.0))
+
+
+def g_truth_2(model, i, j):
+    x = g_truth(model)
+    return x[i] + x[j] + x[i] * x[j]
+
+
+def g_truth_vnc(model, l):
+    x = g_truth(model)
+    others = [i for i in range(len(model)) if i not in l]
+    result = 0.0
+    for j in range(len(model)):
+        for m in itertools.combinations(others, j + 1):
+            result += numpy.prod(x[numpy.array(m)])
+    return result
+
+
+def g_truth_t(model, i): return g_truth(model)[i] * (1.0 + g_truth_vnc(model, [i]))
+
+
+def g_var(model): return g_truth_vnc(model, [])
+
+
+def check_g_function(v):
+    estimate, estimate_t = v.sens * v.var_y, v.sens_t * v.var_y
+    estimate_2, estimate_2n = v.sens_2 * v.var_y, v.sens_2n * v.var_y
+    truth = g_truth(model)
+    assert abs(g_var(model) - v.var_y[0]) < 0.005 and abs(1.0 - v.E_2[0]) < 0.005
+    for i in range(v.k):
+        assert abs(truth[i] - estimate[i, 0]) < 0.005
+        assert abs(g_truth_t(model, i) - estimate_t[i, 0]) < 0.005
+        for j in range(i + 1, v.k):
+            assert abs(g_truth_2(model, i, j) - estimate_2[i, 0, j, 0]) < 0.005
+            assert abs(g_truth_vnc(model, [i, j]) - estimate_2n[i, 0, j, 0]) < 0.005
+
+
+def test_g_function_device_one_shot(vs, golden):
+    """test_g_function.py:52-73 through the one-shot constructor, objective on the GPU."""
+    v = vs.Varsens(vs.objectives.GFunction(model), vs.scale.Identity(), 6, 1024 * 50, verbose=False)
+    check_g_function(v)
+    g = golden("g2_gfunc_k6_n51200")
+    for f in ("E_2", "var_y", "U_j", "U_nj"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-13)
+    # 1e-10 relative on the indices vs the reference's own outputs
+    numpy.testing.assert_allclose(v.sens, g["sens"], rtol=1e-10, atol=1e-14)
+    numpy.testing.assert_allclose(v.sens_t, g["sens_t"], rtol=1e-10, atol=1e-14)
+    numpy.testing.assert_allclose(v.sens_2, g["sens_2"], rtol=1e-10, atol=1e-13)
+    numpy.testing.assert_allclose(v.sens_2n, g["sens_2n"], rtol=1e-10, atol=1e-13)
+
+
+def test_g_function_python_callable(vs, golden):
+    """Config 1 with an opaque Python objective and an opaque scaling lambda (reference usage)."""
+    v = vs.Varsens(g_objective, lambda x: x, 6, 1024, verbose=False)
+    g = golden("g1_gfunc_k6_n1024")
+    assert v.E_2.shape == (1,) and v.sens.shape == (6, 1) and v.sens_2.shape == (6, 1, 6, 1)
+    for f in ("E_2", "var_y", "U_j", "U_nj"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-13)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-10, atol=1e-13)
+
+
+def test_double_g_function(vs, golden):
+    """test_g_function.py:77-88: two outputs, the second with the reversed model."""
+    v = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 1024 * 50, verbose=False)
+    estimate = v.sens * v.var_y
+    truth = g_truth(model)
+    for i in range(v.k):
+        assert abs(truth[i] - estimate[i][0]) < 0.005
+        assert abs(truth[i] - estimate[5 - i][1]) < 0.005
+    g = golden("g3_gfunc2_k6_n1024")
+    v = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 1024, verbose=False)
+    assert v.sens_2.shape == (6, 2, 6, 2)
+    for f in ("E_2", "var_y", "U_j", "U_nj"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-13)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-10, atol=1e-13)
+
+
+def test_ishigami_linear_polynomial_golden(vs, golden):
+    g = golden("g4_ishigami_k3_n4096")
+    v = vs.Varsens(vs.objectives.Ishigami(7.0, 0.1), vs.scale.Linear(g["lower"], g["upper"]), 3, 4096, verbose=False)
+    for f in ("E_2", "var_y", "sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-9, atol=1e-11)   # device sin: ulp-level inputs
+    g = golden("g5_linear_k32_n4096")
+    v = vs.Varsens(vs.objectives.Linear(g["c"]), vs.scale.Identity(), 32, 4096, verbose=False)
+    for f in ("E_2", "var_y", "sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=2e-10, atol=1e-12)
+    g = golden("g5b_poly_k16_n2048")
+    v = vs.Varsens(vs.objectives.Polynomial(g["beta"]), vs.scale.Identity(), 16, 2048, verbose=False)
+    for f in ("E_2", "var_y", "sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=2e-10, atol=1e-12)
+
+
+# ---------------------------------------------------------------- pre-computed values (call stack c)
+
+@pytest.mark.parametrize("name", ["g12_vals_k7_n50_l1", "g12_vals_k7_n50_l3"])
+def test_precomputed_values(vs, golden, name):
+    g = golden(name)
+    k, n, l = int(g["k"]), int(g["n"]), int(g["l"])
+    o = vs.Objective(k, n, objective_vals=g["vals"], verbose=False)
+    v = vs.Varsens(o, verbose=False)
+    assert v.E_2.shape == (l,) and v.sens.shape == (k, l) and v.sens_2n.shape == (k, l, k, l)
+    for f in ("E_2", "var_y", "U_j", "U_nj"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-13)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-9, atol=1e-12)
+
+
+def test_precomputed_values_divided(vs, golden):
+    g = golden("g12_vals_k7_n50_l3_div4")
+    o = vs.Objective(7, 50, verbose=False, obj_vals=g["vals"], scaling=4.0)
+    v = vs.Varsens(o, verbose=False)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-9, atol=1e-12)
+
+
+def test_nan_trim(vs, golden, capsys):
+    g = golden("g6_nantrim_k5_n64_l2")
+    o = vs.Objective(5, 64, objective_vals=g["vals"], verbose=False)
+    assert "3 of 768 objectives were NaN" in capsys.readouterr().out
+    assert o.fM_1.shape == (61, 2) and numpy.array_equal(o.fM_1, g["fM_1"], equal_nan=True)
+    assert numpy.array_equal(o.fN_nj, g["fN_nj"], equal_nan=True)
+    v = vs.Varsens(o, verbose=False)
+    for f in ("E_2", "var_y"):
+        numpy.testing.assert_allclose(getattr(v, f)[0], g[f][0], rtol=1e-13)
+    for f in ("sens", "sens_t"):
+        numpy.testing.assert_allclose(getattr(v, f)[:, 0], g[f][:, 0], rtol=1e-10, atol=1e-13)
+    for f in ("sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f)[:, 0, :, 0], g[f][:, 0, :, 0], rtol=1e-10, atol=1e-12)
+    assert numpy.isnan(v.sens[:, 1]).all()
+
+
+# ---------------------------------------------------------------- varsens/tests/test_import_export.py
+
+def test_import_export(vs):
+    tmpdir = tempfile.mkdtemp()
+    try:
+        k, n = 6, 1024
+        s = vs.Sample(k, n, lambda x: x, verbose=False)
+        v = vs.Varsens(g_objective, verbose=False, sample=s)
+        s.export(tmpdir, "batch", ".csv", 200)                       # 72 files of <= 200 rows
+        for i in range(72):
+            samples = numpy.loadtxt(tmpdir + ("/batch_%d.csv" % (i + 1)))
+            numpy.savetxt(tmpdir + ("/obj_%d.csv" % (i + 1)), numpy.array([g_objective(x) for x in samples]))
+        o = vs.Objective(s.k, s.n, verbose=False, indir=tmpdir, prefix="obj", postfix=".csv", nFiles=72)
+        v2 = vs.Varsens(o, sample=s, verbose=False)
+        # a flat sample file round-trips too (saltelli.py:229-246)
+        s.export(tmpdir, "whole", ".txt")
+        s2 = vs.Sample(k, n, verbose=False, indir=tmpdir, loadFile="whole.txt")
+        assert numpy.array_equal(s2.M_2, s.M_2) and numpy.array_equal(s2.N_nj, s.N_nj)
+    finally:
+        shutil.rmtree(tmpdir)
+    for f in ("var_y", "E_2", "sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), getattr(v2, f), rtol=0, atol=5e-8)   # 7 places

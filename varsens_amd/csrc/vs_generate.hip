@@ -22,7 +22,9 @@ struct vs_base {
     uint32_t b;      // prime base
     uint32_t magic;  // round-up magic multiplier for q / b, q < 2^32
     uint32_t shift;  // ceil(log2 b) - 1
-    uint32_t pad;
+    uint32_t ndig;   // digits of the largest index of this design in base b (0: indices reach 2^32)
+    double den;      // b^ndig
+    double inv_den;  // RN(1 / den)
 };
 
 __device__ __forceinline__ uint32_t vs_div_magic(uint32_t q, uint32_t magic, uint32_t shift) {
@@ -30,25 +32,42 @@ __device__ __forceinline__ uint32_t vs_div_magic(uint32_t q, uint32_t magic, uin
     return (t + ((q - t) >> 1)) >> shift;
 }
 
-// Digit-reversed integer of i over b^digits, one correctly rounded division.
-// num and den stay exact integers in fp64 (i * b < 2^53 is checked on the host).
-__device__ __forceinline__ double vs_radical_inverse(uint64_t i, vs_base B) {
+// Radical inverse of i in base b: the digit-reversed integer of i divided by
+// b^digits, as ONE correctly rounded fp64 quotient of two exact integers
+// (i * b < 2^53 is checked on the host).
+//
+// Fast path (all indices of the design < 2^32): every lane runs the same ndig
+// digit steps; leading zero digits scale numerator and denominator by the same
+// power of b, which leaves the quotient -- and its rounding -- unchanged.  The
+// denominator is then a per-column constant and the division is Markstein's
+// fma sequence on its correctly rounded reciprocal: two Newton steps, the last
+// of which is provably the correctly rounded quotient.  Base 2 is a bit reversal.
+__device__ __forceinline__ double vs_radical_inverse(uint64_t i, const vs_base B) {
+    if (B.ndig != 0) {
+        uint32_t j = (uint32_t)i;
+        if (B.b == 2) return (double)__brev(j) * (1.0 / 4294967296.0);
+        const double bd = (double)B.b;
+        double num = 0.0;
+        for (uint32_t t = 0; t < B.ndig; ++t) {
+            uint32_t q = vs_div_magic(j, B.magic, B.shift);
+            uint32_t d = j - q * B.b;
+            num = fma(num, bd, (double)d);
+            j = q;
+        }
+        double q0 = num * B.inv_den;
+        double r0 = fma(-q0, B.den, num);
+        double q1 = fma(r0, B.inv_den, q0);
+        double r1 = fma(-q1, B.den, num);
+        return fma(r1, B.inv_den, q1);
+    }
     double num = 0.0, den = 1.0;
     const double bd = (double)B.b;
-    while (i >> 32) {  // rare: indices beyond 2^32
+    while (i) {  // indices beyond 2^32: plain 64-bit digit loop and a true division
         uint64_t q = i / B.b;
         uint32_t d = (uint32_t)(i - q * B.b);
         num = fma(num, bd, (double)d);
         den = den * bd;
         i = q;
-    }
-    uint32_t j = (uint32_t)i;
-    while (j) {
-        uint32_t q = vs_div_magic(j, B.magic, B.shift);
-        uint32_t d = j - q * B.b;
-        num = fma(num, bd, (double)d);
-        den = den * bd;
-        j = q;
     }
     return num / den;
 }
@@ -128,21 +147,34 @@ static std::vector<uint32_t> first_primes(int k) {
     return p;
 }
 
-static vs_base make_base(uint32_t b) {
+static vs_base make_base(uint32_t b, uint64_t max_index) {
     vs_base B;
     B.b = b;
     uint32_t L = 0;
     while ((1ull << L) < b) ++L;  // ceil(log2 b), b >= 2 -> L >= 1
     B.magic = (uint32_t)(((1ull << 32) * ((1ull << L) - b)) / b + 1);
     B.shift = L - 1;
-    B.pad = 0;
+    B.ndig = 0;
+    B.den = 1.0;
+    B.inv_den = 1.0;
+    if (max_index < (1ull << 32)) {
+        uint64_t den = 1;
+        for (uint64_t v = max_index; v; v /= b) {
+            ++B.ndig;
+            den *= b;  // <= max_index * b < 2^53
+        }
+        if (B.ndig == 0) { B.ndig = 1; den = b; }
+        B.den = (double)den;
+        B.inv_den = 1.0 / B.den;
+    }
     return B;
 }
 
-static int upload_bases(vs_context* ctx, int k, uint32_t** out_dev, uint32_t* largest) {
+// max_index: largest sequence index the kernels will ask for
+static int upload_bases(vs_context* ctx, int k, uint64_t max_index, uint32_t** out_dev, uint32_t* largest) {
     std::vector<uint32_t> p = first_primes(k);
     std::vector<vs_base> tab(k);
-    for (int c = 0; c < k; ++c) tab[c] = make_base(p[c]);
+    for (int c = 0; c < k; ++c) tab[c] = make_base(p[c], max_index);
     *largest = p[k - 1];
     VS_HIP(hipMalloc(out_dev, sizeof(vs_base) * k));
     VS_HIP(hipMemcpyAsync(*out_dev, tab.data(), sizeof(vs_base) * k, hipMemcpyHostToDevice, ctx->stream));
@@ -192,7 +224,7 @@ extern "C" int vs_halton_fill(vs_context* ctx, int k, uint64_t start, uint64_t c
     VS_REQUIRE(out_dev, "out_dev is null");
     uint32_t* bases = nullptr;
     uint32_t largest = 0;
-    int rc = upload_bases(ctx, k, &bases, &largest);
+    int rc = upload_bases(ctx, k, start + count - 1, &bases, &largest);
     if (rc) return rc;
     if ((long double)(start + count) * largest >= 9007199254740992.0L) {
         hipFree(bases);
@@ -313,7 +345,7 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
     }
     if (desc->generator == VS_GEN_HALTON) {
         uint32_t largest = 0;
-        rc = upload_bases(ctx, k, &g->bases, &largest);
+        rc = upload_bases(ctx, k, desc->first_index + 2 * n - 1, &g->bases, &largest);
         if (rc) return bail(rc);
         if ((long double)(desc->first_index + 2 * n) * largest >= 9007199254740992.0L)
             return bail(vs_fail(VS_ERR_ARG, "Halton index range too large for exact fp64 (index*base >= 2^53)"));
@@ -428,19 +460,29 @@ extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, cons
 // the fused evaluation kernel
 // ---------------------------------------------------------------------------
 //
-// One thread owns one design row r.  It generates (or gathers) the 2k scaled
-// coordinates M_1[r][:], M_2[r][:] into its private column of an LDS tile
-// ([coordinate][thread], conflict-free), then produces all 2k+2 objective values
-// of that row: f(M_1[r]), f(M_2[r]), f(N_j[i][r]), f(N_nj[i][r]).  N_j / N_nj
-// are never built: point (i) is a column select between the two LDS columns.
+// A workgroup of four waves owns 64 design rows (row = lane); the four waves
+// split the work of those rows by column / by output block:
+//   phase 1  wave q generates (or gathers) and scales coordinates c = q, q+4, ..
+//            of M_1[r] and M_2[r] into an LDS tile [coordinate][row]
+//            (conflict-free: consecutive lanes, consecutive doubles);
+//   phase 2  wave q produces the objective values of blocks i = q, q+4, ..:
+//            f(N_j[i][r]) and f(N_nj[i][r]); wave 0 adds f(M_1[r]), f(M_2[r]).
+// N_j / N_nj are never built: point i is a column select between the two LDS
+// columns of the row.  Stores are 512 B contiguous per wave instruction.
 //
 // Separable objectives (g-function, polynomial: product of per-coordinate
 // terms; linear: sum of per-coordinate terms) are folded strictly left to
 // right, so the first i terms of N_j[i] are exactly the running prefix over
-// M_2's terms: cost k^2/2 per family instead of k^2, bit-identical to folding
-// each point on its own.
+// M_2's terms.  A thread carries up to 8 such chains (16 with N_nj) in
+// registers and feeds all of them from one pair of LDS reads per column: k^2/2
+// multiplies per family, bit-identical to folding each point on its own.
 //
 // Output index: f[(block*rows + (r-row_begin))*l + o].
+
+#define VS_EVAL_ROWS 64
+#define VS_EVAL_WAVES 4
+#define VS_CHAINS 8                                 // chains per thread and pass
+#define VS_PASS (VS_EVAL_WAVES * VS_CHAINS)         // blocks i handled per pass
 
 struct vs_eval_args {
     vs_design_dev D;
@@ -463,90 +505,139 @@ __device__ __forceinline__ double vs_fold(double acc, double t) {
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(VS_EVAL_ROWS * VS_EVAL_WAVES)
 eval_kernel(vs_eval_args A) {
     extern __shared__ double lds[];
-    const int T = blockDim.x;
+    constexpr int T = VS_EVAL_ROWS;
+    constexpr bool SEPARABLE = KIND == VS_OBJ_G_FUNCTION || KIND == VS_OBJ_POLYNOMIAL || KIND == VS_OBJ_LINEAR;
     const int k = A.D.k;
-    const int tid = threadIdx.x;
-    double* X1 = lds + tid;                 // X1[c*T]
-    double* X2 = lds + (size_t)k * T + tid; // X2[c*T]
-    const uint64_t lr = (uint64_t)blockIdx.x * T + tid;
-    if (lr >= A.rows) return;  // no barrier is used below
-    const uint64_t r = A.row_begin + lr;
-
-    for (int c = 0; c < k; ++c) {
-        X1[(size_t)c * T] = vs_m1(A.D, r, c);
-        X2[(size_t)c * T] = vs_m2(A.D, r, c);
-    }
-
-    const uint64_t rows = A.rows;
     const int l = A.l;
+    const int lane = threadIdx.x & 63;
+    const int q = threadIdx.x >> 6;
+    const uint64_t rows = A.rows;
+    const uint64_t lr = (uint64_t)blockIdx.x * T + lane;
+    const bool valid = lr < rows;
+    const uint64_t r = A.row_begin + (valid ? lr : rows - 1);  // clamp: loads stay in range, stores are guarded
+    double* X1 = lds + lane;                  // X1[c*T]
+    double* X2 = lds + (size_t)k * T + lane;  // X2[c*T]
     double* f = A.f;
-#define VS_OUT(block, o) f[((uint64_t)(block) * rows + lr) * l + (o)]
+#define VS_OUT(block, o, v)                                               \
+    do {                                                                  \
+        if (valid) f[((uint64_t)(block) * rows + lr) * l + (o)] = (v);    \
+    } while (0)
 
-    if (KIND == VS_OBJ_G_FUNCTION || KIND == VS_OBJ_POLYNOMIAL || KIND == VS_OBJ_LINEAR) {
+    // ---- phase 1: coordinates (for a single-output separable objective: terms)
+    const bool terms_now = SEPARABLE && l == 1;
+    for (int c = q; c < k; c += VS_EVAL_WAVES) {
+        double x1 = vs_m1(A.D, r, c), x2 = vs_m2(A.D, r, c);
+        if (terms_now) {
+            const double p = A.params[c];
+            x1 = vs_term<KIND>(x1, p);
+            x2 = vs_term<KIND>(x2, p);
+        }
+        X1[(size_t)c * T] = x1;
+        X2[(size_t)c * T] = x2;
+    }
+    __syncthreads();
+
+    if (SEPARABLE) {
         double* F1 = X1;
         double* F2 = X2;
         if (l > 1) {  // keep the coordinates; terms go to a second pair of tiles
-            F1 = lds + 2 * (size_t)k * T + tid;
-            F2 = lds + 3 * (size_t)k * T + tid;
+            F1 = lds + 2 * (size_t)k * T + lane;
+            F2 = lds + 3 * (size_t)k * T + lane;
         }
         const double ident = KIND == VS_OBJ_LINEAR ? 0.0 : 1.0;
         for (int o = 0; o < l; ++o) {
-            const double* p = A.params + (size_t)o * k;
-            for (int c = 0; c < k; ++c) {
-                F1[(size_t)c * T] = vs_term<KIND>(X1[(size_t)c * T], p[c]);
-                F2[(size_t)c * T] = vs_term<KIND>(X2[(size_t)c * T], p[c]);
-            }
-            double pa = ident, pb = ident;  // folds of M_1 / M_2 terms over columns < i
-            for (int i = 0; i < k; ++i) {
-                const double ta = F1[(size_t)i * T], tb = F2[(size_t)i * T];
-                double cj = vs_fold<KIND>(pb, ta);  // N_j[i]: M_2 with column i from M_1
-                double dj = vs_fold<KIND>(pa, tb);  // N_nj[i]: M_1 with column i from M_2
-                for (int c = i + 1; c < k; ++c) {
-                    cj = vs_fold<KIND>(cj, F2[(size_t)c * T]);
-                    dj = vs_fold<KIND>(dj, F1[(size_t)c * T]);
+            if (l > 1) {
+                __syncthreads();  // previous output's chains are done with F1/F2
+                const double* p = A.params + (size_t)o * k;
+                for (int c = q; c < k; c += VS_EVAL_WAVES) {
+                    F1[(size_t)c * T] = vs_term<KIND>(X1[(size_t)c * T], p[c]);
+                    F2[(size_t)c * T] = vs_term<KIND>(X2[(size_t)c * T], p[c]);
                 }
-                VS_OUT(2 + i, o) = cj;
-                VS_OUT(2 + k + i, o) = dj;
-                pa = vs_fold<KIND>(pa, ta);
-                pb = vs_fold<KIND>(pb, tb);
+                __syncthreads();
             }
-            VS_OUT(0, o) = pa;
-            VS_OUT(1, o) = pb;
+            double pa = ident, pb = ident;  // folds of M_1 / M_2 terms over columns < c
+            for (int i0 = 0; i0 < k; i0 += VS_PASS) {
+                // this thread's chains: blocks i0 + q + 4m, m = 0..7
+                double cj[VS_CHAINS], dj[VS_CHAINS];
+#pragma unroll
+                for (int m = 0; m < VS_CHAINS; ++m) cj[m] = dj[m] = ident;
+                const int cend = min(k, i0 + VS_PASS);
+                // triangular part: chains start one by one
+                for (int c = i0; c < cend; ++c) {
+                    const double ta = F1[(size_t)c * T], tb = F2[(size_t)c * T];
+                    const int rel = c - i0 - q;  // chain m starts at rel == 4m
+#pragma unroll
+                    for (int m = 0; m < VS_CHAINS; ++m) {
+                        if (rel > 4 * m) {           // wave-uniform
+                            cj[m] = vs_fold<KIND>(cj[m], tb);
+                            dj[m] = vs_fold<KIND>(dj[m], ta);
+                        } else if (rel == 4 * m) {
+                            cj[m] = vs_fold<KIND>(pb, ta);  // N_j[c]: M_2 with column c from M_1
+                            dj[m] = vs_fold<KIND>(pa, tb);  // N_nj[c]: M_1 with column c from M_2
+                        }
+                    }
+                    pa = vs_fold<KIND>(pa, ta);
+                    pb = vs_fold<KIND>(pb, tb);
+                }
+                // rectangular part: every chain of this pass runs to the last column
+                for (int c = cend; c < k; ++c) {
+                    const double ta = F1[(size_t)c * T], tb = F2[(size_t)c * T];
+#pragma unroll
+                    for (int m = 0; m < VS_CHAINS; ++m) {
+                        cj[m] = vs_fold<KIND>(cj[m], tb);
+                        dj[m] = vs_fold<KIND>(dj[m], ta);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < VS_CHAINS; ++m) {
+                    const int i = i0 + q + VS_EVAL_WAVES * m;
+                    if (i < k) {
+                        VS_OUT(2 + i, o, cj[m]);
+                        VS_OUT(2 + k + i, o, dj[m]);
+                    }
+                }
+            }
+            if (q == 0) {
+                VS_OUT(0, o, pa);
+                VS_OUT(1, o, pb);
+            }
         }
     } else if (KIND == VS_OBJ_ISHIGAMI) {
-        const double a = A.params[0], b = A.params[1];
-        double s[2][2], q[2];  // [which sample][coordinate]
-        s[0][0] = sin(X1[0]);
-        s[1][0] = sin(X2[0]);
-        s[0][1] = sin(X1[(size_t)T]);
-        s[1][1] = sin(X2[(size_t)T]);
-        double x3a = X1[2 * (size_t)T], x3b = X2[2 * (size_t)T];
-        q[0] = (x3a * x3a) * (x3a * x3a);
-        q[1] = (x3b * x3b) * (x3b * x3b);
-        // value with coordinate c taken from sample u_c in {0 = M_1, 1 = M_2}
-        auto val = [&](int u0, int u1, int u2) {
-            double s1 = s[u0][0], s2 = s[u1][1];
-            return (s1 + a * (s2 * s2)) + (b * q[u2]) * s1;
-        };
-        VS_OUT(0, 0) = val(0, 0, 0);
-        VS_OUT(1, 0) = val(1, 1, 1);
-        VS_OUT(2, 0) = val(0, 1, 1);  // N_j[i]: M_2 except column i
-        VS_OUT(3, 0) = val(1, 0, 1);
-        VS_OUT(4, 0) = val(1, 1, 0);
-        VS_OUT(5, 0) = val(1, 0, 0);  // N_nj[i]: M_1 except column i
-        VS_OUT(6, 0) = val(0, 1, 0);
-        VS_OUT(7, 0) = val(0, 0, 1);
+        if (q == 0) {
+            const double a = A.params[0], b = A.params[1];
+            double s[2][2], p4[2];  // [which sample][coordinate]
+            s[0][0] = sin(X1[0]);
+            s[1][0] = sin(X2[0]);
+            s[0][1] = sin(X1[(size_t)T]);
+            s[1][1] = sin(X2[(size_t)T]);
+            const double x3a = X1[2 * (size_t)T], x3b = X2[2 * (size_t)T];
+            p4[0] = (x3a * x3a) * (x3a * x3a);
+            p4[1] = (x3b * x3b) * (x3b * x3b);
+            // value with coordinate c taken from sample u_c in {0 = M_1, 1 = M_2}
+            auto val = [&](int u0, int u1, int u2) {
+                const double s1 = s[u0][0], s2 = s[u1][1];
+                return (s1 + a * (s2 * s2)) + (b * p4[u2]) * s1;
+            };
+            VS_OUT(0, 0, val(0, 0, 0));
+            VS_OUT(1, 0, val(1, 1, 1));
+            VS_OUT(2, 0, val(0, 1, 1));  // N_j[i]: M_2 except column i
+            VS_OUT(3, 0, val(1, 0, 1));
+            VS_OUT(4, 0, val(1, 1, 0));
+            VS_OUT(5, 0, val(1, 0, 0));  // N_nj[i]: M_1 except column i
+            VS_OUT(6, 0, val(0, 1, 0));
+            VS_OUT(7, 0, val(0, 0, 1));
+        }
     } else if (KIND == VS_OBJ_INVERT) {
-        for (int o = 0; o < k; ++o) {
+        for (int o = q; o < k; o += VS_EVAL_WAVES) {
             const double ia = 1.0 - X1[(size_t)o * T], ib = 1.0 - X2[(size_t)o * T];
-            VS_OUT(0, o) = ia;
-            VS_OUT(1, o) = ib;
+            VS_OUT(0, o, ia);
+            VS_OUT(1, o, ib);
             for (int i = 0; i < k; ++i) {
-                VS_OUT(2 + i, o) = (i == o) ? ia : ib;
-                VS_OUT(2 + k + i, o) = (i == o) ? ib : ia;
+                VS_OUT(2 + i, o, (i == o) ? ia : ib);
+                VS_OUT(2 + k + i, o, (i == o) ? ib : ia);
             }
         }
     }
@@ -556,22 +647,18 @@ eval_kernel(vs_eval_args A) {
 template <int KIND>
 static int launch_eval(vs_context* ctx, const vs_eval_args& A, int tiles) {
     const int k = A.D.k;
-    // threads per block: as many as keep the LDS tile within budget
-    const size_t per_thread = sizeof(double) * (size_t)tiles * k;
-    const size_t budget = 64 * 1024;   // two blocks per CU of up to 64 KiB each
-    int T = 256;
-    while (T > 64 && per_thread * T > budget) T >>= 1;
-    size_t lds = per_thread * T;
-    VS_REQUIRE(lds <= 160 * 1024, "k=%d (x%d tiles) needs %zu bytes of LDS per 64 rows; limit is 160 KiB", k,
-               tiles, lds);
+    const size_t lds = sizeof(double) * (size_t)tiles * k * VS_EVAL_ROWS;
+    VS_REQUIRE(lds <= 160 * 1024, "k=%d with %d output(s) needs %zu bytes of LDS per 64 rows; the limit is 160 KiB",
+               k, A.l, lds);
     if (lds > 64 * 1024)
         VS_HIP(hipFuncSetAttribute((const void*)eval_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-    uint64_t blocks = (A.rows + T - 1) / T;
+    const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
     {
         vs_launch_scope scope(ctx, VS_KERNEL_EVAL);
-        hipLaunchKernelGGL(eval_kernel<KIND>, dim3((unsigned)blocks), dim3(T), lds, ctx->stream, A);
+        hipLaunchKernelGGL(eval_kernel<KIND>, dim3((unsigned)blocks), dim3(VS_EVAL_ROWS * VS_EVAL_WAVES), lds,
+                           ctx->stream, A);
     }
     VS_HIP(hipGetLastError());
     return VS_OK;

@@ -307,11 +307,16 @@ struct vs_fold_args {
 #define VS_FOLD_COLS 64
 
 // grid.x = ceil(l*plen / 64): block b folds 64 consecutive columns of the
-// flattened (l*plen) record with 16 waves striding over P.
+// flattened (l*plen) record with 16 waves striding over P.  The block that
+// finishes last (agent-scope ticket) lays the folded sums out as the rank's
+// accumulator record, so the whole fold is one launch.
+enum { CNT_TICKET = 3 };
+
 __global__ void __launch_bounds__(VS_FOLD_THREADS)
 fold_first_kernel(vs_fold_args A, double* folded /* [l*plen] scratch */) {
     __shared__ double s_sum[VS_FOLD_THREADS / 64][VS_FOLD_COLS];
     __shared__ double s_cmp[VS_FOLD_THREADS / 64][VS_FOLD_COLS];
+    __shared__ uint32_t s_last;
     if (A.masked && A.counters[CNT_NANFLAG] == 0) return;
     const size_t width = (size_t)A.l * VS_PLEN(A.k);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -329,32 +334,43 @@ fold_first_kernel(vs_fold_args A, double* folded /* [l*plen] scratch */) {
     s_cmp[wave][lane] = comp;
     __syncthreads();
     if (wave == 0 && col < width) {
-        double S = 0.0, C = 0.0;
+        double S = 0.0, Cc = 0.0;
         for (int w = 0; w < VS_FOLD_THREADS / 64; ++w) {
             const double x = s_sum[w][lane];
             const double t = S + x;
-            C += (fabs(S) >= fabs(x)) ? (S - t) + x : (x - t) + S;
+            Cc += (fabs(S) >= fabs(x)) ? (S - t) + x : (x - t) + S;
             S = t;
-            C += s_cmp[w][lane];
+            Cc += s_cmp[w][lane];
         }
-        const double total = S + C;
-        folded[col] = total;
+        const double total = S + Cc;
+        __hip_atomic_store(&folded[col], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!A.masked && total != total) atomicOr(&A.counters[CNT_NANFLAG], 1u);
     }
-}
+    // publish, then take a ticket; the last block builds the record
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = atomicAdd(&A.counters[CNT_TICKET + (A.masked ? 1 : 0)], 1u);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!s_last) return;
 
-// one small block: lay the folded sums out as the rank's accumulator record
-__global__ void __launch_bounds__(256)
-record_first_kernel(vs_fold_args A, const double* folded) {
-    if (A.masked && A.counters[CNT_NANFLAG] == 0) return;
     const int k = A.k, l = A.l;
     const size_t plen = VS_PLEN(k);
     const size_t per_out = VS_ACC_PER_OUTPUT(k);
     const size_t len = VS_ACC_LEN(k, l, A.max_ranks);
     const uint64_t kept = A.masked ? (uint64_t)A.counters[CNT_KEPT] : A.rows;
     const uint64_t shift_row = A.masked ? (uint64_t)A.counters[CNT_FIRST_KEPT] : 0;
+    auto ld = [&](size_t i) { return __hip_atomic_load(&folded[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     double* slot0 = A.acc + VS_ACC_HEADER + (size_t)l * per_out;
+    double* slot = slot0 + (size_t)A.rank * VS_ACC_SLOT(l);
+    const size_t slot_lo = (size_t)(slot - A.acc), slot_hi = slot_lo + VS_ACC_SLOT(l);
     for (size_t i = threadIdx.x; i < len; i += blockDim.x) {
+        if (i >= slot_lo && i < slot_hi) continue;  // written below
         double v = 0.0;
         if (i == 0) v = (double)kept;
         else if (i == 1) v = (double)(A.rows - kept);
@@ -362,20 +378,18 @@ record_first_kernel(vs_fold_args A, const double* folded) {
         else if (i >= VS_ACC_HEADER && i < VS_ACC_HEADER + (size_t)l * per_out) {
             const size_t o = (i - VS_ACC_HEADER) / per_out, c = (i - VS_ACC_HEADER) % per_out;
             // record: sab, sa, sb, ac.. ; partial: sab, sa, sb, s1, s2, ac..
-            v = folded[o * plen + (c < 3 ? c : c + 2)];
+            v = ld(o * plen + (c < 3 ? c : c + 2));
         }
         A.acc[i] = v;
     }
-    __syncthreads();
     // this rank's variance slot: count, mean[l], m2[l]
-    double* slot = slot0 + (size_t)A.rank * VS_ACC_SLOT(l);
     const double cnt = 2.0 * (double)kept;
     if (threadIdx.x == 0) slot[0] = cnt;
     for (int o = threadIdx.x; o < l; o += blockDim.x) {
         double mean = 0.0, m2 = 0.0;
         if (kept > 0) {
             const double shift = shift_row < A.rows ? A.f[shift_row * (uint64_t)l + o] : 0.0;
-            const double s1 = folded[o * plen + VS_P_S1], s2 = folded[o * plen + VS_P_S2];
+            const double s1 = ld(o * plen + VS_P_S1), s2 = ld(o * plen + VS_P_S2);
             mean = shift + s1 / cnt;
             m2 = s2 - s1 * (s1 / cnt);
         }
@@ -466,13 +480,13 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     VS_REQUIRE(rows == 0 || f_dev, "f_dev is null");
     const size_t plen = VS_PLEN(k);
     const size_t width = (size_t)l * plen;
-    const bool fast = (l == 1) && (rows % 2 == 0);
+    const bool fast = (l == 1) && (rows % 2 == 0) && (((uintptr_t)f_dev & 15) == 0);
     const int nv = fast ? env_int("VS_REDUCE_NV", 4) : 8;
     const uint64_t tile = (uint64_t)VS_WG * nv * (fast ? 2 : 1);
     uint64_t ntiles = (rows + tile - 1) / tile;
     if (ntiles < 1) ntiles = 1;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    uint64_t cap = (uint64_t)cus * env_int("VS_REDUCE_WGS_PER_CU", 8);
+    uint64_t cap = (uint64_t)cus * env_int("VS_REDUCE_WGS_PER_CU", 2);
     if (l > 1) cap = (cap + l - 1) / l;
     const uint32_t tile_wgs = (uint32_t)(ntiles < cap ? ntiles : cap);
     const int jchunk = k < VS_JCHUNK ? k : VS_JCHUNK;
@@ -487,7 +501,9 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     ctx->counters_host[CNT_NANFLAG] = 0;
     ctx->counters_host[CNT_FIRST_KEPT] = 0xffffffffu;
     ctx->counters_host[CNT_KEPT] = 0;
-    VS_HIP(hipMemcpyAsync(ctx->counters, ctx->counters_host, 3 * sizeof(uint32_t), hipMemcpyHostToDevice,
+    ctx->counters_host[CNT_TICKET] = 0;
+    ctx->counters_host[CNT_TICKET + 1] = 0;
+    VS_HIP(hipMemcpyAsync(ctx->counters, ctx->counters_host, 5 * sizeof(uint32_t), hipMemcpyHostToDevice,
                           ctx->stream));
 
     vs_reduce_args A;
@@ -553,7 +569,6 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
             vs_launch_scope scope(ctx, VS_KERNEL_FOLD);
             hipLaunchKernelGGL(fold_first_kernel, dim3(fold_blocks), dim3(VS_FOLD_THREADS), 0, ctx->stream, F,
                                folded);
-            hipLaunchKernelGGL(record_first_kernel, dim3(1), dim3(256), 0, ctx->stream, F, (const double*)folded);
         }
         VS_HIP(hipGetLastError());
     }
