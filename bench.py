@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- the Saltelli hot path on MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the whole path over one batch, everything in HBM:
+  fused Halton -> scale -> column swap -> objective kernel (2n(k+1) model evaluations, written
+  as f-values) -> sens/sens_t streaming reduction -> fold -> [RCCL all-reduce of the accumulator
+  record] -> finishing kernel (E_2, var_y, U_j, U_nj, sens, sens_t on the device).
+Workload (BASELINE.json configs[3], weak-scaling form): linear objective f = sum c_i x_i,
+c_i = i+1, identity scaling, k = 32, n = 2^22 draws PER GPU (global n = N * 2^22, rows sharded).
+`value` = samples (= model evaluations) generated, evaluated and reduced per second over all
+GPUs.  `roofline` is the sens/sens_t reduction kernel alone, timed with HIP events on the
+engine's stream inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(k, f_small, n_small, cores):
+    """Reference CPU path, restated (oracle = numpy port), timed on this host.
+    (a) reference-style evaluation: one Python call per sample row (saltelli.py:329-355);
+    (b) compute_varsens with the reference's numpy formulas (saltelli.py:572-622)."""
+    from oracle import saltelli_oracle as orc
+    c = np.arange(1, k + 1, dtype=float)
+    n_eval = 4096
+    S = orc.build_sample(k, n_eval)
+    t0 = time.perf_counter()
+    F = orc.evaluate_callable(lambda x: float(np.dot(c, x)), *S)
+    t_eval = time.perf_counter() - t0
+    evals = 2 * n_eval * (k + 1)
+    blocks = f_small
+    t0 = time.perf_counter()
+    R = orc.compute_varsens(blocks[0], blocks[1], blocks[2:2 + k], blocks[2 + k:], n_small, second_order=False)
+    t_red = time.perf_counter() - t0
+    samples = 2 * n_small * (k + 1)
+    per_sample = t_eval / evals + t_red / samples
+    return {
+        "value": 1.0 / per_sample / 1e9, "unit": "GSamples/s", "cores": cores, "kind": "port",
+        "sample": "python-callable evaluation of %d rows (k=%d, n=%d) + numpy compute_varsens (first order) "
+                  "on k=%d n=%d f-values downloaded from the GPU" % (evals, k, n_eval, k, n_small),
+        "eval_loop_evals_per_s": evals / t_eval, "eval_loop_threads": 1,
+        "reduce_only_gsamples_per_s": samples / t_red / 1e9,
+    }, R
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--log2n", type=int, default=22, help="draws per GPU = 2^log2n")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from varsens_amd import _native, dist
+    from varsens_amd.saltelli import seed1_permutation
+
+    group = dist.HostGroup()
+    if group.world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, group.world))
+    ctx = _native.Context(group.local_rank)
+    comm = dist.RcclComm(ctx, group)
+    world, rank = group.world, group.rank
+
+    k = args.k
+    rows = 1 << args.log2n          # per GPU (weak scaling)
+    n = rows * world                # global draws
+    begin = rank * rows
+    l = 1
+    N_local = 2 * (k + 1) * rows
+    N_total = N_local * world
+
+    perm = seed1_permutation(n)
+    design = ctx.design_create(_native.GEN_HALTON, k, n, 1 + 20 * k, _native.SCALE_IDENTITY, None, None, perm)
+    objective = ctx.objective_create(_native.OBJ_LINEAR, k, l, np.arange(1, k + 1, dtype=float))
+    f = ctx.alloc(8 * N_local)
+    nacc = _native.acc_len(k, l, world)
+    acc = ctx.alloc(8 * nacc)
+    out = ctx.alloc(8 * _native.first_order_len(k, l))
+
+    def step():
+        ctx.eval(design, objective, begin, rows, f)
+        ctx.reduce_first_order(f, rows, k, l, acc, 0, rank, world)
+        comm.allreduce(acc, nacc)
+        ctx.finish_first_order(acc, n, k, l, out, world)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    group.barrier()
+    ctx.profile_begin(8 * args.steps + 8)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    group.barrier()
+    elapsed = time.perf_counter() - t0
+    recs = ctx.profile_end()
+    elapsed = group.max(elapsed)
+
+    per = {}
+    for name, ms in recs:
+        per.setdefault(name, []).append(ms)
+    avg = {name: float(np.mean(v)) for name, v in per.items()}
+    result = ctx.download(out, (2 + 4 * k, l))
+
+    # analytic check of the finished indices (linear objective: S_i = c_i^2 / sum c^2)
+    c = np.arange(1, k + 1, dtype=float)
+    truth = c * c / np.sum(c * c)
+    sens = result[2 + 2 * k:2 + 3 * k, 0]
+    max_err = float(np.max(np.abs(sens - truth)))
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        t_red = avg["reduce_first"] * 1e-3
+        achieved = 8.0 * N_local / t_red / 1e9
+        line = {
+            "metric": "model-evals/sec + sens/sens_t GSamples/s (fp64), k=%d n=2^%d per GPU" % (k, args.log2n),
+            "value": N_total / (elapsed / args.steps) / 1e9,
+            "unit": "GSamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[3] weak-scaling form: linear objective c_i=i+1, identity scaling, "
+                                   "Halton design, k=%d, n=2^%d draws per GPU (global n=%d), rows sharded, "
+                                   "one RCCL all-reduce of %d doubles per step" % (k, args.log2n, n, nacc),
+                       "k": k, "n_per_gpu": rows, "n_global": n, "l": l,
+                       "samples_per_step": N_total, "sharding": "rows/%d" % world},
+            "stages_ms": avg,
+            "model_evals_per_s": N_local / (avg["eval"] * 1e-3) * world,
+            "reduce_gsamples_per_s_per_gpu": N_local / t_red / 1e9,
+            "max_abs_err_sens_vs_analytic": max_err,
+            "roofline": {"kernel": "reduce_first_kernel (sens/sens_t streaming reduction)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": 8 * N_local,
+                         "avg_launch_ms": avg["reduce_first"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n_small = min(rows, 1 << 20)
+            blocks = np.empty((2 * k + 2, n_small, l))
+            for b in range(2 * k + 2):
+                blocks[b] = ctx.download(f, (n_small, l), byte_offset=8 * b * rows * l)
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+            cpu, _ = cpu_baseline(k, blocks, n_small, cores)
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+    comm.close()
+    ctx.close()
+    group.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -292,3 +292,16 @@ def test_reduce_shards_merge_like_one_pass(ctx):
     fin2 = ctx.download(out, (2 + 4 * k, l))
     np.testing.assert_allclose(fin2, fin, rtol=1e-12)
     np.testing.assert_allclose(fin2[1], np.var(np.concatenate([blocks[0], blocks[1]]), axis=0, ddof=1), rtol=1e-12)
+
+
+def test_rccl_single_rank_allreduce(ctx):
+    """dlopen(librccl) + ncclCommInitRank + ncclAllReduce on the engine's stream (1 rank: identity)."""
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, 1, 0)
+    x = np.arange(137, dtype=float)
+    buf = ctx.upload(x)
+    ctx.comm_allreduce(buf, 137)
+    ctx.sync()
+    same(ctx.download(buf, (137,)), x)
+    ctx.comm_destroy()
