@@ -1,0 +1,136 @@
+"""CPU-only checks: the C-ABI library loads and exports what include/varsens_hip.h declares,
+the ctypes binding covers it, host-side logic (scaling helpers, permutation, sharding,
+argument errors) behaves like the reference.  No compute call is made without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__ as entry
+    entry.build()
+    from varsens_amd import _native
+    return _native
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "varsens_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_binds(native):
+    syms = header_symbols()
+    assert len(syms) >= 30
+    assert sorted(native.SIGNATURES) == syms
+
+
+def test_library_exports_every_declared_symbol(native):
+    lib = native.load_library()
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    assert lib.vs_abi_version() == native.ABI_VERSION
+
+
+def test_no_host_fallback(native):
+    """Without a GPU the engine refuses to create a context (and says why); with one it works."""
+    if native.device_count() == 0:
+        with pytest.raises(native.VarsensHipError, match="no HIP device|no host fallback"):
+            native.Context(0)
+    else:
+        native.Context(0).close()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "varsens_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f
+
+
+def test_acc_layout_helpers(native):
+    assert native.acc_len(32, 1, 1) == 4 + 131 + 3
+    assert native.acc_len(6, 2, 8) == 4 + 2 * 27 + 8 * 5
+    assert native.first_order_len(6, 2) == 52
+
+
+# ---- scale.py (varsens/tests/test_scaling.py restated) --------------------------------
+
+def test_scale_functions_match_reference(golden):
+    from varsens_amd import scale
+    g = golden("g9_scale")
+    pts = g["pts"]
+    assert np.array_equal(scale.linear(pts, np.array([-100.0] * 5), np.array([100.0] * 5)), g["linear"])
+    assert np.array_equal(scale.power(pts, np.ones(5), np.full(5, 100.0)), g["power"])
+    assert np.array_equal(scale.percentage(pts, np.array([-10.0, -1, 0, 1, 20]), 33.0), g["percentage"])
+    assert np.array_equal(scale.magnitude(pts, np.array([1, 10, 100, 1000, 1e4])), g["magnitude"])
+    for i, want in enumerate([-100.0, -50.0, 0.0, 50.0, 100.0]):                  # test_scaling.py:9
+        assert abs(g["linear"][i] - want) < 1e-7
+    for i, want in enumerate([-6.7, -0.835, 0.0, 1.165, 26.6]):                   # test_scaling.py:53
+        assert abs(scale.percentage(pts, np.array([-10.0, -1, 0, 1, 20]), 33.0)[i] - want) < 1e-7
+    lo, hi = np.array([1.0, 10, 1000]), np.array([100.0, 20, 2000])
+    assert np.allclose(scale.power(np.zeros(3), lo, hi), lo) and np.allclose(scale.power(np.ones(3), lo, hi), hi)
+    assert np.allclose(scale.linear(np.zeros(3), lo, hi), lo) and np.allclose(scale.linear(np.ones(3), lo, hi), hi)
+
+
+def test_scale_specs_are_callable_and_describe_themselves():
+    from varsens_amd import scale, _native
+    pts = np.linspace(0, 1, 7)[:, None] * np.ones((1, 3))
+    lo, hi = np.array([1.0, 2, 3]), np.array([2.0, 4, 8])
+    assert np.array_equal(scale.Linear(lo, hi)(pts), scale.linear(pts, lo, hi))
+    assert np.array_equal(scale.Power(lo, hi)(pts), scale.power(pts, lo, hi))
+    assert np.array_equal(scale.Percentage(lo, 10.0)(pts), scale.percentage(pts, lo, 10.0))
+    assert np.array_equal(scale.Magnitude(lo, 2.0)(pts), scale.magnitude(pts, lo, 2.0))
+    mode, l, h = scale.Percentage(lo, 10.0).device_spec(3)
+    assert mode == _native.SCALE_LINEAR and np.array_equal(l, lo - 10.0 * lo / 100.0)
+    mode, l, h = scale.Linear(-1.0, 1.0).device_spec(4)
+    assert l.shape == (4,) and h[3] == 1.0
+    with pytest.raises(Exception, match="positive"):
+        scale.Power([-1.0, 1, 1], hi).device_spec(3)
+    assert scale.Identity().device_spec(5)[0] == _native.SCALE_IDENTITY
+
+
+def test_scale_doctests():
+    import doctest
+    from varsens_amd import scale
+    assert doctest.testmod(scale).failed == 0
+
+
+def test_seed1_permutation_matches_reference(golden):
+    from varsens_amd.saltelli import seed1_permutation
+    g = golden("g7_seed1_perm")
+    state = np.random.get_state()[1].copy()
+    for n in (1, 2, 5, 13, 1024):
+        assert np.array_equal(seed1_permutation(n), g["n%d" % n])
+    p = seed1_permutation(100003)
+    assert np.array_equal(np.concatenate([p[:64], p[-64:]]), g["n100003"]) and p.dtype == np.uint32
+    assert np.array_equal(np.random.get_state()[1], state), "the global numpy RNG must be left alone"
+
+
+def test_shard_rows_partition():
+    from varsens_amd.dist import shard_rows
+    for n, w in ((10, 3), (1 << 22, 8), (7, 2), (1, 1), (5, 4), (1000001, 6)):
+        parts = [shard_rows(n, w, r) for r in range(w)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+        assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        assert all(c % 2 == 0 for _, c in parts[:-1])
+    with pytest.raises(Exception):
+        shard_rows(10, 2, 2)
+
+
+def test_objective_specs():
+    from varsens_amd import objectives, _native
+    g = objectives.GFunction([[0, 1, 2], [2, 1, 0]])
+    assert g.outputs(3) == 2 and g.params(3).shape == (2, 3) and g.kind == _native.OBJ_G_FUNCTION
+    assert objectives.Linear([1, 2, 3]).outputs(3) == 1
+    with pytest.raises(Exception, match="k=4"):
+        objectives.Polynomial([1, 2, 3]).params(4)
+    with pytest.raises(Exception, match="k=3"):
+        objectives.Ishigami().params(5)
+    assert objectives.Invert().outputs(9) == 9

@@ -1,0 +1,107 @@
+"""N>1 host path on CPU: two processes, torch.distributed gloo, world_size 2.
+
+Covers what runs on the host in a multi-GPU job: the launcher environment -> HostGroup,
+shipping the 128-byte communicator id, barrier / max-over-ranks timing, the row split, and
+the accumulator-record contract (each rank fills its own variance slot, the SUM over ranks
+finishes to the single-pass result).  The per-rank records are built by the oracle here
+(test-only): the kernels that build them on a GPU are covered by the -m gpu tests.
+"""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    from varsens_amd import dist, _native
+    from oracle import saltelli_oracle as orc
+
+    g = dist.HostGroup()
+    assert g.world == 2
+    uid = bytes(range(128)) if g.rank == 0 else None
+    uid = g.broadcast_bytes(uid, src=0)
+    assert uid == bytes(range(128))
+    g.barrier()
+    assert g.max(10.0 + g.rank) == 11.0
+
+    k, n, l = 5, 1001, 2
+    rng = np.random.RandomState(7)
+    blocks = 3.0 + rng.randn(2 * k + 2, n, l)
+    blocks[:, :400] += 2.0
+    begin, count = dist.shard_rows(n, g.world, g.rank)
+    mine = blocks[:, begin:begin + count]
+    ex = orc.exact_accumulators(mine[0], mine[1], mine[2:2 + k], mine[2 + k:])
+
+    # lay the shard's sums out as the engine's accumulator record (include/varsens_hip.h)
+    per, slot = _native.acc_per_output(k), _native.acc_slot(l)
+    rec = np.zeros(_native.acc_len(k, l, g.world))
+    rec[0], rec[2] = count, 1.0
+    for o in range(l):
+        body = rec[4 + o * per: 4 + (o + 1) * per]
+        body[0], body[1], body[2] = ex["sab"][o], ex["sa"][o], ex["sb"][o]
+        for q, name in enumerate(("ac", "bd", "ad", "bc")):
+            body[3 + q * k: 3 + (q + 1) * k] = ex[name][:, o]
+    s = rec[4 + l * per + g.rank * slot:][:slot]
+    s[0] = 2 * count
+    s[1:1 + l] = ex["mean"]
+    s[1 + l:] = ex["m2"]
+
+    total = g.sum_array(rec)
+    assert total[0] == n and total[2] == 2
+
+    # finish exactly as finish_first_kernel does (pooled variance over the rank slots)
+    slots = total[4 + l * per:].reshape(g.world, slot)
+    cnt = slots[:, 0].sum()
+    mu = (slots[:, :1] * slots[:, 1:1 + l]).sum(axis=0) / cnt
+    m2 = (slots[:, 1 + l:] + slots[:, :1] * (slots[:, 1:1 + l] - mu) ** 2).sum(axis=0)
+    var_y = m2 / (cnt - 1)
+    whole = orc.compute_varsens(blocks[0], blocks[1], blocks[2:2 + k], blocks[2 + k:], n, second_order=False)
+    np.testing.assert_allclose(var_y, whole["var_y"], rtol=1e-12)
+    body = total[4:4 + l * per].reshape(l, per)
+    E_2 = body[:, 0] / n
+    U_j = (body[:, 3:3 + k] / (n - 1) + body[:, 3 + k:3 + 2 * k] / (n - 1)) / 2
+    np.testing.assert_allclose(E_2, whole["E_2"], rtol=1e-13)
+    np.testing.assert_allclose(U_j.T, whole["U_j"], rtol=1e-13)
+    sens = (U_j.T - E_2) / var_y
+    np.testing.assert_allclose(sens, whole["sens"], rtol=1e-9, atol=1e-12)
+    g.close()
+    print("rank", g.rank, "ok")
+""") % ROOT
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_host_path(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out)
+        assert "rank %d ok" % rank in out
