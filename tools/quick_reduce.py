@@ -38,8 +38,21 @@ def timed(fn, reps=10):
 r = timed(lambda: ctx.eval(design, obj, 0, n, f), 5)
 ms = r["eval"][0]
 print("eval: %.3f ms  -> %.1f G evals/s, write %.1f GB/s" % (ms, N / ms / 1e6, 8 * N / ms / 1e6), flush=True)
-for nv in (2, 4, 8):
-    for wpc in (2, 4, 8, 16):
+def pipeline():
+    ctx.eval(design, obj, 0, n, f)
+    ctx.reduce_first_order(f, n, k, 1, acc)
+
+
+for rev in (0, 1):
+    os.environ["VS_REDUCE_REVERSE"] = str(rev)
+    r = timed(pipeline, 10)
+    print("pipeline reverse=%d: eval %.3f reduce %.3f (min %.3f) fold %.3f" %
+          (rev, r["eval"][0], r["reduce_first"][0], r["reduce_first"][1], r["fold"][0]), flush=True)
+    r = timed(lambda: ctx.reduce_first_order(f, n, k, 1, acc))
+    print("reduce alone reverse=%d: %.3f (min %.3f)" % (rev, r["reduce_first"][0], r["reduce_first"][1]), flush=True)
+os.environ["VS_REDUCE_REVERSE"] = "0"
+for nv in (4,):
+    for wpc in (1, 2, 3, 4):
         os.environ["VS_REDUCE_NV"] = str(nv)
         os.environ["VS_REDUCE_WGS_PER_CU"] = str(wpc)
         r = timed(lambda: ctx.reduce_first_order(f, n, k, 1, acc))

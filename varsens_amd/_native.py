@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvarsens_hip.so")
+LIB_PATH = os.environ.get("VARSENS_HIP_LIB") or os.path.join(_HERE, "libvarsens_hip.so")
 
 ABI_VERSION = 1
 COMM_ID_BYTES = 128

@@ -12,6 +12,8 @@
 // Built with -ffp-contract=off: every multiply/add below rounds separately
 // unless written as fma(), so the arithmetic matches numpy's operation for
 // operation.
+#include <cmath>
+
 #include "vs_common.h"
 
 // ---------------------------------------------------------------------------
@@ -25,6 +27,7 @@ struct vs_base {
     uint32_t ndig;   // digits of the largest index of this design in base b (0: indices reach 2^32)
     double den;      // b^ndig
     double inv_den;  // RN(1 / den)
+    double inv_b;    // RN(1 / b) pushed up two ulps: floor(j * inv_b) == j / b for every j < 2^32
 };
 
 __device__ __forceinline__ uint32_t vs_div_magic(uint32_t q, uint32_t magic, uint32_t shift) {
@@ -70,6 +73,50 @@ __device__ __forceinline__ double vs_radical_inverse(uint64_t i, const vs_base B
         i = q;
     }
     return num / den;
+}
+
+// Two radical inverses in the same base with interleaved digit loops (two
+// independent dependency chains per step).  Fast path only (B.ndig != 0).
+__device__ __forceinline__ void vs_radical_inverse_pair(uint32_t i1, uint32_t i2, const vs_base B,
+                                                         double& x1, double& x2) {
+    if (B.b == 2) {
+        x1 = (double)__brev(i1) * (1.0 / 4294967296.0);
+        x2 = (double)__brev(i2) * (1.0 / 4294967296.0);
+        return;
+    }
+    // Digit steps entirely in fp64 (4 instructions per digit and point): with inv_b two ulps
+    // above 1/b, floor(j*inv_b) is the exact quotient for j < 2^32, b < 2^16 -- an exact multiple
+    // can no longer round below its integer, and the inflation (< 2^-17 absolute) is far smaller
+    // than the distance 1/b of any other quotient to the next integer.  The digit j - q*b and the
+    // numerator update are exact fmas on integers below 2^53.
+    const double bd = (double)B.b;
+    double n1 = 0.0, n2 = 0.0;
+    double j1 = (double)i1, j2 = (double)i2;
+    uint32_t t = B.ndig;
+    for (; t >= 2; t -= 2) {  // two digits per trip: no register rotation between steps
+        const double q1 = floor(j1 * B.inv_b);
+        const double q2 = floor(j2 * B.inv_b);
+        n1 = fma(n1, bd, fma(-q1, bd, j1));
+        n2 = fma(n2, bd, fma(-q2, bd, j2));
+        j1 = floor(q1 * B.inv_b);
+        j2 = floor(q2 * B.inv_b);
+        n1 = fma(n1, bd, fma(-j1, bd, q1));
+        n2 = fma(n2, bd, fma(-j2, bd, q2));
+    }
+    if (t) {
+        const double q1 = floor(j1 * B.inv_b);
+        const double q2 = floor(j2 * B.inv_b);
+        n1 = fma(n1, bd, fma(-q1, bd, j1));
+        n2 = fma(n2, bd, fma(-q2, bd, j2));
+    }
+    double a0 = n1 * B.inv_den, b0 = n2 * B.inv_den;
+    double ra = fma(-a0, B.den, n1), rb = fma(-b0, B.den, n2);
+    a0 = fma(ra, B.inv_den, a0);
+    b0 = fma(rb, B.inv_den, b0);
+    ra = fma(-a0, B.den, n1);
+    rb = fma(-b0, B.den, n2);
+    x1 = fma(ra, B.inv_den, a0);
+    x2 = fma(rb, B.inv_den, b0);
 }
 
 __device__ __forceinline__ double vs_sobol_point(uint64_t i, const uint32_t* __restrict__ dir) {
@@ -157,6 +204,7 @@ static vs_base make_base(uint32_t b, uint64_t max_index) {
     B.ndig = 0;
     B.den = 1.0;
     B.inv_den = 1.0;
+    B.inv_b = 0.5;
     if (max_index < (1ull << 32)) {
         uint64_t den = 1;
         for (uint64_t v = max_index; v; v /= b) {
@@ -167,6 +215,7 @@ static vs_base make_base(uint32_t b, uint64_t max_index) {
         B.den = (double)den;
         B.inv_den = 1.0 / B.den;
     }
+    B.inv_b = nextafter(nextafter(1.0 / (double)b, 2.0), 2.0);
     return B;
 }
 
@@ -479,6 +528,13 @@ extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, cons
 //
 // Output index: f[(block*rows + (r-row_begin))*l + o].
 
+#if defined(VS_ABL_NOSTORE)   /* diagnostic build: keep the value live, never store */
+#define VS_STORE(p, v) do { if ((v) == 1.2345e-300) *(p) = (v); } while (0)
+#elif !defined(VS_NO_NT_STORE)
+#define VS_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define VS_STORE(p, v) (*(p) = (v))
+#endif
 #define VS_EVAL_ROWS 64
 #define VS_EVAL_WAVES 4
 #define VS_CHAINS 8                                 // chains per thread and pass
@@ -504,6 +560,33 @@ __device__ __forceinline__ double vs_fold(double acc, double t) {
     return KIND == VS_OBJ_LINEAR ? acc + t : acc * t;
 }
 
+// One full pass (32 consecutive columns i0..i0+31) of the chain scheme for wave Q.
+// Chain m of this wave is block i0+Q+4m; at relative column j the chains with
+// Q+4m < j are running and the one with Q+4m == j starts from the prefixes.
+// Everything about the schedule is a compile-time constant, so the 16 chain
+// values stay in fixed registers.
+template <int KIND, int Q>
+__device__ __forceinline__ void vs_chain_pass(const double* F1, const double* F2, int i0, double& pa, double& pb,
+                                              double (&cj)[VS_CHAINS], double (&dj)[VS_CHAINS]) {
+    constexpr int T = VS_EVAL_ROWS;
+#pragma unroll
+    for (int j = 0; j < VS_PASS; ++j) {
+        const double ta = F1[(size_t)(i0 + j) * T], tb = F2[(size_t)(i0 + j) * T];
+#pragma unroll
+        for (int m = 0; m < VS_CHAINS; ++m) {
+            if (Q + VS_EVAL_WAVES * m < j) {
+                cj[m] = vs_fold<KIND>(cj[m], tb);
+                dj[m] = vs_fold<KIND>(dj[m], ta);
+            } else if (Q + VS_EVAL_WAVES * m == j) {
+                cj[m] = vs_fold<KIND>(pb, ta);  // N_j[i0+j]: M_2 with column i0+j from M_1
+                dj[m] = vs_fold<KIND>(pa, tb);  // N_nj[i0+j]: M_1 with column i0+j from M_2
+            }
+        }
+        pa = vs_fold<KIND>(pa, ta);
+        pb = vs_fold<KIND>(pb, tb);
+    }
+}
+
 template <int KIND>
 __global__ void __launch_bounds__(VS_EVAL_ROWS * VS_EVAL_WAVES)
 eval_kernel(vs_eval_args A) {
@@ -513,23 +596,42 @@ eval_kernel(vs_eval_args A) {
     const int k = A.D.k;
     const int l = A.l;
     const int lane = threadIdx.x & 63;
-    const int q = threadIdx.x >> 6;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index, provably uniform
     const uint64_t rows = A.rows;
     const uint64_t lr = (uint64_t)blockIdx.x * T + lane;
     const bool valid = lr < rows;
     const uint64_t r = A.row_begin + (valid ? lr : rows - 1);  // clamp: loads stay in range, stores are guarded
     double* X1 = lds + lane;                  // X1[c*T]
     double* X2 = lds + (size_t)k * T + lane;  // X2[c*T]
-    double* f = A.f;
+    // block bases are wave-uniform; the lane's place inside a block fits 32 bits (checked on the host)
+    double* f = A.f + (uint64_t)blockIdx.x * T * l;
+    const uint32_t lane_off = (uint32_t)lane * (uint32_t)l;
 #define VS_OUT(block, o, v)                                               \
     do {                                                                  \
-        if (valid) f[((uint64_t)(block) * rows + lr) * l + (o)] = (v);    \
+        if (valid) VS_STORE(f + (uint64_t)(block) * rows * l + (lane_off + (uint32_t)(o)), (v)); \
     } while (0)
 
     // ---- phase 1: coordinates (for a single-output separable objective: terms)
     const bool terms_now = SEPARABLE && l == 1;
+    const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
+    const uint64_t src2 = A.D.n + (A.D.perm ? (uint64_t)A.D.perm[r] : r);  // sequence row behind M_2[r]
     for (int c = q; c < k; c += VS_EVAL_WAVES) {
-        double x1 = vs_m1(A.D, r, c), x2 = vs_m2(A.D, r, c);
+        double x1, x2;
+#ifdef VS_ABL_NOGEN   /* diagnostic build: no generator arithmetic */
+        if (halton_fast) {
+            x1 = (double)(uint32_t)(r + c) * 2.3283064365386963e-10;
+            x2 = (double)(uint32_t)(src2 + c) * 2.3283064365386963e-10;
+        } else
+#endif
+        if (halton_fast) {
+            vs_radical_inverse_pair((uint32_t)(A.D.first_index + r), (uint32_t)(A.D.first_index + src2),
+                                    A.D.bases[c], x1, x2);
+        } else {
+            x1 = vs_unit_point(A.D, r, c);
+            x2 = vs_unit_point(A.D, src2, c);
+        }
+        x1 = vs_apply_scale(A.D, x1, c);
+        x2 = vs_apply_scale(A.D, x2, c);
         if (terms_now) {
             const double p = A.params[c];
             x1 = vs_term<KIND>(x1, p);
@@ -565,25 +667,54 @@ eval_kernel(vs_eval_args A) {
 #pragma unroll
                 for (int m = 0; m < VS_CHAINS; ++m) cj[m] = dj[m] = ident;
                 const int cend = min(k, i0 + VS_PASS);
-                // triangular part: chains start one by one
-                for (int c = i0; c < cend; ++c) {
-                    const double ta = F1[(size_t)c * T], tb = F2[(size_t)c * T];
-                    const int rel = c - i0 - q;  // chain m starts at rel == 4m
+                int c = i0;
+                if (cend - i0 == VS_PASS) {
+                    switch (q) {  // wave-uniform
+                        case 0: vs_chain_pass<KIND, 0>(F1, F2, i0, pa, pb, cj, dj); break;
+                        case 1: vs_chain_pass<KIND, 1>(F1, F2, i0, pa, pb, cj, dj); break;
+                        case 2: vs_chain_pass<KIND, 2>(F1, F2, i0, pa, pb, cj, dj); break;
+                        default: vs_chain_pass<KIND, 3>(F1, F2, i0, pa, pb, cj, dj); break;
+                    }
+                    c = cend;
+                } else {
+                    // partial pass (k not a multiple of 32): same schedule with run-time bounds
+                    for (const int stop = min(cend, i0 + q); c < stop; ++c) {
+                        pa = vs_fold<KIND>(pa, F1[(size_t)c * T]);
+                        pb = vs_fold<KIND>(pb, F2[(size_t)c * T]);
+                    }
 #pragma unroll
                     for (int m = 0; m < VS_CHAINS; ++m) {
-                        if (rel > 4 * m) {           // wave-uniform
-                            cj[m] = vs_fold<KIND>(cj[m], tb);
-                            dj[m] = vs_fold<KIND>(dj[m], ta);
-                        } else if (rel == 4 * m) {
-                            cj[m] = vs_fold<KIND>(pb, ta);  // N_j[c]: M_2 with column c from M_1
-                            dj[m] = vs_fold<KIND>(pa, tb);  // N_nj[c]: M_1 with column c from M_2
+                        if (c < cend) {
+                            const double ta = F1[(size_t)c * T], tb = F2[(size_t)c * T];
+#pragma unroll
+                            for (int mm = 0; mm < m; ++mm) {
+                                cj[mm] = vs_fold<KIND>(cj[mm], tb);
+                                dj[mm] = vs_fold<KIND>(dj[mm], ta);
+                            }
+                            cj[m] = vs_fold<KIND>(pb, ta);
+                            dj[m] = vs_fold<KIND>(pa, tb);
+                            pa = vs_fold<KIND>(pa, ta);
+                            pb = vs_fold<KIND>(pb, tb);
+                            ++c;
+#pragma unroll
+                            for (int s = 1; s < VS_EVAL_WAVES; ++s) {
+                                if (c < cend) {
+                                    const double ua = F1[(size_t)c * T], ub = F2[(size_t)c * T];
+#pragma unroll
+                                    for (int mm = 0; mm <= m; ++mm) {
+                                        cj[mm] = vs_fold<KIND>(cj[mm], ub);
+                                        dj[mm] = vs_fold<KIND>(dj[mm], ua);
+                                    }
+                                    pa = vs_fold<KIND>(pa, ua);
+                                    pb = vs_fold<KIND>(pb, ub);
+                                    ++c;
+                                }
+                            }
                         }
                     }
-                    pa = vs_fold<KIND>(pa, ta);
-                    pb = vs_fold<KIND>(pb, tb);
                 }
-                // rectangular part: every chain of this pass runs to the last column
-                for (int c = cend; c < k; ++c) {
+                // columns of later passes: every chain of this pass runs on to the last column
+                for (; c < k; ++c) {
                     const double ta = F1[(size_t)c * T], tb = F2[(size_t)c * T];
 #pragma unroll
                     for (int m = 0; m < VS_CHAINS; ++m) {
@@ -655,6 +786,7 @@ static int launch_eval(vs_context* ctx, const vs_eval_args& A, int tiles) {
                                    (int)lds));
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
+    VS_REQUIRE((uint64_t)VS_EVAL_ROWS * A.l < (1ull << 31), "too many outputs per evaluation");
     {
         vs_launch_scope scope(ctx, VS_KERNEL_EVAL);
         hipLaunchKernelGGL(eval_kernel<KIND>, dim3((unsigned)blocks), dim3(VS_EVAL_ROWS * VS_EVAL_WAVES), lds,

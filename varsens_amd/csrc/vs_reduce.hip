@@ -74,6 +74,7 @@ struct vs_reduce_args {
     double* partials;   // [tile_wgs][l][VS_PLEN(k)]
     const uint8_t* keep;      // MASKED: 1 = row kept
     const uint32_t* counters; // MASKED: early exit + shift row
+    int reverse;        // walk the tiles from the last row down (see vs_reduce_first_order)
 };
 
 template <int VEC>
@@ -82,7 +83,13 @@ template <>
 struct vs_vec<2> {
     double v[2];
     __device__ __forceinline__ void load(const double* p) {
+#ifndef VS_NO_NT_LOAD
+        double2 t;
+        t.x = __builtin_nontemporal_load(p);
+        t.y = __builtin_nontemporal_load(p + 1);
+#else
         double2 t = *reinterpret_cast<const double2*>(p);
+#endif
         v[0] = t.x;
         v[1] = t.y;
     }
@@ -129,7 +136,8 @@ reduce_first_kernel(vs_reduce_args A) {
 
     double t_sab = 0, t_sa = 0, t_sb = 0, t_s1 = 0, t_s2 = 0;
 
-    for (uint64_t tile = wg; tile < ntiles; tile += A.tile_wgs) {
+    for (uint64_t t = wg; t < ntiles; t += A.tile_wgs) {
+        const uint64_t tile = A.reverse ? ntiles - 1 - t : t;
         const uint64_t base = tile * TILE + (uint64_t)tid * VEC;
         bool ok[NV];
         double keepf[NV][VEC];
@@ -516,6 +524,7 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     A.partials = ctx->partials;
     A.keep = nullptr;
     A.counters = ctx->counters;
+    A.reverse = env_int("VS_REDUCE_REVERSE", 0);
     const dim3 grid(tile_wgs * (fast ? 1 : l), jblocks);
     const size_t lds = sizeof(double) * VS_WAVES * (VS_P_HEAD + 4 * (size_t)jchunk);
 
