@@ -27,6 +27,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "bench_pmc_fetch_write.json")
+
+
+def pmc_traffic(kernel_prefix, k, log2n):
+    """HBM bytes per launch of the reduction kernel from the committed rocprofv3 PMC passes
+    (collected on this exact workload; FETCH_SIZE doubled per the gfx950 correction), or None."""
+    if (k, log2n) != (32, 22) or not os.path.isfile(PMC_SUMMARY):
+        return None
+    try:
+        kernels = json.load(open(PMC_SUMMARY))["kernels"]
+        for name, c in kernels.items():
+            if name.startswith(kernel_prefix):
+                return (2.0 * c["FETCH_SIZE_KB_avg_per_launch"] + c["WRITE_SIZE_KB_avg_per_launch"]) * 1024.0
+    except Exception:
+        return None
+    return None
 
 
 def cpu_baseline(k, f_small, n_small, cores):
@@ -48,9 +64,11 @@ def cpu_baseline(k, f_small, n_small, cores):
     samples = 2 * n_small * (k + 1)
     per_sample = t_eval / evals + t_red / samples
     return {
-        "value": 1.0 / per_sample / 1e9, "unit": "GSamples/s", "cores": cores, "kind": "port",
-        "sample": "python-callable evaluation of %d rows (k=%d, n=%d) + numpy compute_varsens (first order) "
-                  "on k=%d n=%d f-values downloaded from the GPU" % (evals, k, n_eval, k, n_small),
+        "value": 1.0 / per_sample / 1e9, "unit": "GSamples/s", "cores": 1, "host_cores_available": cores,
+        "kind": "port",
+        "sample": "whole path per sample = reference-style evaluation (one Python call per row, %d rows, k=%d, "
+                  "n=%d) + numpy compute_varsens first order on k=%d n=%d f-values downloaded from the GPU; both "
+                  "single-threaded as in the reference" % (evals, k, n_eval, k, n_small),
         "eval_loop_evals_per_s": evals / t_eval, "eval_loop_threads": 1,
         "reduce_only_gsamples_per_s": samples / t_red / 1e9,
     }, R
@@ -146,7 +164,9 @@ def main():
             "max_abs_err_sens_vs_analytic": max_err,
             "roofline": {"kernel": "reduce_first_kernel (sens/sens_t streaming reduction)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic("void reduce_first_kernel", k, args.log2n),
+                         "traffic_source": "profiles/r01/bench_pmc_fetch_write.json (separate rocprofv3 --pmc passes)",
                          "algorithmic_bytes_per_launch": 8 * N_local,
                          "avg_launch_ms": avg["reduce_first"]},
         }
