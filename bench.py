@@ -91,8 +91,19 @@ def main():
     if group.world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, group.world))
     ctx = _native.Context(group.local_rank)
-    comm = dist.RcclComm(ctx, group)
     world, rank = group.world, group.rank
+    exchange = "none (single GPU)" if world == 1 else "rccl all-reduce (xGMI)"
+    try:
+        comm = dist.RcclComm(ctx, group)
+        failed = 0.0
+    except Exception as exc:   # keep the scaling run alive, but say so in the result line
+        comm, failed, why = None, 1.0, str(exc)
+        sys.stderr.write("rank %d: RCCL communicator failed (%s); falling back to a host exchange\n" % (rank, why))
+    if group.max(failed) > 0.0:
+        if comm is not None:
+            comm.close()
+        comm = dist.HostExchange(ctx, group)
+        exchange = "HOST FALLBACK over gloo (RCCL init failed on at least one rank)"
 
     k = args.k
     rows = 1 << args.log2n          # per GPU (weak scaling)
@@ -158,6 +169,7 @@ def main():
                                    "one RCCL all-reduce of %d doubles per step" % (k, args.log2n, n, nacc),
                        "k": k, "n_per_gpu": rows, "n_global": n, "l": l,
                        "samples_per_step": N_total, "sharding": "rows/%d" % world},
+            "exchange": exchange,
             "stages_ms": avg,
             "model_evals_per_s": N_local / (avg["eval"] * 1e-3) * world,
             "reduce_gsamples_per_s_per_gpu": N_local / t_red / 1e9,

@@ -305,3 +305,47 @@ def test_rccl_single_rank_allreduce(ctx):
     ctx.sync()
     same(ctx.download(buf, (137,)), x)
     ctx.comm_destroy()
+
+
+# ------------------------------------------------------------------ second order (fp64 MFMA Gram)
+
+@pytest.mark.parametrize("k,rows,l", [(6, 1000, 1), (32, 5000, 1), (40, 3001, 1), (70, 777, 1), (7, 500, 3),
+                                      (3, 5, 1), (33, 64, 2)])
+def test_second_order_gram(ctx, k, rows, l):
+    rng = np.random.RandomState(k * 7 + rows + l)
+    blocks = 1.0 + rng.randn(2 * k + 2, rows, l)
+    f = ctx.upload(blocks)
+    K = k * l
+    gram = ctx.alloc(8 * 3 * K * K)
+    ctx.reduce_second_order(f, rows, k, l, gram)
+    G = ctx.download(gram, (3, K, K))
+    C = blocks[2:2 + k].transpose(0, 2, 1).reshape(K, rows)
+    D = blocks[2 + k:].transpose(0, 2, 1).reshape(K, rows)
+    scale = np.abs(D @ C.T).max()
+    np.testing.assert_allclose(G[0], D @ C.T, rtol=1e-12, atol=1e-12 * scale)
+    np.testing.assert_allclose(G[1], D @ D.T, rtol=1e-12, atol=1e-12 * scale)
+    np.testing.assert_allclose(G[2], C @ C.T, rtol=1e-12, atol=1e-12 * scale)
+    # exactness spot check against correctly rounded sums
+    import math
+    for (i, j) in ((0, 0), (K - 1, 0), (K // 2, K - 1)):
+        want = math.fsum((D[i] * C[j]).tolist())
+        assert abs(G[0][i, j] - want) <= 1e-13 * max(1.0, abs(want)) * 10
+
+
+def test_second_order_nan_trim(ctx):
+    from varsens_amd import _native
+    rng = np.random.RandomState(9)
+    k, rows = 5, 900
+    blocks = 1.0 + rng.rand(2 * k + 2, rows, 1)
+    bad = rng.choice(rows, 11, replace=False)
+    blocks[rng.randint(0, 2 * k + 2, 11), bad, 0] = np.nan
+    f = ctx.upload(blocks)
+    gram = ctx.alloc(8 * 3 * k * k)
+    ctx.reduce_second_order(f, rows, k, 1, gram, flags=_native.REDUCE_NAN_TRIM)
+    G = ctx.download(gram, (3, k, k))
+    keep = ~np.isnan(blocks[:, :, 0]).any(axis=0)
+    C = blocks[2:2 + k, keep, 0]; D = blocks[2 + k:, keep, 0]
+    np.testing.assert_allclose(G[0], D @ C.T, rtol=1e-12)
+    np.testing.assert_allclose(G[2], C @ C.T, rtol=1e-12)
+    ctx.reduce_second_order(f, rows, k, 1, gram)      # without the flag NaNs propagate
+    assert np.isnan(ctx.download(gram, (3, k, k))).any()

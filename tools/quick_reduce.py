@@ -59,3 +59,15 @@ for nv in (4,):
         ms = r["reduce_first"][0]
         print("reduce nv=%d wgs/cu=%2d: %.3f ms (min %.3f) -> %.0f GB/s = %.1f GSamples/s ; fold %.3f ms" %
               (nv, wpc, ms, r["reduce_first"][1], 8 * N / ms / 1e6, N / ms / 1e6, r["fold"][0]), flush=True)
+
+K2 = k
+gram = ctx.alloc(8 * 3 * K2 * K2)
+for g in (1, 2, 3, 4):
+    os.environ["VS_GRAM_WGS_PER_CU"] = str(g)
+    r = timed(lambda: ctx.reduce_second_order(f, n, k, 1, gram), 5)
+    print("gram wgs/cu=%d: %.3f ms fold %.3f" % (g, r["second_order"][0], r["second_fold"][0]), flush=True)
+del os.environ["VS_GRAM_WGS_PER_CU"]
+r = timed(lambda: ctx.reduce_second_order(f, n, k, 1, gram), 5)
+ms = r["second_order"][0]
+print("second order: %.3f ms (fold %.3f) -> %.1f GB/s algorithmic (16 k n bytes), %.2f TFLOP/s useful (3 k^2 fma/row)" %
+      (ms, r["second_fold"][0], 16.0 * k * n / ms / 1e6, 2.0 * 3 * k * k * n / ms / 1e9), flush=True)

@@ -1,124 +1,187 @@
 // Second-order Gram sums of Varsens.compute_varsens (varsens/saltelli.py:612-622).
 //
 // With C = fN_j and D = fN_nj viewed as (K, rows) matrices, K = k*l, row index
-// I = j*l + o, the reference needs D C^T (+ its transpose), D D^T and C C^T:
-// four numpy.tensordot calls contracting the row axis.  Here: one pass over the
-// 2K streams.  The Gram is cut into 32x32 tiles of index pairs (I-tile <= J-tile);
-// a workgroup stages 64-row chunks of the four operand tiles (C_I, D_I, C_J, D_J)
-// in LDS and every thread keeps a 2x2 register block of each of the four
-// products (D_I.C_J, D_J.C_I, D_I.D_J, C_I.C_J).  fp64 vector fma bound for
-// k >= 32, HBM bound below; reported separately from the first-order pass.
+// j*l + o, the reference needs D C^T (+ its transpose), D D^T and C C^T: four
+// numpy.tensordot calls contracting the row axis.  Stack X = [C; D] (2K index
+// rows): all three are blocks of the Gram matrix G = X X^T.  This is the one
+// GEMM-shaped piece of the path, so it runs on the fp64 matrix cores:
+// v_mfma_f64_16x16x4_f64, D(16x16) += A(16x4) B(4x16), where A and B are both
+// "16 index rows x 4 sample rows" fragments of X (one double per lane).
+//
+// A workgroup (4 waves) owns a pair of 64-index-row super-blocks (SI <= SJ) and
+// walks 64-sample-row chunks: coalesced loads (one index row = 512 B per wave
+// instruction) into an LDS tile [index row][sample row] with a 66-double pitch
+// (conflict-free fragment reads), then each wave takes 16 of the 64 sample rows:
+// 4 MFMA k-steps x up to 16 block pairs, accumulators in registers for the whole
+// kernel.  At the end the four waves' accumulators are added through LDS and one
+// dense 64x64 partial per workgroup goes to HBM; gram_fold_kernel sums the
+// partials (compensated) and scatters them into DC, DD, CC.
+// Roofline: min(HBM: 16*K*rows bytes, fp64 MFMA: (2K)^2/2 * rows fma); both
+// ~0.3 ms at k=32, rows=2^22.  Reported separately from the first-order pass.
 #include "vs_common.h"
 
-#define VS2_TILE 32
-#define VS2_CHUNK 64
-#define VS2_LD (VS2_CHUNK + 1)  // padded leading dimension: conflict-free column reads
-#define VS2_TILE_OUT (4 * VS2_TILE * VS2_TILE)
+#define VS2_SUPER 64                 // index rows per super-block (4 MFMA blocks of 16)
+#define VS2_CHUNK 64                 // sample rows per LDS tile
+#define VS2_PITCH 66                 // doubles per LDS tile row
+#define VS2_TILE_OUT (VS2_SUPER * VS2_SUPER)
 
-enum { CNT_NANFLAG = 0, CNT_FIRST_KEPT = 1, CNT_KEPT = 2, CNT2_FORCE = 8 };
+typedef double vs_d4 __attribute__((ext_vector_type(4)));
+
+enum { CNT_NANFLAG = 0 };
 
 struct vs_gram_args {
     const double* f;
     uint64_t rows;
     int k, l, K;
-    int ntile;           // ceil(K / 32)
+    int nsuper;          // ceil(2K / 64)
     uint32_t slab_wgs;   // grid.x
-    double* partials;    // [slab_wgs][npairs][4][32][32]
+    double* partials;    // [slab_wgs][npairs][64][64]
     const uint8_t* keep;
     const uint32_t* counters;
 };
 
 __device__ __forceinline__ void pair_from_index(int p, int ntile, int& I, int& J) {
-    // enumerate I <= J row by row
+    // pairs 0..ntile-1 are the diagonal (I,I); then I < J row by row
+    if (p < ntile) {
+        I = J = p;
+        return;
+    }
+    p -= ntile;
     I = 0;
-    int rowlen = ntile;
+    int rowlen = ntile - 1;
     while (p >= rowlen) {
         p -= rowlen;
         ++I;
         --rowlen;
     }
-    J = I + p;
+    J = I + 1 + p;
 }
 
-template <bool MASKED>
-__global__ void __launch_bounds__(256)
-gram_kernel(vs_gram_args A) {
-    extern __shared__ double tiles[];  // 4 x [32][VS2_LD]
-    if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
-    double* CI = tiles;
-    double* DI = CI + VS2_TILE * VS2_LD;
-    double* CJ = DI + VS2_TILE * VS2_LD;
-    double* DJ = CJ + VS2_TILE * VS2_LD;
+// address of X[m][r]: index row m < K is C (fN_j), m >= K is D (fN_nj)
+__device__ __forceinline__ const double* x_elem(const vs_gram_args& A, int m, uint64_t r) {
+    const int K = A.K, l = A.l;
+    const int mm = m < K ? m : m - K;
+    const int j = mm / l, o = mm - j * l;
+    const uint64_t block = (m < K ? 2 : 2 + A.k) + (uint64_t)j;
+    return A.f + (block * A.rows + r) * l + o;
+}
 
+template <bool MASKED, bool DIAG>
+__device__ __forceinline__ void gram_body(const vs_gram_args& A, int SI, int SJ, double* tiles) {
+    constexpr int NB = VS2_SUPER / 16;                 // 4 blocks per super-block
+    constexpr int NACC = DIAG ? NB * (NB + 1) / 2 : NB * NB;
+    double* TI = tiles;
+    double* TJ = DIAG ? tiles : tiles + VS2_SUPER * VS2_PITCH;
     const int tid = threadIdx.x;
-    const int ti = tid >> 4, tj = tid & 15;
-    int I, J;
-    pair_from_index(blockIdx.y, A.ntile, I, J);
-    const int l = A.l, k = A.k, K = A.K;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = 2 * A.K;
     const uint64_t rows = A.rows;
 
-    double dc[2][2] = {{0, 0}, {0, 0}}, cd[2][2] = {{0, 0}, {0, 0}}, dd[2][2] = {{0, 0}, {0, 0}},
-           cc[2][2] = {{0, 0}, {0, 0}};
+    vs_d4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
+
+    // this wave stages index rows wave, wave+4, ..: 16 rows of SI (and 16 of SJ), one 512-B
+    // row segment per load instruction.  Row bases are wave-uniform.
+    constexpr int NR = VS2_SUPER / 4;
+    const double* rowI[NR];
+    const double* rowJ[NR];
+    bool okI[NR], okJ[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int mi = SI * VS2_SUPER + wave + 4 * i, mj = SJ * VS2_SUPER + wave + 4 * i;
+        okI[i] = mi < M;
+        okJ[i] = !DIAG && mj < M;
+        rowI[i] = x_elem(A, okI[i] ? mi : 0, 0);
+        rowJ[i] = x_elem(A, okJ[i] ? mj : 0, 0);
+    }
+    const uint64_t lstride = (uint64_t)A.l;
+    double vi[NR], vj[NR];
+    auto fetch = [&](uint64_t ch) {
+        const uint64_t r = ch * VS2_CHUNK + lane;
+        const bool rin = r < rows && (!MASKED || A.keep[r]);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            vi[i] = (rin && okI[i]) ? __builtin_nontemporal_load(rowI[i] + r * lstride) : 0.0;
+            if (!DIAG) vj[i] = (rin && okJ[i]) ? __builtin_nontemporal_load(rowJ[i] + r * lstride) : 0.0;
+        }
+    };
 
     const uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
+    if (blockIdx.x < nchunks) fetch(blockIdx.x);
     for (uint64_t ch = blockIdx.x; ch < nchunks; ch += A.slab_wgs) {
-        const uint64_t r0 = ch * VS2_CHUNK;
         __syncthreads();  // previous chunk fully consumed
-        // stage: 4 tiles x 32 index rows x 64 sample rows; thread -> (index row, sample row)
-        for (int e = tid; e < VS2_TILE * VS2_CHUNK; e += 256) {
-            const int ir = e >> 6, rr = e & 63;
-            const uint64_t r = r0 + rr;
-            const bool in = r < rows && (!MASKED || A.keep[r]);
-            const int gi = I * VS2_TILE + ir, gj = J * VS2_TILE + ir;
-            double ci = 0, di = 0, cj = 0, dj = 0;
-            if (in && gi < K) {
-                const int j = gi / l, o = gi - j * l;
-                ci = A.f[((uint64_t)(2 + j) * rows + r) * l + o];
-                di = A.f[((uint64_t)(2 + k + j) * rows + r) * l + o];
-            }
-            if (in && gj < K) {
-                const int j = gj / l, o = gj - j * l;
-                cj = A.f[((uint64_t)(2 + j) * rows + r) * l + o];
-                dj = A.f[((uint64_t)(2 + k + j) * rows + r) * l + o];
-            }
-            CI[ir * VS2_LD + rr] = ci;
-            DI[ir * VS2_LD + rr] = di;
-            CJ[ir * VS2_LD + rr] = cj;
-            DJ[ir * VS2_LD + rr] = dj;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            TI[(wave + 4 * i) * VS2_PITCH + lane] = vi[i];
+            if (!DIAG) TJ[(wave + 4 * i) * VS2_PITCH + lane] = vj[i];
         }
+        if (ch + A.slab_wgs < nchunks) fetch(ch + A.slab_wgs);  // lands while the MFMAs below run
         __syncthreads();
-#pragma unroll 4
-        for (int rr = 0; rr < VS2_CHUNK; ++rr) {
-            double ci[2], di[2], cj[2], dj[2];
+        // this wave's 16 sample rows: 4 k-steps of 4
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                ci[u] = CI[(ti + 16 * u) * VS2_LD + rr];
-                di[u] = DI[(ti + 16 * u) * VS2_LD + rr];
-                cj[u] = CJ[(tj + 16 * u) * VS2_LD + rr];
-                dj[u] = DJ[(tj + 16 * u) * VS2_LD + rr];
+        for (int s = 0; s < 4; ++s) {
+            const int rr = wave * 16 + s * 4 + (lane >> 4);
+            double fi[NB], fj[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                fi[b] = TI[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
+                if (!DIAG) fj[b] = TJ[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
             }
+            int a = 0;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    dc[u][v] = fma(di[u], cj[v], dc[u][v]);
-                    cd[u][v] = fma(ci[u], dj[v], cd[u][v]);
-                    dd[u][v] = fma(di[u], dj[v], dd[u][v]);
-                    cc[u][v] = fma(ci[u], cj[v], cc[u][v]);
+                for (int bj = DIAG ? bi : 0; bj < NB; ++bj) {
+                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fi[bi], DIAG ? fi[bj] : fj[bj], acc[a], 0, 0, 0);
+                    ++a;
                 }
         }
     }
-    double* out = A.partials + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * VS2_TILE_OUT;
+    // add the four waves' accumulators through LDS (reusing the tile space), fixed order
+    __syncthreads();
+    double* red = tiles;  // [wave][64][64] would not fit: go pair by pair in 16x16 blocks
+    const int npairs = A.nsuper * (A.nsuper + 1) / 2;
+    double* out = A.partials + ((size_t)blockIdx.x * npairs + (DIAG ? blockIdx.y : blockIdx.y + A.nsuper)) * VS2_TILE_OUT;
+    int a = 0;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            const int e = (ti + 16 * u) * VS2_TILE + (tj + 16 * v);
-            out[0 * VS2_TILE * VS2_TILE + e] = dc[u][v];
-            out[1 * VS2_TILE * VS2_TILE + e] = cd[u][v];
-            out[2 * VS2_TILE * VS2_TILE + e] = dd[u][v];
-            out[3 * VS2_TILE * VS2_TILE + e] = cc[u][v];
+        for (int bj = DIAG ? bi : 0; bj < NB; ++bj) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = (lane >> 4) + 4 * v, col = lane & 15;   // f64 C/D layout
+                red[(wave * 256) + row * 16 + col] = acc[a][v];
+            }
+            __syncthreads();
+            {
+                const double t = ((red[tid] + red[256 + tid]) + red[512 + tid]) + red[768 + tid];
+                const int row = tid >> 4, col = tid & 15;
+                out[(bi * 16 + row) * VS2_SUPER + (bj * 16 + col)] = t;
+            }
+            __syncthreads();
+            ++a;
         }
+    if (DIAG) {
+        // blocks below the diagonal are not computed: zero them so the fold sees defined data
+        for (int e = tid; e < VS2_TILE_OUT; e += 256) {
+            const int bi = (e / VS2_SUPER) / 16, bj = (e % VS2_SUPER) / 16;
+            if (bj < bi) out[e] = 0.0;
+        }
+    }
+}
+
+// DIAG: blockIdx.y = super-block index (pairs (y,y)); otherwise blockIdx.y + nsuper indexes I < J.
+// Two kernels so that the common k <= 32 case (one diagonal pair) keeps 10 accumulators, not 16.
+template <bool MASKED, bool DIAG>
+__global__ void __launch_bounds__(256)
+gram_kernel(vs_gram_args A) {
+    extern __shared__ double tiles[];  // [64][VS2_PITCH] (x2 off the diagonal)
+    if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
+    int SI, SJ;
+    pair_from_index(DIAG ? blockIdx.y : blockIdx.y + A.nsuper, A.nsuper, SI, SJ);
+    gram_body<MASKED, DIAG>(A, SI, SJ, tiles);
 }
 
 // keep mask for the second-order pass (same rule as the first-order one)
@@ -137,49 +200,75 @@ nan_mask2_kernel(const double* __restrict__ f, uint64_t rows, int k, int l, uint
     }
 }
 
-// sum the slab partials (compensated) and scatter tile entries into the three
-// row-major (K,K) matrices DC, DD, CC.
+// sum the slab partials (compensated) and scatter the Gram entries into the three
+// row-major (K,K) matrices DC = D C^T, DD = D D^T, CC = C C^T.
 struct vs_gram_fold_args {
     const double* partials;
     uint32_t P;
-    int K, ntile, npairs;
+    int K, nsuper, npairs;
     double* gram;
     uint32_t* counters;
     int masked;
 };
 
-__global__ void __launch_bounds__(256)
+#define VS2_FOLD_THREADS 1024
+
+// block b folds 64 consecutive entries: 16 waves stride over the P partials (coalesced),
+// then wave 0 combines them in fixed order and scatters.
+__global__ void __launch_bounds__(VS2_FOLD_THREADS)
 gram_fold_kernel(vs_gram_fold_args A) {
+    __shared__ double s_sum[VS2_FOLD_THREADS / 64][64];
+    __shared__ double s_cmp[VS2_FOLD_THREADS / 64][64];
     if (A.masked && A.counters[CNT_NANFLAG] == 0) return;
     const size_t width = (size_t)A.npairs * VS2_TILE_OUT;
-    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= width) return;
-    double s = 0.0, comp = 0.0;
-    for (uint32_t p = 0; p < A.P; ++p) {
-        const double x = A.partials[(size_t)p * width + col];
-        const double t = s + x;
-        comp += (fabs(s) >= fabs(x)) ? (s - t) + x : (x - t) + s;
-        s = t;
-    }
-    const double total = s + comp;
-    if (!A.masked && total != total) atomicOr(&A.counters[CNT_NANFLAG], 1u);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t col = (size_t)blockIdx.x * 64 + lane;   // width is a multiple of 64
     const int pair = (int)(col / VS2_TILE_OUT);
-    const int rem = (int)(col % VS2_TILE_OUT);
-    const int which = rem / (VS2_TILE * VS2_TILE);
-    const int e = rem % (VS2_TILE * VS2_TILE);
-    int I, J;
-    pair_from_index(pair, A.ntile, I, J);
-    const int gi = I * VS2_TILE + e / VS2_TILE, gj = J * VS2_TILE + e % VS2_TILE;
+    const int e = (int)(col % VS2_TILE_OUT);
+    int SI, SJ;
+    pair_from_index(pair, A.nsuper, SI, SJ);
+    const int li = e / VS2_SUPER, lj = e % VS2_SUPER;
     const int K = A.K;
-    if (gi >= K || gj >= K) return;
+    const int gi = SI * VS2_SUPER + li, gj = SJ * VS2_SUPER + lj;
+    // entries of mirror blocks (never computed) and of padding rows are skipped
+    const bool live = !(SI == SJ && (lj / 16) < (li / 16)) && gi < 2 * K && gj < 2 * K;
+    double s = 0.0, comp = 0.0;
+    if (live) {
+        for (uint32_t p = wave; p < A.P; p += VS2_FOLD_THREADS / 64) {
+            const double x = A.partials[(size_t)p * width + col];
+            const double t = s + x;
+            comp += (fabs(s) >= fabs(x)) ? (s - t) + x : (x - t) + s;
+            s = t;
+        }
+    }
+    s_sum[wave][lane] = s;
+    s_cmp[wave][lane] = comp;
+    __syncthreads();
+    if (wave != 0 || !live) return;
+    double S = 0.0, Cc = 0.0;
+    for (int w = 0; w < VS2_FOLD_THREADS / 64; ++w) {
+        const double x = s_sum[w][lane];
+        const double t = S + x;
+        Cc += (fabs(S) >= fabs(x)) ? (S - t) + x : (x - t) + S;
+        S = t;
+        Cc += s_cmp[w][lane];
+    }
+    const double total = S + Cc;   // = X_gi . X_gj
+    if (!A.masked && total != total) atomicOr(&A.counters[CNT_NANFLAG], 1u);
     double* DC = A.gram;
     double* DD = DC + (size_t)K * K;
     double* CC = DD + (size_t)K * K;
-    switch (which) {
-        case 0: DC[(size_t)gi * K + gj] = total; break;                       // D_gi . C_gj
-        case 1: if (I != J) DC[(size_t)gj * K + gi] = total; break;            // C_gi . D_gj = DC[gj][gi]
-        case 2: DD[(size_t)gi * K + gj] = total; if (I != J) DD[(size_t)gj * K + gi] = total; break;
-        case 3: CC[(size_t)gi * K + gj] = total; if (I != J) CC[(size_t)gj * K + gi] = total; break;
+    const bool mirror = !(SI == SJ && (li / 16) == (lj / 16));  // diagonal 16-blocks hold both triangles
+    if (gi < K && gj < K) {
+        CC[(size_t)gi * K + gj] = total;
+        if (mirror) CC[(size_t)gj * K + gi] = total;
+    } else if (gi >= K && gj >= K) {
+        DD[(size_t)(gi - K) * K + (gj - K)] = total;
+        if (mirror) DD[(size_t)(gj - K) * K + (gi - K)] = total;
+    } else if (gi < K) {            // C_gi . D_gj
+        DC[(size_t)(gj - K) * K + gi] = total;
+    } else {                        // D_gi . C_gj
+        DC[(size_t)(gi - K) * K + gj] = total;
     }
 }
 
@@ -218,12 +307,14 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     VS_REQUIRE((uint64_t)k * l <= 4096, "k*l=%llu too large for the second-order pass (limit 4096)",
                (unsigned long long)k * l);
     const int K = k * l;
-    const int ntile = (K + VS2_TILE - 1) / VS2_TILE;
-    const int npairs = ntile * (ntile + 1) / 2;
+    const int nsuper = (2 * K + VS2_SUPER - 1) / VS2_SUPER;
+    const int npairs = nsuper * (nsuper + 1) / 2;
     uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
     if (nchunks < 1) nchunks = 1;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    uint64_t want = ((uint64_t)cus * 2 + npairs - 1) / npairs;
+    const char* env = getenv("VS_GRAM_WGS_PER_CU");
+    const int per_cu = env && *env ? atoi(env) : 2;
+    uint64_t want = ((uint64_t)cus * per_cu + npairs - 1) / npairs;
     if (want < 1) want = 1;
     const uint32_t slab_wgs = (uint32_t)(nchunks < want ? nchunks : want);
     const size_t width = (size_t)npairs * VS2_TILE_OUT;
@@ -241,7 +332,7 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     A.k = k;
     A.l = l;
     A.K = K;
-    A.ntile = ntile;
+    A.nsuper = nsuper;
     A.slab_wgs = slab_wgs;
     A.partials = ctx->partials;
     A.keep = nullptr;
@@ -250,14 +341,14 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     F.partials = ctx->partials;
     F.P = slab_wgs;
     F.K = K;
-    F.ntile = ntile;
+    F.nsuper = nsuper;
     F.npairs = npairs;
     F.gram = gram_dev;
     F.counters = ctx->counters;
-    const size_t lds = sizeof(double) * 4 * VS2_TILE * VS2_LD;
-    VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const dim3 grid(slab_wgs, npairs);
+    const size_t lds1 = sizeof(double) * VS2_SUPER * VS2_PITCH, lds2 = 2 * lds1;
+    VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    const dim3 grid_diag(slab_wgs, nsuper), grid_off(slab_wgs, npairs - nsuper);
     for (int pass = 0; pass < 2; ++pass) {
         const bool masked = pass == 1;
         if (masked) {
@@ -271,14 +362,19 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
         }
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
-            if (masked) hipLaunchKernelGGL(gram_kernel<true>, grid, dim3(256), lds, ctx->stream, A);
-            else hipLaunchKernelGGL(gram_kernel<false>, grid, dim3(256), lds, ctx->stream, A);
+            if (masked) {
+                hipLaunchKernelGGL((gram_kernel<true, true>), grid_diag, dim3(256), lds1, ctx->stream, A);
+                if (npairs > nsuper) hipLaunchKernelGGL((gram_kernel<true, false>), grid_off, dim3(256), lds2, ctx->stream, A);
+            } else {
+                hipLaunchKernelGGL((gram_kernel<false, true>), grid_diag, dim3(256), lds1, ctx->stream, A);
+                if (npairs > nsuper) hipLaunchKernelGGL((gram_kernel<false, false>), grid_off, dim3(256), lds2, ctx->stream, A);
+            }
         }
         VS_HIP(hipGetLastError());
         F.masked = masked ? 1 : 0;
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_FOLD);
-            hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, ctx->stream, F);
+            hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)(width / 64)), dim3(VS2_FOLD_THREADS), 0, ctx->stream, F);
         }
         VS_HIP(hipGetLastError());
     }

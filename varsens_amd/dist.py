@@ -105,3 +105,21 @@ class RcclComm(object):
     def close(self):
         if self.world > 1:
             self.ctx.comm_destroy()
+
+
+class HostExchange(object):
+    """Same interface as RcclComm, but the record crosses the host: download, gloo sum, upload.
+    Only a visible, flagged fallback for bench.py when RCCL cannot initialise; never chosen silently."""
+
+    def __init__(self, ctx, group):
+        self.ctx, self.group = ctx, group
+        self.world, self.rank = group.world, group.rank
+
+    def allreduce(self, buf, count):
+        if self.world > 1:
+            self.ctx.sync()
+            total = self.group.sum_array(self.ctx.download(buf, (int(count),)))
+            self.ctx.upload_into(buf, total)
+
+    def close(self):
+        pass
