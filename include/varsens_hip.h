@@ -160,12 +160,24 @@ enum {
     VS_OBJ_ISHIGAMI = 2,
     VS_OBJ_LINEAR = 3,
     VS_OBJ_POLYNOMIAL = 4,
-    VS_OBJ_INVERT = 5
+    VS_OBJ_INVERT = 5,
+    VS_OBJ_SOURCE = 6 /* created by vs_objective_create_source */
 };
 
 int vs_objective_create(vs_context* ctx, int kind, int k, int l, const double* params,
                         size_t nparams, vs_objective** out);
 int vs_objective_destroy(vs_context* ctx, vs_objective* obj);
+
+/* A user objective given as the BODY of
+ *     void objective(const vs_point& x, int k, const double* p, double* out)
+ * in HIP C++: x[c] is coordinate c of the evaluation point (already scaled), p the `nparams`
+ * parameters, out[0..l) the outputs.  Example body: "out[0] = sin(x[0]) + p[0]*x[1]*x[1];".
+ * Compiled with hiprtc for gfx950 (-ffp-contract=off) into the same fused generate->evaluate
+ * kernel as the built-ins; on a compile error returns VS_ERR_COMPILE and vs_last_error() holds
+ * the compiler log.  Device counterpart of the arbitrary Python callable the reference takes
+ * (varsens/saltelli.py:308,329-355). */
+int vs_objective_create_source(vs_context* ctx, int k, int l, const char* body, const double* params,
+                               size_t nparams, vs_objective** out);
 
 /* Replaces the four evaluation loops of Objective.__init__ (saltelli.py:329-355)
  * for design rows [row_begin, row_begin+row_count) (a shard of r in [0,n)).

@@ -1,0 +1,71 @@
+"""User objectives compiled with hiprtc into the fused generate->evaluate kernel."""
+import numpy as np
+import pytest
+
+from oracle import saltelli_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+A6 = [0, 0.5, 3, 9, 99, 99]
+G_BODY = """
+    double acc = 1.0;
+    for (int i = 0; i < k; ++i) acc = acc * ((fabs(4.0 * x[i] - 2.0) + p[i]) / (1.0 + p[i]));
+    out[0] = acc;
+"""
+
+
+@pytest.fixture(scope="module")
+def vs():
+    import varsens_amd
+    return varsens_amd
+
+
+def test_expression_equals_builtin_gfunction_bit_for_bit(vs):
+    k, n = 6, 4096
+    s = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
+    o1 = vs.Objective(k, n, s, vs.objectives.GFunction(A6), verbose=False)
+    o2 = vs.Objective(k, n, s, vs.objectives.Expression(G_BODY, params=A6), verbose=False)
+    assert np.array_equal(o1.flat(), o2.flat())
+    S = orc.build_sample(k, n)
+    F = orc.evaluate_rows(lambda X: orc.g_function_rows(X, A6), *S)
+    assert np.array_equal(o2.flat(), orc.flat_objective(*F))
+
+
+def test_expression_ishigami_matches_builtin_and_truth(vs):
+    body = """
+        const double s1 = sin(x[0]), s2 = sin(x[1]), x3 = x[2];
+        out[0] = (s1 + p[0] * (s2 * s2)) + (p[1] * ((x3 * x3) * (x3 * x3))) * s1;
+    """
+    sc = vs.scale.Linear([-np.pi] * 3, [np.pi] * 3)
+    v1 = vs.Varsens(vs.objectives.Ishigami(7.0, 0.1), sc, 3, 1 << 16, verbose=False)
+    v2 = vs.Varsens(vs.objectives.Expression(body, params=[7.0, 0.1]), sc, 3, 1 << 16, verbose=False)
+    assert np.array_equal(v1.objective.flat(), v2.objective.flat())
+    assert np.array_equal(v1.sens, v2.sens) and np.array_equal(v1.sens_2, v2.sens_2)
+    V, S, ST = orc.ishigami_truth()
+    np.testing.assert_allclose(v2.sens[:, 0], S, atol=0.01)
+    np.testing.assert_allclose(v2.sens_t[:, 0], ST, atol=0.01)
+
+
+def test_expression_two_outputs_and_large_k(vs):
+    k, n = 70, 300      # 70 KiB of LDS per workgroup: the > 64 KiB dynamic-LDS path
+    body = """
+        double s = 0.0, t = 0.0;
+        for (int i = 0; i < k; ++i) { s = s + p[i] * x[i]; t = t + x[i] * x[i]; }
+        out[0] = s; out[1] = t;
+    """
+    c = np.arange(1, k + 1, dtype=float)
+    s = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
+    o = vs.Objective(k, n, s, vs.objectives.Expression(body, outputs=2, params=c), verbose=False)
+    S = orc.build_sample(k, n)
+    rows = lambda X: np.stack([orc.linear_rows(X, c), orc.linear_rows(X * X, np.ones(k))], axis=-1)
+    F = orc.evaluate_rows(rows, *S)
+    assert np.array_equal(o.flat(), orc.flat_objective(*F))
+    v = vs.Varsens(o, verbose=False)
+    assert v.sens.shape == (k, 2) and v.sens_2.shape == (k, 2, k, 2)
+
+
+def test_expression_compile_error_is_reported(vs):
+    from varsens_amd._native import VarsensHipError
+    s = vs.Sample(3, 8, vs.scale.Identity(), verbose=False)
+    with pytest.raises(VarsensHipError, match="does not compile"):
+        vs.Objective(3, 8, s, vs.objectives.Expression("out[0] = not_a_symbol(x[0]);"), verbose=False)

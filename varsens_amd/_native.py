@@ -17,7 +17,7 @@ COMM_ID_BYTES = 128
 
 GEN_HALTON, GEN_SOBOL, GEN_RAW = 0, 1, 2
 SCALE_IDENTITY, SCALE_LINEAR, SCALE_POWER = 0, 1, 2
-OBJ_G_FUNCTION, OBJ_ISHIGAMI, OBJ_LINEAR, OBJ_POLYNOMIAL, OBJ_INVERT = 1, 2, 3, 4, 5
+OBJ_G_FUNCTION, OBJ_ISHIGAMI, OBJ_LINEAR, OBJ_POLYNOMIAL, OBJ_INVERT, OBJ_SOURCE = 1, 2, 3, 4, 5, 6
 REDUCE_NAN_TRIM = 1
 
 KERNEL_NAMES = {
@@ -89,6 +89,8 @@ SIGNATURES = {
     "vs_objective_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_void_p)]),
     "vs_objective_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vs_objective_create_source": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_size_t,
+                                             C.POINTER(C.c_void_p)]),
     "vs_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "vs_reduce_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_void_p]),
@@ -291,6 +293,17 @@ class Context(object):
             n = arr.size
         h = C.c_void_p()
         _check(self.lib.vs_objective_create(self.handle, int(kind), int(k), int(l), p, n, C.byref(h)))
+        return Handle(self, h, self.lib.vs_objective_destroy)
+
+    def objective_create_source(self, k, l, body, params=None):
+        if params is None or len(params) == 0:
+            p, n = None, 0
+        else:
+            arr, p = _host(np.asarray(params, dtype=np.float64).ravel(), np.float64)
+            n = arr.size
+        h = C.c_void_p()
+        _check(self.lib.vs_objective_create_source(self.handle, int(k), int(l), body.encode("utf-8"), p, n,
+                                                   C.byref(h)))
         return Handle(self, h, self.lib.vs_objective_destroy)
 
     # -- compute

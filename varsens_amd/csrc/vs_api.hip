@@ -1,7 +1,7 @@
 // Context, memory, error and profiling plumbing of libvarsens_hip.so.
 #include "vs_common.h"
 
-static thread_local char g_err[1024] = "";
+static thread_local char g_err[8192] = "";
 
 int vs_fail(int code, const char* fmt, ...) {
     va_list ap;

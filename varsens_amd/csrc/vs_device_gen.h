@@ -1,0 +1,171 @@
+// Device-side generator code shared by the precompiled kernels (vs_generate.hip) and by the
+// kernels hiprtc builds at run time for user objectives (vs_rtc.hip embeds this file as text).
+// Device code only; fixed-width types are spelled vs_u32 / vs_u64 so that the text also compiles
+// under hiprtc without <cstdint>.
+#ifndef VS_DEVICE_GEN_H
+#define VS_DEVICE_GEN_H
+
+typedef unsigned int vs_u32;
+typedef unsigned long long vs_u64;
+
+#ifndef VARSENS_HIP_H
+enum { VS_GEN_HALTON = 0, VS_GEN_SOBOL = 1, VS_GEN_RAW = 2 };
+enum { VS_SCALE_IDENTITY = 0, VS_SCALE_LINEAR = 1, VS_SCALE_POWER = 2 };
+#endif
+
+#define VS_EVAL_ROWS 64
+#define VS_EVAL_WAVES 4
+
+#ifndef VS_NO_NT_STORE
+#define VS_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define VS_STORE(p, v) (*(p) = (v))
+#endif
+
+// ---------------------------------------------------------------------------
+// Halton radical inverse
+// ---------------------------------------------------------------------------
+
+struct vs_base {
+    vs_u32 b;        // prime base
+    vs_u32 ndig;     // digits of the largest index of this design in base b (0: indices reach 2^32)
+    double den;      // b^ndig
+    double inv_den;  // RN(1 / den)
+    double inv_b;    // RN(1 / b) pushed up two ulps: floor(j * inv_b) == j / b for every j < 2^32
+};
+
+// Radical inverse of i in base b: the digit-reversed integer of i divided by
+// b^digits, as ONE correctly rounded fp64 quotient of two exact integers
+// (i * b < 2^53 is checked on the host).
+//
+// Fast path (all indices of the design < 2^32): every lane runs the same ndig
+// digit steps; leading zero digits scale numerator and denominator by the same
+// power of b, which leaves the quotient -- and its rounding -- unchanged.  The
+// denominator is then a per-column constant and the division is Markstein's
+// fma sequence on its correctly rounded reciprocal: two Newton steps, the last
+// of which is provably the correctly rounded quotient.  Base 2 is a bit reversal.
+__device__ __forceinline__ double vs_radical_inverse(vs_u64 i, const vs_base B) {
+    if (B.ndig != 0) {
+        const vs_u32 j = (vs_u32)i;
+        if (B.b == 2) return (double)__brev(j) * (1.0 / 4294967296.0);
+        const double bd = (double)B.b;
+        double num = 0.0, jd = (double)j;
+        for (vs_u32 t = 0; t < B.ndig; ++t) {   // see vs_radical_inverse_pair for why floor() is exact
+            const double q = floor(jd * B.inv_b);
+            num = fma(num, bd, fma(-q, bd, jd));
+            jd = q;
+        }
+        double q0 = num * B.inv_den;
+        double r0 = fma(-q0, B.den, num);
+        double q1 = fma(r0, B.inv_den, q0);
+        double r1 = fma(-q1, B.den, num);
+        return fma(r1, B.inv_den, q1);
+    }
+    double num = 0.0, den = 1.0;
+    const double bd = (double)B.b;
+    while (i) {  // indices beyond 2^32: plain 64-bit digit loop and a true division
+        vs_u64 q = i / B.b;
+        vs_u32 d = (vs_u32)(i - q * B.b);
+        num = fma(num, bd, (double)d);
+        den = den * bd;
+        i = q;
+    }
+    return num / den;
+}
+
+// Two radical inverses in the same base with interleaved digit loops (two
+// independent dependency chains per step).  Fast path only (B.ndig != 0).
+__device__ __forceinline__ void vs_radical_inverse_pair(vs_u32 i1, vs_u32 i2, const vs_base B,
+                                                         double& x1, double& x2) {
+    if (B.b == 2) {
+        x1 = (double)__brev(i1) * (1.0 / 4294967296.0);
+        x2 = (double)__brev(i2) * (1.0 / 4294967296.0);
+        return;
+    }
+    // Digit steps entirely in fp64 (4 instructions per digit and point): with inv_b two ulps
+    // above 1/b, floor(j*inv_b) is the exact quotient for j < 2^32, b < 2^16 -- an exact multiple
+    // can no longer round below its integer, and the inflation (< 2^-17 absolute) is far smaller
+    // than the distance 1/b of any other quotient to the next integer.  The digit j - q*b and the
+    // numerator update are exact fmas on integers below 2^53.
+    const double bd = (double)B.b;
+    double n1 = 0.0, n2 = 0.0;
+    double j1 = (double)i1, j2 = (double)i2;
+    vs_u32 t = B.ndig;
+    for (; t >= 2; t -= 2) {  // two digits per trip: no register rotation between steps
+        const double q1 = floor(j1 * B.inv_b);
+        const double q2 = floor(j2 * B.inv_b);
+        n1 = fma(n1, bd, fma(-q1, bd, j1));
+        n2 = fma(n2, bd, fma(-q2, bd, j2));
+        j1 = floor(q1 * B.inv_b);
+        j2 = floor(q2 * B.inv_b);
+        n1 = fma(n1, bd, fma(-j1, bd, q1));
+        n2 = fma(n2, bd, fma(-j2, bd, q2));
+    }
+    if (t) {
+        const double q1 = floor(j1 * B.inv_b);
+        const double q2 = floor(j2 * B.inv_b);
+        n1 = fma(n1, bd, fma(-q1, bd, j1));
+        n2 = fma(n2, bd, fma(-q2, bd, j2));
+    }
+    double a0 = n1 * B.inv_den, b0 = n2 * B.inv_den;
+    double ra = fma(-a0, B.den, n1), rb = fma(-b0, B.den, n2);
+    a0 = fma(ra, B.inv_den, a0);
+    b0 = fma(rb, B.inv_den, b0);
+    ra = fma(-a0, B.den, n1);
+    rb = fma(-b0, B.den, n2);
+    x1 = fma(ra, B.inv_den, a0);
+    x2 = fma(rb, B.inv_den, b0);
+}
+
+__device__ __forceinline__ double vs_sobol_point(vs_u64 i, const vs_u32* __restrict__ dir) {
+    vs_u32 g = (vs_u32)(i ^ (i >> 1));
+    vs_u32 x = 0;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) x ^= ((g >> j) & 1u) ? dir[j] : 0u;
+    return (double)x * (1.0 / 4294967296.0);
+}
+
+struct vs_design_dev {
+    int generator, k, scale_mode;
+    vs_u64 n, first_index;
+    const double* lower;
+    const double* width;
+    const vs_u32* perm;
+    const double* raw;
+    const vs_u32* dirs;
+    const vs_base* bases;
+};
+
+// Unit-cube coordinate c of sequence row `seq_row` (0..2n-1: first half feeds
+// M_1, second half M_2 before the shuffle).
+__device__ __forceinline__ double vs_unit_point(const vs_design_dev& D, vs_u64 seq_row, int c) {
+    if (D.generator == VS_GEN_HALTON) return vs_radical_inverse(D.first_index + seq_row, D.bases[c]);
+    if (D.generator == VS_GEN_SOBOL) return vs_sobol_point(D.first_index + seq_row, D.dirs + 32 * c);
+    return D.raw[seq_row * (vs_u64)D.k + c];
+}
+
+__device__ __forceinline__ double vs_apply_scale(const vs_design_dev& D, double p, int c) {
+    if (D.scale_mode == VS_SCALE_LINEAR) return p * D.width[c] + D.lower[c];   // scale.py:33
+    if (D.scale_mode == VS_SCALE_POWER) return D.lower[c] * pow(D.width[c], p); // scale.py:62
+    return p;
+}
+
+// M_1[r][c] / M_2[r][c] (M_2 after the shuffle)
+__device__ __forceinline__ double vs_m1(const vs_design_dev& D, vs_u64 r, int c) {
+    return vs_apply_scale(D, vs_unit_point(D, r, c), c);
+}
+__device__ __forceinline__ double vs_m2(const vs_design_dev& D, vs_u64 r, int c) {
+    vs_u64 src = D.perm ? (vs_u64)D.perm[r] : r;
+    return vs_apply_scale(D, vs_unit_point(D, D.n + src, c), c);
+}
+
+
+struct vs_eval_args {
+    vs_design_dev D;
+    int kind, l;
+    const double* params;
+    vs_u64 row_begin, rows;
+    double* f;
+};
+
+#endif  // VS_DEVICE_GEN_H

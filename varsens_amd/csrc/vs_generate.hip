@@ -16,150 +16,7 @@
 
 #include "vs_common.h"
 
-// ---------------------------------------------------------------------------
-// Halton radical inverse
-// ---------------------------------------------------------------------------
-
-struct vs_base {
-    uint32_t b;      // prime base
-    uint32_t magic;  // round-up magic multiplier for q / b, q < 2^32
-    uint32_t shift;  // ceil(log2 b) - 1
-    uint32_t ndig;   // digits of the largest index of this design in base b (0: indices reach 2^32)
-    double den;      // b^ndig
-    double inv_den;  // RN(1 / den)
-    double inv_b;    // RN(1 / b) pushed up two ulps: floor(j * inv_b) == j / b for every j < 2^32
-};
-
-__device__ __forceinline__ uint32_t vs_div_magic(uint32_t q, uint32_t magic, uint32_t shift) {
-    uint32_t t = __umulhi(q, magic);
-    return (t + ((q - t) >> 1)) >> shift;
-}
-
-// Radical inverse of i in base b: the digit-reversed integer of i divided by
-// b^digits, as ONE correctly rounded fp64 quotient of two exact integers
-// (i * b < 2^53 is checked on the host).
-//
-// Fast path (all indices of the design < 2^32): every lane runs the same ndig
-// digit steps; leading zero digits scale numerator and denominator by the same
-// power of b, which leaves the quotient -- and its rounding -- unchanged.  The
-// denominator is then a per-column constant and the division is Markstein's
-// fma sequence on its correctly rounded reciprocal: two Newton steps, the last
-// of which is provably the correctly rounded quotient.  Base 2 is a bit reversal.
-__device__ __forceinline__ double vs_radical_inverse(uint64_t i, const vs_base B) {
-    if (B.ndig != 0) {
-        uint32_t j = (uint32_t)i;
-        if (B.b == 2) return (double)__brev(j) * (1.0 / 4294967296.0);
-        const double bd = (double)B.b;
-        double num = 0.0;
-        for (uint32_t t = 0; t < B.ndig; ++t) {
-            uint32_t q = vs_div_magic(j, B.magic, B.shift);
-            uint32_t d = j - q * B.b;
-            num = fma(num, bd, (double)d);
-            j = q;
-        }
-        double q0 = num * B.inv_den;
-        double r0 = fma(-q0, B.den, num);
-        double q1 = fma(r0, B.inv_den, q0);
-        double r1 = fma(-q1, B.den, num);
-        return fma(r1, B.inv_den, q1);
-    }
-    double num = 0.0, den = 1.0;
-    const double bd = (double)B.b;
-    while (i) {  // indices beyond 2^32: plain 64-bit digit loop and a true division
-        uint64_t q = i / B.b;
-        uint32_t d = (uint32_t)(i - q * B.b);
-        num = fma(num, bd, (double)d);
-        den = den * bd;
-        i = q;
-    }
-    return num / den;
-}
-
-// Two radical inverses in the same base with interleaved digit loops (two
-// independent dependency chains per step).  Fast path only (B.ndig != 0).
-__device__ __forceinline__ void vs_radical_inverse_pair(uint32_t i1, uint32_t i2, const vs_base B,
-                                                         double& x1, double& x2) {
-    if (B.b == 2) {
-        x1 = (double)__brev(i1) * (1.0 / 4294967296.0);
-        x2 = (double)__brev(i2) * (1.0 / 4294967296.0);
-        return;
-    }
-    // Digit steps entirely in fp64 (4 instructions per digit and point): with inv_b two ulps
-    // above 1/b, floor(j*inv_b) is the exact quotient for j < 2^32, b < 2^16 -- an exact multiple
-    // can no longer round below its integer, and the inflation (< 2^-17 absolute) is far smaller
-    // than the distance 1/b of any other quotient to the next integer.  The digit j - q*b and the
-    // numerator update are exact fmas on integers below 2^53.
-    const double bd = (double)B.b;
-    double n1 = 0.0, n2 = 0.0;
-    double j1 = (double)i1, j2 = (double)i2;
-    uint32_t t = B.ndig;
-    for (; t >= 2; t -= 2) {  // two digits per trip: no register rotation between steps
-        const double q1 = floor(j1 * B.inv_b);
-        const double q2 = floor(j2 * B.inv_b);
-        n1 = fma(n1, bd, fma(-q1, bd, j1));
-        n2 = fma(n2, bd, fma(-q2, bd, j2));
-        j1 = floor(q1 * B.inv_b);
-        j2 = floor(q2 * B.inv_b);
-        n1 = fma(n1, bd, fma(-j1, bd, q1));
-        n2 = fma(n2, bd, fma(-j2, bd, q2));
-    }
-    if (t) {
-        const double q1 = floor(j1 * B.inv_b);
-        const double q2 = floor(j2 * B.inv_b);
-        n1 = fma(n1, bd, fma(-q1, bd, j1));
-        n2 = fma(n2, bd, fma(-q2, bd, j2));
-    }
-    double a0 = n1 * B.inv_den, b0 = n2 * B.inv_den;
-    double ra = fma(-a0, B.den, n1), rb = fma(-b0, B.den, n2);
-    a0 = fma(ra, B.inv_den, a0);
-    b0 = fma(rb, B.inv_den, b0);
-    ra = fma(-a0, B.den, n1);
-    rb = fma(-b0, B.den, n2);
-    x1 = fma(ra, B.inv_den, a0);
-    x2 = fma(rb, B.inv_den, b0);
-}
-
-__device__ __forceinline__ double vs_sobol_point(uint64_t i, const uint32_t* __restrict__ dir) {
-    uint32_t g = (uint32_t)(i ^ (i >> 1));
-    uint32_t x = 0;
-#pragma unroll 8
-    for (int j = 0; j < 32; ++j) x ^= ((g >> j) & 1u) ? dir[j] : 0u;
-    return (double)x * (1.0 / 4294967296.0);
-}
-
-struct vs_design_dev {
-    int generator, k, scale_mode;
-    uint64_t n, first_index;
-    const double* lower;
-    const double* width;
-    const uint32_t* perm;
-    const double* raw;
-    const uint32_t* dirs;
-    const vs_base* bases;
-};
-
-// Unit-cube coordinate c of sequence row `seq_row` (0..2n-1: first half feeds
-// M_1, second half M_2 before the shuffle).
-__device__ __forceinline__ double vs_unit_point(const vs_design_dev& D, uint64_t seq_row, int c) {
-    if (D.generator == VS_GEN_HALTON) return vs_radical_inverse(D.first_index + seq_row, D.bases[c]);
-    if (D.generator == VS_GEN_SOBOL) return vs_sobol_point(D.first_index + seq_row, D.dirs + 32 * c);
-    return D.raw[seq_row * (uint64_t)D.k + c];
-}
-
-__device__ __forceinline__ double vs_apply_scale(const vs_design_dev& D, double p, int c) {
-    if (D.scale_mode == VS_SCALE_LINEAR) return p * D.width[c] + D.lower[c];   // scale.py:33
-    if (D.scale_mode == VS_SCALE_POWER) return D.lower[c] * pow(D.width[c], p); // scale.py:62
-    return p;
-}
-
-// M_1[r][c] / M_2[r][c] (M_2 after the shuffle)
-__device__ __forceinline__ double vs_m1(const vs_design_dev& D, uint64_t r, int c) {
-    return vs_apply_scale(D, vs_unit_point(D, r, c), c);
-}
-__device__ __forceinline__ double vs_m2(const vs_design_dev& D, uint64_t r, int c) {
-    uint64_t src = D.perm ? (uint64_t)D.perm[r] : r;
-    return vs_apply_scale(D, vs_unit_point(D, D.n + src, c), c);
-}
+#include "vs_device_gen.h"
 
 static vs_design_dev to_dev(const vs_design* g) {
     vs_design_dev D;
@@ -197,10 +54,6 @@ static std::vector<uint32_t> first_primes(int k) {
 static vs_base make_base(uint32_t b, uint64_t max_index) {
     vs_base B;
     B.b = b;
-    uint32_t L = 0;
-    while ((1ull << L) < b) ++L;  // ceil(log2 b), b >= 2 -> L >= 1
-    B.magic = (uint32_t)(((1ull << 32) * ((1ull << L) - b)) / b + 1);
-    B.shift = L - 1;
     B.ndig = 0;
     B.den = 1.0;
     B.inv_den = 1.0;
@@ -461,6 +314,7 @@ extern "C" int vs_objective_destroy(vs_context* ctx, vs_objective* obj) {
     if (!obj) return VS_OK;
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (obj->params) hipFree(obj->params);
+    vs_rtc_release(obj);
     delete obj;
     return VS_OK;
 }
@@ -505,6 +359,35 @@ extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, cons
     return VS_OK;
 }
 
+extern "C" int vs_objective_create_source(vs_context* ctx, int k, int l, const char* body, const double* params,
+                                          size_t nparams, vs_objective** out) {
+    VS_REQUIRE(ctx && out && body, "null argument");
+    *out = nullptr;
+    VS_REQUIRE(k >= 1 && l >= 1 && l <= 1024, "k and l must be positive (l <= 1024)");
+    VS_REQUIRE(nparams == 0 || params, "params is null");
+    vs_objective* o = new vs_objective();
+    o->kind = VS_OBJ_SOURCE;
+    o->k = k;
+    o->l = l;
+    o->nparams = nparams;
+    if (nparams) {
+        if (hipMalloc(&o->params, sizeof(double) * nparams) != hipSuccess ||
+            hipMemcpyAsync(o->params, params, sizeof(double) * nparams, hipMemcpyHostToDevice, ctx->stream) !=
+                hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            vs_objective_destroy(ctx, o);
+            return vs_fail(VS_ERR_HIP, "uploading objective parameters failed");
+        }
+    }
+    int rc = vs_rtc_build(ctx, o, body);
+    if (rc) {
+        vs_objective_destroy(ctx, o);
+        return rc;
+    }
+    *out = o;
+    return VS_OK;
+}
+
 // ---------------------------------------------------------------------------
 // the fused evaluation kernel
 // ---------------------------------------------------------------------------
@@ -529,24 +412,12 @@ extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, cons
 // Output index: f[(block*rows + (r-row_begin))*l + o].
 
 #if defined(VS_ABL_NOSTORE)   /* diagnostic build: keep the value live, never store */
+#undef VS_STORE
 #define VS_STORE(p, v) do { if ((v) == 1.2345e-300) *(p) = (v); } while (0)
-#elif !defined(VS_NO_NT_STORE)
-#define VS_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define VS_STORE(p, v) (*(p) = (v))
 #endif
-#define VS_EVAL_ROWS 64
-#define VS_EVAL_WAVES 4
 #define VS_CHAINS 8                                 // chains per thread and pass
 #define VS_PASS (VS_EVAL_WAVES * VS_CHAINS)         // blocks i handled per pass
 
-struct vs_eval_args {
-    vs_design_dev D;
-    int kind, l;
-    const double* params;
-    uint64_t row_begin, rows;
-    double* f;
-};
 
 template <int KIND>
 __device__ __forceinline__ double vs_term(double x, double p) {
@@ -820,6 +691,13 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
         case VS_OBJ_LINEAR: return launch_eval<VS_OBJ_LINEAR>(ctx, A, sep_tiles);
         case VS_OBJ_ISHIGAMI: return launch_eval<VS_OBJ_ISHIGAMI>(ctx, A, 2);
         case VS_OBJ_INVERT: return launch_eval<VS_OBJ_INVERT>(ctx, A, 2);
+        case VS_OBJ_SOURCE: {
+            const size_t lds = sizeof(double) * 2 * (size_t)design->d.k * VS_EVAL_ROWS;
+            VS_REQUIRE(lds <= 160 * 1024, "k=%d needs %zu bytes of LDS per 64 rows; the limit is 160 KiB", design->d.k, lds);
+            const uint64_t blocks = (row_count + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
+            VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
+            return vs_rtc_launch(ctx, obj, &A, sizeof(A), (unsigned)blocks, lds);
+        }
     }
     return vs_fail(VS_ERR_ARG, "unknown objective kind %d", obj->kind);
 }

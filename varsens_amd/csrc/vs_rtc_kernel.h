@@ -1,0 +1,55 @@
+// Kernel template compiled by hiprtc for a user objective (vs_objective_create_source).
+// Text-included after vs_device_gen.h and after the generated definition of
+//   #define VS_USER_L <outputs>
+//   __device__ void vs_user_objective(const vs_point& x, int k, const double* p, double* out) { <body> }
+// Same structure as eval_kernel: four waves share 64 design rows; phase 1 stages the scaled
+// coordinates of M_1[r], M_2[r] in LDS, phase 2 evaluates the 2k+2 points of the row, wave q
+// taking blocks q, q+4, ...  A point is a column select between the two LDS columns.
+
+extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_user_eval(vs_eval_args A) {
+    extern __shared__ double lds[];
+    const int T = VS_EVAL_ROWS;
+    const int k = A.D.k;
+    const int l = A.l;
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const vs_u64 rows = A.rows;
+    const vs_u64 lr = (vs_u64)blockIdx.x * T + lane;
+    const bool valid = lr < rows;
+    const vs_u64 r = A.row_begin + (valid ? lr : rows - 1);
+    double* X1 = lds + lane;
+    double* X2 = lds + (size_t)k * T + lane;
+    double* f = A.f + (vs_u64)blockIdx.x * T * l;
+    const vs_u32 lane_off = (vs_u32)lane * (vs_u32)l;
+
+    const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
+    const vs_u64 src2 = A.D.n + (A.D.perm ? (vs_u64)A.D.perm[r] : r);
+    for (int c = q; c < k; c += VS_EVAL_WAVES) {
+        double x1, x2;
+        if (halton_fast) {
+            vs_radical_inverse_pair((vs_u32)(A.D.first_index + r), (vs_u32)(A.D.first_index + src2), A.D.bases[c],
+                                    x1, x2);
+        } else {
+            x1 = vs_unit_point(A.D, r, c);
+            x2 = vs_unit_point(A.D, src2, c);
+        }
+        X1[(size_t)c * T] = vs_apply_scale(A.D, x1, c);
+        X2[(size_t)c * T] = vs_apply_scale(A.D, x2, c);
+    }
+    __syncthreads();
+
+    const int nblocks = 2 * k + 2;
+    for (int blk = q; blk < nblocks; blk += VS_EVAL_WAVES) {
+        vs_point x;
+        if (blk == 0) { x.a = X1; x.b = X1; x.swap = -1; }                    // M_1[r]
+        else if (blk == 1) { x.a = X2; x.b = X2; x.swap = -1; }               // M_2[r]
+        else if (blk < 2 + k) { x.a = X2; x.b = X1; x.swap = blk - 2; }       // N_j[i]: M_2, column i from M_1
+        else { x.a = X1; x.b = X2; x.swap = blk - 2 - k; }                    // N_nj[i]: M_1, column i from M_2
+        double out[VS_USER_L];
+        for (int o = 0; o < VS_USER_L; ++o) out[o] = 0.0;
+        vs_user_objective(x, k, A.params, out);
+        if (valid)
+            for (int o = 0; o < VS_USER_L; ++o)
+                VS_STORE(f + (vs_u64)blk * rows * l + (lane_off + (vs_u32)o), out[o]);
+    }
+}

@@ -88,3 +88,27 @@ class Invert(DeviceObjective):
 
     def outputs(self, k):
         return k
+
+
+class Expression(DeviceObjective):
+    """A user objective written as a HIP C++ body, compiled at run time (hiprtc) into the fused
+    generate->evaluate kernel -- the device counterpart of an arbitrary Python callable.
+
+    ``body`` sees ``x[c]`` (scaled coordinate c of the point), ``k``, ``p[...]`` (``params``) and
+    writes ``out[0..outputs)``::
+
+        Expression("out[0] = sin(x[0]) + p[0]*sin(x[1])*sin(x[1]) + p[1]*pow(x[2],4.0)*sin(x[0]);",
+                   params=[7.0, 0.1])
+    """
+    kind = _native.OBJ_SOURCE
+
+    def __init__(self, body, outputs=1, params=()):
+        self.body = str(body)
+        self._outputs = int(outputs)
+        self._params = numpy.asarray(params, dtype=numpy.float64).ravel()
+
+    def outputs(self, k):
+        return self._outputs
+
+    def params(self, k):
+        return self._params

@@ -295,7 +295,10 @@ class Objective(object):
         k = int(self.k)
         spec = self.objective_func
         self._l = int(spec.outputs(k))
-        handle = self._ctx.objective_create(spec.kind, k, self._l, spec.params(k))
+        if spec.kind == _native.OBJ_SOURCE:
+            handle = self._ctx.objective_create_source(k, self._l, spec.body, spec.params(k))
+        else:
+            handle = self._ctx.objective_create(spec.kind, k, self._l, spec.params(k))
         self._f = self._ctx.alloc(8 * 2 * (k + 1) * self._rows * self._l)
         self._ctx.eval(self.sample._design, handle, self._row_begin, self._rows, self._f)
         self._ctx.sync()
