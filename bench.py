@@ -118,14 +118,28 @@ def main():
     objective = ctx.objective_create(_native.OBJ_LINEAR, k, l, np.arange(1, k + 1, dtype=float))
     f = ctx.alloc(8 * N_local)
     nacc = _native.acc_len(k, l, world)
-    acc = ctx.alloc(8 * nacc)
-    out = ctx.alloc(8 * _native.first_order_len(k, l))
+    accs = [ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)]
+    outs = [ctx.alloc(8 * _native.first_order_len(k, l)) for _ in range(2)]
+    counter = [0]
 
     def step():
+        """eval + reduce on the main stream; the exchange and the finishing kernel of this pass go to
+        the auxiliary stream so that they run beside the NEXT pass's evaluation (records and result
+        buffers alternate; events order the two streams)."""
+        b = counter[0] & 1
+        counter[0] += 1
+        ctx.stream_select(0)
         ctx.eval(design, objective, begin, rows, f)
-        ctx.reduce_first_order(f, rows, k, l, acc, 0, rank, world)
-        comm.allreduce(acc, nacc)
-        ctx.finish_first_order(acc, n, k, l, out, world)
+        ctx.stream_wait_event(0, b)             # pass i-2 is done with record b
+        ctx.reduce_first_order(f, rows, k, l, accs[b], 0, rank, world)
+        ctx.event_record(2 + b, 0)
+        ctx.stream_wait_event(1, 2 + b)
+        ctx.stream_select(1)
+        comm.allreduce(accs[b], nacc)
+        ctx.finish_first_order(accs[b], n, k, l, outs[b], world)
+        ctx.event_record(b, 1)
+        ctx.stream_select(0)
+        return outs[b]
 
     for _ in range(args.warmup):
         step()
@@ -133,8 +147,9 @@ def main():
     group.barrier()
     ctx.profile_begin(8 * args.steps + 8)
     t0 = time.perf_counter()
+    out = None
     for _ in range(args.steps):
-        step()
+        out = step()
     ctx.sync()
     group.barrier()
     elapsed = time.perf_counter() - t0

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Accuracy profile of the first-order estimator on random Sobol g-functions, on the GPU.
+
+Restates the study behind the reference's only published numbers
+(varsens/profile/parameters.py:51-83, error-profile-dim*.csv): for a Halton design of n draws in k
+dimensions, draw b random models a_i ~ U(0,99), estimate S_i * var_y for each and record
+sum_i (V_i - S_i*var_y)^2.  Columns as in the reference's CSVs: n, mean, sd, lower CI, upper CI, max.
+
+    python examples/accuracy_profile.py --k 6 --b 30
+    python examples/accuracy_profile.py --k 24 --b 30 --nmax 1310720     # far beyond the reference's 20480
+
+Every model is evaluated and reduced on the device (fused generate->evaluate kernel, streaming
+reduction); the design is built once per n, as in the reference.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import varsens_amd as vs  # noqa: E402
+
+# mean column of varsens/profile/error-profile-dim6.csv (n -> published mean), for side-by-side reading
+PUBLISHED_DIM6 = {5: 5.98e-2, 80: 1.58e-4, 1280: 7.43e-7, 5120: 3.86e-8, 20480: 2.41e-9}
+
+
+def g_truth(a):
+    return 1.0 / (3.0 * (np.asarray(a) + 1.0) ** 2)
+
+
+def profile_row(k, n, b, rng):
+    s = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
+    errs = []
+    for _ in range(b):
+        a = rng.uniform(0.0, 99.0, size=k)
+        v = vs.Varsens(vs.objectives.GFunction(a), sample=s, verbose=False, second_order=False)
+        estimate = v.sens[:, 0] * v.var_y[0]
+        errs.append(float(np.sum((g_truth(a) - estimate) ** 2)))
+    errs = np.array(errs)
+    mu, sd = errs.mean(), errs.std()
+    half = 0.0
+    if b > 1:
+        from scipy.stats import t
+        half = sd / np.sqrt(b) * t.isf(0.025, b - 1)
+    return n, mu, sd, mu - half, mu + half, errs.max()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--k", type=int, default=6)
+    ap.add_argument("--b", type=int, default=30)
+    ap.add_argument("--nmax", type=int, default=20480)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.RandomState(args.seed)
+    n = 5
+    print("# k=%d b=%d  columns: n, mean, sd, lci, uci, max%s" %
+          (args.k, args.b, "   [published dim6 mean]" if args.k == 6 else ""))
+    while n <= args.nmax:
+        row = profile_row(args.k, n, args.b, rng)
+        extra = ""
+        if args.k == 6 and n in PUBLISHED_DIM6:
+            extra = "   [%.2e]" % PUBLISHED_DIM6[n]
+        print("%d,%.6e,%.6e,%.6e,%.6e,%.6e%s" % (row + (extra,)), flush=True)
+        n *= 2
+
+
+if __name__ == "__main__":
+    main()

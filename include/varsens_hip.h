@@ -66,7 +66,16 @@ typedef struct vs_device_info {
 int vs_context_create(int device, vs_context** out);
 int vs_context_destroy(vs_context* ctx);
 int vs_context_info(vs_context* ctx, vs_device_info* out);
-int vs_sync(vs_context* ctx);
+int vs_sync(vs_context* ctx);   /* waits for both streams */
+
+/* A context owns two HIP streams: 0 = main (default), 1 = auxiliary.  vs_stream_select routes
+ * every following launch / collective of this context to that stream; vs_event_record marks a
+ * point on a stream (8 slots), vs_stream_wait_event makes a stream wait for a marked point (a
+ * never-recorded slot is a no-op).  Used to run the exchange + finishing of pass i beside the
+ * evaluation of pass i+1. */
+int vs_stream_select(vs_context* ctx, int which);
+int vs_event_record(vs_context* ctx, int slot, int which);
+int vs_stream_wait_event(vs_context* ctx, int which, int slot);
 
 int vs_alloc(vs_context* ctx, size_t bytes, void** dptr);
 int vs_free(vs_context* ctx, void* dptr);

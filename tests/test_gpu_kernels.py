@@ -349,3 +349,30 @@ def test_second_order_nan_trim(ctx):
     np.testing.assert_allclose(G[2], C @ C.T, rtol=1e-12)
     ctx.reduce_second_order(f, rows, k, 1, gram)      # without the flag NaNs propagate
     assert np.isnan(ctx.download(gram, (3, k, k))).any()
+
+
+def test_two_stream_pipeline_matches_serial(ctx):
+    """Exchange/finish of pass i on the auxiliary stream beside pass i+1 on the main stream (bench.py's
+    schedule) gives the results of the serial schedule."""
+    from varsens_amd import _native
+    rng = np.random.RandomState(21)
+    k, rows = 8, 40000
+    data = [1.0 + rng.rand(2 * k + 2, rows, 1) for _ in range(4)]
+    serial = [reduce_dev(ctx, d, rows)[1] for d in data]
+    bufs = [ctx.upload(d) for d in data]
+    accs = [ctx.alloc(8 * _native.acc_len(k, 1, 1)) for _ in range(2)]
+    outs = [ctx.alloc(8 * _native.first_order_len(k, 1)) for _ in range(4)]
+    for i, f in enumerate(bufs):
+        b = i & 1
+        ctx.stream_select(0)
+        ctx.stream_wait_event(0, b)
+        ctx.reduce_first_order(f, rows, k, 1, accs[b])
+        ctx.event_record(2 + b, 0)
+        ctx.stream_wait_event(1, 2 + b)
+        ctx.stream_select(1)
+        ctx.finish_first_order(accs[b], rows, k, 1, outs[i])
+        ctx.event_record(b, 1)
+        ctx.stream_select(0)
+    ctx.sync()
+    for i in range(4):
+        same(ctx.download(outs[i], (2 + 4 * k, 1)), serial[i])

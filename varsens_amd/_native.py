@@ -74,6 +74,9 @@ SIGNATURES = {
     "vs_context_destroy": (C.c_int, [C.c_void_p]),
     "vs_context_info": (C.c_int, [C.c_void_p, C.POINTER(DeviceInfo)]),
     "vs_sync": (C.c_int, [C.c_void_p]),
+    "vs_stream_select": (C.c_int, [C.c_void_p, C.c_int]),
+    "vs_event_record": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "vs_stream_wait_event": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "vs_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vs_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vs_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -206,6 +209,15 @@ class Context(object):
 
     def sync(self):
         _check(self.lib.vs_sync(self.handle))
+
+    def stream_select(self, which):
+        _check(self.lib.vs_stream_select(self.handle, int(which)))
+
+    def event_record(self, slot, stream):
+        _check(self.lib.vs_event_record(self.handle, int(slot), int(stream)))
+
+    def stream_wait_event(self, stream, slot):
+        _check(self.lib.vs_stream_wait_event(self.handle, int(stream), int(slot)))
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

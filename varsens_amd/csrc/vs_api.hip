@@ -49,10 +49,17 @@ extern "C" int vs_context_create(int device, vs_context** out) {
         delete ctx;
         return vs_fail(VS_ERR_NODEVICE, "device %d is %s; this library holds gfx950 code only", device, arch);
     }
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ctx->streams[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->streams[1], hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return vs_fail(VS_ERR_HIP, "hipStreamCreate failed");
     }
+    ctx->stream = ctx->streams[0];
+    for (int i = 0; i < 8; ++i)
+        if (hipEventCreateWithFlags(&ctx->events[i], hipEventDisableTiming) != hipSuccess) {
+            delete ctx;
+            return vs_fail(VS_ERR_HIP, "hipEventCreate failed");
+        }
     if (hipMalloc(&ctx->counters, 64 * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc(&ctx->counters_host, 64 * sizeof(uint32_t)) != hipSuccess) {
         delete ctx;
@@ -66,7 +73,10 @@ extern "C" int vs_context_destroy(vs_context* ctx) {
     if (!ctx) return VS_OK;
     hipSetDevice(ctx->device);
     if (ctx->comm) vs_comm_destroy(ctx);
-    hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->streams[0]);
+    hipStreamSynchronize(ctx->streams[1]);
+    for (int i = 0; i < 8; ++i)
+        if (ctx->events[i]) hipEventDestroy(ctx->events[i]);
     for (auto& s : ctx->prof_pool) {
         hipEventDestroy(s.start);
         hipEventDestroy(s.stop);
@@ -75,7 +85,8 @@ extern "C" int vs_context_destroy(vs_context* ctx) {
     if (ctx->keep) hipFree(ctx->keep);
     if (ctx->counters) hipFree(ctx->counters);
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
-    hipStreamDestroy(ctx->stream);
+    hipStreamDestroy(ctx->streams[0]);
+    hipStreamDestroy(ctx->streams[1]);
     delete ctx;
     return VS_OK;
 }
@@ -95,7 +106,28 @@ extern "C" int vs_context_info(vs_context* ctx, vs_device_info* out) {
 
 extern "C" int vs_sync(vs_context* ctx) {
     VS_REQUIRE(ctx, "ctx is null");
-    VS_HIP(hipStreamSynchronize(ctx->stream));
+    VS_HIP(hipStreamSynchronize(ctx->streams[0]));
+    VS_HIP(hipStreamSynchronize(ctx->streams[1]));
+    return VS_OK;
+}
+
+extern "C" int vs_stream_select(vs_context* ctx, int which) {
+    VS_REQUIRE(ctx && (which == 0 || which == 1), "stream must be 0 (main) or 1 (auxiliary)");
+    ctx->stream = ctx->streams[which];
+    return VS_OK;
+}
+
+extern "C" int vs_event_record(vs_context* ctx, int slot, int which) {
+    VS_REQUIRE(ctx && slot >= 0 && slot < 8 && (which == 0 || which == 1), "bad slot or stream");
+    VS_HIP(hipEventRecord(ctx->events[slot], ctx->streams[which]));
+    ctx->event_set[slot] = true;
+    return VS_OK;
+}
+
+extern "C" int vs_stream_wait_event(vs_context* ctx, int which, int slot) {
+    VS_REQUIRE(ctx && slot >= 0 && slot < 8 && (which == 0 || which == 1), "bad slot or stream");
+    if (!ctx->event_set[slot]) return VS_OK;  // nothing recorded yet: nothing to wait for
+    VS_HIP(hipStreamWaitEvent(ctx->streams[which], ctx->events[slot], 0));
     return VS_OK;
 }
 
@@ -111,7 +143,8 @@ extern "C" int vs_alloc(vs_context* ctx, size_t bytes, void** dptr) {
 extern "C" int vs_free(vs_context* ctx, void* dptr) {
     VS_REQUIRE(ctx, "ctx is null");
     if (!dptr) return VS_OK;
-    VS_HIP(hipStreamSynchronize(ctx->stream));
+    VS_HIP(hipStreamSynchronize(ctx->streams[0]));
+    VS_HIP(hipStreamSynchronize(ctx->streams[1]));
     VS_HIP(hipFree(dptr));
     return VS_OK;
 }
@@ -185,7 +218,8 @@ extern "C" int vs_profile_begin(vs_context* ctx, int capacity) {
 extern "C" int vs_profile_end(vs_context* ctx, vs_profile_record* out, int capacity, int* count) {
     VS_REQUIRE(ctx && count, "null argument");
     ctx->profiling = false;
-    VS_HIP(hipStreamSynchronize(ctx->stream));
+    VS_HIP(hipStreamSynchronize(ctx->streams[0]));
+    VS_HIP(hipStreamSynchronize(ctx->streams[1]));
     int n = 0;
     for (auto& s : ctx->prof) {
         if (n >= capacity || !out) break;

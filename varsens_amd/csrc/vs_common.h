@@ -18,7 +18,10 @@ struct vs_prof_slot {
 
 struct vs_context {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream launches currently go to (streams[selected])
+    hipStream_t streams[2] = {nullptr, nullptr};  // 0 = main, 1 = auxiliary (exchange / finishing)
+    hipEvent_t events[8] = {};         // cross-stream ordering slots (vs_event_record / vs_stream_wait_event)
+    bool event_set[8] = {};
     hipDeviceProp_t prop;
     // partial-sum workspace of the reductions (grown on demand, never shrunk)
     double* partials = nullptr;
