@@ -97,8 +97,11 @@ def oracle_blocks(F):
     return np.concatenate([fM_1[None], fM_2[None], fN_j, fN_nj], axis=0)
 
 
-@pytest.mark.parametrize("k,n,l", [(6, 1024, 1), (6, 1024, 2), (1, 7, 1), (33, 300, 1), (70, 129, 1)])
+@pytest.mark.parametrize("k,n,l", [(6, 1024, 1), (6, 1024, 2), (1, 7, 1), (33, 300, 1), (70, 129, 1),
+                                   (197, 700, 1), (100, 200, 2), (300, 70, 1)])
 def test_eval_gfunction_bit_exact(ctx, k, n, l):
+    """k = 197 (the reference's accuracy study), 300, and k = 100 with two outputs exceed the LDS tile:
+    they run with the tile in an HBM scratch slice (persistent workgroups)."""
     from varsens_amd import _native
     rng = np.random.RandomState(k)
     a = np.array(A6, dtype=float) if k == 6 else rng.rand(k) * 10
@@ -108,6 +111,22 @@ def test_eval_gfunction_bit_exact(ctx, k, n, l):
     S = orc.build_sample(k, n)
     F = orc.evaluate_rows(lambda X: np.stack([orc.g_function_rows(X, A[o]) for o in range(l)], axis=-1), *S)
     same(got, oracle_blocks(F))
+
+
+def test_eval_scratch_tile_path_forced(ctx, monkeypatch):
+    """The HBM-scratch tile variant on a size that also fits LDS: identical bits, several blocks per workgroup."""
+    from varsens_amd import _native
+    k, n = 12, 300000
+    a = np.linspace(0.1, 9.0, k)
+    d = make_design(ctx, k, n)
+    _, want = eval_dev(ctx, d, _native.OBJ_G_FUNCTION, k, 1, a, n)
+    monkeypatch.setenv("VS_EVAL_SCRATCH", "1")
+    _, got = eval_dev(ctx, d, _native.OBJ_G_FUNCTION, k, 1, a, n)
+    same(got, want)
+    _, got = eval_dev(ctx, d, _native.OBJ_INVERT, k, k, None, 5000)
+    monkeypatch.delenv("VS_EVAL_SCRATCH")
+    _, want = eval_dev(ctx, d, _native.OBJ_INVERT, k, k, None, 5000)
+    same(got, want)
 
 
 def test_eval_linear_polynomial_bit_exact(ctx):

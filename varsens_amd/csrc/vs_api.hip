@@ -83,6 +83,7 @@ extern "C" int vs_context_destroy(vs_context* ctx) {
     }
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->keep) hipFree(ctx->keep);
+    if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->counters) hipFree(ctx->counters);
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
     hipStreamDestroy(ctx->streams[0]);
@@ -195,6 +196,20 @@ int vs_workspace_keep(vs_context* ctx, size_t bytes) {
     }
     VS_HIP(hipMalloc(&ctx->keep, bytes));
     ctx->keep_bytes = bytes;
+    return VS_OK;
+}
+
+int vs_workspace_scratch(vs_context* ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return VS_OK;
+    if (ctx->scratch) {
+        VS_HIP(hipStreamSynchronize(ctx->streams[0]));
+        VS_HIP(hipStreamSynchronize(ctx->streams[1]));
+        VS_HIP(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    VS_HIP(hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
     return VS_OK;
 }
 

@@ -26,6 +26,9 @@ struct vs_context {
     // partial-sum workspace of the reductions (grown on demand, never shrunk)
     double* partials = nullptr;
     size_t partials_bytes = 0;
+    // HBM tile scratch of the evaluation kernel for k beyond the LDS budget
+    double* scratch = nullptr;
+    size_t scratch_bytes = 0;
     // NaN-trim keep mask workspace (one byte per row)
     uint8_t* keep = nullptr;
     size_t keep_bytes = 0;
@@ -91,6 +94,7 @@ struct vs_launch_scope {
 
 int vs_workspace_partials(vs_context* ctx, size_t bytes);
 int vs_workspace_keep(vs_context* ctx, size_t bytes);
+int vs_workspace_scratch(vs_context* ctx, size_t bytes);
 
 // ---- device helpers -------------------------------------------------------
 #ifdef __HIPCC__

@@ -431,18 +431,30 @@ __device__ __forceinline__ double vs_fold(double acc, double t) {
     return KIND == VS_OBJ_LINEAR ? acc + t : acc * t;
 }
 
+// Tile reads.  The coordinate / term tile normally lives in LDS.  For k too large for LDS it
+// lives in a per-workgroup slice of an HBM scratch buffer that a persistent workgroup rewrites
+// for every 64-row block; those reads must not be served from this CU's L1 (it may still hold
+// the previous block's lines), so they are agent-scope relaxed loads (L2), ordered behind the
+// writers' stores by the workgroup barrier (which drains vmcnt).
+template <bool SCRATCH>
+__device__ __forceinline__ double vs_tile_ld(const double* p) {
+    if (SCRATCH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
 // One full pass (32 consecutive columns i0..i0+31) of the chain scheme for wave Q.
 // Chain m of this wave is block i0+Q+4m; at relative column j the chains with
 // Q+4m < j are running and the one with Q+4m == j starts from the prefixes.
 // Everything about the schedule is a compile-time constant, so the 16 chain
 // values stay in fixed registers.
-template <int KIND, int Q>
+template <int KIND, int Q, bool SCRATCH>
 __device__ __forceinline__ void vs_chain_pass(const double* F1, const double* F2, int i0, double& pa, double& pb,
                                               double (&cj)[VS_CHAINS], double (&dj)[VS_CHAINS]) {
     constexpr int T = VS_EVAL_ROWS;
 #pragma unroll
     for (int j = 0; j < VS_PASS; ++j) {
-        const double ta = F1[(size_t)(i0 + j) * T], tb = F2[(size_t)(i0 + j) * T];
+        const double ta = vs_tile_ld<SCRATCH>(F1 + (size_t)(i0 + j) * T);
+        const double tb = vs_tile_ld<SCRATCH>(F2 + (size_t)(i0 + j) * T);
 #pragma unroll
         for (int m = 0; m < VS_CHAINS; ++m) {
             if (Q + VS_EVAL_WAVES * m < j) {
@@ -458,24 +470,32 @@ __device__ __forceinline__ void vs_chain_pass(const double* F1, const double* F2
     }
 }
 
-template <int KIND>
-__global__ void __launch_bounds__(VS_EVAL_ROWS * VS_EVAL_WAVES)
-eval_kernel(vs_eval_args A) {
-    extern __shared__ double lds[];
+#ifndef VS_EVAL_MIN_WAVES
+#define VS_EVAL_MIN_WAVES 1
+#endif
+template <int KIND, bool SCRATCH>
+__global__ void __launch_bounds__(VS_EVAL_ROWS * VS_EVAL_WAVES, VS_EVAL_MIN_WAVES)
+eval_kernel(vs_eval_args A, double* scratch, int tiles) {
+    extern __shared__ double lds_tile[];
     constexpr int T = VS_EVAL_ROWS;
+#define TL(p) vs_tile_ld<SCRATCH>(p)
     constexpr bool SEPARABLE = KIND == VS_OBJ_G_FUNCTION || KIND == VS_OBJ_POLYNOMIAL || KIND == VS_OBJ_LINEAR;
     const int k = A.D.k;
     const int l = A.l;
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index, provably uniform
     const uint64_t rows = A.rows;
-    const uint64_t lr = (uint64_t)blockIdx.x * T + lane;
+    double* lds = SCRATCH ? scratch + (size_t)blockIdx.x * tiles * k * T : lds_tile;
+    const uint64_t nblocks = (rows + T - 1) / T;
+    // one 64-row block per workgroup (LDS tile) or a persistent walk over blocks (scratch tile)
+    for (uint64_t rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+    const uint64_t lr = rb * T + lane;
     const bool valid = lr < rows;
     const uint64_t r = A.row_begin + (valid ? lr : rows - 1);  // clamp: loads stay in range, stores are guarded
     double* X1 = lds + lane;                  // X1[c*T]
     double* X2 = lds + (size_t)k * T + lane;  // X2[c*T]
     // block bases are wave-uniform; the lane's place inside a block fits 32 bits (checked on the host)
-    double* f = A.f + (uint64_t)blockIdx.x * T * l;
+    double* f = A.f + rb * T * l;
     const uint32_t lane_off = (uint32_t)lane * (uint32_t)l;
 #define VS_OUT(block, o, v)                                               \
     do {                                                                  \
@@ -526,8 +546,8 @@ eval_kernel(vs_eval_args A) {
                 __syncthreads();  // previous output's chains are done with F1/F2
                 const double* p = A.params + (size_t)o * k;
                 for (int c = q; c < k; c += VS_EVAL_WAVES) {
-                    F1[(size_t)c * T] = vs_term<KIND>(X1[(size_t)c * T], p[c]);
-                    F2[(size_t)c * T] = vs_term<KIND>(X2[(size_t)c * T], p[c]);
+                    F1[(size_t)c * T] = vs_term<KIND>(TL(X1 + (size_t)c * T), p[c]);
+                    F2[(size_t)c * T] = vs_term<KIND>(TL(X2 + (size_t)c * T), p[c]);
                 }
                 __syncthreads();
             }
@@ -541,22 +561,22 @@ eval_kernel(vs_eval_args A) {
                 int c = i0;
                 if (cend - i0 == VS_PASS) {
                     switch (q) {  // wave-uniform
-                        case 0: vs_chain_pass<KIND, 0>(F1, F2, i0, pa, pb, cj, dj); break;
-                        case 1: vs_chain_pass<KIND, 1>(F1, F2, i0, pa, pb, cj, dj); break;
-                        case 2: vs_chain_pass<KIND, 2>(F1, F2, i0, pa, pb, cj, dj); break;
-                        default: vs_chain_pass<KIND, 3>(F1, F2, i0, pa, pb, cj, dj); break;
+                        case 0: vs_chain_pass<KIND, 0, SCRATCH>(F1, F2, i0, pa, pb, cj, dj); break;
+                        case 1: vs_chain_pass<KIND, 1, SCRATCH>(F1, F2, i0, pa, pb, cj, dj); break;
+                        case 2: vs_chain_pass<KIND, 2, SCRATCH>(F1, F2, i0, pa, pb, cj, dj); break;
+                        default: vs_chain_pass<KIND, 3, SCRATCH>(F1, F2, i0, pa, pb, cj, dj); break;
                     }
                     c = cend;
                 } else {
                     // partial pass (k not a multiple of 32): same schedule with run-time bounds
                     for (const int stop = min(cend, i0 + q); c < stop; ++c) {
-                        pa = vs_fold<KIND>(pa, F1[(size_t)c * T]);
-                        pb = vs_fold<KIND>(pb, F2[(size_t)c * T]);
+                        pa = vs_fold<KIND>(pa, TL(F1 + (size_t)c * T));
+                        pb = vs_fold<KIND>(pb, TL(F2 + (size_t)c * T));
                     }
 #pragma unroll
                     for (int m = 0; m < VS_CHAINS; ++m) {
                         if (c < cend) {
-                            const double ta = F1[(size_t)c * T], tb = F2[(size_t)c * T];
+                            const double ta = TL(F1 + (size_t)c * T), tb = TL(F2 + (size_t)c * T);
 #pragma unroll
                             for (int mm = 0; mm < m; ++mm) {
                                 cj[mm] = vs_fold<KIND>(cj[mm], tb);
@@ -570,7 +590,7 @@ eval_kernel(vs_eval_args A) {
 #pragma unroll
                             for (int s = 1; s < VS_EVAL_WAVES; ++s) {
                                 if (c < cend) {
-                                    const double ua = F1[(size_t)c * T], ub = F2[(size_t)c * T];
+                                    const double ua = TL(F1 + (size_t)c * T), ub = TL(F2 + (size_t)c * T);
 #pragma unroll
                                     for (int mm = 0; mm <= m; ++mm) {
                                         cj[mm] = vs_fold<KIND>(cj[mm], ub);
@@ -586,7 +606,7 @@ eval_kernel(vs_eval_args A) {
                 }
                 // columns of later passes: every chain of this pass runs on to the last column
                 for (; c < k; ++c) {
-                    const double ta = F1[(size_t)c * T], tb = F2[(size_t)c * T];
+                    const double ta = TL(F1 + (size_t)c * T), tb = TL(F2 + (size_t)c * T);
 #pragma unroll
                     for (int m = 0; m < VS_CHAINS; ++m) {
                         cj[m] = vs_fold<KIND>(cj[m], tb);
@@ -611,11 +631,11 @@ eval_kernel(vs_eval_args A) {
         if (q == 0) {
             const double a = A.params[0], b = A.params[1];
             double s[2][2], p4[2];  // [which sample][coordinate]
-            s[0][0] = sin(X1[0]);
-            s[1][0] = sin(X2[0]);
-            s[0][1] = sin(X1[(size_t)T]);
-            s[1][1] = sin(X2[(size_t)T]);
-            const double x3a = X1[2 * (size_t)T], x3b = X2[2 * (size_t)T];
+            s[0][0] = sin(TL(X1));
+            s[1][0] = sin(TL(X2));
+            s[0][1] = sin(TL(X1 + (size_t)T));
+            s[1][1] = sin(TL(X2 + (size_t)T));
+            const double x3a = TL(X1 + 2 * (size_t)T), x3b = TL(X2 + 2 * (size_t)T);
             p4[0] = (x3a * x3a) * (x3a * x3a);
             p4[1] = (x3b * x3b) * (x3b * x3b);
             // value with coordinate c taken from sample u_c in {0 = M_1, 1 = M_2}
@@ -634,7 +654,7 @@ eval_kernel(vs_eval_args A) {
         }
     } else if (KIND == VS_OBJ_INVERT) {
         for (int o = q; o < k; o += VS_EVAL_WAVES) {
-            const double ia = 1.0 - X1[(size_t)o * T], ib = 1.0 - X2[(size_t)o * T];
+            const double ia = 1.0 - TL(X1 + (size_t)o * T), ib = 1.0 - TL(X2 + (size_t)o * T);
             VS_OUT(0, o, ia);
             VS_OUT(1, o, ib);
             for (int i = 0; i < k; ++i) {
@@ -643,25 +663,38 @@ eval_kernel(vs_eval_args A) {
             }
         }
     }
+    if (!SCRATCH) break;  // LDS tile: exactly one block per workgroup (no loop in the generated code)
+    __syncthreads();      // scratch tile: it is rewritten by the next block
+    }
 #undef VS_OUT
+#undef TL
 }
 
 template <int KIND>
 static int launch_eval(vs_context* ctx, const vs_eval_args& A, int tiles) {
     const int k = A.D.k;
     const size_t lds = sizeof(double) * (size_t)tiles * k * VS_EVAL_ROWS;
-    VS_REQUIRE(lds <= 160 * 1024, "k=%d with %d output(s) needs %zu bytes of LDS per 64 rows; the limit is 160 KiB",
-               k, A.l, lds);
-    if (lds > 64 * 1024)
-        VS_HIP(hipFuncSetAttribute((const void*)eval_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
     VS_REQUIRE((uint64_t)VS_EVAL_ROWS * A.l < (1ull << 31), "too many outputs per evaluation");
-    {
+    const char* force = getenv("VS_EVAL_SCRATCH");
+    if (lds <= 160 * 1024 && !(force && *force == '1')) {
+        if (lds > 64 * 1024)
+            VS_HIP(hipFuncSetAttribute((const void*)eval_kernel<KIND, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         vs_launch_scope scope(ctx, VS_KERNEL_EVAL);
-        hipLaunchKernelGGL(eval_kernel<KIND>, dim3((unsigned)blocks), dim3(VS_EVAL_ROWS * VS_EVAL_WAVES), lds,
-                           ctx->stream, A);
+        hipLaunchKernelGGL((eval_kernel<KIND, false>), dim3((unsigned)blocks), dim3(VS_EVAL_ROWS * VS_EVAL_WAVES), lds,
+                           ctx->stream, A, (double*)nullptr, tiles);
+    } else {
+        // the tile of one workgroup does not fit LDS: persistent workgroups, tile in an HBM scratch slice
+        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        uint64_t slots = (uint64_t)cus * 4;
+        if (slots > blocks) slots = blocks;
+        int rc = vs_workspace_scratch(ctx, (size_t)slots * lds);
+        if (rc) return rc;
+        vs_launch_scope scope(ctx, VS_KERNEL_EVAL);
+        hipLaunchKernelGGL((eval_kernel<KIND, true>), dim3((unsigned)slots), dim3(VS_EVAL_ROWS * VS_EVAL_WAVES), 0,
+                           ctx->stream, A, ctx->scratch, tiles);
     }
     VS_HIP(hipGetLastError());
     return VS_OK;
