@@ -64,6 +64,16 @@ def test_expression_two_outputs_and_large_k(vs):
     assert v.sens.shape == (k, 2) and v.sens_2.shape == (k, 2, k, 2)
 
 
+def test_expression_beyond_lds_budget(vs):
+    """k = 200: the coordinate tile of a 64-row block is 200 KiB, so the compiled kernel keeps it in HBM scratch."""
+    k, n = 200, 150
+    a = np.linspace(0.0, 50.0, k)
+    s = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
+    o1 = vs.Objective(k, n, s, vs.objectives.GFunction(a), verbose=False)
+    o2 = vs.Objective(k, n, s, vs.objectives.Expression(G_BODY, params=a), verbose=False)
+    assert np.array_equal(o1.flat(), o2.flat())
+
+
 def test_expression_compile_error_is_reported(vs):
     from varsens_amd._native import VarsensHipError
     s = vs.Sample(3, 8, vs.scale.Identity(), verbose=False)

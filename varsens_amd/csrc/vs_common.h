@@ -63,11 +63,13 @@ struct vs_objective {
     size_t nparams = 0;
     void* module = nullptr;    // hipModule_t of a run-time compiled objective
     void* function = nullptr;  // hipFunction_t (vs_user_eval)
+    bool scratch_tile = false; // compiled for the HBM scratch tile (k beyond the LDS budget)
 };
 
 int vs_rtc_build(vs_context* ctx, vs_objective* o, const char* body);
 void vs_rtc_release(vs_objective* o);
-int vs_rtc_launch(vs_context* ctx, const vs_objective* o, void* args, size_t args_bytes, unsigned blocks, size_t lds);
+int vs_rtc_launch(vs_context* ctx, const vs_objective* o, const void* eval_args, size_t eval_args_bytes,
+                  unsigned blocks, size_t lds);
 
 int vs_fail(int code, const char* fmt, ...);
 

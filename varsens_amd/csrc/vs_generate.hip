@@ -726,7 +726,6 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
         case VS_OBJ_INVERT: return launch_eval<VS_OBJ_INVERT>(ctx, A, 2);
         case VS_OBJ_SOURCE: {
             const size_t lds = sizeof(double) * 2 * (size_t)design->d.k * VS_EVAL_ROWS;
-            VS_REQUIRE(lds <= 160 * 1024, "k=%d needs %zu bytes of LDS per 64 rows; the limit is 160 KiB", design->d.k, lds);
             const uint64_t blocks = (row_count + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
             VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
             return vs_rtc_launch(ctx, obj, &A, sizeof(A), (unsigned)blocks, lds);

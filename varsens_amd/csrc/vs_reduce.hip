@@ -331,11 +331,20 @@ fold_first_kernel(vs_fold_args A, double* folded /* [l*plen] scratch */) {
     const size_t col = (size_t)blockIdx.x * VS_FOLD_COLS + lane;
     double s = 0.0, comp = 0.0;
     if (col < width) {
-        for (uint32_t p = wave; p < A.P; p += VS_FOLD_THREADS / 64) {
-            const double x = A.partials[(size_t)p * width + col];
-            const double t = s + x;  // Neumaier compensated sum
-            comp += (fabs(s) >= fabs(x)) ? (s - t) + x : (x - t) + s;
-            s = t;
+        constexpr uint32_t STEP = VS_FOLD_THREADS / 64, BATCH = 8;
+        for (uint32_t p0 = wave; p0 < A.P; p0 += STEP * BATCH) {
+            double x[BATCH];  // issue the loads of a batch together: the fold is latency-, not bandwidth-bound
+#pragma unroll
+            for (uint32_t i = 0; i < BATCH; ++i) {
+                const uint32_t p = p0 + i * STEP;
+                x[i] = p < A.P ? A.partials[(size_t)p * width + col] : 0.0;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < BATCH; ++i) {
+                const double t = s + x[i];  // Neumaier compensated sum
+                comp += (fabs(s) >= fabs(x[i])) ? (s - t) + x[i] : (x[i] - t) + s;
+                s = t;
+            }
         }
     }
     s_sum[wave][lane] = s;

@@ -6,20 +6,26 @@
 // coordinates of M_1[r], M_2[r] in LDS, phase 2 evaluates the 2k+2 points of the row, wave q
 // taking blocks q, q+4, ...  A point is a column select between the two LDS columns.
 
-extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_user_eval(vs_eval_args A) {
-    extern __shared__ double lds[];
+// VS_USER_SCRATCH = 1: the tile does not fit LDS; it lives in a per-workgroup slice of an HBM
+// scratch buffer, workgroups are persistent and tile reads are L2-scoped (see vs_tile_ld in
+// vs_generate.hip).
+extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_user_eval(vs_eval_args A, double* scratch) {
+    extern __shared__ double lds_tile[];
     const int T = VS_EVAL_ROWS;
     const int k = A.D.k;
     const int l = A.l;
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const vs_u64 rows = A.rows;
-    const vs_u64 lr = (vs_u64)blockIdx.x * T + lane;
+    double* lds = VS_USER_SCRATCH ? scratch + (size_t)blockIdx.x * 2 * k * T : lds_tile;
+    const vs_u64 nblocks = (rows + T - 1) / T;
+    for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+    const vs_u64 lr = rb * T + lane;
     const bool valid = lr < rows;
     const vs_u64 r = A.row_begin + (valid ? lr : rows - 1);
     double* X1 = lds + lane;
     double* X2 = lds + (size_t)k * T + lane;
-    double* f = A.f + (vs_u64)blockIdx.x * T * l;
+    double* f = A.f + rb * T * l;
     const vs_u32 lane_off = (vs_u32)lane * (vs_u32)l;
 
     const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
@@ -51,5 +57,8 @@ extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_use
         if (valid)
             for (int o = 0; o < VS_USER_L; ++o)
                 VS_STORE(f + (vs_u64)blk * rows * l + (lane_off + (vs_u32)o), out[o]);
+    }
+    if (!VS_USER_SCRATCH) break;
+    __syncthreads();
     }
 }

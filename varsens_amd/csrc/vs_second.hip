@@ -234,11 +234,20 @@ gram_fold_kernel(vs_gram_fold_args A) {
     const bool live = !(SI == SJ && (lj / 16) < (li / 16)) && gi < 2 * K && gj < 2 * K;
     double s = 0.0, comp = 0.0;
     if (live) {
-        for (uint32_t p = wave; p < A.P; p += VS2_FOLD_THREADS / 64) {
-            const double x = A.partials[(size_t)p * width + col];
-            const double t = s + x;
-            comp += (fabs(s) >= fabs(x)) ? (s - t) + x : (x - t) + s;
-            s = t;
+        constexpr uint32_t STEP = VS2_FOLD_THREADS / 64, BATCH = 8;
+        for (uint32_t p0 = wave; p0 < A.P; p0 += STEP * BATCH) {
+            double x[BATCH];
+#pragma unroll
+            for (uint32_t i = 0; i < BATCH; ++i) {
+                const uint32_t p = p0 + i * STEP;
+                x[i] = p < A.P ? A.partials[(size_t)p * width + col] : 0.0;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < BATCH; ++i) {
+                const double t = s + x[i];
+                comp += (fabs(s) >= fabs(x[i])) ? (s - t) + x[i] : (x[i] - t) + s;
+                s = t;
+            }
         }
     }
     s_sum[wave][lane] = s;
