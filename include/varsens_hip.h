@@ -188,11 +188,16 @@ int vs_objective_destroy(vs_context* ctx, vs_objective* obj);
 int vs_objective_create_source(vs_context* ctx, int k, int l, const char* body, const double* params,
                                size_t nparams, vs_objective** out);
 
-/* Replaces the four evaluation loops of Objective.__init__ (saltelli.py:329-355)
- * for design rows [row_begin, row_begin+row_count) (a shard of r in [0,n)).
- * Output: f_dev[(block*row_count + (r-row_begin))*l + o], block order
- * [fM_1, fM_2, fN_j[0..k), fN_nj[0..k)] -- Objective.flat() of the shard
- * (saltelli.py:357-391); 2(k+1)*row_count*l doubles. */
+/* F-VALUE LAYOUT on the device ("planar"): one plane per output o, each plane the
+ * shard's Objective.flat() order (saltelli.py:357-391) for that output:
+ *     f_dev[(o*(2k+2) + block)*rows + r],  block order [fM_1, fM_2, fN_j[0..k), fN_nj[0..k)]
+ * i.e. the reference's (2(k+1)*rows, l) array transposed to (l, 2(k+1)*rows).  For l = 1 the two
+ * coincide.  Every block of every output is one contiguous stream, so all kernels run at the
+ * l = 1 speed for any l.  Host code holding reference-order values transposes before vs_upload.
+ *
+ * vs_eval replaces the four evaluation loops of Objective.__init__ (saltelli.py:329-355)
+ * for design rows [row_begin, row_begin+row_count) (a shard of r in [0,n)) and writes
+ * 2(k+1)*row_count*l doubles in that layout. */
 int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,
             uint64_t row_begin, uint64_t row_count, double* f_dev);
 
@@ -212,8 +217,8 @@ int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,
 
 enum { VS_REDUCE_NAN_TRIM = 1 };
 
-/* The sens/sens_t streaming reduction over a shard's f-values (layout of
- * vs_eval).  One pass over HBM; replaces saltelli.py:577 (E_2 sum), :583
+/* The sens/sens_t streaming reduction over a shard's f-values (planar layout
+ * above).  One pass over HBM; replaces saltelli.py:577 (E_2 sum), :583
  * (variance sums) and :591-596 (the 4k dot products).  With VS_REDUCE_NAN_TRIM,
  * rows holding a NaN in output 0 of any block are left out of every sum
  * (saltelli.py:474-492).  Writes this rank's record (slot `rank` of

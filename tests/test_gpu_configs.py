@@ -51,7 +51,8 @@ def spot(ctx, f, k, rows_total, l, rows):
     out = np.empty((2 * k + 2, len(rows), l))
     for b in range(2 * k + 2):
         for i, r in enumerate(rows):
-            out[b, i] = ctx.download(f, (l,), byte_offset=8 * ((b * rows_total + int(r)) * l))
+            for o in range(l):
+                out[b, i, o] = ctx.download(f, (1,), byte_offset=8 * ((o * (2 * k + 2) + b) * rows_total + int(r)))[0]
     return out
 
 
@@ -156,8 +157,8 @@ def test_reduction_power_of_two_scaling_is_exact(ctx):
     rng = np.random.RandomState(8)
     k, rows = 16, 1 << 18
     blocks = rng.randn(2 * k + 2, rows, 1)
-    r1, f1 = first_order(ctx, ctx.upload(blocks), rows, rows, k)
-    r2, f2 = first_order(ctx, ctx.upload(2.0 * blocks), rows, rows, k)
+    r1, f1 = first_order(ctx, ctx.upload(_native.to_planar(blocks)), rows, rows, k)
+    r2, f2 = first_order(ctx, ctx.upload(_native.to_planar(2.0 * blocks)), rows, rows, k)
     per = _native.acc_per_output(k)
     body1, body2 = r1[4:4 + per], r2[4:4 + per]
     assert np.array_equal(body2[0], 4.0 * body1[0]) and np.array_equal(body2[3:], 4.0 * body1[3:])

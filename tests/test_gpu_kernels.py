@@ -89,7 +89,8 @@ def eval_dev(ctx, design, kind, k, l, params, n, begin=0, count=None):
     obj = ctx.objective_create(kind, k, l, params)
     f = ctx.alloc(8 * 2 * (k + 1) * count * l)
     ctx.eval(design, obj, begin, count, f)
-    return f, ctx.download(f, (2 * k + 2, count, l))
+    from varsens_amd._native import from_planar
+    return f, from_planar(ctx.download(f, (l, 2 * k + 2, count)))
 
 
 def oracle_blocks(F):
@@ -171,7 +172,7 @@ def reduce_dev(ctx, blocks, n, flags=0, rank=0, world=1):
     from varsens_amd import _native
     nb, rows, l = blocks.shape
     k = (nb - 2) // 2
-    f = ctx.upload(blocks)
+    f = ctx.upload(_native.to_planar(blocks))
     acc = ctx.alloc(8 * _native.acc_len(k, l, world))
     ctx.reduce_first_order(f, rows, k, l, acc, flags, rank, world)
     out = ctx.alloc(8 * _native.first_order_len(k, l))
@@ -301,7 +302,7 @@ def test_reduce_shards_merge_like_one_pass(ctx):
     world = 2
     recs = []
     for rank, (b, e) in enumerate([(0, 4000), (4000, rows)]):
-        f = ctx.upload(np.ascontiguousarray(blocks[:, b:e]))
+        f = ctx.upload(_native.to_planar(blocks[:, b:e]))
         acc = ctx.alloc(8 * _native.acc_len(k, l, world))
         ctx.reduce_first_order(f, e - b, k, l, acc, 0, rank, world)
         recs.append(ctx.download(acc, (_native.acc_len(k, l, world),)))
@@ -333,7 +334,8 @@ def test_rccl_single_rank_allreduce(ctx):
 def test_second_order_gram(ctx, k, rows, l):
     rng = np.random.RandomState(k * 7 + rows + l)
     blocks = 1.0 + rng.randn(2 * k + 2, rows, l)
-    f = ctx.upload(blocks)
+    from varsens_amd._native import to_planar
+    f = ctx.upload(to_planar(blocks))
     K = k * l
     gram = ctx.alloc(8 * 3 * K * K)
     ctx.reduce_second_order(f, rows, k, l, gram)
@@ -358,7 +360,7 @@ def test_second_order_nan_trim(ctx):
     blocks = 1.0 + rng.rand(2 * k + 2, rows, 1)
     bad = rng.choice(rows, 11, replace=False)
     blocks[rng.randint(0, 2 * k + 2, 11), bad, 0] = np.nan
-    f = ctx.upload(blocks)
+    f = ctx.upload(_native.to_planar(blocks))
     gram = ctx.alloc(8 * 3 * k * k)
     ctx.reduce_second_order(f, rows, k, 1, gram, flags=_native.REDUCE_NAN_TRIM)
     G = ctx.download(gram, (3, k, k))
@@ -378,7 +380,7 @@ def test_two_stream_pipeline_matches_serial(ctx):
     k, rows = 8, 40000
     data = [1.0 + rng.rand(2 * k + 2, rows, 1) for _ in range(4)]
     serial = [reduce_dev(ctx, d, rows)[1] for d in data]
-    bufs = [ctx.upload(d) for d in data]
+    bufs = [ctx.upload(_native.to_planar(d)) for d in data]
     accs = [ctx.alloc(8 * _native.acc_len(k, 1, 1)) for _ in range(2)]
     outs = [ctx.alloc(8 * _native.first_order_len(k, 1)) for _ in range(4)]
     for i, f in enumerate(bufs):

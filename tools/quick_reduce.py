@@ -71,3 +71,16 @@ r = timed(lambda: ctx.reduce_second_order(f, n, k, 1, gram), 5)
 ms = r["second_order"][0]
 print("second order: %.3f ms (fold %.3f) -> %.1f GB/s algorithmic (16 k n bytes), %.2f TFLOP/s useful (3 k^2 fma/row)" %
       (ms, r["second_fold"][0], 16.0 * k * n / ms / 1e6, 2.0 * 3 * k * k * n / ms / 1e9), flush=True)
+
+# multi-output reduction throughput (planar layout): l = 4 on a quarter of the rows = same bytes
+l4, n4 = 4, n // 4
+f4 = ctx.alloc(8 * 2 * (k + 1) * n4 * l4)
+obj4 = ctx.objective_create(_native.OBJ_LINEAR, k, l4, np.tile(np.arange(1, k + 1, dtype=float), (l4, 1)) * np.arange(1, l4 + 1)[:, None])
+perm4 = seed1_permutation(n4)
+design4 = ctx.design_create(_native.GEN_HALTON, k, n4, 1 + 20 * k, 0, None, None, perm4)
+acc4 = ctx.alloc(8 * _native.acc_len(k, l4, 1))
+r = timed(lambda: ctx.eval(design4, obj4, 0, n4, f4), 5)
+print("eval l=4 n/4: %.3f ms" % r["eval"][0], flush=True)
+r = timed(lambda: ctx.reduce_first_order(f4, n4, k, l4, acc4))
+ms = r["reduce_first"][0]
+print("reduce l=4 n/4: %.3f ms -> %.0f GB/s" % (ms, 8.0 * 2 * (k + 1) * n4 * l4 / ms / 1e6), flush=True)

@@ -44,6 +44,16 @@ def first_order_len(k, l):
     return (2 + 4 * k) * l
 
 
+def to_planar(blocks):
+    """[2k+2][rows][l] (the reference's flat order, reshaped) -> the device layout [l][2k+2][rows]."""
+    return np.ascontiguousarray(np.asarray(blocks, dtype=np.float64).transpose(2, 0, 1))
+
+
+def from_planar(planes):
+    """Device layout [l][2k+2][rows] -> [2k+2][rows][l]."""
+    return np.ascontiguousarray(np.asarray(planes).transpose(1, 2, 0))
+
+
 class VarsensHipError(RuntimeError):
     """A call into libvarsens_hip.so failed."""
 

@@ -409,7 +409,7 @@ extern "C" int vs_objective_create_source(vs_context* ctx, int k, int l, const c
 // registers and feeds all of them from one pair of LDS reads per column: k^2/2
 // multiplies per family, bit-identical to folding each point on its own.
 //
-// Output index: f[(block*rows + (r-row_begin))*l + o].
+// Output index: f[((o*(2k+2) + block)*rows + (r-row_begin)] (planar, see varsens_hip.h).
 
 #if defined(VS_ABL_NOSTORE)   /* diagnostic build: keep the value live, never store */
 #undef VS_STORE
@@ -494,12 +494,12 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
     const uint64_t r = A.row_begin + (valid ? lr : rows - 1);  // clamp: loads stay in range, stores are guarded
     double* X1 = lds + lane;                  // X1[c*T]
     double* X2 = lds + (size_t)k * T + lane;  // X2[c*T]
-    // block bases are wave-uniform; the lane's place inside a block fits 32 bits (checked on the host)
-    double* f = A.f + rb * T * l;
-    const uint32_t lane_off = (uint32_t)lane * (uint32_t)l;
+    // planar f-values: f[((o*(2k+2) + block)*rows + row]; plane/block bases are wave-uniform
+    double* f = A.f + rb * T + lane;
+    const uint64_t plane = (2 * (uint64_t)k + 2) * rows;
 #define VS_OUT(block, o, v)                                               \
     do {                                                                  \
-        if (valid) VS_STORE(f + (uint64_t)(block) * rows * l + (lane_off + (uint32_t)(o)), (v)); \
+        if (valid) VS_STORE(f + ((uint64_t)(o) * plane + (uint64_t)(block) * rows), (v)); \
     } while (0)
 
     // ---- phase 1: coordinates (for a single-output separable objective: terms)
@@ -676,7 +676,6 @@ static int launch_eval(vs_context* ctx, const vs_eval_args& A, int tiles) {
     const size_t lds = sizeof(double) * (size_t)tiles * k * VS_EVAL_ROWS;
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
-    VS_REQUIRE((uint64_t)VS_EVAL_ROWS * A.l < (1ull << 31), "too many outputs per evaluation");
     const char* force = getenv("VS_EVAL_SCRATCH");
     if (lds <= 160 * 1024 && !(force && *force == '1')) {
         if (lds > 64 * 1024)

@@ -21,8 +21,10 @@
 //   * at the end the four wave rows are added and one partial record per
 //     workgroup goes to HBM; a small fold kernel sums the records with
 //     compensated addition.
-// Output l > 1 (or an odd row count) runs the same code with scalar strided
-// loads, one (tile, output) pair per workgroup.
+// f-values are stored output-major ("planar", see varsens_hip.h): output o is its own
+// [2k+2][rows] array, so l > 1 is l independent runs of the same streaming code
+// (blockIdx.x = tile workgroup * l + output).  An odd row count (16-byte loads would
+// straddle blocks) runs the same code with 8-byte loads.
 #include "vs_common.h"
 
 #define VS_WG 256
@@ -100,7 +102,7 @@ struct vs_vec<1> {
     __device__ __forceinline__ void load(const double* p) { v[0] = *p; }
 };
 
-// VEC = 2: l == 1 and rows even (double2 loads); VEC = 1: any l, element stride l.
+// VEC = 2: rows even (16-byte loads); VEC = 1: 8-byte loads.
 template <int VEC, int NV, bool MASKED>
 __global__ void __launch_bounds__(VS_WG)
 reduce_first_kernel(vs_reduce_args A) {
@@ -112,8 +114,8 @@ reduce_first_kernel(vs_reduce_args A) {
     const int wave = tid >> 6;
     const int k = A.k;
     const int l = A.l;
-    const uint32_t o = VEC == 2 ? 0u : blockIdx.x % (uint32_t)l;
-    const uint32_t wg = VEC == 2 ? blockIdx.x : blockIdx.x / (uint32_t)l;
+    const uint32_t o = blockIdx.x % (uint32_t)l;
+    const uint32_t wg = blockIdx.x / (uint32_t)l;
     const int j0 = blockIdx.y * A.jchunk;
     const int j1 = min(k, j0 + A.jchunk);
     const int nj = j1 - j0;
@@ -125,8 +127,8 @@ reduce_first_kernel(vs_reduce_args A) {
     __syncthreads();
 
     const uint64_t rows = A.rows;
-    const uint64_t estride = (uint64_t)l;  // doubles between consecutive rows
-    const double* fo = A.f + o;
+    constexpr uint64_t estride = 1;  // planar layout: consecutive rows are consecutive doubles
+    const double* fo = A.f + (uint64_t)o * (2 * (uint64_t)k + 2) * rows;  // plane of output o
     // common shift of the variance sums: the first (kept) a-value of this output
     const uint64_t shift_row = MASKED ? (uint64_t)A.counters[CNT_FIRST_KEPT] : 0;
     const double shift = (shift_row < rows) ? fo[shift_row * estride] : 0.0;
@@ -276,7 +278,7 @@ nan_mask_kernel(const double* __restrict__ f, uint64_t rows, int k, int l, uint8
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
         bool bad = false;
         for (int b = 0; b < 2 * k + 2; ++b) {
-            double x = f[((uint64_t)b * rows + r) * l];
+            double x = f[(uint64_t)b * rows + r];  // plane of output 0 (saltelli.py:482)
             bad |= (x != x);
         }
         keep[r] = bad ? 0 : 1;
@@ -405,7 +407,7 @@ fold_first_kernel(vs_fold_args A, double* folded /* [l*plen] scratch */) {
     for (int o = threadIdx.x; o < l; o += blockDim.x) {
         double mean = 0.0, m2 = 0.0;
         if (kept > 0) {
-            const double shift = shift_row < A.rows ? A.f[shift_row * (uint64_t)l + o] : 0.0;
+            const double shift = shift_row < A.rows ? A.f[(uint64_t)o * (2 * (uint64_t)k + 2) * A.rows + shift_row] : 0.0;
             const double s1 = ld(o * plen + VS_P_S1), s2 = ld(o * plen + VS_P_S2);
             mean = shift + s1 / cnt;
             m2 = s2 - s1 * (s1 / cnt);
@@ -497,7 +499,7 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     VS_REQUIRE(rows == 0 || f_dev, "f_dev is null");
     const size_t plen = VS_PLEN(k);
     const size_t width = (size_t)l * plen;
-    const bool fast = (l == 1) && (rows % 2 == 0) && (((uintptr_t)f_dev & 15) == 0);
+    const bool fast = (rows % 2 == 0) && (((uintptr_t)f_dev & 15) == 0);
     const int nv = fast ? env_int("VS_REDUCE_NV", 4) : 8;
     const uint64_t tile = (uint64_t)VS_WG * nv * (fast ? 2 : 1);
     uint64_t ntiles = (rows + tile - 1) / tile;
@@ -534,7 +536,7 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     A.keep = nullptr;
     A.counters = ctx->counters;
     A.reverse = env_int("VS_REDUCE_REVERSE", 0);
-    const dim3 grid(tile_wgs * (fast ? 1 : l), jblocks);
+    const dim3 grid(tile_wgs * l, jblocks);
     const size_t lds = sizeof(double) * VS_WAVES * (VS_P_HEAD + 4 * (size_t)jchunk);
 
     vs_fold_args F;

@@ -63,7 +63,7 @@ __device__ __forceinline__ const double* x_elem(const vs_gram_args& A, int m, ui
     const int mm = m < K ? m : m - K;
     const int j = mm / l, o = mm - j * l;
     const uint64_t block = (m < K ? 2 : 2 + A.k) + (uint64_t)j;
-    return A.f + (block * A.rows + r) * l + o;
+    return A.f + ((uint64_t)o * (2 * (uint64_t)A.k + 2) + block) * A.rows + r;  // planar f-values
 }
 
 template <bool MASKED, bool DIAG>
@@ -96,7 +96,7 @@ __device__ __forceinline__ void gram_body(const vs_gram_args& A, int SI, int SJ,
         rowI[i] = x_elem(A, okI[i] ? mi : 0, 0);
         rowJ[i] = x_elem(A, okJ[i] ? mj : 0, 0);
     }
-    const uint64_t lstride = (uint64_t)A.l;
+    constexpr uint64_t lstride = 1;  // planar layout: sample rows are contiguous
     double vi[NR], vj[NR];
     auto fetch = [&](uint64_t ch) {
         const uint64_t r = ch * VS2_CHUNK + lane;
@@ -193,7 +193,7 @@ nan_mask2_kernel(const double* __restrict__ f, uint64_t rows, int k, int l, uint
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
         bool bad = false;
         for (int b = 0; b < 2 * k + 2; ++b) {
-            double x = f[((uint64_t)b * rows + r) * l];
+            double x = f[(uint64_t)b * rows + r];  // plane of output 0
             bad |= (x != x);
         }
         keep[r] = bad ? 0 : 1;

@@ -270,7 +270,7 @@ class Objective(object):
         self.objective_func = objective_func
         self.verbose = verbose
         self._row_begin, self._rows = _shard_rows(int(n), shard)
-        self._f = None          # device buffer, [2k+2][rows][l]
+        self._f = None          # device buffer, planar: [l][2k+2][rows] (include/varsens_hip.h)
         self._l = None
         self._nan_trim = False  # only values that come through load() are trimmed (saltelli.py:474-495)
         self._host_cache = None
@@ -327,7 +327,7 @@ class Objective(object):
                     vals[block, c0 + i] = func(pts[i])
                     step += 1
                     if self.verbose and step % report == 0: print(str(int(round(100. * step / total))) + "%")
-        self._f = self._ctx.upload(vals)
+        self._f = self._ctx.upload(_native.to_planar(vals))
 
     # -- access ---------------------------------------------------------------------------
     def _blocks(self):
@@ -336,7 +336,7 @@ class Objective(object):
             k = int(self.k)
             if 8 * (2 * k + 2) * self._rows * self._l > HOST_MATERIALISE_LIMIT:
                 raise Exception("refusing to copy the objective values to the host (VARSENS_HOST_LIMIT_BYTES)")
-            v = self._ctx.download(self._f, (2 * k + 2, self._rows, self._l))
+            v = _native.from_planar(self._ctx.download(self._f, (self._l, 2 * k + 2, self._rows)))
             if self._nan_trim:
                 drop = numpy.isnan(v[:, :, 0]).any(axis=0)     # first output only (saltelli.py:482)
                 v = v[:, ~drop]
@@ -404,7 +404,7 @@ class Objective(object):
         blocks = x.reshape(2 * k + 2, n, self._l)
         if (self._row_begin, self._rows) != (0, n):
             blocks = blocks[:, self._row_begin:self._row_begin + self._rows]
-        self._f = self._ctx.upload(blocks)
+        self._f = self._ctx.upload(_native.to_planar(blocks))
         self._nan_trim = True
         self._host_cache = None
         first = blocks[:, :, 0]
