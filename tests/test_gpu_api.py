@@ -335,3 +335,51 @@ def test_empty_shard(vs):
     ctx.reduce_first_order(o._f, 0, 4, 1, acc, 0, 1, 2)
     rec = ctx.download(acc, (_native.acc_len(4, 1, 2),))
     assert rec[0] == 0 and rec[2] == 1 and not numpy.isnan(rec).any() and numpy.all(rec[4:] == 0)
+
+
+# ---------------------------------------------------------------- file formats (saltelli.py:173-250, 393-472)
+
+def test_sample_file_variants(vs, tmp_path):
+    k, n = 4, 30
+    lo, hi = numpy.array([1.0, 2, 3, 4]), numpy.array([2.0, 4, 6, 8])
+    s = vs.Sample(k, n, vs.scale.Linear(lo, hi), verbose=False)
+    d = str(tmp_path)
+    # several files, custom prefix/postfix/delimiter, then read them back with offset/nFiles
+    s.export(d, "my sample", ".csv", 100, ",")
+    import os
+    names = sorted(os.listdir(d))
+    assert names == ["my_sample_1.csv", "my_sample_2.csv", "my_sample_3.csv"]       # 300 rows / 100
+    s2 = vs.Sample(k, n, verbose=False, indir=d, prefix="my_sample", postfix=".csv", nFiles=3, delimiter=",")
+    assert numpy.array_equal(s2.flat(), s.flat()) and numpy.array_equal(s2.N_j, s.N_j)
+    # an UNSCALED (2n,k) file, e.g. from an external Sobol generator (quantlib/sobolGen.cpp output format)
+    unit = numpy.random.RandomState(3).rand(2 * n, k)
+    numpy.savetxt(os.path.join(d, "unit.txt"), unit, delimiter=",")
+    s3 = vs.Sample(k, n, vs.scale.Linear(lo, hi), verbose=False, indir=d, loadFile="unit.txt", delimiter=",")
+    want = orc.build_sample(k, n, lambda x: orc.scale_linear(x, lo, hi), raw=numpy.loadtxt(os.path.join(d, "unit.txt"), delimiter=","))
+    assert numpy.array_equal(s3.M_1, want[0]) and numpy.array_equal(s3.M_2, want[1])
+    with pytest.raises(Exception, match="requires that a 'scaling' function"):
+        vs.Sample(k, n, verbose=False, indir=d, loadFile="unit.txt", delimiter=",")
+    with pytest.raises(Exception, match="Cannot find input file"):
+        vs.Sample(k, n, verbose=False, indir=d, loadFile="nope.txt")
+    with pytest.raises(Exception, match="requires defining 'nFiles'"):
+        vs.Sample(k, n, verbose=False, indir=d, prefix="my_sample")
+    numpy.savetxt(os.path.join(d, "bad.txt"), numpy.zeros((7, k)), delimiter="\t")
+    with pytest.raises(Exception, match=r"Loaded sample has shape \(7, 4\)"):
+        vs.Sample(k, n, lambda x: x, verbose=False, indir=d, loadFile="bad.txt")
+
+
+def test_objective_file_variants(vs, tmp_path):
+    k, n = 3, 20
+    s = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
+    d = str(tmp_path)
+    for spec, l in ((vs.objectives.GFunction([0.0, 1.0, 4.5]), 1), (vs.objectives.GFunction([[0.0, 1.0, 4.5], [9, 1, 0]]), 2)):
+        o = vs.Objective(k, n, s, spec, verbose=False)
+        o.export(d, "obj l%d" % l, ".dat", 50)
+        o2 = vs.Objective(k, n, verbose=False, indir=d, prefix="obj_l%d" % l, postfix=".dat", nFiles=4)
+        assert o2.flat().shape == (2 * n * (k + 1), l)
+        numpy.testing.assert_allclose(o2.flat(), o.flat(), rtol=1e-15)       # %.18e text round trip
+        v, v2 = vs.Varsens(o, verbose=False), vs.Varsens(o2, verbose=False)
+        numpy.testing.assert_allclose(v2.sens, v.sens, rtol=1e-9, atol=1e-12)
+        numpy.testing.assert_allclose(v2.sens_2n, v.sens_2n, rtol=1e-9, atol=1e-12)
+    with pytest.raises(Exception, match="Either 'loadFile' or 'prefix'"):
+        vs.Objective(k, n, verbose=False, indir=d)
