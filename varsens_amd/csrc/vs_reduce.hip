@@ -108,6 +108,16 @@ __global__ void __launch_bounds__(VS_WG)
 reduce_first_kernel(vs_reduce_args A) {
     extern __shared__ double wacc[];  // [VS_WAVES][plen_local]
     if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
+    if (!MASKED && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        // the un-masked pass opens every call: it resets the counters the LATER kernels of this
+        // call use (fold ticket, NaN flag, keep statistics) -- no host copy on the stream
+        uint32_t* c = const_cast<uint32_t*>(A.counters);
+        c[CNT_NANFLAG] = 0;
+        c[CNT_FIRST_KEPT] = 0xffffffffu;
+        c[CNT_KEPT] = 0;
+        c[3] = 0;  // CNT_TICKET (un-masked fold)
+        c[4] = 0;  // CNT_TICKET + 1 (masked fold)
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -515,15 +525,6 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     int rc = vs_workspace_partials(ctx, sizeof(double) * ((size_t)tile_wgs * width + width));
     if (rc) return rc;
     double* folded = ctx->partials + (size_t)tile_wgs * width;
-
-    // counters: nan flag 0, first kept = max, kept = 0
-    ctx->counters_host[CNT_NANFLAG] = 0;
-    ctx->counters_host[CNT_FIRST_KEPT] = 0xffffffffu;
-    ctx->counters_host[CNT_KEPT] = 0;
-    ctx->counters_host[CNT_TICKET] = 0;
-    ctx->counters_host[CNT_TICKET + 1] = 0;
-    VS_HIP(hipMemcpyAsync(ctx->counters, ctx->counters_host, 5 * sizeof(uint32_t), hipMemcpyHostToDevice,
-                          ctx->stream));
 
     vs_reduce_args A;
     A.f = f_dev;

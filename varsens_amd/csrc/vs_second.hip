@@ -330,9 +330,7 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     int rc = vs_workspace_partials(ctx, sizeof(double) * (size_t)slab_wgs * width);
     if (rc) return rc;
 
-    ctx->counters_host[8] = 0;
-    VS_HIP(hipMemcpyAsync(ctx->counters + CNT_NANFLAG, ctx->counters_host + 8, sizeof(uint32_t),
-                          hipMemcpyHostToDevice, ctx->stream));
+    VS_HIP(hipMemsetAsync(ctx->counters + CNT_NANFLAG, 0, sizeof(uint32_t), ctx->stream));
     VS_HIP(hipMemsetAsync(gram_dev, 0, sizeof(double) * 3 * (size_t)K * K, ctx->stream));
 
     vs_gram_args A;
