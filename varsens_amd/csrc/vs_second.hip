@@ -70,8 +70,6 @@ template <bool MASKED, bool DIAG>
 __device__ __forceinline__ void gram_body(const vs_gram_args& A, int SI, int SJ, double* tiles) {
     constexpr int NB = VS2_SUPER / 16;                 // 4 blocks per super-block
     constexpr int NACC = DIAG ? NB * (NB + 1) / 2 : NB * NB;
-    double* TI = tiles;
-    double* TJ = DIAG ? tiles : tiles + VS2_SUPER * VS2_PITCH;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,36 +106,57 @@ __device__ __forceinline__ void gram_body(const vs_gram_args& A, int SI, int SJ,
         }
     };
 
+    // Software pipeline, one barrier per chunk: while the MFMAs of chunk c run out of LDS buffer
+    // `cur`, the global loads of chunk c+1 are in flight into registers; they are written to the
+    // other LDS buffer after the MFMAs and published by the barrier.
+    constexpr int TILE_DOUBLES = (DIAG ? 1 : 2) * VS2_SUPER * VS2_PITCH;
     const uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
-    if (blockIdx.x < nchunks) fetch(blockIdx.x);
-    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += A.slab_wgs) {
-        __syncthreads();  // previous chunk fully consumed
+    auto stash = [&](int buf) {
+        double* bi = tiles + buf * TILE_DOUBLES;
+        double* bj = bi + VS2_SUPER * VS2_PITCH;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            TI[(wave + 4 * i) * VS2_PITCH + lane] = vi[i];
-            if (!DIAG) TJ[(wave + 4 * i) * VS2_PITCH + lane] = vj[i];
+            bi[(wave + 4 * i) * VS2_PITCH + lane] = vi[i];
+            if (!DIAG) bj[(wave + 4 * i) * VS2_PITCH + lane] = vj[i];
         }
-        if (ch + A.slab_wgs < nchunks) fetch(ch + A.slab_wgs);  // lands while the MFMAs below run
-        __syncthreads();
-        // this wave's 16 sample rows: 4 k-steps of 4
+    };
+    int cur = 0;
+    if (blockIdx.x < nchunks) {
+        fetch(blockIdx.x);
+        stash(0);
+    }
+    __syncthreads();
+    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += A.slab_wgs) {
+        const bool more = ch + A.slab_wgs < nchunks;
+        if (more) fetch(ch + A.slab_wgs);
+        const double* bi = tiles + cur * TILE_DOUBLES;
+        const double* bj = DIAG ? bi : bi + VS2_SUPER * VS2_PITCH;
+        // this wave's 16 sample rows = 4 k-steps of 4; all fragments first, then the MFMAs back to back
+        double fi[4][NB], fj[4][NB];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int rr = wave * 16 + s * 4 + (lane >> 4);
-            double fi[NB], fj[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                fi[b] = TI[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
-                if (!DIAG) fj[b] = TJ[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
+                fi[s][b] = bi[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
+                if (!DIAG) fj[s][b] = bj[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
             }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
             int a = 0;
 #pragma unroll
-            for (int bi = 0; bi < NB; ++bi)
+            for (int bi_ = 0; bi_ < NB; ++bi_)
 #pragma unroll
-                for (int bj = DIAG ? bi : 0; bj < NB; ++bj) {
-                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fi[bi], DIAG ? fi[bj] : fj[bj], acc[a], 0, 0, 0);
+                for (int bj_ = DIAG ? bi_ : 0; bj_ < NB; ++bj_) {
+                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fi[s][bi_], DIAG ? fi[s][bj_] : fj[s][bj_], acc[a],
+                                                                  0, 0, 0);
                     ++a;
                 }
         }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
     }
     // add the four waves' accumulators through LDS (reusing the tile space), fixed order
     __syncthreads();
@@ -352,7 +371,9 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     F.npairs = npairs;
     F.gram = gram_dev;
     F.counters = ctx->counters;
-    const size_t lds1 = sizeof(double) * VS2_SUPER * VS2_PITCH, lds2 = 2 * lds1;
+    const size_t lds1 = 2 * sizeof(double) * VS2_SUPER * VS2_PITCH, lds2 = 2 * lds1;  // double-buffered tiles
+    VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     const dim3 grid_diag(slab_wgs, nsuper), grid_off(slab_wgs, npairs - nsuper);
