@@ -226,6 +226,15 @@ enum { VS_REDUCE_NAN_TRIM = 1 };
 int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                           int flags, int rank, int max_ranks, double* acc_dev);
 
+/* Fused path: evaluates the shard's 2(k+1)*row_count points and reduces them in registers --
+ * no f-values are written or read (the record equals vs_eval + vs_reduce_first_order's up to
+ * summation order).  Covers single-output G_FUNCTION / POLYNOMIAL / LINEAR objectives with
+ * k <= 32; returns VS_ERR_ARG otherwise (callers then use the two-kernel path).  NaN values
+ * propagate (as on the reference's live-evaluation route, saltelli.py:329-355). */
+int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* design, const vs_objective* obj,
+                               uint64_t row_begin, uint64_t row_count, int rank, int max_ranks,
+                               double* acc_dev);
+
 /* Finished indices from a (summed) record; divisors use the REQUESTED global n
  * even when rows were trimmed (saltelli.py:576-577,591).  out_dev layout
  * (doubles): E_2[l], var_y[l], U_j[k][l], U_nj[k][l], sens[k][l], sens_t[k][l]

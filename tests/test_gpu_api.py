@@ -383,3 +383,23 @@ def test_objective_file_variants(vs, tmp_path):
         numpy.testing.assert_allclose(v2.sens_2n, v.sens_2n, rtol=1e-9, atol=1e-12)
     with pytest.raises(Exception, match="Either 'loadFile' or 'prefix'"):
         vs.Objective(k, n, verbose=False, indir=d)
+
+
+# ---------------------------------------------------------------- fused evaluate+reduce through the API
+
+def test_fused_first_order_through_api(vs, golden):
+    g = golden("g2_gfunc_k6_n51200")
+    v = vs.Varsens(vs.objectives.GFunction(model), vs.scale.Identity(), 6, 51200, verbose=False, second_order=False)
+    assert v.objective._f is None                       # nothing was written to HBM
+    for f in ("E_2", "var_y", "U_j", "U_nj"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-13)
+    numpy.testing.assert_allclose(v.sens, g["sens"], rtol=1e-10, atol=1e-14)
+    numpy.testing.assert_allclose(v.sens_t, g["sens_t"], rtol=1e-10, atol=1e-14)
+    assert not hasattr(v, "sens_2")
+    v2 = vs.Varsens(vs.objectives.GFunction(model), vs.scale.Identity(), 6, 51200, verbose=False, second_order=False,
+                    fused=False)
+    numpy.testing.assert_allclose(v.sens, v2.sens, rtol=1e-10, atol=1e-14)
+    # the values are still there for whoever asks (evaluated on first access)
+    assert v.objective.fM_1.shape == (51200, 1) and numpy.array_equal(v.objective.fM_1, v2.objective.fM_1)
+    with pytest.raises(Exception, match="fused=True needs"):
+        vs.Varsens(vs.objectives.Ishigami(), vs.scale.Identity(), 3, 64, verbose=False, second_order=False, fused=True)

@@ -397,3 +397,41 @@ def test_two_stream_pipeline_matches_serial(ctx):
     ctx.sync()
     for i in range(4):
         same(ctx.download(outs[i], (2 + 4 * k, 1)), serial[i])
+
+
+# ------------------------------------------------------------------ fused evaluate + reduce
+
+@pytest.mark.parametrize("kind,k,n", [("g", 6, 5000), ("g", 32, 20001), ("lin", 32, 70000), ("poly", 16, 333),
+                                      ("lin", 1, 64), ("g", 31, 1)])
+def test_fused_matches_two_kernel_path(ctx, kind, k, n):
+    from varsens_amd import _native
+    rng = np.random.RandomState(k + n)
+    params = {"g": rng.rand(k) * 5, "lin": np.arange(1, k + 1, dtype=float), "poly": 1.0 / (1.0 + np.arange(k) / 8.0)}[kind]
+    code = {"g": _native.OBJ_G_FUNCTION, "lin": _native.OBJ_LINEAR, "poly": _native.OBJ_POLYNOMIAL}[kind]
+    d = make_design(ctx, k, n)
+    obj = ctx.objective_create(code, k, 1, params)
+    nacc = _native.acc_len(k, 1, 1)
+    f = ctx.alloc(8 * 2 * (k + 1) * n)
+    ctx.eval(d, obj, 0, n, f)
+    acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
+    ctx.reduce_first_order(f, n, k, 1, acc1)
+    ctx.eval_reduce_first_order(d, obj, 0, n, acc2)
+    r1, r2 = ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,))
+    assert r1[0] == r2[0] == n
+    np.testing.assert_allclose(r2[4:4 + 3 + 4 * k], r1[4:4 + 3 + 4 * k], rtol=1e-13)
+    if n > 1:
+        out1, out2 = ctx.alloc(8 * (2 + 4 * k)), ctx.alloc(8 * (2 + 4 * k))
+        ctx.finish_first_order(acc1, n, k, 1, out1)
+        ctx.finish_first_order(acc2, n, k, 1, out2)
+        a, b = ctx.download(out1, (2 + 4 * k,)), ctx.download(out2, (2 + 4 * k,))
+        np.testing.assert_allclose(b[:2 + 2 * k], a[:2 + 2 * k], rtol=1e-12)
+        np.testing.assert_allclose(b[2 + 2 * k:], a[2 + 2 * k:], rtol=1e-9, atol=1e-12)
+
+
+def test_fused_refuses_what_it_does_not_cover(ctx):
+    from varsens_amd import _native
+    d = make_design(ctx, 40, 100)
+    obj = ctx.objective_create(_native.OBJ_LINEAR, 40, 1, np.ones(40))
+    acc = ctx.alloc(8 * _native.acc_len(40, 1, 1))
+    with pytest.raises(_native.VarsensHipError, match="fused path covers"):
+        ctx.eval_reduce_first_order(d, obj, 0, 100, acc)

@@ -84,3 +84,9 @@ print("eval l=4 n/4: %.3f ms" % r["eval"][0], flush=True)
 r = timed(lambda: ctx.reduce_first_order(f4, n4, k, l4, acc4))
 ms = r["reduce_first"][0]
 print("reduce l=4 n/4: %.3f ms -> %.0f GB/s" % (ms, 8.0 * 2 * (k + 1) * n4 * l4 / ms / 1e6), flush=True)
+
+for w in (1, 2, 3):
+    os.environ["VS_FUSED_WGS_PER_CU"] = str(w)
+    r = timed(lambda: ctx.eval_reduce_first_order(design, obj, 0, n, acc), 10)
+    print("fused wgs/cu=%d: %.3f ms (min %.3f) fold %.3f -> %.1f GSamples/s" %
+          (w, r["fused"][0], r["fused"][1], r["fold"][0], N / r["fused"][0] / 1e6), flush=True)

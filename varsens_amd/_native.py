@@ -107,6 +107,8 @@ SIGNATURES = {
     "vs_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "vs_reduce_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_void_p]),
+    "vs_eval_reduce_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int,
+                                             C.c_int, C.c_void_p]),
     "vs_finish_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
     "vs_reduce_second_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
@@ -340,6 +342,10 @@ class Context(object):
     def reduce_first_order(self, f_buf, rows, k, l, acc_buf, flags=0, rank=0, max_ranks=1):
         _check(self.lib.vs_reduce_first_order(self.handle, C.c_void_p(f_buf.ptr), int(rows), int(k), int(l),
                                               int(flags), int(rank), int(max_ranks), C.c_void_p(acc_buf.ptr)))
+
+    def eval_reduce_first_order(self, design, objective, row_begin, row_count, acc_buf, rank=0, max_ranks=1):
+        _check(self.lib.vs_eval_reduce_first_order(self.handle, design.h, objective.h, int(row_begin), int(row_count),
+                                                   int(rank), int(max_ranks), C.c_void_p(acc_buf.ptr)))
 
     def finish_first_order(self, acc_buf, n, k, l, out_buf, max_ranks=1):
         _check(self.lib.vs_finish_first_order(self.handle, C.c_void_p(acc_buf.ptr), int(n), int(k), int(l),

@@ -98,8 +98,40 @@ int vs_workspace_partials(vs_context* ctx, size_t bytes);
 int vs_workspace_keep(vs_context* ctx, size_t bytes);
 int vs_workspace_scratch(vs_context* ctx, size_t bytes);
 
+int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, const double* shift_dev, int rank,
+                     int max_ranks, double* acc_dev);
+
+// partial record of one workgroup for one output: 5 head values + 4 per block j
+#define VS_P_SAB 0
+#define VS_P_SA 1
+#define VS_P_SB 2
+#define VS_P_S1 3
+#define VS_P_S2 4
+#define VS_P_HEAD 5
+#define VS_PLEN(k) (VS_P_HEAD + 4 * (size_t)(k))
+
 // ---- device helpers -------------------------------------------------------
 #ifdef __HIPCC__
+// wave-wide sum with DPP; total valid in lanes 48..63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double vs_dpp_add(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(thi, tlo);
+}
+
+__device__ __forceinline__ double vs_wave_sum_dpp(double v) {
+    v = vs_dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = vs_dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = vs_dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = vs_dpp_add<0x140, 0xf>(v);  // row_mirror: every lane holds its row's sum
+    v = vs_dpp_add<0x142, 0xa>(v);  // row_bcast15 into rows 1,3
+    v = vs_dpp_add<0x143, 0xc>(v);  // row_bcast31 into rows 2,3
+    return v;                       // rows 3 (lanes 48..63): sum of all 64 lanes
+}
+
+
 // Sum over the 64 lanes of a wavefront; result valid in every lane.
 __device__ __forceinline__ double vs_wave_sum(double v) {
 #pragma unroll

@@ -699,6 +699,215 @@ static int launch_eval(vs_context* ctx, const vs_eval_args& A, int tiles) {
     return VS_OK;
 }
 
+// ---------------------------------------------------------------------------
+// fused evaluate + first-order reduce: no f-values are written
+// ---------------------------------------------------------------------------
+//
+// Same two phases as eval_kernel for a single-output separable objective with k <= 32 (one chain
+// pass).  After phase 2 a thread holds a = f(M_1[r]), b = f(M_2[r]) and the values c_i, d_i of the
+// blocks i = q, q+4, .. it owns; their four products go straight into 32 register accumulators
+// that live for the whole kernel (persistent workgroups walk the row blocks).  Block i belongs to
+// exactly one wave, so the only reduction left at the end is the DPP wave sum; one partial record
+// per workgroup, same layout and same fold as reduce_first_kernel's.
+
+#ifndef VS_FUSED_MIN_WAVES
+#define VS_FUSED_MIN_WAVES 1
+#endif
+template <int KIND>
+__global__ void __launch_bounds__(VS_EVAL_ROWS * VS_EVAL_WAVES, VS_FUSED_MIN_WAVES)
+fused_first_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
+    extern __shared__ double lds[];
+    constexpr int T = VS_EVAL_ROWS;
+    const int k = A.D.k;  // <= VS_PASS
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t rows = A.rows;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the fold that follows (see reduce_first_kernel)
+        counters[0] = 0;
+        counters[1] = 0xffffffffu;
+        counters[2] = 0;
+        counters[3] = 0;
+        counters[4] = 0;
+    }
+    const double shift = *shift_src;
+    double* X1 = lds + lane;
+    double* X2 = lds + (size_t)k * T + lane;
+    const double ident = KIND == VS_OBJ_LINEAR ? 0.0 : 1.0;
+    const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
+
+    double acc[VS_CHAINS][4];
+#pragma unroll
+    for (int m = 0; m < VS_CHAINS; ++m) acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0.0;
+    double t_sab = 0, t_sa = 0, t_sb = 0, t_s1 = 0, t_s2 = 0;
+
+    const uint64_t nblocks = (rows + T - 1) / T;
+    for (uint64_t rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+        const uint64_t lr = rb * T + lane;
+        const bool valid = lr < rows;
+        const uint64_t r = A.row_begin + (valid ? lr : rows - 1);
+        const uint64_t src2 = A.D.n + (A.D.perm ? (uint64_t)A.D.perm[r] : r);
+        for (int c = q; c < k; c += VS_EVAL_WAVES) {
+            double x1, x2;
+            if (halton_fast) {
+                vs_radical_inverse_pair((uint32_t)(A.D.first_index + r), (uint32_t)(A.D.first_index + src2),
+                                        A.D.bases[c], x1, x2);
+            } else {
+                x1 = vs_unit_point(A.D, r, c);
+                x2 = vs_unit_point(A.D, src2, c);
+            }
+            const double p = A.params[c];
+            X1[(size_t)c * T] = vs_term<KIND>(vs_apply_scale(A.D, x1, c), p);
+            X2[(size_t)c * T] = vs_term<KIND>(vs_apply_scale(A.D, x2, c), p);
+        }
+        __syncthreads();
+
+        double pa = ident, pb = ident;
+        double cj[VS_CHAINS], dj[VS_CHAINS];
+#pragma unroll
+        for (int m = 0; m < VS_CHAINS; ++m) cj[m] = dj[m] = ident;
+        if (k == VS_PASS) {
+            switch (q) {
+                case 0: vs_chain_pass<KIND, 0, false>(X1, X2, 0, pa, pb, cj, dj); break;
+                case 1: vs_chain_pass<KIND, 1, false>(X1, X2, 0, pa, pb, cj, dj); break;
+                case 2: vs_chain_pass<KIND, 2, false>(X1, X2, 0, pa, pb, cj, dj); break;
+                default: vs_chain_pass<KIND, 3, false>(X1, X2, 0, pa, pb, cj, dj); break;
+            }
+        } else {
+            int c = 0;
+            for (const int stop = min(k, q); c < stop; ++c) {
+                pa = vs_fold<KIND>(pa, X1[(size_t)c * T]);
+                pb = vs_fold<KIND>(pb, X2[(size_t)c * T]);
+            }
+#pragma unroll
+            for (int m = 0; m < VS_CHAINS; ++m) {
+                if (c < k) {
+                    const double ta = X1[(size_t)c * T], tb = X2[(size_t)c * T];
+#pragma unroll
+                    for (int mm = 0; mm < m; ++mm) {
+                        cj[mm] = vs_fold<KIND>(cj[mm], tb);
+                        dj[mm] = vs_fold<KIND>(dj[mm], ta);
+                    }
+                    cj[m] = vs_fold<KIND>(pb, ta);
+                    dj[m] = vs_fold<KIND>(pa, tb);
+                    pa = vs_fold<KIND>(pa, ta);
+                    pb = vs_fold<KIND>(pb, tb);
+                    ++c;
+#pragma unroll
+                    for (int s = 1; s < VS_EVAL_WAVES; ++s) {
+                        if (c < k) {
+                            const double ua = X1[(size_t)c * T], ub = X2[(size_t)c * T];
+#pragma unroll
+                            for (int mm = 0; mm <= m; ++mm) {
+                                cj[mm] = vs_fold<KIND>(cj[mm], ub);
+                                dj[mm] = vs_fold<KIND>(dj[mm], ua);
+                            }
+                            pa = vs_fold<KIND>(pa, ua);
+                            pb = vs_fold<KIND>(pb, ub);
+                            ++c;
+                        }
+                    }
+                }
+            }
+        }
+        if (valid) {  // a = pa, b = pb, c_i = cj, d_i = dj
+#pragma unroll
+            for (int m = 0; m < VS_CHAINS; ++m) {
+                acc[m][0] = fma(pa, cj[m], acc[m][0]);  // a.c_i   (chains beyond k hold the identity and are dropped below)
+                acc[m][1] = fma(pb, dj[m], acc[m][1]);  // b.d_i
+                acc[m][2] = fma(pa, dj[m], acc[m][2]);  // a.d_i
+                acc[m][3] = fma(pb, cj[m], acc[m][3]);  // b.c_i
+            }
+            if (q == 0) {
+                const double dx = pa - shift, dy = pb - shift;
+                t_sab = fma(pa, pb, t_sab);
+                t_sa += pa;
+                t_sb += pb;
+                t_s1 += dx + dy;
+                t_s2 = fma(dx, dx, t_s2);
+                t_s2 = fma(dy, dy, t_s2);
+            }
+        }
+        __syncthreads();  // the tile is rewritten by the next block
+    }
+
+    double* out = partials + (size_t)blockIdx.x * VS_PLEN(k);
+#pragma unroll
+    for (int m = 0; m < VS_CHAINS; ++m) {
+        const int i = q + VS_EVAL_WAVES * m;
+#pragma unroll
+        for (int z = 0; z < 4; ++z) {
+            const double v = vs_wave_sum_dpp(acc[m][z]);
+            if (lane == 63 && i < k) out[VS_P_HEAD + (size_t)z * k + i] = v;
+        }
+    }
+    if (q == 0) {
+        t_sab = vs_wave_sum_dpp(t_sab);
+        t_sa = vs_wave_sum_dpp(t_sa);
+        t_sb = vs_wave_sum_dpp(t_sb);
+        t_s1 = vs_wave_sum_dpp(t_s1);
+        t_s2 = vs_wave_sum_dpp(t_s2);
+        if (lane == 63) {
+            out[VS_P_SAB] = t_sab;
+            out[VS_P_SA] = t_sa;
+            out[VS_P_SB] = t_sb;
+            out[VS_P_S1] = t_s1;
+            out[VS_P_S2] = t_s2;
+        }
+    }
+}
+
+template <int KIND>
+static int launch_fused(vs_context* ctx, const vs_eval_args& A, uint32_t P, const double* shift_dev) {
+    const size_t lds = sizeof(double) * 2 * (size_t)A.D.k * VS_EVAL_ROWS;
+    vs_launch_scope scope(ctx, VS_KERNEL_FUSED);
+    hipLaunchKernelGGL(fused_first_kernel<KIND>, dim3(P), dim3(VS_EVAL_ROWS * VS_EVAL_WAVES), lds, ctx->stream, A,
+                       shift_dev, ctx->partials, ctx->counters);
+    return VS_OK;
+}
+
+extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* design, const vs_objective* obj,
+                                          uint64_t row_begin, uint64_t row_count, int rank, int max_ranks,
+                                          double* acc_dev) {
+    VS_REQUIRE(ctx && design && obj && acc_dev, "null argument");
+    VS_REQUIRE(obj->k == design->d.k, "objective has k=%d, design has k=%d", obj->k, design->d.k);
+    VS_REQUIRE(row_begin <= design->d.n && row_count <= design->d.n - row_begin, "rows exceed n");
+    VS_REQUIRE(max_ranks >= 1 && rank >= 0 && rank < max_ranks, "rank %d not in [0,%d)", rank, max_ranks);
+    const bool separable = obj->kind == VS_OBJ_G_FUNCTION || obj->kind == VS_OBJ_POLYNOMIAL || obj->kind == VS_OBJ_LINEAR;
+    VS_REQUIRE(separable && obj->l == 1 && obj->k <= VS_PASS && row_count >= 1,
+               "the fused path covers single-output g-function / polynomial / linear objectives with k <= %d; "
+               "use vs_eval + vs_reduce_first_order", VS_PASS);
+    const int k = obj->k;
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    const uint64_t blocks = (row_count + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
+    const char* env = getenv("VS_FUSED_WGS_PER_CU");
+    uint64_t Pw = (uint64_t)cus * (env && *env ? atoi(env) : 2);  // 2 resident workgroups per CU (204 VGPRs)
+    if (Pw > blocks) Pw = blocks;
+    const uint32_t P = (uint32_t)Pw;
+    const size_t plen = VS_PLEN(k);
+    // workspace: [P][plen] partials + [plen] folded + 8 doubles for the shift row's f-values (2k+2)
+    int rc = vs_workspace_partials(ctx, sizeof(double) * ((size_t)P * plen + plen + 2 * (size_t)k + 2));
+    if (rc) return rc;
+    double* shift_buf = ctx->partials + (size_t)P * plen + plen;
+    // the variance shift is f(M_1[row_begin]): one-row launch of the ordinary evaluation kernel
+    rc = vs_eval(ctx, design, obj, row_begin, 1, shift_buf);
+    if (rc) return rc;
+    vs_eval_args A;
+    A.D = to_dev(design);
+    A.kind = obj->kind;
+    A.l = 1;
+    A.params = obj->params;
+    A.row_begin = row_begin;
+    A.rows = row_count;
+    A.f = nullptr;
+    switch (obj->kind) {
+        case VS_OBJ_G_FUNCTION: launch_fused<VS_OBJ_G_FUNCTION>(ctx, A, P, shift_buf); break;
+        case VS_OBJ_POLYNOMIAL: launch_fused<VS_OBJ_POLYNOMIAL>(ctx, A, P, shift_buf); break;
+        default: launch_fused<VS_OBJ_LINEAR>(ctx, A, P, shift_buf); break;
+    }
+    VS_HIP(hipGetLastError());
+    return vs_fold_partials(ctx, P, k, 1, row_count, shift_buf, rank, max_ranks, acc_dev);
+}
+
 extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                        uint64_t row_begin, uint64_t row_count, double* f_dev) {
     VS_REQUIRE(ctx && design && obj, "null argument");

@@ -31,37 +31,7 @@
 #define VS_WAVES (VS_WG / 64)
 #define VS_JCHUNK 512  // blocks j handled per workgroup (bounds the LDS accumulator)
 
-// partial record of one workgroup for one output: 5 head values + 4 per block j
-#define VS_P_SAB 0
-#define VS_P_SA 1
-#define VS_P_SB 2
-#define VS_P_S1 3
-#define VS_P_S2 4
-#define VS_P_HEAD 5
-#define VS_PLEN(k) (VS_P_HEAD + 4 * (size_t)(k))
-
 enum { CNT_NANFLAG = 0, CNT_FIRST_KEPT = 1, CNT_KEPT = 2 };
-
-// ---------------------------------------------------------------------------
-// wave-wide sum with DPP; total valid in lanes 48..63
-// ---------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double vs_dpp_add(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    return v + __hiloint2double(thi, tlo);
-}
-
-__device__ __forceinline__ double vs_wave_sum_dpp(double v) {
-    v = vs_dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-    v = vs_dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-    v = vs_dpp_add<0x141, 0xf>(v);  // row_half_mirror
-    v = vs_dpp_add<0x140, 0xf>(v);  // row_mirror: every lane holds its row's sum
-    v = vs_dpp_add<0x142, 0xa>(v);  // row_bcast15 into rows 1,3
-    v = vs_dpp_add<0x143, 0xc>(v);  // row_bcast31 into rows 2,3
-    return v;                       // rows 3 (lanes 48..63): sum of all 64 lanes
-}
 
 // ---------------------------------------------------------------------------
 // the streaming kernel
@@ -316,7 +286,8 @@ struct vs_fold_args {
     uint32_t P;
     int k, l;
     uint64_t rows;
-    const double* f;    // for the shift value
+    const double* f;    // for the shift value (block 0, row shift_row of each output plane) ...
+    const double* shift_values;  // ... or, when non-null, l explicit shift values (fused path: no f-values exist)
     double* acc;        // record (device)
     int rank, max_ranks;
     uint32_t* counters;
@@ -417,7 +388,8 @@ fold_first_kernel(vs_fold_args A, double* folded /* [l*plen] scratch */) {
     for (int o = threadIdx.x; o < l; o += blockDim.x) {
         double mean = 0.0, m2 = 0.0;
         if (kept > 0) {
-            const double shift = shift_row < A.rows ? A.f[(uint64_t)o * (2 * (uint64_t)k + 2) * A.rows + shift_row] : 0.0;
+            const double shift = A.shift_values ? A.shift_values[o]
+                                 : (shift_row < A.rows ? A.f[(uint64_t)o * (2 * (uint64_t)k + 2) * A.rows + shift_row] : 0.0);
             const double s1 = ld(o * plen + VS_P_S1), s2 = ld(o * plen + VS_P_S2);
             mean = shift + s1 / cnt;
             m2 = s2 - s1 * (s1 / cnt);
@@ -547,6 +519,7 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     F.l = l;
     F.rows = rows;
     F.f = f_dev;
+    F.shift_values = nullptr;
     F.acc = acc_dev;
     F.rank = rank;
     F.max_ranks = max_ranks;
@@ -593,6 +566,35 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
         }
         VS_HIP(hipGetLastError());
     }
+    return VS_OK;
+}
+
+// Fold `P` workgroup records sitting in ctx->partials ([P][l][VS_PLEN(k)]) into this rank's
+// accumulator record.  Used by the fused evaluate+reduce kernel (vs_generate.hip), whose
+// records have the layout of reduce_first_kernel's.
+int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, const double* shift_dev, int rank,
+                     int max_ranks, double* acc_dev) {
+    const size_t width = (size_t)l * VS_PLEN(k);
+    vs_fold_args F;
+    F.partials = ctx->partials;
+    F.P = P;
+    F.k = k;
+    F.l = l;
+    F.rows = rows;
+    F.f = nullptr;
+    F.shift_values = shift_dev;
+    F.acc = acc_dev;
+    F.rank = rank;
+    F.max_ranks = max_ranks;
+    F.counters = ctx->counters;
+    F.masked = 0;
+    double* folded = ctx->partials + (size_t)P * width;
+    const unsigned fold_blocks = (unsigned)((width + VS_FOLD_COLS - 1) / VS_FOLD_COLS);
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_FOLD);
+        hipLaunchKernelGGL(fold_first_kernel, dim3(fold_blocks), dim3(VS_FOLD_THREADS), 0, ctx->stream, F, folded);
+    }
+    VS_HIP(hipGetLastError());
     return VS_OK;
 }
 

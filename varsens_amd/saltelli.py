@@ -264,6 +264,7 @@ class Objective(object):
     def __init__(self, k, n, sample=None, objective_func=None, objective_vals=[], verbose=True, **loadArgs):
         self._ctx = loadArgs.pop('context', None) or (sample._ctx if sample is not None else default_context())
         shard = loadArgs.pop('shard', None)
+        lazy = loadArgs.pop('lazy', False)   # device objectives only: evaluate when the values are first needed
         self.k = k
         self.n = n
         self.sample = sample
@@ -286,19 +287,31 @@ class Objective(object):
             elif not self.objective_func:
                 raise Exception("Generating a fresh objective requires that an 'objective_func' be defined.")
             if isinstance(objective_func, _objectives.DeviceObjective):
-                self._evaluate_on_device()
+                self._l = int(objective_func.outputs(int(self.k)))
+                if not lazy:
+                    self._evaluate_on_device()
             else:
                 self._evaluate_on_host()
 
     # -- evaluation -----------------------------------------------------------------------
+    def _device_objective(self):
+        k = int(self.k)
+        spec = self.objective_func
+        if spec.kind == _native.OBJ_SOURCE:
+            return self._ctx.objective_create_source(k, self._l, spec.body, spec.params(k))
+        return self._ctx.objective_create(spec.kind, k, self._l, spec.params(k))
+
+    def _values(self):
+        """The device buffer of f-values, evaluating now if that was deferred."""
+        if self._f is None and isinstance(self.objective_func, _objectives.DeviceObjective):
+            self._evaluate_on_device()
+        return self._f
+
     def _evaluate_on_device(self):
         k = int(self.k)
         spec = self.objective_func
         self._l = int(spec.outputs(k))
-        if spec.kind == _native.OBJ_SOURCE:
-            handle = self._ctx.objective_create_source(k, self._l, spec.body, spec.params(k))
-        else:
-            handle = self._ctx.objective_create(spec.kind, k, self._l, spec.params(k))
+        handle = self._device_objective()
         self._f = self._ctx.alloc(8 * 2 * (k + 1) * self._rows * self._l)
         self._ctx.eval(self.sample._design, handle, self._row_begin, self._rows, self._f)
         self._ctx.sync()
@@ -336,7 +349,7 @@ class Objective(object):
             k = int(self.k)
             if 8 * (2 * k + 2) * self._rows * self._l > HOST_MATERIALISE_LIMIT:
                 raise Exception("refusing to copy the objective values to the host (VARSENS_HOST_LIMIT_BYTES)")
-            v = _native.from_planar(self._ctx.download(self._f, (self._l, 2 * k + 2, self._rows)))
+            v = _native.from_planar(self._ctx.download(self._values(), (self._l, 2 * k + 2, self._rows)))
             if self._nan_trim:
                 drop = numpy.isnan(v[:, :, 0]).any(axis=0)     # first output only (saltelli.py:482)
                 v = v[:, ~drop]
@@ -433,6 +446,7 @@ class Varsens(object):
         self.verbose = verbose
         self._second_order = extra.pop('second_order', True)
         self._comm = extra.pop('comm', None)
+        self._fused = extra.pop('fused', 'auto')   # 'auto' | True | False: fused evaluate+reduce kernel
         ctx = extra.pop('context', None)
         shard = extra.pop('shard', None)
         if extra:
@@ -455,9 +469,22 @@ class Varsens(object):
             self.n = objective.n
         else:
             kw = dict(shard=shard) if shard is not None else {}
+            if self._fused_eligible(objective):
+                kw['lazy'] = True   # the values are only produced if somebody asks for them
+            elif self._fused is True:
+                raise Exception("fused=True needs first order only (second_order=False) and a single-output "
+                                "GFunction / Polynomial / Linear device objective with k <= 32")
             self.objective = Objective(self.k, self.n, self.sample, objective, verbose=verbose, **kw)
         self._ctx = self.objective._ctx
         self.compute_varsens()
+
+    def _fused_eligible(self, objective):
+        if self._fused is False or self._second_order:
+            return False
+        if not isinstance(objective, _objectives.DeviceObjective):
+            return False
+        separable = objective.kind in (_native.OBJ_G_FUNCTION, _native.OBJ_POLYNOMIAL, _native.OBJ_LINEAR)
+        return separable and int(self.k) <= 32 and objective.outputs(int(self.k)) == 1
 
     def compute_varsens(self):
         """E_2, var_y, U_j, U_nj, sens, sens_t, sens_2, sens_2n (varsens/saltelli.py:572-622)."""
@@ -470,7 +497,14 @@ class Varsens(object):
 
         nacc = _native.acc_len(k, l, world)
         acc = ctx.alloc(8 * nacc)
-        ctx.reduce_first_order(obj._f, obj._rows, k, l, acc, flags, rank, world)
+        if obj._f is None and obj._rows > 0 and self._fused_eligible(obj.objective_func):
+            # evaluate and reduce in one kernel: the 2n(k+1) values never reach HBM
+            handle = obj._device_objective()
+            ctx.eval_reduce_first_order(obj.sample._design, handle, obj._row_begin, obj._rows, acc, rank, world)
+            ctx.sync()
+            handle.free()
+        else:
+            ctx.reduce_first_order(obj._values(), obj._rows, k, l, acc, flags, rank, world)
         if world > 1:
             self._comm.allreduce(acc, nacc)
         first = ctx.alloc(8 * _native.first_order_len(k, l))
@@ -487,7 +521,7 @@ class Varsens(object):
         if self._second_order:
             K = k * l
             gram = ctx.alloc(8 * 3 * K * K)
-            ctx.reduce_second_order(obj._f, obj._rows, k, l, gram, flags)
+            ctx.reduce_second_order(obj._values(), obj._rows, k, l, gram, flags)
             if world > 1:
                 self._comm.allreduce(gram, 3 * K * K)
             s2 = ctx.alloc(8 * K * K)
