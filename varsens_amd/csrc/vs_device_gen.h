@@ -117,16 +117,29 @@ __device__ __forceinline__ void vs_radical_inverse_pair(vs_u32 i1, vs_u32 i2, co
     x2 = fma(rb, B.inv_den, b0);
 }
 
-__device__ __forceinline__ double vs_sobol_point(vs_u64 i, const vs_u32* __restrict__ dir) {
-    vs_u32 g = (vs_u32)(i ^ (i >> 1));
+// Sobol point of index i for one coordinate: XOR of the direction integers selected by the set
+// bits of the Gray code of i.  The 32 direction integers of the column are fetched up front (wide
+// scalar loads) so that the bit loop is pure VALU; bits above `nbits` (the Gray-code bits any
+// index of the design can set) are skipped eight at a time.
+__device__ __forceinline__ double vs_sobol_point(vs_u64 i, const vs_u32* __restrict__ dir, int nbits) {
+    const vs_u32 g = (vs_u32)(i ^ (i >> 1));
     vs_u32 x = 0;
-#pragma unroll 8
-    for (int j = 0; j < 32; ++j) x ^= ((g >> j) & 1u) ? dir[j] : 0u;
+#pragma unroll
+    for (int j0 = 0; j0 < 32; j0 += 8) {
+        if (j0 < nbits) {
+            vs_u32 d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = dir[j0 + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x ^= (vs_u32)(-(int)((g >> (j0 + j)) & 1u)) & d[j];
+        }
+    }
     return (double)x * (1.0 / 4294967296.0);
 }
 
 struct vs_design_dev {
     int generator, k, scale_mode;
+    int sobol_bits;  // Gray-code bits in use (VS_GEN_SOBOL)
     vs_u64 n, first_index;
     const double* lower;
     const double* width;
@@ -140,7 +153,7 @@ struct vs_design_dev {
 // M_1, second half M_2 before the shuffle).
 __device__ __forceinline__ double vs_unit_point(const vs_design_dev& D, vs_u64 seq_row, int c) {
     if (D.generator == VS_GEN_HALTON) return vs_radical_inverse(D.first_index + seq_row, D.bases[c]);
-    if (D.generator == VS_GEN_SOBOL) return vs_sobol_point(D.first_index + seq_row, D.dirs + 32 * c);
+    if (D.generator == VS_GEN_SOBOL) return vs_sobol_point(D.first_index + seq_row, D.dirs + 32 * c, D.sobol_bits);
     return D.raw[seq_row * (vs_u64)D.k + c];
 }
 

@@ -23,6 +23,13 @@ static vs_design_dev to_dev(const vs_design* g) {
     D.generator = g->d.generator;
     D.k = g->d.k;
     D.scale_mode = g->d.scale_mode;
+    D.sobol_bits = 32;
+    if (g->d.generator == VS_GEN_SOBOL) {
+        const uint64_t top = g->d.first_index + 2 * g->d.n;  // Gray code of i < 2^b stays below 2^b
+        int b = 1;
+        while (b < 32 && (1ull << b) < top) ++b;
+        D.sobol_bits = b;
+    }
     D.n = g->d.n;
     D.first_index = g->d.first_index;
     D.lower = g->lower;
@@ -108,7 +115,7 @@ sobol_fill_kernel(const uint32_t* __restrict__ dirs, int k, uint64_t start, uint
     for (; e < total; e += stride) {
         uint64_t row = e / (uint32_t)k;
         int c = (int)(e - row * (uint32_t)k);
-        out[e] = vs_sobol_point(start + row, dirs + 32 * c);
+        out[e] = vs_sobol_point(start + row, dirs + 32 * c, 32);
     }
 }
 
