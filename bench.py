@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--log2n", type=int, default=22, help="draws per GPU = 2^log2n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=["rccl", "host"], default="rccl",
+                    help="host = rehearsal of the multi-rank flow without RCCL (records cross the host over gloo)")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses GPU 0")
     args = ap.parse_args()
 
     from varsens_amd import _native, dist
@@ -90,10 +94,12 @@ def main():
     group = dist.HostGroup()
     if group.world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, group.world))
-    ctx = _native.Context(group.local_rank)
+    ctx = _native.Context(0 if args.shared_device else group.local_rank)
     world, rank = group.world, group.rank
     exchange = "none (single GPU)" if world == 1 else "rccl all-reduce (xGMI)"
     try:
+        if args.exchange == "host" and world > 1:
+            raise RuntimeError("--exchange host requested")
         comm = dist.RcclComm(ctx, group)
         failed = 0.0
     except Exception as exc:   # keep the scaling run alive, but say so in the result line
@@ -103,7 +109,8 @@ def main():
         if comm is not None:
             comm.close()
         comm = dist.HostExchange(ctx, group)
-        exchange = "HOST FALLBACK over gloo (RCCL init failed on at least one rank)"
+        exchange = ("host exchange over gloo (requested: rehearsal)" if args.exchange == "host" else
+                    "HOST FALLBACK over gloo (RCCL init failed on at least one rank)")
 
     k = args.k
     rows = 1 << args.log2n          # per GPU (weak scaling)
