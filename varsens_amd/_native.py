@@ -130,6 +130,13 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    if not os.path.isfile(p) and path is None and not os.environ.get("VARSENS_HIP_LIB"):
+        # not built yet (fresh checkout): build it now if a hipcc is around; there is nothing else to load
+        try:
+            from . import build as _build
+            _build.build(verbose=False)
+        except Exception as exc:
+            raise VarsensHipError("libvarsens_hip.so is missing and could not be built: %s" % exc)
     if not os.path.isfile(p):
         raise VarsensHipError(
             "libvarsens_hip.so not found at %s -- build it with "
