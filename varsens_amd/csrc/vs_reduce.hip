@@ -487,7 +487,7 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     uint64_t ntiles = (rows + tile - 1) / tile;
     if (ntiles < 1) ntiles = 1;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    uint64_t cap = (uint64_t)cus * env_int("VS_REDUCE_WGS_PER_CU", 2);
+    uint64_t cap = (uint64_t)cus * env_int("VS_REDUCE_WGS_PER_CU", 1);
     if (l > 1) cap = (cap + l - 1) / l;
     const uint32_t tile_wgs = (uint32_t)(ntiles < cap ? ntiles : cap);
     const int jchunk = k < VS_JCHUNK ? k : VS_JCHUNK;
