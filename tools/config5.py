@@ -1,0 +1,37 @@
+"""BASELINE configs[4] on ONE MI355X: polynomial objective, k=128, n=2^24 (34.6 GB of f-values)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from varsens_amd import _native
+from varsens_amd.saltelli import seed1_permutation
+from oracle import saltelli_oracle as orc
+
+k, n = 128, 1 << int(os.environ.get("LOG2N", 24))
+beta = 1.0 / (1.0 + np.arange(k) / 8.0)
+ctx = _native.Context(0)
+t0 = time.time(); perm = seed1_permutation(n); print("perm %.2fs" % (time.time() - t0), flush=True)
+design = ctx.design_create(_native.GEN_HALTON, k, n, 1 + 20 * k, 0, None, None, perm)
+obj = ctx.objective_create(_native.OBJ_POLYNOMIAL, k, 1, beta)
+N = 2 * (k + 1) * n
+f = ctx.alloc(8 * N)
+acc = ctx.alloc(8 * _native.acc_len(k, 1, 1)); out = ctx.alloc(8 * _native.first_order_len(k, 1))
+gram = ctx.alloc(8 * 3 * k * k)
+ctx.profile_begin(64)
+for _ in range(2):
+    ctx.eval(design, obj, 0, n, f)
+    ctx.reduce_first_order(f, n, k, 1, acc)
+    ctx.finish_first_order(acc, n, k, 1, out)
+    ctx.reduce_second_order(f, n, k, 1, gram)
+rec = ctx.profile_end()
+last = {}
+for name, ms in rec:
+    last[name] = ms
+print({a: round(b, 3) for a, b in last.items()}, flush=True)
+print("eval %.1f G evals/s ; reduce %.0f GB/s (%.1f%% of 8 TB/s) ; second order %.0f GB/s algorithmic, %.1f TFLOP/s (upper-triangle MFMA)" %
+      (N / last["eval"] / 1e6, 8 * N / last["reduce_first"] / 1e6, 100 * 8 * N / last["reduce_first"] / 1e6 / 8000,
+       16.0 * k * n / last["second_order"] / 1e6, 2.0 * (2 * k) * (2 * k + 16) / 2 * n / last["second_order"] / 1e9))
+fin = ctx.download(out, (2 + 4 * k, 1))
+V = beta ** 2 / 12.0
+total, S, ST = orc.product_form_indices(V)
+print("var_y %.6e (analytic %.6e)  max|sens-S| %.2e  max|sens_t-ST| %.2e" %
+      (fin[1, 0], total, np.max(np.abs(fin[2 + 2 * k:2 + 3 * k, 0] - S)), np.max(np.abs(fin[2 + 3 * k:, 0] - ST))))
