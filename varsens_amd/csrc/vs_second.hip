@@ -120,43 +120,71 @@ __device__ __forceinline__ void gram_body(const vs_gram_args& A, int SI, int SJ,
             if (!DIAG) bj[(wave + 4 * i) * VS2_PITCH + lane] = vj[i];
         }
     };
+    // Diagonal pairs (one tile, 10 accumulators) double-buffer the LDS tile: one barrier per chunk.
+    // Off-diagonal pairs (two tiles, 16 accumulators) keep ONE buffer so that two workgroups fit a
+    // CU and overlap each other instead.
+    constexpr bool DOUBLE = DIAG;
     int cur = 0;
     if (blockIdx.x < nchunks) {
         fetch(blockIdx.x);
-        stash(0);
+        if (DOUBLE) stash(0);
     }
-    __syncthreads();
+    if (DOUBLE) __syncthreads();
     for (uint64_t ch = blockIdx.x; ch < nchunks; ch += A.slab_wgs) {
         const bool more = ch + A.slab_wgs < nchunks;
+        if (!DOUBLE) {
+            __syncthreads();  // previous chunk fully consumed
+            stash(0);
+            __syncthreads();
+        }
         if (more) fetch(ch + A.slab_wgs);
         const double* bi = tiles + cur * TILE_DOUBLES;
         const double* bj = DIAG ? bi : bi + VS2_SUPER * VS2_PITCH;
-        // this wave's 16 sample rows = 4 k-steps of 4; all fragments first, then the MFMAs back to back
-        double fi[4][NB], fj[4][NB];
+        // this wave's 16 sample rows = 4 k-steps of 4
+        if (DOUBLE) {
+            double fi[4][NB];  // all fragments first, then the MFMAs back to back
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int rr = wave * 16 + s * 4 + (lane >> 4);
+            for (int s = 0; s < 4; ++s) {
+                const int rr = wave * 16 + s * 4 + (lane >> 4);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                fi[s][b] = bi[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
-                if (!DIAG) fj[s][b] = bj[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
+                for (int b = 0; b < NB; ++b) fi[s][b] = bi[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                int a = 0;
+#pragma unroll
+                for (int bi_ = 0; bi_ < NB; ++bi_)
+#pragma unroll
+                    for (int bj_ = bi_; bj_ < NB; ++bj_) {
+                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fi[s][bi_], fi[s][bj_], acc[a], 0, 0, 0);
+                        ++a;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int rr = wave * 16 + s * 4 + (lane >> 4);
+                double fi[NB], fj[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    fi[b] = bi[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
+                    fj[b] = bj[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
+                }
+                int a = 0;
+#pragma unroll
+                for (int bi_ = 0; bi_ < NB; ++bi_)
+#pragma unroll
+                    for (int bj_ = DIAG ? bi_ : 0; bj_ < NB; ++bj_) {
+                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fi[bi_], fj[bj_], acc[a], 0, 0, 0);
+                        ++a;
+                    }
             }
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            int a = 0;
-#pragma unroll
-            for (int bi_ = 0; bi_ < NB; ++bi_)
-#pragma unroll
-                for (int bj_ = DIAG ? bi_ : 0; bj_ < NB; ++bj_) {
-                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fi[s][bi_], DIAG ? fi[s][bj_] : fj[s][bj_], acc[a],
-                                                                  0, 0, 0);
-                    ++a;
-                }
+        if (DOUBLE) {
+            if (more) stash(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
         }
-        if (more) stash(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
     }
     // add the four waves' accumulators through LDS (reusing the tile space), fixed order
     __syncthreads();
@@ -341,7 +369,7 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     if (nchunks < 1) nchunks = 1;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     const char* env = getenv("VS_GRAM_WGS_PER_CU");
-    const int per_cu = env && *env ? atoi(env) : 2;
+    const int per_cu = env && *env ? atoi(env) : (npairs == 1 ? 2 : 4);  // measured: k=32 -> 2, k=128 -> 4
     uint64_t want = ((uint64_t)cus * per_cu + npairs - 1) / npairs;
     if (want < 1) want = 1;
     const uint32_t slab_wgs = (uint32_t)(nchunks < want ? nchunks : want);
@@ -371,7 +399,8 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     F.npairs = npairs;
     F.gram = gram_dev;
     F.counters = ctx->counters;
-    const size_t lds1 = 2 * sizeof(double) * VS2_SUPER * VS2_PITCH, lds2 = 2 * lds1;  // double-buffered tiles
+    const size_t lds1 = 2 * sizeof(double) * VS2_SUPER * VS2_PITCH;  // diagonal: one tile, double-buffered
+    const size_t lds2 = lds1;                                           // off-diagonal: two tiles, single buffer
     VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
