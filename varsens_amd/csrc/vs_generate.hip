@@ -454,20 +454,21 @@ __device__ __forceinline__ double vs_tile_ld(const double* p) {
 // Q+4m < j are running and the one with Q+4m == j starts from the prefixes.
 // Everything about the schedule is a compile-time constant, so the 16 chain
 // values stay in fixed registers.
-template <int KIND, int Q, bool SCRATCH>
+template <int KIND, int Q, bool SCRATCH, int W = VS_EVAL_WAVES>
 __device__ __forceinline__ void vs_chain_pass(const double* F1, const double* F2, int i0, double& pa, double& pb,
-                                              double (&cj)[VS_CHAINS], double (&dj)[VS_CHAINS]) {
+                                              double (&cj)[VS_PASS / W], double (&dj)[VS_PASS / W]) {
     constexpr int T = VS_EVAL_ROWS;
+    constexpr int CH = VS_PASS / W;
 #pragma unroll
     for (int j = 0; j < VS_PASS; ++j) {
         const double ta = vs_tile_ld<SCRATCH>(F1 + (size_t)(i0 + j) * T);
         const double tb = vs_tile_ld<SCRATCH>(F2 + (size_t)(i0 + j) * T);
 #pragma unroll
-        for (int m = 0; m < VS_CHAINS; ++m) {
-            if (Q + VS_EVAL_WAVES * m < j) {
+        for (int m = 0; m < CH; ++m) {
+            if (Q + W * m < j) {
                 cj[m] = vs_fold<KIND>(cj[m], tb);
                 dj[m] = vs_fold<KIND>(dj[m], ta);
-            } else if (Q + VS_EVAL_WAVES * m == j) {
+            } else if (Q + W * m == j) {
                 cj[m] = vs_fold<KIND>(pb, ta);  // N_j[i0+j]: M_2 with column i0+j from M_1
                 dj[m] = vs_fold<KIND>(pa, tb);  // N_nj[i0+j]: M_1 with column i0+j from M_2
             }
@@ -477,12 +478,30 @@ __device__ __forceinline__ void vs_chain_pass(const double* F1, const double* F2
     }
 }
 
+// run vs_chain_pass<.., Q = q, ..> for the (wave-uniform) run-time q in [0, W)
+template <int KIND, bool SCRATCH, int W, int Q = 0>
+struct vs_chain_dispatch {
+    static __device__ __forceinline__ void run(int q, const double* F1, const double* F2, int i0, double& pa,
+                                               double& pb, double (&cj)[VS_PASS / W], double (&dj)[VS_PASS / W]) {
+        if (q == Q) vs_chain_pass<KIND, Q, SCRATCH, W>(F1, F2, i0, pa, pb, cj, dj);
+        else vs_chain_dispatch<KIND, SCRATCH, W, Q + 1>::run(q, F1, F2, i0, pa, pb, cj, dj);
+    }
+};
+template <int KIND, bool SCRATCH, int W>
+struct vs_chain_dispatch<KIND, SCRATCH, W, W> {
+    static __device__ __forceinline__ void run(int, const double*, const double*, int, double&, double&,
+                                               double (&)[VS_PASS / W], double (&)[VS_PASS / W]) {}
+};
+
 #ifndef VS_EVAL_MIN_WAVES
 #define VS_EVAL_MIN_WAVES 1
 #endif
-template <int KIND, bool SCRATCH>
-__global__ void __launch_bounds__(VS_EVAL_ROWS * VS_EVAL_WAVES, VS_EVAL_MIN_WAVES)
+// W = waves per workgroup (4 or 8) sharing the 64-row tile: the larger the LDS tile (k), the
+// fewer workgroups fit a CU, so more waves per workgroup keep the SIMDs busy.
+template <int KIND, bool SCRATCH, int W>
+__global__ void __launch_bounds__(VS_EVAL_ROWS * W, VS_EVAL_MIN_WAVES)
 eval_kernel(vs_eval_args A, double* scratch, int tiles) {
+    constexpr int CH = VS_PASS / W;  // chains per thread and pass
     extern __shared__ double lds_tile[];
     constexpr int T = VS_EVAL_ROWS;
 #define TL(p) vs_tile_ld<SCRATCH>(p)
@@ -513,7 +532,7 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
     const bool terms_now = SEPARABLE && l == 1;
     const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
     const uint64_t src2 = A.D.n + (A.D.perm ? (uint64_t)A.D.perm[r] : r);  // sequence row behind M_2[r]
-    for (int c = q; c < k; c += VS_EVAL_WAVES) {
+    for (int c = q; c < k; c += W) {
         double x1, x2;
 #ifdef VS_ABL_NOGEN   /* diagnostic build: no generator arithmetic */
         if (halton_fast) {
@@ -552,7 +571,7 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
             if (l > 1) {
                 __syncthreads();  // previous output's chains are done with F1/F2
                 const double* p = A.params + (size_t)o * k;
-                for (int c = q; c < k; c += VS_EVAL_WAVES) {
+                for (int c = q; c < k; c += W) {
                     F1[(size_t)c * T] = vs_term<KIND>(TL(X1 + (size_t)c * T), p[c]);
                     F2[(size_t)c * T] = vs_term<KIND>(TL(X2 + (size_t)c * T), p[c]);
                 }
@@ -561,18 +580,13 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
             double pa = ident, pb = ident;  // folds of M_1 / M_2 terms over columns < c
             for (int i0 = 0; i0 < k; i0 += VS_PASS) {
                 // this thread's chains: blocks i0 + q + 4m, m = 0..7
-                double cj[VS_CHAINS], dj[VS_CHAINS];
+                double cj[CH], dj[CH];
 #pragma unroll
-                for (int m = 0; m < VS_CHAINS; ++m) cj[m] = dj[m] = ident;
+                for (int m = 0; m < CH; ++m) cj[m] = dj[m] = ident;
                 const int cend = min(k, i0 + VS_PASS);
                 int c = i0;
                 if (cend - i0 == VS_PASS) {
-                    switch (q) {  // wave-uniform
-                        case 0: vs_chain_pass<KIND, 0, SCRATCH>(F1, F2, i0, pa, pb, cj, dj); break;
-                        case 1: vs_chain_pass<KIND, 1, SCRATCH>(F1, F2, i0, pa, pb, cj, dj); break;
-                        case 2: vs_chain_pass<KIND, 2, SCRATCH>(F1, F2, i0, pa, pb, cj, dj); break;
-                        default: vs_chain_pass<KIND, 3, SCRATCH>(F1, F2, i0, pa, pb, cj, dj); break;
-                    }
+                    vs_chain_dispatch<KIND, SCRATCH, W>::run(q, F1, F2, i0, pa, pb, cj, dj);  // wave-uniform q
                     c = cend;
                 } else {
                     // partial pass (k not a multiple of 32): same schedule with run-time bounds
@@ -581,7 +595,7 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
                         pb = vs_fold<KIND>(pb, TL(F2 + (size_t)c * T));
                     }
 #pragma unroll
-                    for (int m = 0; m < VS_CHAINS; ++m) {
+                    for (int m = 0; m < CH; ++m) {
                         if (c < cend) {
                             const double ta = TL(F1 + (size_t)c * T), tb = TL(F2 + (size_t)c * T);
 #pragma unroll
@@ -595,7 +609,7 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
                             pb = vs_fold<KIND>(pb, tb);
                             ++c;
 #pragma unroll
-                            for (int s = 1; s < VS_EVAL_WAVES; ++s) {
+                            for (int s = 1; s < W; ++s) {
                                 if (c < cend) {
                                     const double ua = TL(F1 + (size_t)c * T), ub = TL(F2 + (size_t)c * T);
 #pragma unroll
@@ -615,14 +629,14 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
                 for (; c < k; ++c) {
                     const double ta = TL(F1 + (size_t)c * T), tb = TL(F2 + (size_t)c * T);
 #pragma unroll
-                    for (int m = 0; m < VS_CHAINS; ++m) {
+                    for (int m = 0; m < CH; ++m) {
                         cj[m] = vs_fold<KIND>(cj[m], tb);
                         dj[m] = vs_fold<KIND>(dj[m], ta);
                     }
                 }
 #pragma unroll
-                for (int m = 0; m < VS_CHAINS; ++m) {
-                    const int i = i0 + q + VS_EVAL_WAVES * m;
+                for (int m = 0; m < CH; ++m) {
+                    const int i = i0 + q + W * m;
                     if (i < k) {
                         VS_OUT(2 + i, o, cj[m]);
                         VS_OUT(2 + k + i, o, dj[m]);
@@ -660,7 +674,7 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
             VS_OUT(7, 0, val(0, 0, 1));
         }
     } else if (KIND == VS_OBJ_INVERT) {
-        for (int o = q; o < k; o += VS_EVAL_WAVES) {
+        for (int o = q; o < k; o += W) {
             const double ia = 1.0 - TL(X1 + (size_t)o * T), ib = 1.0 - TL(X2 + (size_t)o * T);
             VS_OUT(0, o, ia);
             VS_OUT(1, o, ib);
@@ -677,6 +691,30 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
 #undef TL
 }
 
+template <int KIND, int W>
+static int launch_eval_w(vs_context* ctx, const vs_eval_args& A, int tiles, size_t lds, uint64_t blocks, bool scratch) {
+    if (!scratch) {
+        if (lds > 64 * 1024)
+            VS_HIP(hipFuncSetAttribute((const void*)eval_kernel<KIND, false, W>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        vs_launch_scope scope(ctx, VS_KERNEL_EVAL);
+        hipLaunchKernelGGL((eval_kernel<KIND, false, W>), dim3((unsigned)blocks), dim3(VS_EVAL_ROWS * W), lds,
+                           ctx->stream, A, (double*)nullptr, tiles);
+    } else {
+        // the tile of one workgroup does not fit LDS: persistent workgroups, tile in an HBM scratch slice
+        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        uint64_t slots = (uint64_t)cus * (16 / W);
+        if (slots > blocks) slots = blocks;
+        int rc = vs_workspace_scratch(ctx, (size_t)slots * lds);
+        if (rc) return rc;
+        vs_launch_scope scope(ctx, VS_KERNEL_EVAL);
+        hipLaunchKernelGGL((eval_kernel<KIND, true, W>), dim3((unsigned)slots), dim3(VS_EVAL_ROWS * W), 0, ctx->stream,
+                           A, ctx->scratch, tiles);
+    }
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
 template <int KIND>
 static int launch_eval(vs_context* ctx, const vs_eval_args& A, int tiles) {
     const int k = A.D.k;
@@ -684,26 +722,17 @@ static int launch_eval(vs_context* ctx, const vs_eval_args& A, int tiles) {
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
     const char* force = getenv("VS_EVAL_SCRATCH");
-    if (lds <= 160 * 1024 && !(force && *force == '1')) {
-        if (lds > 64 * 1024)
-            VS_HIP(hipFuncSetAttribute((const void*)eval_kernel<KIND, false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        vs_launch_scope scope(ctx, VS_KERNEL_EVAL);
-        hipLaunchKernelGGL((eval_kernel<KIND, false>), dim3((unsigned)blocks), dim3(VS_EVAL_ROWS * VS_EVAL_WAVES), lds,
-                           ctx->stream, A, (double*)nullptr, tiles);
-    } else {
-        // the tile of one workgroup does not fit LDS: persistent workgroups, tile in an HBM scratch slice
-        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-        uint64_t slots = (uint64_t)cus * 4;
-        if (slots > blocks) slots = blocks;
-        int rc = vs_workspace_scratch(ctx, (size_t)slots * lds);
-        if (rc) return rc;
-        vs_launch_scope scope(ctx, VS_KERNEL_EVAL);
-        hipLaunchKernelGGL((eval_kernel<KIND, true>), dim3((unsigned)slots), dim3(VS_EVAL_ROWS * VS_EVAL_WAVES), 0,
-                           ctx->stream, A, ctx->scratch, tiles);
-    }
-    VS_HIP(hipGetLastError());
-    return VS_OK;
+    const bool scratch = lds > 160 * 1024 || (force && *force == '1');
+    constexpr bool SEPARABLE = KIND == VS_OBJ_G_FUNCTION || KIND == VS_OBJ_POLYNOMIAL || KIND == VS_OBJ_LINEAR;
+    // waves per workgroup: with a big tile only one or two workgroups fit a CU, and eight waves
+    // sharing the tile keep the SIMDs busier than four (measured: k=48 4 waves 0.72 / 8 waves 0.79 ms,
+    // k=64 1.12 / 0.98, k=96 2.79 / 2.07, k=128 9.0 / 6.9; sixteen waves were never better)
+    int W = 4;
+    if (SEPARABLE && !scratch && lds > 56 * 1024) W = 8;
+    const char* wenv = getenv("VS_EVAL_WAVES_PER_WG");
+    if (SEPARABLE && wenv && *wenv) W = atoi(wenv) == 8 ? 8 : 4;
+    if (SEPARABLE && W == 8) return launch_eval_w<KIND, 8>(ctx, A, tiles, lds, blocks, scratch);
+    return launch_eval_w<KIND, 4>(ctx, A, tiles, lds, blocks, scratch);
 }
 
 // ---------------------------------------------------------------------------
