@@ -179,7 +179,10 @@ extern "C" int vs_sobol_fill(vs_context* ctx, int k, const uint32_t* directions,
 
 extern "C" int vs_design_destroy(vs_context* ctx, vs_design* g) {
     if (!g) return VS_OK;
-    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (ctx) {  // kernels on either stream may still read the tables
+        hipStreamSynchronize(ctx->streams[0]);
+        hipStreamSynchronize(ctx->streams[1]);
+    }
     if (g->lower) hipFree(g->lower);
     if (g->width) hipFree(g->width);
     if (g->perm) hipFree(g->perm);
@@ -319,7 +322,10 @@ extern "C" int vs_sample_flat(vs_context* ctx, const vs_design* design, uint64_t
 
 extern "C" int vs_objective_destroy(vs_context* ctx, vs_objective* obj) {
     if (!obj) return VS_OK;
-    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (ctx) {
+        hipStreamSynchronize(ctx->streams[0]);
+        hipStreamSynchronize(ctx->streams[1]);
+    }
     if (obj->params) hipFree(obj->params);
     vs_rtc_release(obj);
     delete obj;
