@@ -435,3 +435,19 @@ def test_fused_refuses_what_it_does_not_cover(ctx):
     acc = ctx.alloc(8 * _native.acc_len(40, 1, 1))
     with pytest.raises(_native.VarsensHipError, match="fused path covers"):
         ctx.eval_reduce_first_order(d, obj, 0, 100, acc)
+
+
+def test_variance_with_outlier_in_first_value(ctx):
+    """The variance shift is a leading-sample mean, not the first value: an extreme first value must not
+    cost accuracy (numpy's two-pass variance is the reference, saltelli.py:583)."""
+    rng = np.random.RandomState(13)
+    blocks = 5.0 + rng.randn(2 * 3 + 2, 50000, 1)
+    blocks[0, 0, 0] = 1e9
+    rec, fin = reduce_dev(ctx, blocks, 50000)
+    want = np.var(np.concatenate([blocks[0], blocks[1]]), axis=0, ddof=1)
+    np.testing.assert_allclose(fin[1], want, rtol=1e-9)
+    blocks[0, 0, 0] = 5.0
+    blocks[0, 70, 0] = -1e7          # outlier inside the leading sample
+    rec, fin = reduce_dev(ctx, blocks, 50000)
+    want = np.var(np.concatenate([blocks[0], blocks[1]]), axis=0, ddof=1)
+    np.testing.assert_allclose(fin[1], want, rtol=1e-10)

@@ -132,10 +132,27 @@ __device__ __forceinline__ double vs_wave_sum_dpp(double v) {
 }
 
 
+// Common shift of the one-pass variance sums: the mean of the first min(rows, 1024) values of a
+// block, summed in a fixed order by ONE wave (every lane returns the same bits, and every wave or
+// kernel that calls it gets the same bits).  A sample mean is within a small fraction of sigma of the
+// true mean, so sum (x-s)^2 - (sum (x-s))^2/N loses nothing to cancellation, and one outlier among
+// the leading values moves it by outlier/1024 only.
+__device__ __forceinline__ double vs_shift_estimate(const double* a, uint64_t rows);
+
 // Sum over the 64 lanes of a wavefront; result valid in every lane.
 __device__ __forceinline__ double vs_wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+__device__ __forceinline__ double vs_shift_estimate(const double* a, uint64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t m = rows < 1024 ? rows : 1024;
+    double s = 0.0;
+    for (uint64_t i = lane; i < m; i += 64) s += a[i];
+    s = vs_wave_sum_dpp(s);  // total in lanes 48..63
+    const int lo = __builtin_amdgcn_readlane(__double2loint(s), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(s), 63);
+    return m ? __hiloint2double(hi, lo) / (double)m : 0.0;
 }
 #endif

@@ -109,9 +109,10 @@ reduce_first_kernel(vs_reduce_args A) {
     const uint64_t rows = A.rows;
     constexpr uint64_t estride = 1;  // planar layout: consecutive rows are consecutive doubles
     const double* fo = A.f + (uint64_t)o * (2 * (uint64_t)k + 2) * rows;  // plane of output o
-    // common shift of the variance sums: the first (kept) a-value of this output
+    // common shift of the variance sums: a leading-sample mean of fM_1 (un-masked pass), or the first
+    // kept a-value (masked pass: the leading values may hold the NaNs)
     const uint64_t shift_row = MASKED ? (uint64_t)A.counters[CNT_FIRST_KEPT] : 0;
-    const double shift = (shift_row < rows) ? fo[shift_row * estride] : 0.0;
+    const double shift = MASKED ? ((shift_row < rows) ? fo[shift_row * estride] : 0.0) : vs_shift_estimate(fo, rows);
 
     constexpr uint64_t TILE = (uint64_t)VS_WG * NV * VEC;
     const uint64_t ntiles = (rows + TILE - 1) / TILE;
@@ -385,17 +386,21 @@ fold_first_kernel(vs_fold_args A, double* folded /* [l*plen] scratch */) {
     // this rank's variance slot: count, mean[l], m2[l]
     const double cnt = 2.0 * (double)kept;
     if (threadIdx.x == 0) slot[0] = cnt;
-    for (int o = threadIdx.x; o < l; o += blockDim.x) {
+    for (int o = 0; o < l; ++o) {  // every thread walks the outputs: vs_shift_estimate is a wave-wide call
         double mean = 0.0, m2 = 0.0;
         if (kept > 0) {
+            const double* a_block = A.f ? A.f + (uint64_t)o * (2 * (uint64_t)k + 2) * A.rows : nullptr;
             const double shift = A.shift_values ? A.shift_values[o]
-                                 : (shift_row < A.rows ? A.f[(uint64_t)o * (2 * (uint64_t)k + 2) * A.rows + shift_row] : 0.0);
+                                 : (A.masked ? (shift_row < A.rows ? a_block[shift_row] : 0.0)
+                                             : vs_shift_estimate(a_block, A.rows));
             const double s1 = ld(o * plen + VS_P_S1), s2 = ld(o * plen + VS_P_S2);
             mean = shift + s1 / cnt;
             m2 = s2 - s1 * (s1 / cnt);
         }
-        slot[1 + o] = mean;
-        slot[1 + l + o] = m2;
+        if (threadIdx.x == 0) {
+            slot[1 + o] = mean;
+            slot[1 + l + o] = m2;
+        }
     }
 }
 
