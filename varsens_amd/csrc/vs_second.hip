@@ -8,8 +8,9 @@
 // v_mfma_f64_16x16x4_f64, D(16x16) += A(16x4) B(4x16), where A and B are both
 // "16 index rows x 4 sample rows" fragments of X (one double per lane).
 //
-// A workgroup (4 waves) owns a pair of 64-index-row super-blocks (SI <= SJ) and
-// walks 64-sample-row chunks: coalesced loads (one index row = 512 B per wave
+// A workgroup owns a pair of 64-index-row super-blocks (SI <= SJ) and walks
+// 64-sample-row chunks (diagonal pairs: 4 waves splitting the sample rows, below;
+// off-diagonal pairs: 8 waves splitting the 16 output tiles, gram_offdiag_kernel): coalesced loads (one index row = 512 B per wave
 // instruction) into an LDS tile [index row][sample row] with a 66-double pitch
 // (conflict-free fragment reads), then each wave takes 16 of the 64 sample rows:
 // 4 MFMA k-steps x up to 16 block pairs, accumulators in registers for the whole
@@ -231,6 +232,82 @@ gram_kernel(vs_gram_args A) {
     gram_body<MASKED, DIAG>(A, SI, SJ, tiles);
 }
 
+// Off-diagonal super-block pairs (SI < SJ): all 16 block pairs are needed.  Eight waves share the
+// two 64x64 LDS tiles and split the OUTPUT: wave w owns tiles (bi = w/2, bj = 2(w%2), 2(w%2)+1) and
+// walks all 16 k-steps of a chunk.  Two accumulator tiles per wave (16 VGPRs) instead of sixteen, so
+// four waves per SIMD stay resident; a tile belongs to one wave, so no cross-wave sum at the end.
+template <bool MASKED>
+__global__ void __launch_bounds__(512)
+gram_offdiag_kernel(vs_gram_args A) {
+    extern __shared__ double tiles[];  // TI, TJ: [64][VS2_PITCH] each
+    if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
+    int SI, SJ;
+    pair_from_index(blockIdx.y + A.nsuper, A.nsuper, SI, SJ);
+    double* TI = tiles;
+    double* TJ = tiles + VS2_SUPER * VS2_PITCH;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+    const int M = 2 * A.K;
+    const uint64_t rows = A.rows;
+    const int bi = wave >> 1, bj0 = (wave & 1) * 2;
+
+    vs_d4 acc0 = (vs_d4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+
+    // staging: wave w loads index rows w, w+8, .. of both super-blocks (8 + 8 loads of 512 B)
+    constexpr int NR = VS2_SUPER / 8;
+    const double* rowI[NR];
+    const double* rowJ[NR];
+    bool okI[NR], okJ[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int mi = SI * VS2_SUPER + wave + 8 * i, mj = SJ * VS2_SUPER + wave + 8 * i;
+        okI[i] = mi < M;
+        okJ[i] = mj < M;
+        rowI[i] = x_elem(A, okI[i] ? mi : 0, 0);
+        rowJ[i] = x_elem(A, okJ[i] ? mj : 0, 0);
+    }
+    double vi[NR], vj[NR];
+    auto fetch = [&](uint64_t ch) {
+        const uint64_t r = ch * VS2_CHUNK + lane;
+        const bool rin = r < rows && (!MASKED || A.keep[r]);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            vi[i] = (rin && okI[i]) ? __builtin_nontemporal_load(rowI[i] + r) : 0.0;
+            vj[i] = (rin && okJ[i]) ? __builtin_nontemporal_load(rowJ[i] + r) : 0.0;
+        }
+    };
+    const uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
+    if (blockIdx.x < nchunks) fetch(blockIdx.x);
+    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += A.slab_wgs) {
+        __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            TI[(wave + 8 * i) * VS2_PITCH + lane] = vi[i];
+            TJ[(wave + 8 * i) * VS2_PITCH + lane] = vj[i];
+        }
+        if (ch + A.slab_wgs < nchunks) fetch(ch + A.slab_wgs);  // lands while the MFMAs below run
+        __syncthreads();
+        const double* pi = TI + (bi * 16 + (lane & 15)) * VS2_PITCH + (lane >> 4);
+        const double* pj0 = TJ + (bj0 * 16 + (lane & 15)) * VS2_PITCH + (lane >> 4);
+        const double* pj1 = pj0 + 16 * VS2_PITCH;
+#pragma unroll
+        for (int s = 0; s < VS2_CHUNK / 4; ++s) {
+            const double fi = pi[4 * s], f0 = pj0[4 * s], f1 = pj1[4 * s];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, f0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, f1, acc1, 0, 0, 0);
+        }
+    }
+    const int npairs = A.nsuper * (A.nsuper + 1) / 2;
+    double* out = A.partials + ((size_t)blockIdx.x * npairs + (blockIdx.y + A.nsuper)) * VS2_TILE_OUT;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int row = (lane >> 4) + 4 * v, col = lane & 15;   // f64 C/D layout
+        out[(bi * 16 + row) * VS2_SUPER + (bj0 * 16 + col)] = acc0[v];
+        out[(bi * 16 + row) * VS2_SUPER + ((bj0 + 1) * 16 + col)] = acc1[v];
+    }
+}
+
 // keep mask for the second-order pass (same rule as the first-order one)
 __global__ void __launch_bounds__(256)
 nan_mask2_kernel(const double* __restrict__ f, uint64_t rows, int k, int l, uint8_t* __restrict__ keep,
@@ -369,7 +446,7 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     if (nchunks < 1) nchunks = 1;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     const char* env = getenv("VS_GRAM_WGS_PER_CU");
-    const int per_cu = env && *env ? atoi(env) : (npairs == 1 ? 2 : 4);  // measured: k=32 -> 2, k=128 -> 4
+    const int per_cu = env && *env ? atoi(env) : (npairs == 1 ? 2 : 8);  // measured: k=32 -> 2, k=128 -> 8
     uint64_t want = ((uint64_t)cus * per_cu + npairs - 1) / npairs;
     if (want < 1) want = 1;
     const uint32_t slab_wgs = (uint32_t)(nchunks < want ? nchunks : want);
@@ -403,8 +480,8 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     const size_t lds2 = lds1;                                           // off-diagonal: two tiles, single buffer
     VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    VS_HIP(hipFuncSetAttribute((const void*)gram_offdiag_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    VS_HIP(hipFuncSetAttribute((const void*)gram_offdiag_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     const dim3 grid_diag(slab_wgs, nsuper), grid_off(slab_wgs, npairs - nsuper);
     for (int pass = 0; pass < 2; ++pass) {
         const bool masked = pass == 1;
@@ -421,10 +498,10 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
             if (masked) {
                 hipLaunchKernelGGL((gram_kernel<true, true>), grid_diag, dim3(256), lds1, ctx->stream, A);
-                if (npairs > nsuper) hipLaunchKernelGGL((gram_kernel<true, false>), grid_off, dim3(256), lds2, ctx->stream, A);
+                if (npairs > nsuper) hipLaunchKernelGGL(gram_offdiag_kernel<true>, grid_off, dim3(512), lds2, ctx->stream, A);
             } else {
                 hipLaunchKernelGGL((gram_kernel<false, true>), grid_diag, dim3(256), lds1, ctx->stream, A);
-                if (npairs > nsuper) hipLaunchKernelGGL((gram_kernel<false, false>), grid_off, dim3(256), lds2, ctx->stream, A);
+                if (npairs > nsuper) hipLaunchKernelGGL(gram_offdiag_kernel<false>, grid_off, dim3(512), lds2, ctx->stream, A);
             }
         }
         VS_HIP(hipGetLastError());
