@@ -232,6 +232,74 @@ gram_kernel(vs_gram_args A) {
     gram_body<MASKED, DIAG>(A, SI, SJ, tiles);
 }
 
+// Diagonal super-block pairs (SI == SJ), tile-split form: ten waves share ONE 64x64 LDS tile, wave w
+// owns the w-th of the ten block pairs (bi <= bj) and walks all 16 k-steps of a chunk.  One
+// accumulator tile per wave, no cross-wave sum.  (VS_GRAM_DIAG_SPLIT=0 selects the 4-wave
+// sample-row-split kernel above instead.)
+template <bool MASKED>
+__global__ void __launch_bounds__(640)
+gram_diag_tile_kernel(vs_gram_args A) {
+    extern __shared__ double tiles[];  // [64][VS2_PITCH]
+    if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
+    const int S = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..9
+    const int M = 2 * A.K;
+    const uint64_t rows = A.rows;
+    // wave -> (bi, bj), bi <= bj, row by row: (0,0..3) (1,1..3) (2,2..3) (3,3)
+    int bi = 0, rest = wave, len = 4;
+    while (rest >= len) { rest -= len; ++bi; --len; }
+    const int bj = bi + rest;
+
+    vs_d4 acc = (vs_d4){0.0, 0.0, 0.0, 0.0};
+    // staging: wave w loads index rows w, w+10, .. (7 or 6 rows of 512 B)
+    constexpr int NR = 7;
+    const double* rowp[NR];
+    bool okr[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int ir = wave + 10 * i;
+        const int m = S * VS2_SUPER + ir;
+        okr[i] = ir < VS2_SUPER && m < M;
+        rowp[i] = x_elem(A, okr[i] ? m : 0, 0);
+    }
+    double vr[NR];
+    auto fetch = [&](uint64_t ch) {
+        const uint64_t r = ch * VS2_CHUNK + lane;
+        const bool rin = r < rows && (!MASKED || A.keep[r]);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) vr[i] = (rin && okr[i]) ? __builtin_nontemporal_load(rowp[i] + r) : 0.0;
+    };
+    const uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
+    if (blockIdx.x < nchunks) fetch(blockIdx.x);
+    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += A.slab_wgs) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+            if (wave + 10 * i < VS2_SUPER) tiles[(wave + 10 * i) * VS2_PITCH + lane] = vr[i];
+        if (ch + A.slab_wgs < nchunks) fetch(ch + A.slab_wgs);
+        __syncthreads();
+        const double* pi = tiles + (bi * 16 + (lane & 15)) * VS2_PITCH + (lane >> 4);
+        const double* pj = tiles + (bj * 16 + (lane & 15)) * VS2_PITCH + (lane >> 4);
+#pragma unroll
+        for (int s = 0; s < VS2_CHUNK / 4; ++s)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pi[4 * s], pj[4 * s], acc, 0, 0, 0);
+    }
+    const int npairs = A.nsuper * (A.nsuper + 1) / 2;
+    double* out = A.partials + ((size_t)blockIdx.x * npairs + S) * VS2_TILE_OUT;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int row = (lane >> 4) + 4 * v, col = lane & 15;
+        out[(bi * 16 + row) * VS2_SUPER + (bj * 16 + col)] = acc[v];
+    }
+    // blocks below the diagonal are not computed: zero them so the fold sees defined data
+    for (int e = tid; e < VS2_TILE_OUT; e += 640) {
+        const int ebi = (e / VS2_SUPER) / 16, ebj = (e % VS2_SUPER) / 16;
+        if (ebj < ebi) out[e] = 0.0;
+    }
+}
+
 // Off-diagonal super-block pairs (SI < SJ): all 16 block pairs are needed.  Eight waves share the
 // two 64x64 LDS tiles and split the OUTPUT: wave w owns tiles (bi = w/2, bj = 2(w%2), 2(w%2)+1) and
 // walks all 16 k-steps of a chunk.  Two accumulator tiles per wave (16 VGPRs) instead of sixteen, so
@@ -496,12 +564,19 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
         }
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
-            if (masked) {
-                hipLaunchKernelGGL((gram_kernel<true, true>), grid_diag, dim3(256), lds1, ctx->stream, A);
-                if (npairs > nsuper) hipLaunchKernelGGL(gram_offdiag_kernel<true>, grid_off, dim3(512), lds2, ctx->stream, A);
+            const char* dsplit = getenv("VS_GRAM_DIAG_SPLIT");
+            const bool tile_split = !(dsplit && *dsplit == '0');
+            const size_t lds_t = sizeof(double) * VS2_SUPER * VS2_PITCH;
+            if (tile_split) {
+                if (masked) hipLaunchKernelGGL(gram_diag_tile_kernel<true>, grid_diag, dim3(640), lds_t, ctx->stream, A);
+                else hipLaunchKernelGGL(gram_diag_tile_kernel<false>, grid_diag, dim3(640), lds_t, ctx->stream, A);
             } else {
-                hipLaunchKernelGGL((gram_kernel<false, true>), grid_diag, dim3(256), lds1, ctx->stream, A);
-                if (npairs > nsuper) hipLaunchKernelGGL(gram_offdiag_kernel<false>, grid_off, dim3(512), lds2, ctx->stream, A);
+                if (masked) hipLaunchKernelGGL((gram_kernel<true, true>), grid_diag, dim3(256), lds1, ctx->stream, A);
+                else hipLaunchKernelGGL((gram_kernel<false, true>), grid_diag, dim3(256), lds1, ctx->stream, A);
+            }
+            if (npairs > nsuper) {
+                if (masked) hipLaunchKernelGGL(gram_offdiag_kernel<true>, grid_off, dim3(512), lds2, ctx->stream, A);
+                else hipLaunchKernelGGL(gram_offdiag_kernel<false>, grid_off, dim3(512), lds2, ctx->stream, A);
             }
         }
         VS_HIP(hipGetLastError());
