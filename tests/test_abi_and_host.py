@@ -134,3 +134,20 @@ def test_objective_specs():
     with pytest.raises(Exception, match="k=3"):
         objectives.Ishigami().params(5)
     assert objectives.Invert().outputs(9) == 9
+
+
+def test_bench_cpu_baseline_leg():
+    """bench.py's cpu_baseline (oracle timed on host cores) on a tiny input: keys and sanity."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    k, n = 32, 256
+    rng = np.random.RandomState(0)
+    blocks = 1.0 + rng.rand(2 * k + 2, n, 1)
+    cpu, R = bench.cpu_baseline(k, blocks, n, 8)
+    for key in ("value", "unit", "cores", "kind", "sample", "eval_loop_evals_per_s", "reduce_only_gsamples_per_s"):
+        assert key in cpu
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["unit"] == "GSamples/s" and cpu["value"] > 0
+    assert R["sens"].shape == (k, 1)
+    assert bench.pmc_traffic("void reduce_first_kernel", 32, 22) is None or bench.pmc_traffic("void reduce_first_kernel", 32, 22) > 2.2e9
