@@ -46,13 +46,25 @@ def default_context(device=None):
     return _default_ctx[device]
 
 
+_perm_cache = {}
+
+
 def seed1_permutation(n):
     """Row order the reference's ``numpy.random.seed(1); numpy.random.shuffle(M_2)``
     produces (varsens/saltelli.py:100-101): shuffled[r] = original[perm[r]].
     A private legacy RandomState(1) draws the same MT19937 stream; numpy's global
-    RNG is left alone (the reference reseeds it as a side effect)."""
-    order = numpy.arange(n, dtype=numpy.uint32)
-    numpy.random.RandomState(1).shuffle(order)
+    RNG is left alone (the reference reseeds it as a side effect).  The Fisher-Yates
+    walk is sequential (about 12 ns per row on the host), so the last few
+    permutations are kept: repeated designs of one size (bootstraps) pay it once."""
+    n = int(n)
+    order = _perm_cache.get(n)
+    if order is None:
+        order = numpy.arange(n, dtype=numpy.uint32)
+        numpy.random.RandomState(1).shuffle(order)
+        order.setflags(write=False)
+        if len(_perm_cache) >= 4:
+            _perm_cache.pop(next(iter(_perm_cache)))
+        _perm_cache[n] = order
     return order
 
 
