@@ -435,3 +435,19 @@ def test_two_process_sharded_run_equals_single_process(vs, tmp_path):
         numpy.testing.assert_allclose(two[f], getattr(one, f), rtol=1e-13)
     for f in ("sens", "sens_t", "sens_2", "sens_2n"):
         numpy.testing.assert_allclose(two[f], getattr(one, f), rtol=1e-9, atol=1e-12)
+
+
+def test_sobol_with_opaque_scaling_and_discard(vs):
+    from scipy.stats import qmc
+    k, n, discard = 5, 32, 7
+    lo, hi = numpy.arange(1.0, 6.0), numpy.arange(2.0, 12.0, 2.0)
+    s = vs.Sample(k, n, lambda x: vs.scale.linear(x, lo, hi), discard, verbose=False, generator='sobol')
+    eng = qmc.Sobol(d=k, scramble=False, bits=30)
+    eng.fast_forward(4096 + discard)
+    pts = orc.scale_linear(eng.random(2 * n), lo, hi)
+    assert numpy.array_equal(s.M_1, pts[:n])
+    assert numpy.array_equal(s.M_2, pts[n:][orc.seed1_permutation(n)])
+    s2 = vs.Sample(k, n, vs.scale.Linear(lo, hi), discard, verbose=False, generator='sobol')
+    assert numpy.array_equal(s2.flat(), s.flat())
+    with pytest.raises(Exception, match="generator must be"):
+        vs.Sample(k, n, vs.scale.Identity(), verbose=False, generator='faure')
