@@ -752,26 +752,15 @@ static int launch_eval(vs_context* ctx, const vs_eval_args& A, int tiles) {
 // exactly one wave, so the only reduction left at the end is the DPP wave sum; one partial record
 // per workgroup, same layout and same fold as reduce_first_kernel's.
 
-#ifndef VS_FUSED_MIN_WAVES
-#define VS_FUSED_MIN_WAVES 1
-#endif
-template <int KIND>
-__global__ void __launch_bounds__(VS_EVAL_ROWS * VS_EVAL_WAVES, VS_FUSED_MIN_WAVES)
-fused_first_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
-    extern __shared__ double lds[];
+// The whole persistent walk of one wave, specialised on its index Q in the workgroup: the chain
+// schedule (which chain starts at which column) is then a compile-time constant in straight-line
+// code, and the accumulators never move between registers.
+template <int KIND, int Q>
+__device__ __forceinline__ void fused_rows(const vs_eval_args& A, double shift, double* lds, double* partials) {
     constexpr int T = VS_EVAL_ROWS;
     const int k = A.D.k;  // <= VS_PASS
     const int lane = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t rows = A.rows;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the fold that follows (see reduce_first_kernel)
-        counters[0] = 0;
-        counters[1] = 0xffffffffu;
-        counters[2] = 0;
-        counters[3] = 0;
-        counters[4] = 0;
-    }
-    const double shift = *shift_src;
     double* X1 = lds + lane;
     double* X2 = lds + (size_t)k * T + lane;
     const double ident = KIND == VS_OBJ_LINEAR ? 0.0 : 1.0;
@@ -788,7 +777,7 @@ fused_first_kernel(vs_eval_args A, const double* shift_src, double* partials, ui
         const bool valid = lr < rows;
         const uint64_t r = A.row_begin + (valid ? lr : rows - 1);
         const uint64_t src2 = A.D.n + (A.D.perm ? (uint64_t)A.D.perm[r] : r);
-        for (int c = q; c < k; c += VS_EVAL_WAVES) {
+        for (int c = Q; c < k; c += VS_EVAL_WAVES) {
             double x1, x2;
             if (halton_fast) {
                 vs_radical_inverse_pair((uint32_t)(A.D.first_index + r), (uint32_t)(A.D.first_index + src2),
@@ -808,47 +797,24 @@ fused_first_kernel(vs_eval_args A, const double* shift_src, double* partials, ui
 #pragma unroll
         for (int m = 0; m < VS_CHAINS; ++m) cj[m] = dj[m] = ident;
         if (k == VS_PASS) {
-            switch (q) {
-                case 0: vs_chain_pass<KIND, 0, false>(X1, X2, 0, pa, pb, cj, dj); break;
-                case 1: vs_chain_pass<KIND, 1, false>(X1, X2, 0, pa, pb, cj, dj); break;
-                case 2: vs_chain_pass<KIND, 2, false>(X1, X2, 0, pa, pb, cj, dj); break;
-                default: vs_chain_pass<KIND, 3, false>(X1, X2, 0, pa, pb, cj, dj); break;
-            }
+            vs_chain_pass<KIND, Q, false>(X1, X2, 0, pa, pb, cj, dj);
         } else {
-            int c = 0;
-            for (const int stop = min(k, q); c < stop; ++c) {
-                pa = vs_fold<KIND>(pa, X1[(size_t)c * T]);
-                pb = vs_fold<KIND>(pb, X2[(size_t)c * T]);
-            }
+            // k < 32: same schedule with run-time bounds (chain m of this wave starts at column Q+4m)
+            for (int c = 0; c < k; ++c) {
+                const double ta = X1[(size_t)c * T], tb = X2[(size_t)c * T];
 #pragma unroll
-            for (int m = 0; m < VS_CHAINS; ++m) {
-                if (c < k) {
-                    const double ta = X1[(size_t)c * T], tb = X2[(size_t)c * T];
-#pragma unroll
-                    for (int mm = 0; mm < m; ++mm) {
-                        cj[mm] = vs_fold<KIND>(cj[mm], tb);
-                        dj[mm] = vs_fold<KIND>(dj[mm], ta);
-                    }
-                    cj[m] = vs_fold<KIND>(pb, ta);
-                    dj[m] = vs_fold<KIND>(pa, tb);
-                    pa = vs_fold<KIND>(pa, ta);
-                    pb = vs_fold<KIND>(pb, tb);
-                    ++c;
-#pragma unroll
-                    for (int s = 1; s < VS_EVAL_WAVES; ++s) {
-                        if (c < k) {
-                            const double ua = X1[(size_t)c * T], ub = X2[(size_t)c * T];
-#pragma unroll
-                            for (int mm = 0; mm <= m; ++mm) {
-                                cj[mm] = vs_fold<KIND>(cj[mm], ub);
-                                dj[mm] = vs_fold<KIND>(dj[mm], ua);
-                            }
-                            pa = vs_fold<KIND>(pa, ua);
-                            pb = vs_fold<KIND>(pb, ub);
-                            ++c;
-                        }
+                for (int m = 0; m < VS_CHAINS; ++m) {
+                    const int start = Q + VS_EVAL_WAVES * m;
+                    if (c > start) {
+                        cj[m] = vs_fold<KIND>(cj[m], tb);
+                        dj[m] = vs_fold<KIND>(dj[m], ta);
+                    } else if (c == start) {
+                        cj[m] = vs_fold<KIND>(pb, ta);
+                        dj[m] = vs_fold<KIND>(pa, tb);
                     }
                 }
+                pa = vs_fold<KIND>(pa, ta);
+                pb = vs_fold<KIND>(pb, tb);
             }
         }
         if (valid) {  // a = pa, b = pb, c_i = cj, d_i = dj
@@ -859,7 +825,7 @@ fused_first_kernel(vs_eval_args A, const double* shift_src, double* partials, ui
                 acc[m][2] = fma(pa, dj[m], acc[m][2]);  // a.d_i
                 acc[m][3] = fma(pb, cj[m], acc[m][3]);  // b.c_i
             }
-            if (q == 0) {
+            if (Q == 0) {
                 const double dx = pa - shift, dy = pb - shift;
                 t_sab = fma(pa, pb, t_sab);
                 t_sa += pa;
@@ -875,14 +841,14 @@ fused_first_kernel(vs_eval_args A, const double* shift_src, double* partials, ui
     double* out = partials + (size_t)blockIdx.x * VS_PLEN(k);
 #pragma unroll
     for (int m = 0; m < VS_CHAINS; ++m) {
-        const int i = q + VS_EVAL_WAVES * m;
+        const int i = Q + VS_EVAL_WAVES * m;
 #pragma unroll
         for (int z = 0; z < 4; ++z) {
             const double v = vs_wave_sum_dpp(acc[m][z]);
             if (lane == 63 && i < k) out[VS_P_HEAD + (size_t)z * k + i] = v;
         }
     }
-    if (q == 0) {
+    if (Q == 0) {
         t_sab = vs_wave_sum_dpp(t_sab);
         t_sa = vs_wave_sum_dpp(t_sa);
         t_sb = vs_wave_sum_dpp(t_sb);
@@ -895,6 +861,30 @@ fused_first_kernel(vs_eval_args A, const double* shift_src, double* partials, ui
             out[VS_P_S1] = t_s1;
             out[VS_P_S2] = t_s2;
         }
+    }
+}
+
+#ifndef VS_FUSED_MIN_WAVES
+#define VS_FUSED_MIN_WAVES 1
+#endif
+template <int KIND>
+__global__ void __launch_bounds__(VS_EVAL_ROWS * VS_EVAL_WAVES, VS_FUSED_MIN_WAVES)
+fused_first_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
+    extern __shared__ double lds[];
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the fold that follows (see reduce_first_kernel)
+        counters[0] = 0;
+        counters[1] = 0xffffffffu;
+        counters[2] = 0;
+        counters[3] = 0;
+        counters[4] = 0;
+    }
+    const double shift = *shift_src;
+    switch (q) {  // wave-uniform: one straight-line specialisation per wave index
+        case 0: fused_rows<KIND, 0>(A, shift, lds, partials); break;
+        case 1: fused_rows<KIND, 1>(A, shift, lds, partials); break;
+        case 2: fused_rows<KIND, 2>(A, shift, lds, partials); break;
+        default: fused_rows<KIND, 3>(A, shift, lds, partials); break;
     }
 }
 
