@@ -1,0 +1,98 @@
+"""Randomised shapes (hypothesis): the kernels against the oracle over many small (k, rows, l) combinations,
+including the edges of tiles, passes and blocks (k around 32/64, rows around 64/512/2048, odd rows)."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import saltelli_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+_ctx = {}
+
+
+def ctx():
+    if "c" not in _ctx:
+        from varsens_amd import _native
+        _ctx["c"] = _native.Context(0)
+    return _ctx["c"]
+
+
+EDGE_ROWS = st.one_of(st.integers(1, 70), st.sampled_from([63, 64, 65, 127, 128, 129, 511, 512, 513, 2047, 2048, 2049, 4097]),
+                      st.integers(71, 6000))
+EDGE_K = st.one_of(st.integers(1, 12), st.sampled_from([15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 70]))
+COMMON = dict(deadline=None, max_examples=150, suppress_health_check=list(HealthCheck), derandomize=True)
+
+
+@settings(**COMMON)
+@given(k=EDGE_K, rows=EDGE_ROWS, l=st.integers(1, 3), seed=st.integers(0, 2 ** 20), offset=st.sampled_from([0.0, 1.0, -3.0, 1e4]))
+def test_reduction_any_shape(k, rows, l, seed, offset):
+    from varsens_amd import _native
+    c = ctx()
+    rng = np.random.RandomState(seed)
+    blocks = offset + rng.randn(2 * k + 2, rows, l)
+    f = c.upload(_native.to_planar(blocks))
+    nacc = _native.acc_len(k, l, 1)
+    acc = c.alloc(8 * nacc)
+    c.reduce_first_order(f, rows, k, l, acc)
+    rec = c.download(acc, (nacc,))
+    per = _native.acc_per_output(k)
+    body = rec[4:4 + l * per].reshape(l, per)
+    a, b, C, D = blocks[0], blocks[1], blocks[2:2 + k], blocks[2 + k:]
+    scale = max(1.0, float(np.abs(blocks).max()) ** 2 * rows)
+    np.testing.assert_allclose(body[:, 0], (a * b).sum(axis=0), rtol=1e-11, atol=1e-13 * scale)
+    np.testing.assert_allclose(body[:, 3:3 + k].T, (a[None] * C).sum(axis=1), rtol=1e-11, atol=1e-13 * scale)
+    np.testing.assert_allclose(body[:, 3 + k:3 + 2 * k].T, (b[None] * D).sum(axis=1), rtol=1e-11, atol=1e-13 * scale)
+    np.testing.assert_allclose(body[:, 3 + 2 * k:3 + 3 * k].T, (a[None] * D).sum(axis=1), rtol=1e-11, atol=1e-13 * scale)
+    np.testing.assert_allclose(body[:, 3 + 3 * k:3 + 4 * k].T, (b[None] * C).sum(axis=1), rtol=1e-11, atol=1e-13 * scale)
+    if rows >= 2:
+        out = c.alloc(8 * _native.first_order_len(k, l))
+        c.finish_first_order(acc, rows, k, l, out)
+        fin = c.download(out, (2 + 4 * k, l))
+        np.testing.assert_allclose(fin[1], np.var(np.concatenate([a, b]), axis=0, ddof=1), rtol=1e-9)
+        K = k * l
+        gram = c.alloc(8 * 3 * K * K)
+        c.reduce_second_order(f, rows, k, l, gram)
+        G = c.download(gram, (3, K, K))
+        Cm = C.transpose(0, 2, 1).reshape(K, rows); Dm = D.transpose(0, 2, 1).reshape(K, rows)
+        np.testing.assert_allclose(G[0], Dm @ Cm.T, rtol=1e-10, atol=1e-12 * scale)
+        np.testing.assert_allclose(G[1], Dm @ Dm.T, rtol=1e-10, atol=1e-12 * scale)
+        gram.free(); out.free()
+    f.free(); acc.free()
+
+
+@settings(**COMMON)
+@given(k=EDGE_K, n=st.one_of(st.integers(1, 200), st.sampled_from([63, 64, 65, 128, 1000])),
+       kind=st.sampled_from(["g", "lin", "poly", "inv"]), l=st.integers(1, 2), discard=st.integers(0, 50),
+       begin_frac=st.floats(0, 1), mode=st.sampled_from([0, 1]))
+def test_evaluation_any_shape(k, n, kind, l, discard, begin_frac, mode):
+    from varsens_amd import _native
+    c = ctx()
+    rng = np.random.RandomState(k * 1000 + n)
+    lo = rng.rand(k) - 0.5
+    hi = lo + 0.5 + rng.rand(k)
+    perm = orc.seed1_permutation(n).astype(np.uint32)
+    d = c.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k, discard), mode, lo if mode else None,
+                        hi if mode else None, perm)
+    scaling = (lambda x: orc.scale_linear(x, lo, hi)) if mode else None
+    S = orc.build_sample(k, n, scaling, discard=discard)
+    if kind == "inv":
+        lo_, params, code = k, None, _native.OBJ_INVERT
+        rows_func = lambda X: 1.0 - X
+    else:
+        lo_ = l
+        P = 0.5 + rng.rand(l, k)
+        params = P
+        code = {"g": _native.OBJ_G_FUNCTION, "lin": _native.OBJ_LINEAR, "poly": _native.OBJ_POLYNOMIAL}[kind]
+        one = {"g": orc.g_function_rows, "lin": orc.linear_rows, "poly": orc.polynomial_rows}[kind]
+        rows_func = lambda X: np.stack([one(X, P[o]) for o in range(l)], axis=-1)
+    want = orc.evaluate_rows(rows_func, *S)
+    want = np.concatenate([want[0][None], want[1][None], want[2], want[3]], axis=0)
+    begin = int(begin_frac * (n - 1))
+    count = n - begin
+    obj = c.objective_create(code, k, lo_, params)
+    f = c.alloc(8 * 2 * (k + 1) * count * lo_)
+    c.eval(d, obj, begin, count, f)
+    got = _native.from_planar(c.download(f, (lo_, 2 * k + 2, count)))
+    assert np.array_equal(got, want[:, begin:begin + count])
+    f.free(); obj.free(); d.free()
