@@ -147,6 +147,11 @@ typedef struct vs_design_desc {
     const uint32_t* sobol_directions; /* host (k,32) for VS_GEN_SOBOL, uploaded */
 } vs_design_desc;
 
+/* Host helper (no GPU involved): out[r] = index of the row that numpy.random.seed(1);
+ * numpy.random.shuffle(M_2) (saltelli.py:100-101) moves to position r -- MT19937 init_genrand(1),
+ * Fisher-Yates from the last row down, masked-rejection draws.  Feed it to vs_design_desc.perm. */
+int vs_seed1_permutation(uint32_t* out, uint64_t n);
+
 int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_design** out);
 int vs_design_destroy(vs_context* ctx, vs_design* design);
 

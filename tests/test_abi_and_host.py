@@ -113,6 +113,17 @@ def test_seed1_permutation_matches_reference(golden):
     assert np.array_equal(np.random.get_state()[1], state), "the global numpy RNG must be left alone"
 
 
+def test_native_permutation_is_numpys_legacy_shuffle(native):
+    """vs_seed1_permutation (C restatement of MT19937 + legacy shuffle) == numpy RandomState(1).shuffle."""
+    import time
+    for n in (0, 1, 2, 3, 5, 13, 624, 625, 1024, 4097, 100003, 1 << 20):
+        want = np.arange(n, dtype=np.uint32)
+        np.random.RandomState(1).shuffle(want)
+        assert np.array_equal(native.seed1_permutation(n), want), n
+    t0 = time.perf_counter(); native.seed1_permutation(1 << 22); t = time.perf_counter() - t0
+    assert t < 2.0
+
+
 def test_shard_rows_partition():
     from varsens_amd.dist import shard_rows
     for n, w in ((10, 3), (1 << 22, 8), (7, 2), (1, 1), (5, 4), (1000001, 6)):

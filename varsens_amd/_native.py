@@ -96,6 +96,7 @@ SIGNATURES = {
     "vs_profile_end": (C.c_int, [C.c_void_p, C.POINTER(ProfileRecord), C.c_int, C.POINTER(C.c_int)]),
     "vs_halton_fill": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "vs_sobol_fill": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "vs_seed1_permutation": (C.c_int, [C.c_void_p, C.c_uint64]),
     "vs_design_create": (C.c_int, [C.c_void_p, C.POINTER(DesignDesc), C.POINTER(C.c_void_p)]),
     "vs_design_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vs_sample_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
@@ -157,6 +158,13 @@ def load_library(path=None):
 def _check(rc):
     if rc != 0:
         raise VarsensHipError("%s (status %d)" % (load_library().vs_last_error().decode("utf-8", "replace"), rc))
+
+
+def seed1_permutation(n):
+    """The reference's seed-1 row shuffle as a permutation (host code of the engine, no GPU needed)."""
+    out = np.empty(int(n), dtype=np.uint32)
+    _check(load_library().vs_seed1_permutation(out.ctypes.data_as(C.c_void_p), int(n)))
+    return out
 
 
 def device_count():

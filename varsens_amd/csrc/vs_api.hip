@@ -213,6 +213,72 @@ int vs_workspace_scratch(vs_context* ctx, size_t bytes) {
     return VS_OK;
 }
 
+// ---- the seed-1 row shuffle (host) ------------------------------------------------------
+//
+// numpy.random.seed(1); numpy.random.shuffle(M_2) (varsens/saltelli.py:100-101) is numpy's legacy
+// generator: MT19937 seeded by init_genrand(1), Fisher-Yates from the last row down, each index drawn
+// by masked rejection on 32-bit outputs.  Restated here so that the permutation does not depend on
+// numpy keeping its legacy RandomState; tests pin it to numpy's own output and to golden G7.
+namespace {
+struct mt19937 {
+    uint32_t key[624];
+    int pos;
+    explicit mt19937(uint32_t seed) {
+        for (int i = 0; i < 624; ++i) {
+            key[i] = seed;
+            seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)i + 1u;
+        }
+        pos = 624;
+    }
+    void refill() {
+        const uint32_t UP = 0x80000000u, LOW = 0x7fffffffu, MAT = 0x9908b0dfu;
+        int i;
+        for (i = 0; i < 624 - 397; ++i) {
+            uint32_t y = (key[i] & UP) | (key[i + 1] & LOW);
+            key[i] = key[i + 397] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MAT);
+        }
+        for (; i < 623; ++i) {
+            uint32_t y = (key[i] & UP) | (key[i + 1] & LOW);
+            key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MAT);
+        }
+        uint32_t y = (key[623] & UP) | (key[0] & LOW);
+        key[623] = key[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MAT);
+        pos = 0;
+    }
+    uint32_t next() {
+        if (pos == 624) refill();
+        uint32_t y = key[pos++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+};
+}  // namespace
+
+extern "C" int vs_seed1_permutation(uint32_t* out, uint64_t n) {
+    VS_REQUIRE(out || n == 0, "out is null");
+    VS_REQUIRE(n <= 0xffffffffull, "n=%llu out of range", (unsigned long long)n);
+    for (uint64_t i = 0; i < n; ++i) out[i] = (uint32_t)i;
+    mt19937 rng(1u);
+    for (uint64_t i = n; i-- > 1;) {  // i = n-1 .. 1
+        uint32_t mask = (uint32_t)i;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        uint32_t j;
+        while ((j = rng.next() & mask) > (uint32_t)i) {
+        }
+        const uint32_t t = out[i];
+        out[i] = out[j];
+        out[j] = t;
+    }
+    return VS_OK;
+}
+
 // ---- profiling --------------------------------------------------------------
 
 extern "C" int vs_profile_begin(vs_context* ctx, int capacity) {

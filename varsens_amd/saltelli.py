@@ -52,15 +52,15 @@ _perm_cache = {}
 def seed1_permutation(n):
     """Row order the reference's ``numpy.random.seed(1); numpy.random.shuffle(M_2)``
     produces (varsens/saltelli.py:100-101): shuffled[r] = original[perm[r]].
-    A private legacy RandomState(1) draws the same MT19937 stream; numpy's global
-    RNG is left alone (the reference reseeds it as a side effect).  The Fisher-Yates
-    walk is sequential (about 12 ns per row on the host), so the last few
-    permutations are kept: repeated designs of one size (bootstraps) pay it once."""
+    Computed by the engine's own restatement of numpy's legacy generator
+    (vs_seed1_permutation: MT19937 seeded with 1, Fisher-Yates, masked rejection);
+    numpy's global RNG is left alone (the reference reseeds it as a side effect).
+    The walk is sequential (a few ns per row on the host), so the last few permutations
+    are kept: repeated designs of one size (bootstraps) pay it once."""
     n = int(n)
     order = _perm_cache.get(n)
     if order is None:
-        order = numpy.arange(n, dtype=numpy.uint32)
-        numpy.random.RandomState(1).shuffle(order)
+        order = _native.seed1_permutation(n)
         order.setflags(write=False)
         if len(_perm_cache) >= 4:
             _perm_cache.pop(next(iter(_perm_cache)))
