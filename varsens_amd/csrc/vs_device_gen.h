@@ -121,7 +121,9 @@ __device__ __forceinline__ void vs_radical_inverse_pair(vs_u32 i1, vs_u32 i2, co
 // bits of the Gray code of i.  The 32 direction integers of the column are fetched up front (wide
 // scalar loads) so that the bit loop is pure VALU; bits above `nbits` (the Gray-code bits any
 // index of the design can set) are skipped eight at a time.
-__device__ __forceinline__ double vs_sobol_point(vs_u64 i, const vs_u32* __restrict__ dir, int nbits) {
+// (noinline: its 32 scalar direction words must not raise the SGPR pressure of the Halton path, where
+// the kernels spilled scalars into vector lanes in their prologue when this was inlined)
+__device__ __attribute__((noinline)) double vs_sobol_point(vs_u64 i, const vs_u32* __restrict__ dir, int nbits) {
     const vs_u32 g = (vs_u32)(i ^ (i >> 1));
     vs_u32 x = 0;
 #pragma unroll
