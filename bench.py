@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the Saltelli hot path on MI355X, one process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -77,8 +77,8 @@ def cpu_baseline(k, f_small, n_small, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)  # ~0.2 s of GPU time: past the clock ramp of short runs
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--log2n", type=int, default=22, help="draws per GPU = 2^log2n")
     ap.add_argument("--strong", action="store_true",
