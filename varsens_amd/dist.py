@@ -97,6 +97,11 @@ class RcclComm(object):
             uid = ctx.comm_unique_id() if group.rank == 0 else None
             uid = group.broadcast_bytes(uid, src=0)
             ctx.comm_init(uid, self.world, self.rank)
+            # RCCL builds its rings/connections on the first collective: pay that here, not in a timed pass
+            warm = ctx.upload(numpy.zeros(8))
+            ctx.comm_allreduce(warm, 8)
+            ctx.sync()
+            warm.free()
 
     def allreduce(self, buf, count):
         if self.world > 1:
