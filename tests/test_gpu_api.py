@@ -451,3 +451,18 @@ def test_sobol_with_opaque_scaling_and_discard(vs):
     assert numpy.array_equal(s2.flat(), s.flat())
     with pytest.raises(Exception, match="generator must be"):
         vs.Sample(k, n, vs.scale.Identity(), verbose=False, generator='faure')
+
+
+def test_vectorized_host_objective(vs, golden):
+    """Extension: a numpy-vectorised host objective is called per block of rows, same values as row by row."""
+    def g_block(X):
+        return numpy.prod((numpy.abs(4.0 * X - 2.0) + numpy.array(model)) / (1.0 + numpy.array(model)), axis=1)
+    v = vs.Varsens(g_block, lambda x: x, 6, 1024, verbose=False, vectorized=True)
+    g = golden("g1_gfunc_k6_n1024")
+    for f in ("E_2", "var_y"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-12)
+    numpy.testing.assert_allclose(v.sens, g["sens"], rtol=1e-9, atol=1e-12)
+    two = vs.Varsens(lambda X: numpy.stack([g_block(X), 2.0 * g_block(X)], axis=1), lambda x: x, 6, 256, verbose=False,
+                     vectorized=True)
+    assert two.sens.shape == (6, 2)
+    numpy.testing.assert_allclose(two.sens[:, 0], two.sens[:, 1], rtol=1e-9)

@@ -270,13 +270,16 @@ class Objective(object):
     as varsens/saltelli.py:287.  ``objective_func`` may be a device objective
     (``varsens_amd.objectives``) or any Python callable on one sample row.
     Keyword-only extras: ``shard=(row_begin, row_count)`` restricts a rank to a
-    slice of the n draws (multi-GPU), ``context``.
+    slice of the n draws (multi-GPU), ``context``, ``vectorized=True`` (a host
+    callable that maps a (rows,k) block to (rows,) or (rows,l) values is called
+    once per block of rows instead of once per row).
     """
 
     def __init__(self, k, n, sample=None, objective_func=None, objective_vals=[], verbose=True, **loadArgs):
         self._ctx = loadArgs.pop('context', None) or (sample._ctx if sample is not None else default_context())
         shard = loadArgs.pop('shard', None)
         lazy = loadArgs.pop('lazy', False)   # device objectives only: evaluate when the values are first needed
+        self._vectorized = loadArgs.pop('vectorized', False)  # host callables: f takes a (rows,k) block at once
         self.k = k
         self.n = n
         self.sample = sample
@@ -334,11 +337,16 @@ class Objective(object):
         here one row at a time as in varsens/saltelli.py:329-355, the values go back to HBM."""
         k, n = int(self.k), int(self.n)
         func = self.objective_func
-        test = func(self.sample._rows(self._row_begin, 1)[0])
-        try:
-            l = len(test)
-        except TypeError:
-            l = 1
+        first = self.sample._rows(self._row_begin, 1)
+        if self._vectorized:
+            test = numpy.asarray(func(first))
+            l = 1 if test.ndim <= 1 else test.shape[1]
+        else:
+            test = func(first[0])
+            try:
+                l = len(test)
+            except TypeError:
+                l = 1
         self._l = l
         rows = self._rows
         vals = numpy.zeros((2 * k + 2, rows, l))
@@ -348,6 +356,9 @@ class Objective(object):
             for c0 in range(0, rows, _HOST_CHUNK_ROWS):
                 c1 = min(rows, c0 + _HOST_CHUNK_ROWS)
                 pts = self.sample._rows(block * n + self._row_begin + c0, c1 - c0)
+                if self._vectorized:   # extension: one call per block of rows (numpy-vectorised models)
+                    vals[block, c0:c1] = numpy.asarray(func(pts), dtype=numpy.float64).reshape(c1 - c0, l)
+                    continue
                 for i in range(c1 - c0):
                     vals[block, c0 + i] = func(pts[i])
                     step += 1
@@ -459,6 +470,7 @@ class Varsens(object):
         self._second_order = extra.pop('second_order', True)
         self._comm = extra.pop('comm', None)
         self._fused = extra.pop('fused', 'auto')   # 'auto' | True | False: fused evaluate+reduce kernel
+        vectorized = extra.pop('vectorized', False)  # host callable takes a (rows,k) block (extension)
         ctx = extra.pop('context', None)
         shard = extra.pop('shard', None)
         if extra:
@@ -481,6 +493,8 @@ class Varsens(object):
             self.n = objective.n
         else:
             kw = dict(shard=shard) if shard is not None else {}
+            if vectorized:
+                kw['vectorized'] = True
             if self._fused_eligible(objective):
                 kw['lazy'] = True   # the values are only produced if somebody asks for them
             elif self._fused is True:
