@@ -193,6 +193,15 @@ int vs_objective_destroy(vs_context* ctx, vs_objective* obj);
 int vs_objective_create_source(vs_context* ctx, int k, int l, const char* body, const double* params,
                                size_t nparams, vs_objective** out);
 
+/* A user objective of SEPARABLE shape, f(x) = t_0(x_0) op t_1(x_1) op ... (op = * or +, folded left to
+ * right), given as the BODY of `double term(double x, int c, const double* p)` (the value of term c at
+ * coordinate value x).  Compiled into the chain-scheme kernel of the built-in separable objectives, so
+ * it runs at their speed (k^2/2 folds per family instead of k per point); one output, k <= 160.
+ * Example (Sobol g-function): "return (fabs(4.0*x - 2.0) + p[c]) / (1.0 + p[c]);" with VS_FOLD_PRODUCT. */
+enum { VS_FOLD_PRODUCT = 0, VS_FOLD_SUM = 1 };
+int vs_objective_create_separable(vs_context* ctx, int k, const char* term_body, int fold,
+                                  const double* params, size_t nparams, vs_objective** out);
+
 /* F-VALUE LAYOUT on the device ("planar"): one plane per output o, each plane the
  * shard's Objective.flat() order (saltelli.py:357-391) for that output:
  *     f_dev[(o*(2k+2) + block)*rows + r],  block order [fM_1, fM_2, fN_j[0..k), fN_nj[0..k)]

@@ -74,6 +74,24 @@ def test_expression_beyond_lds_budget(vs):
     assert np.array_equal(o1.flat(), o2.flat())
 
 
+@pytest.mark.parametrize("k,n", [(6, 4096), (32, 1000), (45, 300), (3, 5)])
+def test_separable_expression_equals_builtins_bit_for_bit(vs, k, n):
+    """A user term function compiled into the chain-scheme kernel: same bits as the built-in objectives."""
+    rng = np.random.RandomState(k)
+    a = rng.rand(k) * 9.0
+    s = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
+    built = vs.Objective(k, n, s, vs.objectives.GFunction(a), verbose=False)
+    user = vs.Objective(k, n, s, vs.objectives.SeparableExpression(
+        "return (fabs(4.0 * x - 2.0) + p[c]) / (1.0 + p[c]);", fold="prod", params=a), verbose=False)
+    assert np.array_equal(built.flat(), user.flat())
+    built = vs.Objective(k, n, s, vs.objectives.Linear(a), verbose=False)
+    user = vs.Objective(k, n, s, vs.objectives.SeparableExpression("return p[c] * x;", fold="sum", params=a),
+                        verbose=False)
+    assert np.array_equal(built.flat(), user.flat())
+    v = vs.Varsens(user, verbose=False)
+    assert v.sens.shape == (k, 1)
+
+
 def test_expression_compile_error_is_reported(vs):
     from varsens_amd._native import VarsensHipError
     s = vs.Sample(3, 8, vs.scale.Identity(), verbose=False)

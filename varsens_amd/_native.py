@@ -103,6 +103,8 @@ SIGNATURES = {
     "vs_objective_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_void_p)]),
     "vs_objective_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vs_objective_create_separable": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t,
+                                                C.POINTER(C.c_void_p)]),
     "vs_objective_create_source": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_size_t,
                                              C.POINTER(C.c_void_p)]),
     "vs_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
@@ -343,6 +345,17 @@ class Context(object):
         h = C.c_void_p()
         _check(self.lib.vs_objective_create_source(self.handle, int(k), int(l), body.encode("utf-8"), p, n,
                                                    C.byref(h)))
+        return Handle(self, h, self.lib.vs_objective_destroy)
+
+    def objective_create_separable(self, k, term_body, fold_sum, params=None):
+        if params is None or len(params) == 0:
+            p, n = None, 0
+        else:
+            arr, p = _host(np.asarray(params, dtype=np.float64).ravel(), np.float64)
+            n = arr.size
+        h = C.c_void_p()
+        _check(self.lib.vs_objective_create_separable(self.handle, int(k), term_body.encode("utf-8"),
+                                                      1 if fold_sum else 0, p, n, C.byref(h)))
         return Handle(self, h, self.lib.vs_objective_destroy)
 
     # -- compute

@@ -14,7 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvarsens_hip.so")
 SOURCES = ["vs_api.hip", "vs_generate.hip", "vs_reduce.hip", "vs_second.hip", "vs_comm.hip", "vs_rtc.hip"]
 # device sources hiprtc needs at run time, embedded into the library as C++ raw strings
-EMBED = {"vs_device_gen.h": "vs_rtc_embed_gen.inc", "vs_rtc_kernel.h": "vs_rtc_embed_kernel.inc"}
+EMBED = {"vs_device_gen.h": "vs_rtc_embed_gen.inc", "vs_rtc_kernel.h": "vs_rtc_embed_kernel.inc",
+         "vs_rtc_kernel_sep.h": "vs_rtc_embed_kernel_sep.inc"}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          # numpy-exact arithmetic: no implicit fma contraction; fmas are written out
          "-ffp-contract=off",

@@ -66,7 +66,7 @@ struct vs_objective {
     bool scratch_tile = false; // compiled for the HBM scratch tile (k beyond the LDS budget)
 };
 
-int vs_rtc_build(vs_context* ctx, vs_objective* o, const char* body);
+int vs_rtc_build(vs_context* ctx, vs_objective* o, const char* body, int fold);
 void vs_rtc_release(vs_objective* o);
 int vs_rtc_launch(vs_context* ctx, const vs_objective* o, const void* eval_args, size_t eval_args_bytes,
                   unsigned blocks, size_t lds);

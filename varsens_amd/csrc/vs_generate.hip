@@ -392,7 +392,37 @@ extern "C" int vs_objective_create_source(vs_context* ctx, int k, int l, const c
             return vs_fail(VS_ERR_HIP, "uploading objective parameters failed");
         }
     }
-    int rc = vs_rtc_build(ctx, o, body);
+    int rc = vs_rtc_build(ctx, o, body, 0);
+    if (rc) {
+        vs_objective_destroy(ctx, o);
+        return rc;
+    }
+    *out = o;
+    return VS_OK;
+}
+
+extern "C" int vs_objective_create_separable(vs_context* ctx, int k, const char* term_body, int fold,
+                                             const double* params, size_t nparams, vs_objective** out) {
+    VS_REQUIRE(ctx && out && term_body, "null argument");
+    *out = nullptr;
+    VS_REQUIRE(k >= 1 && k <= 160, "a separable source objective needs 1 <= k <= 160 (LDS tile)");
+    VS_REQUIRE(fold == VS_FOLD_PRODUCT || fold == VS_FOLD_SUM, "fold must be VS_FOLD_PRODUCT or VS_FOLD_SUM");
+    VS_REQUIRE(nparams == 0 || params, "params is null");
+    vs_objective* o = new vs_objective();
+    o->kind = VS_OBJ_SOURCE;
+    o->k = k;
+    o->l = 1;
+    o->nparams = nparams;
+    if (nparams) {
+        if (hipMalloc(&o->params, sizeof(double) * nparams) != hipSuccess ||
+            hipMemcpyAsync(o->params, params, sizeof(double) * nparams, hipMemcpyHostToDevice, ctx->stream) !=
+                hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            vs_objective_destroy(ctx, o);
+            return vs_fail(VS_ERR_HIP, "uploading objective parameters failed");
+        }
+    }
+    int rc = vs_rtc_build(ctx, o, term_body, fold == VS_FOLD_SUM ? 2 : 1);
     if (rc) {
         vs_objective_destroy(ctx, o);
         return rc;
@@ -428,76 +458,12 @@ extern "C" int vs_objective_create_source(vs_context* ctx, int k, int l, const c
 #undef VS_STORE
 #define VS_STORE(p, v) do { if ((v) == 1.2345e-300) *(p) = (v); } while (0)
 #endif
-#define VS_CHAINS 8                                 // chains per thread and pass
-#define VS_PASS (VS_EVAL_WAVES * VS_CHAINS)         // blocks i handled per pass
-
-
 template <int KIND>
 __device__ __forceinline__ double vs_term(double x, double p) {
     if (KIND == VS_OBJ_G_FUNCTION) return (fabs(4.0 * x - 2.0) + p) / (1.0 + p);
     if (KIND == VS_OBJ_POLYNOMIAL) return 1.0 + p * (x - 0.5);
     return p * x;  // VS_OBJ_LINEAR
 }
-
-template <int KIND>
-__device__ __forceinline__ double vs_fold(double acc, double t) {
-    return KIND == VS_OBJ_LINEAR ? acc + t : acc * t;
-}
-
-// Tile reads.  The coordinate / term tile normally lives in LDS.  For k too large for LDS it
-// lives in a per-workgroup slice of an HBM scratch buffer that a persistent workgroup rewrites
-// for every 64-row block; those reads must not be served from this CU's L1 (it may still hold
-// the previous block's lines), so they are agent-scope relaxed loads (L2), ordered behind the
-// writers' stores by the workgroup barrier (which drains vmcnt).
-template <bool SCRATCH>
-__device__ __forceinline__ double vs_tile_ld(const double* p) {
-    if (SCRATCH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-
-// One full pass (32 consecutive columns i0..i0+31) of the chain scheme for wave Q.
-// Chain m of this wave is block i0+Q+4m; at relative column j the chains with
-// Q+4m < j are running and the one with Q+4m == j starts from the prefixes.
-// Everything about the schedule is a compile-time constant, so the 16 chain
-// values stay in fixed registers.
-template <int KIND, int Q, bool SCRATCH, int W = VS_EVAL_WAVES>
-__device__ __forceinline__ void vs_chain_pass(const double* F1, const double* F2, int i0, double& pa, double& pb,
-                                              double (&cj)[VS_PASS / W], double (&dj)[VS_PASS / W]) {
-    constexpr int T = VS_EVAL_ROWS;
-    constexpr int CH = VS_PASS / W;
-#pragma unroll
-    for (int j = 0; j < VS_PASS; ++j) {
-        const double ta = vs_tile_ld<SCRATCH>(F1 + (size_t)(i0 + j) * T);
-        const double tb = vs_tile_ld<SCRATCH>(F2 + (size_t)(i0 + j) * T);
-#pragma unroll
-        for (int m = 0; m < CH; ++m) {
-            if (Q + W * m < j) {
-                cj[m] = vs_fold<KIND>(cj[m], tb);
-                dj[m] = vs_fold<KIND>(dj[m], ta);
-            } else if (Q + W * m == j) {
-                cj[m] = vs_fold<KIND>(pb, ta);  // N_j[i0+j]: M_2 with column i0+j from M_1
-                dj[m] = vs_fold<KIND>(pa, tb);  // N_nj[i0+j]: M_1 with column i0+j from M_2
-            }
-        }
-        pa = vs_fold<KIND>(pa, ta);
-        pb = vs_fold<KIND>(pb, tb);
-    }
-}
-
-// run vs_chain_pass<.., Q = q, ..> for the (wave-uniform) run-time q in [0, W)
-template <int KIND, bool SCRATCH, int W, int Q = 0>
-struct vs_chain_dispatch {
-    static __device__ __forceinline__ void run(int q, const double* F1, const double* F2, int i0, double& pa,
-                                               double& pb, double (&cj)[VS_PASS / W], double (&dj)[VS_PASS / W]) {
-        if (q == Q) vs_chain_pass<KIND, Q, SCRATCH, W>(F1, F2, i0, pa, pb, cj, dj);
-        else vs_chain_dispatch<KIND, SCRATCH, W, Q + 1>::run(q, F1, F2, i0, pa, pb, cj, dj);
-    }
-};
-template <int KIND, bool SCRATCH, int W>
-struct vs_chain_dispatch<KIND, SCRATCH, W, W> {
-    static __device__ __forceinline__ void run(int, const double*, const double*, int, double&, double&,
-                                               double (&)[VS_PASS / W], double (&)[VS_PASS / W]) {}
-};
 
 #ifndef VS_EVAL_MIN_WAVES
 #define VS_EVAL_MIN_WAVES 1

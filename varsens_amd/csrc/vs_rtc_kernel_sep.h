@@ -1,0 +1,91 @@
+// Kernel template compiled by hiprtc for a user SEPARABLE objective (vs_objective_create_separable):
+//   f(x) = t_0(x_0) (+|*) t_1(x_1) (+|*) ... folded strictly left to right,
+// text-included after vs_device_gen.h and after the generated definitions of
+//   #define VS_USER_FOLD_KIND  VS_OBJ_LINEAR (sum) | VS_OBJ_POLYNOMIAL (product)
+//   __device__ double vs_user_term(double x, int c, const double* p) { <body> }
+// Phase 1 stores the terms t_c(M_1[r][c]), t_c(M_2[r][c]); phase 2 is the chain scheme of
+// eval_kernel (prefix sharing, 8+8 chains per thread, per-wave static schedule for full passes),
+// so a user model of this shape runs at the speed of the built-in g-function / linear kernels.
+
+extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_user_eval(vs_eval_args A, double* scratch) {
+    extern __shared__ double lds[];
+    constexpr int T = VS_EVAL_ROWS;
+    constexpr int KIND = VS_USER_FOLD_KIND;
+    const int k = A.D.k;
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const vs_u64 rows = A.rows;
+    const vs_u64 lr = (vs_u64)blockIdx.x * T + lane;
+    const bool valid = lr < rows;
+    const vs_u64 r = A.row_begin + (valid ? lr : rows - 1);
+    double* F1 = lds + lane;
+    double* F2 = lds + (size_t)k * T + lane;
+    double* f = A.f + (vs_u64)blockIdx.x * T + lane;  // planar f-values, one output
+
+    const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
+    const vs_u64 src2 = A.D.n + (A.D.perm ? (vs_u64)A.D.perm[r] : r);
+    for (int c = q; c < k; c += VS_EVAL_WAVES) {
+        double x1, x2;
+        if (halton_fast) {
+            vs_radical_inverse_pair((vs_u32)(A.D.first_index + r), (vs_u32)(A.D.first_index + src2), A.D.bases[c],
+                                    x1, x2);
+        } else {
+            x1 = vs_unit_point(A.D, r, c);
+            x2 = vs_unit_point(A.D, src2, c);
+        }
+        F1[(size_t)c * T] = vs_user_term(vs_apply_scale(A.D, x1, c), c, A.params);
+        F2[(size_t)c * T] = vs_user_term(vs_apply_scale(A.D, x2, c), c, A.params);
+    }
+    __syncthreads();
+
+    const double ident = KIND == VS_OBJ_LINEAR ? 0.0 : 1.0;
+    double pa = ident, pb = ident;
+    for (int i0 = 0; i0 < k; i0 += VS_PASS) {
+        double cj[VS_CHAINS], dj[VS_CHAINS];
+#pragma unroll
+        for (int m = 0; m < VS_CHAINS; ++m) cj[m] = dj[m] = ident;
+        const int cend = min(k, i0 + VS_PASS);
+        int c = i0;
+        if (cend - i0 == VS_PASS) {
+            vs_chain_dispatch<KIND, false, VS_EVAL_WAVES>::run(q, F1, F2, i0, pa, pb, cj, dj);
+            c = cend;
+        } else {
+            for (; c < cend; ++c) {  // partial pass: same schedule with run-time bounds
+                const double ta = F1[(size_t)c * T], tb = F2[(size_t)c * T];
+#pragma unroll
+                for (int m = 0; m < VS_CHAINS; ++m) {
+                    const int start = i0 + q + VS_EVAL_WAVES * m;
+                    if (c > start) {
+                        cj[m] = vs_fold<KIND>(cj[m], tb);
+                        dj[m] = vs_fold<KIND>(dj[m], ta);
+                    } else if (c == start) {
+                        cj[m] = vs_fold<KIND>(pb, ta);
+                        dj[m] = vs_fold<KIND>(pa, tb);
+                    }
+                }
+                pa = vs_fold<KIND>(pa, ta);
+                pb = vs_fold<KIND>(pb, tb);
+            }
+        }
+        for (; c < k; ++c) {  // columns of later passes
+            const double ta = F1[(size_t)c * T], tb = F2[(size_t)c * T];
+#pragma unroll
+            for (int m = 0; m < VS_CHAINS; ++m) {
+                cj[m] = vs_fold<KIND>(cj[m], tb);
+                dj[m] = vs_fold<KIND>(dj[m], ta);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < VS_CHAINS; ++m) {
+            const int i = i0 + q + VS_EVAL_WAVES * m;
+            if (i < k && valid) {
+                VS_STORE(f + (vs_u64)(2 + i) * rows, cj[m]);
+                VS_STORE(f + (vs_u64)(2 + k + i) * rows, dj[m]);
+            }
+        }
+    }
+    if (q == 0 && valid) {
+        VS_STORE(f, pa);
+        VS_STORE(f + rows, pb);
+    }
+}

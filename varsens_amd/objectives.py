@@ -112,3 +112,23 @@ class Expression(DeviceObjective):
 
     def params(self, k):
         return self._params
+
+
+class SeparableExpression(DeviceObjective):
+    """A user objective of separable shape, f(x) = t_0(x_0) op t_1(x_1) op ... with op = '*' or '+',
+    given as the body of ``double term(double x, int c, const double* p)``.  Compiled at run time
+    into the chain-scheme kernel of the built-in separable objectives, so it runs at their speed::
+
+        SeparableExpression("return (fabs(4.0*x - 2.0) + p[c]) / (1.0 + p[c]);", fold="prod", params=a)
+    """
+    kind = _native.OBJ_SOURCE
+
+    def __init__(self, term_body, fold="prod", params=()):
+        if fold not in ("prod", "sum"):
+            raise Exception("fold must be 'prod' or 'sum'")
+        self.term_body = str(term_body)
+        self.fold_sum = fold == "sum"
+        self._params = numpy.asarray(params, dtype=numpy.float64).ravel()
+
+    def params(self, k):
+        return self._params

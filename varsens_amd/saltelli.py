@@ -312,6 +312,8 @@ class Objective(object):
     def _device_objective(self):
         k = int(self.k)
         spec = self.objective_func
+        if isinstance(spec, _objectives.SeparableExpression):
+            return self._ctx.objective_create_separable(k, spec.term_body, spec.fold_sum, spec.params(k))
         if spec.kind == _native.OBJ_SOURCE:
             return self._ctx.objective_create_source(k, self._l, spec.body, spec.params(k))
         return self._ctx.objective_create(spec.kind, k, self._l, spec.params(k))
