@@ -451,3 +451,23 @@ def test_variance_with_outlier_in_first_value(ctx):
     rec, fin = reduce_dev(ctx, blocks, 50000)
     want = np.var(np.concatenate([blocks[0], blocks[1]]), axis=0, ddof=1)
     np.testing.assert_allclose(fin[1], want, rtol=1e-10)
+
+
+def test_reduce_very_wide_k(ctx):
+    """k = 600 > 512: the LDS accumulator is split over blockIdx.y; k = 200 second order = 7 super-blocks."""
+    rng = np.random.RandomState(600)
+    k, rows = 600, 301
+    blocks = 1.0 + rng.rand(2 * k + 2, rows, 1)
+    rec, fin = reduce_dev(ctx, blocks, rows)
+    check_against_exact(rec, fin, blocks, rows)
+    from varsens_amd import _native
+    k2, rows2 = 200, 150
+    b2 = rng.randn(2 * k2 + 2, rows2, 1)
+    f = ctx.upload(_native.to_planar(b2))
+    gram = ctx.alloc(8 * 3 * k2 * k2)
+    ctx.reduce_second_order(f, rows2, k2, 1, gram)
+    G = ctx.download(gram, (3, k2, k2))
+    C, D = b2[2:2 + k2, :, 0], b2[2 + k2:, :, 0]
+    np.testing.assert_allclose(G[0], D @ C.T, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(G[1], D @ D.T, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(G[2], C @ C.T, rtol=1e-11, atol=1e-11)

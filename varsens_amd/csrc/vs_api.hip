@@ -317,6 +317,8 @@ extern "C" int vs_profile_end(vs_context* ctx, vs_profile_record* out, int capac
 
 vs_launch_scope::vs_launch_scope(vs_context* c, int kernel_id) : ctx(c) {
     if (!ctx->profiling || ctx->prof.size() >= ctx->prof_capacity) return;
+    static const long mask = getenv("VS_PROFILE_MASK") ? strtol(getenv("VS_PROFILE_MASK"), nullptr, 0) : -1L;
+    if (!((mask >> kernel_id) & 1)) return;  // tuning aid: bracket only some kernel ids
     slot = (int)ctx->prof.size();
     vs_prof_slot s = ctx->prof_pool[slot];
     s.kernel_id = kernel_id;
