@@ -454,10 +454,6 @@ extern "C" int vs_objective_create_separable(vs_context* ctx, int k, const char*
 //
 // Output index: f[((o*(2k+2) + block)*rows + (r-row_begin)] (planar, see varsens_hip.h).
 
-#if defined(VS_ABL_NOSTORE)   /* diagnostic build: keep the value live, never store */
-#undef VS_STORE
-#define VS_STORE(p, v) do { if ((v) == 1.2345e-300) *(p) = (v); } while (0)
-#endif
 template <int KIND>
 __device__ __forceinline__ double vs_term(double x, double p) {
     if (KIND == VS_OBJ_G_FUNCTION) return (fabs(4.0 * x - 2.0) + p) / (1.0 + p);
@@ -506,12 +502,6 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
     const uint64_t src2 = A.D.n + (A.D.perm ? (uint64_t)A.D.perm[r] : r);  // sequence row behind M_2[r]
     for (int c = q; c < k; c += W) {
         double x1, x2;
-#ifdef VS_ABL_NOGEN   /* diagnostic build: no generator arithmetic */
-        if (halton_fast) {
-            x1 = (double)(uint32_t)(r + c) * 2.3283064365386963e-10;
-            x2 = (double)(uint32_t)(src2 + c) * 2.3283064365386963e-10;
-        } else
-#endif
         if (halton_fast) {
             vs_radical_inverse_pair((uint32_t)(A.D.first_index + r), (uint32_t)(A.D.first_index + src2),
                                     A.D.bases[c], x1, x2);
