@@ -1,16 +1,21 @@
-"""Run only the second-order Gram kernel a few times (for rocprofv3 counter passes)."""
+"""Run only the second-order Gram kernel a few times and print its median time (also for rocprofv3 passes)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from varsens_amd import _native
 from varsens_amd.saltelli import seed1_permutation
-k, n = 32, 1 << 22
+k, n = int(os.environ.get("K", 32)), 1 << int(os.environ.get("LOG2N", 22))
 ctx = _native.Context(0)
 design = ctx.design_create(_native.GEN_HALTON, k, n, 1 + 20 * k, 0, None, None, seed1_permutation(n))
 obj = ctx.objective_create(_native.OBJ_LINEAR, k, 1, np.arange(1, k + 1, dtype=float))
 f = ctx.alloc(8 * 2 * (k + 1) * n)
 ctx.eval(design, obj, 0, n, f)
 gram = ctx.alloc(8 * 3 * k * k)
-for _ in range(4):
+for _ in range(3):
     ctx.reduce_second_order(f, n, k, 1, gram)
 ctx.sync()
+ctx.profile_begin(64)
+for _ in range(10):
+    ctx.reduce_second_order(f, n, k, 1, gram)
+r = [ms for nm, ms in ctx.profile_end() if nm == "second_order"]
+print("second order k=%d n=2^%d: %.3f ms (min %.3f)" % (k, int(np.log2(n)), np.median(r), min(r)))
