@@ -218,7 +218,32 @@ def main():
     save("g13_discard37_k3_n16", k=3, n=16, discard=37, M_1=s.M_1, M_2=s.M_2)
 
 
+def wire_formats():
+    """G14: the text wire formats (Sample.export / Objective.export, saltelli.py:173-193,393-413):
+    file names and exact bytes written by the reference for a tiny design."""
+    import tempfile
+    ref, rscale = load_reference()
+    k, n = 3, 4
+    s = ref.Sample(k, n, lambda x: x, verbose=False)
+    o = ref.Objective(k, n, s, lambda x: [float(x[0] + 2 * x[1]), float(x[2] * x[2])], verbose=False)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        s.export(d, "my sample", ".csv", 10, ",")           # 32 rows -> 4 files
+        s.export(d, "whole", ".txt")                        # one file, tab separated
+        o.export(d, "obj", ".dat", 20)                      # 32 rows -> 2 files
+        names = sorted(os.listdir(d))
+        out["names"] = np.array(names)
+        for name in names:
+            with open(os.path.join(d, name), "rb") as fh:
+                out["file_" + name.replace(".", "_")] = np.frombuffer(fh.read(), dtype=np.uint8)
+    save("g14_wire_formats_k3_n4", k=k, n=n, **out)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference checkout not found at %s" % REF)
-    main()
+    if "--only-wire" in sys.argv:
+        wire_formats()
+    else:
+        main()
+        wire_formats()

@@ -466,3 +466,21 @@ def test_vectorized_host_objective(vs, golden):
                      vectorized=True)
     assert two.sens.shape == (6, 2)
     numpy.testing.assert_allclose(two.sens[:, 0], two.sens[:, 1], rtol=1e-9)
+
+
+def test_export_files_are_byte_identical_to_the_reference(vs, golden, tmp_path):
+    """Text wire formats (saltelli.py:173-193, 393-413): same file names, same bytes as the reference wrote
+    for the same design (golden G14)."""
+    import os
+    g = golden("g14_wire_formats_k3_n4")
+    k, n = int(g["k"]), int(g["n"])
+    s = vs.Sample(k, n, lambda x: x, verbose=False)
+    o = vs.Objective(k, n, s, lambda x: [float(x[0] + 2 * x[1]), float(x[2] * x[2])], verbose=False)
+    d = str(tmp_path)
+    s.export(d, "my sample", ".csv", 10, ",")
+    s.export(d, "whole", ".txt")
+    o.export(d, "obj", ".dat", 20)
+    assert sorted(os.listdir(d)) == [str(x) for x in g["names"]]
+    for name in os.listdir(d):
+        with open(os.path.join(d, name), "rb") as fh:
+            assert fh.read() == bytes(g["file_" + name.replace(".", "_")]), name

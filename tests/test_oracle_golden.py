@@ -219,3 +219,23 @@ def test_exact_accumulators_reproduce_reference_within_rounding(golden):
     s2, s2n = orc.exact_second_order(F[2], F[3], R["E_2"], R["var_y"], 1024)
     np.testing.assert_allclose(s2, g["sens_2"], rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(s2n, g["sens_2n"], rtol=1e-10, atol=1e-13)
+
+
+def test_wire_format_golden_is_savetxt_of_the_flat_arrays(golden, tmp_path):
+    """G14: what the reference writes is numpy.savetxt of flat()[b*blocksize:(b+1)*blocksize] with '%.18e'."""
+    import io
+    g = golden("g14_wire_formats_k3_n4")
+    S = orc.build_sample(3, 4)
+    flat = orc.flat_sample(*S)
+    buf = io.BytesIO()
+    np.savetxt(buf, flat, delimiter="\t")
+    assert buf.getvalue() == bytes(g["file_whole_txt"])
+    for b in range(4):
+        buf = io.BytesIO()
+        np.savetxt(buf, flat[b * 10:(b + 1) * 10], delimiter=",")
+        assert buf.getvalue() == bytes(g["file_my_sample_%d_csv" % (b + 1)])
+    F = orc.evaluate_callable(lambda x: [float(x[0] + 2 * x[1]), float(x[2] * x[2])], *S)
+    fo = orc.flat_objective(*F)
+    buf = io.BytesIO()
+    np.savetxt(buf, fo[:20])
+    assert buf.getvalue() == bytes(g["file_obj_1_dat"])
