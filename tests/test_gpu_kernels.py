@@ -471,3 +471,50 @@ def test_reduce_very_wide_k(ctx):
     np.testing.assert_allclose(G[0], D @ C.T, rtol=1e-11, atol=1e-11)
     np.testing.assert_allclose(G[1], D @ D.T, rtol=1e-11, atol=1e-11)
     np.testing.assert_allclose(G[2], C @ C.T, rtol=1e-11, atol=1e-11)
+
+
+def test_abi_argument_errors(ctx):
+    """Bad arguments come back as VS_ERR_ARG with a message, never as a crash."""
+    from varsens_amd import _native
+    E = _native.VarsensHipError
+    with pytest.raises(E, match="out of range"):
+        ctx.design_create(_native.GEN_HALTON, 0, 10, 1)
+    with pytest.raises(E, match="unknown generator"):
+        ctx.design_create(7, 3, 10, 1)
+    with pytest.raises(E, match="bounds are required"):
+        ctx.design_create(_native.GEN_HALTON, 3, 10, 1, _native.SCALE_LINEAR)
+    with pytest.raises(E, match="not a row of the second half"):
+        ctx.design_create(_native.GEN_HALTON, 3, 4, 1, 0, None, None, np.array([0, 1, 2, 9], dtype=np.uint32))
+    d = make_design(ctx, 3, 16)
+    with pytest.raises(E, match="parameters"):
+        ctx.objective_create(_native.OBJ_LINEAR, 3, 1, [1.0, 2.0])
+    with pytest.raises(E, match="unknown objective"):
+        ctx.objective_create(99, 3, 1, [1.0, 2.0, 3.0])
+    o4 = ctx.objective_create(_native.OBJ_LINEAR, 4, 1, np.ones(4))
+    f = ctx.alloc(8 * 8 * 16)
+    with pytest.raises(E, match="objective has k=4, design has k=3"):
+        ctx.eval(d, o4, 0, 16, f)
+    o3 = ctx.objective_create(_native.OBJ_LINEAR, 3, 1, np.ones(3))
+    with pytest.raises(E, match="exceed n"):
+        ctx.eval(d, o3, 10, 7, f)
+    acc = ctx.alloc(8 * _native.acc_len(3, 1, 2))
+    with pytest.raises(E, match="rank 2 not in"):
+        ctx.reduce_first_order(f, 16, 3, 1, acc, 0, 2, 2)
+    with pytest.raises(E, match="exceed 2n"):
+        ctx.sample_flat(d, 120, 20, f)
+    with pytest.raises(E, match="not been called"):
+        ctx.comm_allreduce(acc, 4)
+
+
+def test_very_large_k(ctx):
+    """k = 1000: Halton bases up to 7919, scratch-tile evaluation, first order split over blockIdx.y."""
+    from varsens_amd import _native
+    k, n = 1000, 70
+    c = 1.0 / np.arange(1, k + 1)
+    d = make_design(ctx, k, n)
+    f, got = eval_dev(ctx, d, _native.OBJ_LINEAR, k, 1, c, n)
+    S = orc.build_sample(k, n)
+    want = oracle_blocks(orc.evaluate_rows(lambda X: orc.linear_rows(X, c), *S))
+    same(got, want)
+    rec, fin = reduce_dev(ctx, got, n)
+    check_against_exact(rec, fin, got, n)
