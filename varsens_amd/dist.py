@@ -14,6 +14,7 @@ the job was started by ``torch.distributed.run``; nothing on the data path
 touches torch.
 """
 import os
+import sys
 
 import numpy
 
@@ -46,7 +47,17 @@ class HostGroup(object):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if not dist.is_initialized():
-                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+                # gloo announces its connections on the C-level stdout; a bench line must stay alone there
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+                    dist.barrier()
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(saved, 1)
+                    os.close(saved)
             self._dist = dist
 
     def barrier(self):
