@@ -330,7 +330,7 @@ def test_rccl_single_rank_allreduce(ctx):
 # ------------------------------------------------------------------ second order (fp64 MFMA Gram)
 
 @pytest.mark.parametrize("k,rows,l", [(6, 1000, 1), (32, 5000, 1), (40, 3001, 1), (70, 777, 1), (7, 500, 3),
-                                      (3, 5, 1), (33, 64, 2)])
+                                      (3, 5, 1), (33, 64, 2), (6, 200000, 1), (12, 100003, 1), (24, 65536, 1)])
 def test_second_order_gram(ctx, k, rows, l):
     rng = np.random.RandomState(k * 7 + rows + l)
     blocks = 1.0 + rng.randn(2 * k + 2, rows, l)
@@ -353,10 +353,10 @@ def test_second_order_gram(ctx, k, rows, l):
         assert abs(G[0][i, j] - want) <= 1e-13 * max(1.0, abs(want)) * 10
 
 
-def test_second_order_nan_trim(ctx):
+@pytest.mark.parametrize("k,rows", [(5, 900), (9, 50001)])
+def test_second_order_nan_trim(ctx, k, rows):
     from varsens_amd import _native
     rng = np.random.RandomState(9)
-    k, rows = 5, 900
     blocks = 1.0 + rng.rand(2 * k + 2, rows, 1)
     bad = rng.choice(rows, 11, replace=False)
     blocks[rng.randint(0, 2 * k + 2, 11), bad, 0] = np.nan

@@ -18,4 +18,6 @@ ctx.profile_begin(64)
 for _ in range(10):
     ctx.reduce_second_order(f, n, k, 1, gram)
 r = [ms for nm, ms in ctx.profile_end() if nm == "second_order"]
+g = ctx.download(gram, (3, k, k))
+print("gram checksum %.17g  DC[3,5]=%.17g" % (float(g.sum()), float(g[0, 3, 5])))
 print("second order k=%d n=2^%d: %.3f ms (min %.3f)" % (k, int(np.log2(n)), np.median(r), min(r)))

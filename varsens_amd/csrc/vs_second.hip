@@ -8,17 +8,19 @@
 // v_mfma_f64_16x16x4_f64, D(16x16) += A(16x4) B(4x16), where A and B are both
 // "16 index rows x 4 sample rows" fragments of X (one double per lane).
 //
-// A workgroup owns a pair of 64-index-row super-blocks (SI <= SJ) and walks
-// 64-sample-row chunks (diagonal pairs: 4 waves splitting the sample rows, below;
-// off-diagonal pairs: 8 waves splitting the 16 output tiles, gram_offdiag_kernel): coalesced loads (one index row = 512 B per wave
-// instruction) into an LDS tile [index row][sample row] with a 66-double pitch
-// (conflict-free fragment reads), then each wave takes 16 of the 64 sample rows:
-// 4 MFMA k-steps x up to 16 block pairs, accumulators in registers for the whole
-// kernel.  At the end the four waves' accumulators are added through LDS and one
-// dense 64x64 partial per workgroup goes to HBM; gram_fold_kernel sums the
-// partials (compensated) and scatters them into DC, DD, CC.
-// Roofline: min(HBM: 16*K*rows bytes, fp64 MFMA: (2K)^2/2 * rows fma); both
-// ~0.3 ms at k=32, rows=2^22.  Reported separately from the first-order pass.
+// The 2K index rows are cut into 64-row super-blocks; a launch covers pairs (SI <= SJ):
+//   diagonal pairs (all of them when k*l <= 32): gram_diag_wave_kernel -- every wave keeps the ten
+//     16x16 accumulator tiles of the super-block and walks its own 16-sample-row chunks through a
+//     private LDS tile, no workgroup barrier in the loop;
+//   off-diagonal pairs: gram_offdiag_kernel -- eight waves share two 64x64 LDS tiles (66-double
+//     pitch) and split the 16 output tiles.
+// One dense 64x64 partial per workgroup and pair goes to HBM; gram_fold_kernel sums the partials
+// (compensated) and scatters them into DC, DD, CC.
+// Roofline at k=32, rows=2^22: HBM 16*K*rows bytes = 2.15 GB => 0.31 ms; matrix pipe: 10 tiles x
+// rows/4 MFMAs.  The fp64 MFMA sustains 47-49 TFLOP/s on this chip (99 cycles per 16x16x4 with
+// two or more waves per SIMD; tools/mfma_f64_peak.hip), not the 78.6 of the data sheet, and shares
+// its units with v_fma_f64 (tools/mfma_f64_valu_shadow.hip) => 0.44 ms: the kernel is
+// matrix-pipe-bound.  Reported separately from the first-order pass.
 #include "vs_common.h"
 
 #define VS2_SUPER 64                 // index rows per super-block (4 MFMA blocks of 16)
@@ -67,136 +69,141 @@ __device__ __forceinline__ const double* x_elem(const vs_gram_args& A, int m, ui
     return A.f + ((uint64_t)o * (2 * (uint64_t)A.k + 2) + block) * A.rows + r;  // planar f-values
 }
 
-template <bool MASKED, bool DIAG>
-__device__ __forceinline__ void gram_body(const vs_gram_args& A, int SI, int SJ, double* tiles) {
-    constexpr int NB = VS2_SUPER / 16;                 // 4 blocks per super-block
-    constexpr int NACC = DIAG ? NB * (NB + 1) / 2 : NB * NB;
+// Diagonal super-block pairs, wave-private form (the default when the row count is even): no
+// workgroup barrier in the loop.  A wave owns 16-sample-row chunks (the four waves of a
+// workgroup take adjacent chunks: 512 contiguous bytes per index row between them), keeps ALL
+// NB(NB+1)/2 accumulator tiles of the super-block in registers and stages its chunk through a
+// private LDS tile [64 index rows][16 sample rows], pitch 20 doubles:
+//   global: lane L loads 16 B = sample rows 2(L&7), 2(L&7)+1 of index row 8j + (L>>3): one
+//           instruction = 8 index rows x 128 contiguous bytes, non-temporal;
+//   LDS:    ds_write_b128 of the same, then per 16-row block two ds_read_b128 fragments
+//           (index row = lane&15, sample rows 2q, 2q+1 and 8+2q, 8+2q+1, q = lane>>4) -- pitch 20
+//           is conflict-free for the b128 lane groups of gfx950 (MI355X_MICROARCH.md, LDS);
+//   MFMA:   4 k-steps x NB(NB+1)/2 tiles; A and B fragments come from the same lane->sample map,
+//           and a Gram sum does not care in which order the sample rows are contracted.
+// The next chunk's global loads are in flight while the MFMAs of the current one run; with 3
+// waves per SIMD the matrix pipe always has a wave with operands ready.
+#define VS2_WCHUNK 16
+#define VS2_WPITCH 20
+typedef double vs_d2 __attribute__((ext_vector_type(2)));
+
+template <int NB, bool MASKED, bool ALIGNED>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+gram_diag_wave_kernel(vs_gram_args A) {
+    extern __shared__ double tiles[];  // [4 waves][64][VS2_WPITCH]
+    if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
+    constexpr int NT = NB * (NB + 1) / 2;
+    constexpr int NJ = 2 * NB;          // 8-row groups to load
+    const int S = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = 2 * A.K;
     const uint64_t rows = A.rows;
+    double* tile = tiles + wave * (VS2_SUPER * VS2_WPITCH);
 
-    vs_d4 acc[NACC];
+    const int lrow = lane >> 3, piece = lane & 7;
+    const double* rp[NJ];
+    bool ok[NJ];
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
-
-    // this wave stages index rows wave, wave+4, ..: 16 rows of SI (and 16 of SJ), one 512-B
-    // row segment per load instruction.  Row bases are wave-uniform.
-    constexpr int NR = VS2_SUPER / 4;
-    const double* rowI[NR];
-    const double* rowJ[NR];
-    bool okI[NR], okJ[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int mi = SI * VS2_SUPER + wave + 4 * i, mj = SJ * VS2_SUPER + wave + 4 * i;
-        okI[i] = mi < M;
-        okJ[i] = !DIAG && mj < M;
-        rowI[i] = x_elem(A, okI[i] ? mi : 0, 0);
-        rowJ[i] = x_elem(A, okJ[i] ? mj : 0, 0);
+    for (int j = 0; j < NJ; ++j) {
+        const int m = S * VS2_SUPER + 8 * j + lrow;
+        ok[j] = m < M;
+        rp[j] = x_elem(A, ok[j] ? m : 0, 0) + 2 * piece;
     }
-    constexpr uint64_t lstride = 1;  // planar layout: sample rows are contiguous
-    double vi[NR], vj[NR];
-    auto fetch = [&](uint64_t ch) {
-        const uint64_t r = ch * VS2_CHUNK + lane;
-        const bool rin = r < rows && (!MASKED || A.keep[r]);
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            vi[i] = (rin && okI[i]) ? __builtin_nontemporal_load(rowI[i] + r * lstride) : 0.0;
-            if (!DIAG) vj[i] = (rin && okJ[i]) ? __builtin_nontemporal_load(rowJ[i] + r * lstride) : 0.0;
-        }
-    };
+    double* wr = tile + lrow * VS2_WPITCH + 2 * piece;                       // + 8j rows
+    const double* rd = tile + (lane & 15) * VS2_WPITCH + 2 * (lane >> 4);    // + 16b rows, + 8h
 
-    // Software pipeline, one barrier per chunk: while the MFMAs of chunk c run out of LDS buffer
-    // `cur`, the global loads of chunk c+1 are in flight into registers; they are written to the
-    // other LDS buffer after the MFMAs and published by the barrier.
-    constexpr int TILE_DOUBLES = (DIAG ? 1 : 2) * VS2_SUPER * VS2_PITCH;
-    const uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
-    auto stash = [&](int buf) {
-        double* bi = tiles + buf * TILE_DOUBLES;
-        double* bj = bi + VS2_SUPER * VS2_PITCH;
+    vs_d4 acc[NT];
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            bi[(wave + 4 * i) * VS2_PITCH + lane] = vi[i];
-            if (!DIAG) bj[(wave + 4 * i) * VS2_PITCH + lane] = vj[i];
-        }
-    };
-    // Diagonal pairs (one tile, 10 accumulators) double-buffer the LDS tile: one barrier per chunk.
-    // Off-diagonal pairs (two tiles, 16 accumulators) keep ONE buffer so that two workgroups fit a
-    // CU and overlap each other instead.
-    constexpr bool DOUBLE = DIAG;
-    int cur = 0;
-    if (blockIdx.x < nchunks) {
-        fetch(blockIdx.x);
-        if (DOUBLE) stash(0);
-    }
-    if (DOUBLE) __syncthreads();
-    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += A.slab_wgs) {
-        const bool more = ch + A.slab_wgs < nchunks;
-        if (!DOUBLE) {
-            __syncthreads();  // previous chunk fully consumed
-            stash(0);
-            __syncthreads();
-        }
-        if (more) fetch(ch + A.slab_wgs);
-        const double* bi = tiles + cur * TILE_DOUBLES;
-        const double* bj = DIAG ? bi : bi + VS2_SUPER * VS2_PITCH;
-        // this wave's 16 sample rows = 4 k-steps of 4
-        if (DOUBLE) {
-            double fi[4][NB];  // all fragments first, then the MFMAs back to back
+    for (int i = 0; i < NT; ++i) acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
+
+    const uint64_t nfull = rows / VS2_WCHUNK;
+    const uint64_t nch = nfull + ((rows % VS2_WCHUNK) ? 1 : 0);
+    const uint64_t W = (uint64_t)gridDim.x * 4;
+    vs_d2 raw[NJ];
+    bool k0 = true, k1 = true;
+    // fetch only issues the loads; padding / keep masks are applied where the values are consumed,
+    // one iteration later, so nothing waits on them while the MFMAs of the current chunk run
+    auto fetch = [&](uint64_t c) {
+        const uint64_t s0 = c * VS2_WCHUNK;
+        if (c < nfull) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int rr = wave * 16 + s * 4 + (lane >> 4);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) fi[s][b] = bi[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                int a = 0;
-#pragma unroll
-                for (int bi_ = 0; bi_ < NB; ++bi_)
-#pragma unroll
-                    for (int bj_ = bi_; bj_ < NB; ++bj_) {
-                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fi[s][bi_], fi[s][bj_], acc[a], 0, 0, 0);
-                        ++a;
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int rr = wave * 16 + s * 4 + (lane >> 4);
-                double fi[NB], fj[NB];
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    fi[b] = bi[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
-                    fj[b] = bj[(b * 16 + (lane & 15)) * VS2_PITCH + rr];
+            for (int j = 0; j < NJ; ++j) {
+                if (ALIGNED) {
+                    raw[j] = __builtin_nontemporal_load((const vs_d2*)(rp[j] + s0));
+                } else {  // odd row count: every other planar block starts 8 bytes off a 16-byte boundary
+                    raw[j].x = __builtin_nontemporal_load(rp[j] + s0);
+                    raw[j].y = __builtin_nontemporal_load(rp[j] + s0 + 1);
                 }
+            }
+        } else {  // the ragged last chunk
+            const uint64_t s = s0 + 2 * piece;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                raw[j].x = s < rows ? rp[j][s0] : 0.0;
+                raw[j].y = s + 1 < rows ? rp[j][s0 + 1] : 0.0;
+            }
+        }
+        if (MASKED) {
+            const uint64_t s = s0 + 2 * piece;
+            k0 = s < rows && A.keep[s];
+            k1 = s + 1 < rows && A.keep[s + 1];
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            vs_d2 v = raw[j];
+            if (MASKED) {
+                v.x = k0 ? v.x : 0.0;
+                v.y = k1 ? v.y : 0.0;
+            }
+            if (!ok[j]) v = (vs_d2){0.0, 0.0};
+            *(vs_d2*)(wr + 8 * j * VS2_WPITCH) = v;
+        }
+    };
+
+    uint64_t c = (uint64_t)blockIdx.x * 4 + wave;
+    if (c < nch) fetch(c);
+    for (; c < nch; c += W) {
+        stash();
+        if (c + W < nch) fetch(c + W);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        vs_d2 fr[NB][2];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            fr[b][0] = *(const vs_d2*)(rd + 16 * b * VS2_WPITCH);
+            fr[b][1] = *(const vs_d2*)(rd + 16 * b * VS2_WPITCH + 8);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
                 int a = 0;
 #pragma unroll
-                for (int bi_ = 0; bi_ < NB; ++bi_)
+                for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-                    for (int bj_ = DIAG ? bi_ : 0; bj_ < NB; ++bj_) {
-                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fi[bi_], fj[bj_], acc[a], 0, 0, 0);
+                    for (int bj = bi; bj < NB; ++bj) {
+                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[bi][h][t], fr[bj][h][t], acc[a], 0, 0, 0);
                         ++a;
                     }
             }
-        }
-        if (DOUBLE) {
-            if (more) stash(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
-        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    // add the four waves' accumulators through LDS (reusing the tile space), fixed order
+    // add the four waves' accumulators through LDS (the tiles are free now), fixed order
     __syncthreads();
-    double* red = tiles;  // [wave][64][64] would not fit: go pair by pair in 16x16 blocks
+    double* red = tiles;
     const int npairs = A.nsuper * (A.nsuper + 1) / 2;
-    double* out = A.partials + ((size_t)blockIdx.x * npairs + (DIAG ? blockIdx.y : blockIdx.y + A.nsuper)) * VS2_TILE_OUT;
+    double* out = A.partials + ((size_t)blockIdx.x * npairs + S) * VS2_TILE_OUT;
     int a = 0;
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-        for (int bj = DIAG ? bi : 0; bj < NB; ++bj) {
+        for (int bj = bi; bj < NB; ++bj) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int row = (lane >> 4) + 4 * v, col = lane & 15;   // f64 C/D layout
@@ -211,93 +218,6 @@ __device__ __forceinline__ void gram_body(const vs_gram_args& A, int SI, int SJ,
             __syncthreads();
             ++a;
         }
-    if (DIAG) {
-        // blocks below the diagonal are not computed: zero them so the fold sees defined data
-        for (int e = tid; e < VS2_TILE_OUT; e += 256) {
-            const int bi = (e / VS2_SUPER) / 16, bj = (e % VS2_SUPER) / 16;
-            if (bj < bi) out[e] = 0.0;
-        }
-    }
-}
-
-// DIAG: blockIdx.y = super-block index (pairs (y,y)); otherwise blockIdx.y + nsuper indexes I < J.
-// Two kernels so that the common k <= 32 case (one diagonal pair) keeps 10 accumulators, not 16.
-template <bool MASKED, bool DIAG>
-__global__ void __launch_bounds__(256)
-gram_kernel(vs_gram_args A) {
-    extern __shared__ double tiles[];  // [64][VS2_PITCH] (x2 off the diagonal)
-    if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
-    int SI, SJ;
-    pair_from_index(DIAG ? blockIdx.y : blockIdx.y + A.nsuper, A.nsuper, SI, SJ);
-    gram_body<MASKED, DIAG>(A, SI, SJ, tiles);
-}
-
-// Diagonal super-block pairs (SI == SJ), tile-split form: ten waves share ONE 64x64 LDS tile, wave w
-// owns the w-th of the ten block pairs (bi <= bj) and walks all 16 k-steps of a chunk.  One
-// accumulator tile per wave, no cross-wave sum.  (VS_GRAM_DIAG_SPLIT=0 selects the 4-wave
-// sample-row-split kernel above instead.)
-template <bool MASKED>
-__global__ void __launch_bounds__(640)
-gram_diag_tile_kernel(vs_gram_args A) {
-    extern __shared__ double tiles[];  // [64][VS2_PITCH]
-    if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
-    const int S = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..9
-    const int M = 2 * A.K;
-    const uint64_t rows = A.rows;
-    // wave -> (bi, bj), bi <= bj, row by row: (0,0..3) (1,1..3) (2,2..3) (3,3)
-    int bi = 0, rest = wave, len = 4;
-    while (rest >= len) { rest -= len; ++bi; --len; }
-    const int bj = bi + rest;
-
-    vs_d4 acc = (vs_d4){0.0, 0.0, 0.0, 0.0};
-    // staging: wave w loads index rows w, w+10, .. (7 or 6 rows of 512 B)
-    constexpr int NR = 7;
-    const double* rowp[NR];
-    bool okr[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int ir = wave + 10 * i;
-        const int m = S * VS2_SUPER + ir;
-        okr[i] = ir < VS2_SUPER && m < M;
-        rowp[i] = x_elem(A, okr[i] ? m : 0, 0);
-    }
-    double vr[NR];
-    auto fetch = [&](uint64_t ch) {
-        const uint64_t r = ch * VS2_CHUNK + lane;
-        const bool rin = r < rows && (!MASKED || A.keep[r]);
-#pragma unroll
-        for (int i = 0; i < NR; ++i) vr[i] = (rin && okr[i]) ? __builtin_nontemporal_load(rowp[i] + r) : 0.0;
-    };
-    const uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
-    if (blockIdx.x < nchunks) fetch(blockIdx.x);
-    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += A.slab_wgs) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NR; ++i)
-            if (wave + 10 * i < VS2_SUPER) tiles[(wave + 10 * i) * VS2_PITCH + lane] = vr[i];
-        if (ch + A.slab_wgs < nchunks) fetch(ch + A.slab_wgs);
-        __syncthreads();
-        const double* pi = tiles + (bi * 16 + (lane & 15)) * VS2_PITCH + (lane >> 4);
-        const double* pj = tiles + (bj * 16 + (lane & 15)) * VS2_PITCH + (lane >> 4);
-#pragma unroll
-        for (int s = 0; s < VS2_CHUNK / 4; ++s)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pi[4 * s], pj[4 * s], acc, 0, 0, 0);
-    }
-    const int npairs = A.nsuper * (A.nsuper + 1) / 2;
-    double* out = A.partials + ((size_t)blockIdx.x * npairs + S) * VS2_TILE_OUT;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int row = (lane >> 4) + 4 * v, col = lane & 15;
-        out[(bi * 16 + row) * VS2_SUPER + (bj * 16 + col)] = acc[v];
-    }
-    // blocks below the diagonal are not computed: zero them so the fold sees defined data
-    for (int e = tid; e < VS2_TILE_OUT; e += 640) {
-        const int ebi = (e / VS2_SUPER) / 16, ebj = (e % VS2_SUPER) / 16;
-        if (ebj < ebi) out[e] = 0.0;
-    }
 }
 
 // Off-diagonal super-block pairs (SI < SJ): all 16 block pairs are needed.  Eight waves share the
@@ -514,7 +434,9 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     if (nchunks < 1) nchunks = 1;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     const char* env = getenv("VS_GRAM_WGS_PER_CU");
-    const int per_cu = env && *env ? atoi(env) : (npairs == 1 ? 2 : 8);  // measured: k=32 -> 2, k=128 -> 8
+    // 16-byte loads need an even row count: planar blocks start at multiples of `rows` doubles
+    const bool aligned = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
+    const int per_cu = env && *env ? atoi(env) : (npairs == 1 ? 3 : 8);  // measured (tools/gram_only.py)
     uint64_t want = ((uint64_t)cus * per_cu + npairs - 1) / npairs;
     if (want < 1) want = 1;
     const uint32_t slab_wgs = (uint32_t)(nchunks < want ? nchunks : want);
@@ -544,10 +466,8 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     F.npairs = npairs;
     F.gram = gram_dev;
     F.counters = ctx->counters;
-    const size_t lds1 = 2 * sizeof(double) * VS2_SUPER * VS2_PITCH;  // diagonal: one tile, double-buffered
-    const size_t lds2 = lds1;                                           // off-diagonal: two tiles, single buffer
-    VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    VS_HIP(hipFuncSetAttribute((const void*)gram_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    const size_t lds_w = sizeof(double) * 4 * VS2_SUPER * VS2_WPITCH;  // diagonal: one private tile per wave
+    const size_t lds2 = 2 * sizeof(double) * VS2_SUPER * VS2_PITCH;    // off-diagonal: two shared tiles
     VS_HIP(hipFuncSetAttribute((const void*)gram_offdiag_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     VS_HIP(hipFuncSetAttribute((const void*)gram_offdiag_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     const dim3 grid_diag(slab_wgs, nsuper), grid_off(slab_wgs, npairs - nsuper);
@@ -564,16 +484,24 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
         }
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
-            const char* dsplit = getenv("VS_GRAM_DIAG_SPLIT");
-            const bool tile_split = !(dsplit && *dsplit == '0');
-            const size_t lds_t = sizeof(double) * VS2_SUPER * VS2_PITCH;
-            if (tile_split) {
-                if (masked) hipLaunchKernelGGL(gram_diag_tile_kernel<true>, grid_diag, dim3(640), lds_t, ctx->stream, A);
-                else hipLaunchKernelGGL(gram_diag_tile_kernel<false>, grid_diag, dim3(640), lds_t, ctx->stream, A);
-            } else {
-                if (masked) hipLaunchKernelGGL((gram_kernel<true, true>), grid_diag, dim3(256), lds1, ctx->stream, A);
-                else hipLaunchKernelGGL((gram_kernel<false, true>), grid_diag, dim3(256), lds1, ctx->stream, A);
+            const int nb = nsuper > 1 ? 4 : (2 * K + 15) / 16;
+#define VS2_LAUNCH_WAVE2(NBV, MK, AL) \
+    hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, MK, AL>), grid_diag, dim3(256), lds_w, ctx->stream, A)
+#define VS2_LAUNCH_WAVE(NBV)                                        \
+    do {                                                            \
+        if (masked && aligned) VS2_LAUNCH_WAVE2(NBV, true, true);   \
+        else if (masked) VS2_LAUNCH_WAVE2(NBV, true, false);        \
+        else if (aligned) VS2_LAUNCH_WAVE2(NBV, false, true);       \
+        else VS2_LAUNCH_WAVE2(NBV, false, false);                   \
+    } while (0)
+            switch (nb) {
+                case 1: VS2_LAUNCH_WAVE(1); break;
+                case 2: VS2_LAUNCH_WAVE(2); break;
+                case 3: VS2_LAUNCH_WAVE(3); break;
+                default: VS2_LAUNCH_WAVE(4); break;
             }
+#undef VS2_LAUNCH_WAVE
+#undef VS2_LAUNCH_WAVE2
             if (npairs > nsuper) {
                 if (masked) hipLaunchKernelGGL(gram_offdiag_kernel<true>, grid_off, dim3(512), lds2, ctx->stream, A);
                 else hipLaunchKernelGGL(gram_offdiag_kernel<false>, grid_off, dim3(512), lds2, ctx->stream, A);
