@@ -15,7 +15,7 @@ R=os.environ["GRAFT_REPO_ROOT"]
 agg=collections.defaultdict(list)
 for f in glob.glob(R+"/gpurun_out/pmcg/p*/**/*counter_collection.csv",recursive=True):
     for row in csv.DictReader(open(f)):
-        if "gram_kernel" in row["Kernel_Name"]:
+        if "gram_diag_wave_kernel" in row["Kernel_Name"] or "gram_offdiag_kernel" in row["Kernel_Name"]:
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(agg):
     v=agg[k]; print("%-28s %14.0f (n=%d)" % (k,sum(v)/len(v),len(v)))
