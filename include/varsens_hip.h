@@ -264,6 +264,15 @@ int vs_finish_first_order(vs_context* ctx, const double* acc_dev, uint64_t n, in
 int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                            int flags, double* gram_dev);
 
+/* a8-a10 + a12 in ONE pass over the f-values: Varsens.compute_varsens always needs both
+ * (saltelli.py:572-622), and both passes read the same 2k blocks.  Fills acc_dev exactly like
+ * vs_reduce_first_order and gram_dev exactly like vs_reduce_second_order.  Single-output
+ * designs with k <= 32 and no NaN trimming take the combined kernel (the first-order dot
+ * products ride on the Gram kernel's operand fragments); every other shape runs the two
+ * separate passes internally, so the call is always valid. */
+int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
+                                 int flags, int rank, int max_ranks, double* acc_dev, double* gram_dev);
+
 /* sens_2, sens_2n (each (k,l,k,l) row-major) from summed Gram matrices and the
  * finished first-order block (E_2, var_y) (saltelli.py:612-622). */
 int vs_finish_second_order(vs_context* ctx, const double* gram_dev, const double* first_dev,

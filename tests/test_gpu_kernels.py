@@ -353,6 +353,57 @@ def test_second_order_gram(ctx, k, rows, l):
         assert abs(G[0][i, j] - want) <= 1e-13 * max(1.0, abs(want)) * 10
 
 
+@pytest.mark.parametrize("k,rows,l", [(6, 1000, 1), (32, 5000, 1), (16, 200000, 1), (3, 5, 1), (12, 100003, 1),
+                                      (1, 17, 1), (25, 4096, 1), (40, 3000, 1), (5, 700, 2)])
+def test_first_and_second_order_in_one_pass(ctx, k, rows, l):
+    """vs_reduce_first_second_order fills the record and the Gram matrices of the two separate passes
+    (k <= 32, l == 1: the combined kernel; other shapes: the separate kernels behind the same call)."""
+    from varsens_amd import _native
+    rng = np.random.RandomState(k * 13 + rows + l)
+    blocks = 3.0 + rng.randn(2 * k + 2, rows, l)
+    f = ctx.upload(_native.to_planar(blocks))
+    K = k * l
+    nacc = _native.acc_len(k, l, 1)
+    acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
+    g1, g2 = ctx.alloc(8 * 3 * K * K), ctx.alloc(8 * 3 * K * K)
+    ctx.reduce_first_order(f, rows, k, l, acc1)
+    ctx.reduce_second_order(f, rows, k, l, g1)
+    ctx.reduce_first_second_order(f, rows, k, l, acc2, g2)
+    a1, a2 = ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,))
+    G1, G2 = ctx.download(g1, (3, K, K)), ctx.download(g2, (3, K, K))
+    assert np.array_equal(a1[:4], a2[:4])
+    np.testing.assert_allclose(a2, a1, rtol=2e-13, atol=1e-9)
+    np.testing.assert_allclose(G2, G1, rtol=1e-13)
+    first = ctx.alloc(8 * _native.first_order_len(k, l))
+    first1 = ctx.alloc(8 * _native.first_order_len(k, l))
+    ctx.finish_first_order(acc2, rows, k, l, first)
+    ctx.finish_first_order(acc1, rows, k, l, first1)
+    np.testing.assert_allclose(ctx.download(first, (2 + 4 * k, l)), ctx.download(first1, (2 + 4 * k, l)),
+                               rtol=1e-11, atol=1e-12)
+
+
+def test_one_pass_with_nan_trim_takes_the_separate_kernels(ctx):
+    from varsens_amd import _native
+    rng = np.random.RandomState(3)
+    k, rows = 6, 1200
+    blocks = 1.0 + rng.rand(2 * k + 2, rows, 1)
+    blocks[3, 17, 0] = np.nan
+    blocks[0, 900, 0] = np.nan
+    f = ctx.upload(_native.to_planar(blocks))
+    nacc = _native.acc_len(k, 1, 1)
+    acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
+    g1, g2 = ctx.alloc(8 * 3 * k * k), ctx.alloc(8 * 3 * k * k)
+    ctx.reduce_first_order(f, rows, k, 1, acc1, flags=_native.REDUCE_NAN_TRIM)
+    ctx.reduce_second_order(f, rows, k, 1, g1, flags=_native.REDUCE_NAN_TRIM)
+    ctx.reduce_first_second_order(f, rows, k, 1, acc2, g2, flags=_native.REDUCE_NAN_TRIM)
+    assert np.array_equal(ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,)))
+    assert np.array_equal(ctx.download(g1, (3, k, k)), ctx.download(g2, (3, k, k)))
+    assert ctx.download(acc2, (nacc,))[1] == 2.0     # rows dropped
+    # without the flag the combined kernel runs and the NaNs propagate, as in the separate passes
+    ctx.reduce_first_second_order(f, rows, k, 1, acc2, g2)
+    assert np.isnan(ctx.download(acc2, (nacc,))).any() and np.isnan(ctx.download(g2, (3, k, k))).any()
+
+
 @pytest.mark.parametrize("k,rows", [(5, 900), (9, 50001)])
 def test_second_order_nan_trim(ctx, k, rows):
     from varsens_amd import _native

@@ -20,4 +20,20 @@ for _ in range(10):
 r = [ms for nm, ms in ctx.profile_end() if nm == "second_order"]
 g = ctx.download(gram, (3, k, k))
 print("gram checksum %.17g  DC[3,5]=%.17g" % (float(g.sum()), float(g[0, 3, 5])))
+acc = ctx.alloc(8 * _native.acc_len(k, 1, 1))
+for _ in range(3):
+    ctx.reduce_first_order(f, n, k, 1, acc)
+ctx.sync()
+ctx.profile_begin(64)
+for _ in range(10):
+    ctx.reduce_first_order(f, n, k, 1, acc)
+r1 = [ms for nm, ms in ctx.profile_end() if nm == "reduce_first"]
+for _ in range(3):
+    ctx.reduce_first_second_order(f, n, k, 1, acc, gram)
+ctx.sync()
+ctx.profile_begin(64)
+for _ in range(10):
+    ctx.reduce_first_second_order(f, n, k, 1, acc, gram)
+rb = [ms for nm, ms in ctx.profile_end() if nm == "second_order"]
+print("first order alone %.3f ms; first+second in one pass %.3f ms (min %.3f)" % (np.median(r1), np.median(rb), min(rb)))
 print("second order k=%d n=2^%d: %.3f ms (min %.3f)" % (k, int(np.log2(n)), np.median(r), min(r)))

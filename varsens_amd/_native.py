@@ -116,6 +116,8 @@ SIGNATURES = {
                                         C.c_void_p]),
     "vs_reduce_second_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p]),
+    "vs_reduce_first_second_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vs_finish_second_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p]),
     "vs_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -382,6 +384,12 @@ class Context(object):
     def reduce_second_order(self, f_buf, rows, k, l, gram_buf, flags=0):
         _check(self.lib.vs_reduce_second_order(self.handle, C.c_void_p(f_buf.ptr), int(rows), int(k), int(l),
                                                int(flags), C.c_void_p(gram_buf.ptr)))
+
+    def reduce_first_second_order(self, f_buf, rows, k, l, acc_buf, gram_buf, flags=0, rank=0, max_ranks=1):
+        """Both reductions of compute_varsens in one pass over the f-values where the shape allows."""
+        _check(self.lib.vs_reduce_first_second_order(self.handle, C.c_void_p(f_buf.ptr), int(rows), int(k), int(l),
+                                                     int(flags), int(rank), int(max_ranks), C.c_void_p(acc_buf.ptr),
+                                                     C.c_void_p(gram_buf.ptr)))
 
     def finish_second_order(self, gram_buf, first_buf, n, k, l, s2_buf, s2n_buf):
         _check(self.lib.vs_finish_second_order(self.handle, C.c_void_p(gram_buf.ptr), C.c_void_p(first_buf.ptr),

@@ -98,8 +98,8 @@ int vs_workspace_partials(vs_context* ctx, size_t bytes);
 int vs_workspace_keep(vs_context* ctx, size_t bytes);
 int vs_workspace_scratch(vs_context* ctx, size_t bytes);
 
-int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, const double* shift_dev, int rank,
-                     int max_ranks, double* acc_dev);
+int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, const double* shift_dev,
+                     const double* f_dev, int rank, int max_ranks, double* acc_dev);
 
 // partial record of one workgroup for one output: 5 head values + 4 per block j
 #define VS_P_SAB 0

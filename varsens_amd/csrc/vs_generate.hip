@@ -893,7 +893,7 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
         default: launch_fused<VS_OBJ_LINEAR>(ctx, A, P, shift_buf); break;
     }
     VS_HIP(hipGetLastError());
-    return vs_fold_partials(ctx, P, k, 1, row_count, shift_buf, rank, max_ranks, acc_dev);
+    return vs_fold_partials(ctx, P, k, 1, row_count, shift_buf, nullptr, rank, max_ranks, acc_dev);
 }
 
 extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,

@@ -575,10 +575,12 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
 }
 
 // Fold `P` workgroup records sitting in ctx->partials ([P][l][VS_PLEN(k)]) into this rank's
-// accumulator record.  Used by the fused evaluate+reduce kernel (vs_generate.hip), whose
-// records have the layout of reduce_first_kernel's.
-int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, const double* shift_dev, int rank,
-                     int max_ranks, double* acc_dev) {
+// accumulator record.  Used by the fused evaluate+reduce kernel (vs_generate.hip) and by the
+// combined first+second-order kernel (vs_second.hip), whose records have the layout of
+// reduce_first_kernel's.  The variance shift comes from shift_dev (l values) or, when that is
+// null, from the leading a-values of f_dev as in the first-order pass.
+int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, const double* shift_dev,
+                     const double* f_dev, int rank, int max_ranks, double* acc_dev) {
     const size_t width = (size_t)l * VS_PLEN(k);
     vs_fold_args F;
     F.partials = ctx->partials;
@@ -586,7 +588,7 @@ int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, c
     F.k = k;
     F.l = l;
     F.rows = rows;
-    F.f = nullptr;
+    F.f = f_dev;
     F.shift_values = shift_dev;
     F.acc = acc_dev;
     F.rank = rank;

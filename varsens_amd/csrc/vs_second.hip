@@ -39,6 +39,7 @@ struct vs_gram_args {
     int nsuper;          // ceil(2K / 64)
     uint32_t slab_wgs;   // grid.x
     double* partials;    // [slab_wgs][npairs][64][64]
+    double* first_partials;  // combined pass only: [slab_wgs][VS_PLEN(k)] first-order records
     const uint8_t* keep;
     const uint32_t* counters;
 };
@@ -87,11 +88,27 @@ __device__ __forceinline__ const double* x_elem(const vs_gram_args& A, int m, ui
 #define VS2_WPITCH 20
 typedef double vs_d2 __attribute__((ext_vector_type(2)));
 
-template <int NB, bool MASKED, bool ALIGNED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+//
+// FIRST (vs_reduce_first_second_order; l == 1, one super-block, no mask): the first-order sums of
+// reduce_first_kernel ride along.  a = fM_1 and b = fM_2 are loaded in the fragment layout (the
+// sample rows a lane's fragments hold), so each fragment element meets its a and b in two fmas:
+// index row m < k is c_m (-> ac, bc), m >= k is d_{m-k} (-> ad, bd).  Sixteen lanes hold the same
+// a, b; lane&15 == 0 of each group carries the scalar sums (sab, sa, sb, shifted variance sums).
+// 58 more VGPRs: two waves per SIMD, which still saturates the matrix pipe.
+template <int NB, bool MASKED, bool ALIGNED, bool FIRST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FIRST ? 2 : 3, FIRST ? 2 : 3)))
 gram_diag_wave_kernel(vs_gram_args A) {
     extern __shared__ double tiles[];  // [4 waves][64][VS2_WPITCH]
     if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
+    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) {
+        // this kernel opens the call: reset the counters the two folds use (cf. reduce_first_kernel)
+        uint32_t* c = const_cast<uint32_t*>(A.counters);
+        c[0] = 0;            // NaN flag
+        c[1] = 0xffffffffu;  // first kept row
+        c[2] = 0;            // kept rows
+        c[3] = 0;            // fold tickets
+        c[4] = 0;
+    }
     constexpr int NT = NB * (NB + 1) / 2;
     constexpr int NJ = 2 * NB;          // 8-row groups to load
     const int S = blockIdx.y;
@@ -121,6 +138,17 @@ gram_diag_wave_kernel(vs_gram_args A) {
     const uint64_t nfull = rows / VS2_WCHUNK;
     const uint64_t nch = nfull + ((rows % VS2_WCHUNK) ? 1 : 0);
     const uint64_t W = (uint64_t)gridDim.x * 4;
+    // first-order state (FIRST only): planes 0 and 1 of the single output are a and b
+    const int fq = lane >> 4;
+    const double* ap = A.f + 2 * fq;
+    const double* bp = ap + rows;
+    double shift = 0.0;
+    if (FIRST) shift = vs_shift_estimate(A.f, rows);  // wave-wide call, same bits in every wave and in the fold
+    vs_d2 an[2], bn[2];
+    double pa[NB], pb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) pa[b] = pb[b] = 0.0;
+    double t_sab = 0.0, t_sa = 0.0, t_sb = 0.0, t_s1 = 0.0, t_s2 = 0.0;
     vs_d2 raw[NJ];
     bool k0 = true, k1 = true;
     // fetch only issues the loads; padding / keep masks are applied where the values are consumed,
@@ -150,6 +178,22 @@ gram_diag_wave_kernel(vs_gram_args A) {
             k0 = s < rows && A.keep[s];
             k1 = s + 1 < rows && A.keep[s + 1];
         }
+        if (FIRST) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint64_t s = s0 + 8 * h;
+                if (c < nfull && ALIGNED) {
+                    an[h] = __builtin_nontemporal_load((const vs_d2*)(ap + s));
+                    bn[h] = __builtin_nontemporal_load((const vs_d2*)(bp + s));
+                } else {
+                    const uint64_t e = s + 2 * fq;
+                    an[h].x = e < rows ? ap[s] : 0.0;
+                    an[h].y = e + 1 < rows ? ap[s + 1] : 0.0;
+                    bn[h].x = e < rows ? bp[s] : 0.0;
+                    bn[h].y = e + 1 < rows ? bp[s + 1] : 0.0;
+                }
+            }
+        }
     };
     auto stash = [&]() {
 #pragma unroll
@@ -168,6 +212,11 @@ gram_diag_wave_kernel(vs_gram_args A) {
     if (c < nch) fetch(c);
     for (; c < nch; c += W) {
         stash();
+        vs_d2 ac_[2], bc_[2];
+        if (FIRST) {
+            ac_[0] = an[0]; ac_[1] = an[1];
+            bc_[0] = bn[0]; bc_[1] = bn[1];
+        }
         if (c + W < nch) fetch(c + W);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -191,6 +240,28 @@ gram_diag_wave_kernel(vs_gram_args A) {
                         ++a;
                     }
             }
+        if (FIRST) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const double a = ac_[h][t], b = bc_[h][t];
+#pragma unroll
+                    for (int blk = 0; blk < NB; ++blk) {
+                        pa[blk] = fma(a, fr[blk][h][t], pa[blk]);
+                        pb[blk] = fma(b, fr[blk][h][t], pb[blk]);
+                    }
+                    const bool live = c < nfull || c * VS2_WCHUNK + 8 * h + 2 * fq + t < rows;
+                    const double dx = live ? a - shift : 0.0;
+                    const double dy = live ? b - shift : 0.0;
+                    t_sab = fma(a, b, t_sab);
+                    t_sa += a;
+                    t_sb += b;
+                    t_s1 += dx + dy;
+                    t_s2 = fma(dx, dx, t_s2);
+                    t_s2 = fma(dy, dy, t_s2);
+                }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -218,6 +289,43 @@ gram_diag_wave_kernel(vs_gram_args A) {
             __syncthreads();
             ++a;
         }
+    if (FIRST) {
+        // first-order record of this workgroup: 16 (wave, q) groups hold a share of every sum
+        const int k = A.k;
+        const int g = wave * 4 + fq, i = lane & 15;
+        double* r2 = tiles;                          // [16][NB*16][2]
+        double* r3 = tiles + 16 * (NB * 16) * 2;     // [16][5]
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            r2[((size_t)g * (NB * 16) + blk * 16 + i) * 2 + 0] = pa[blk];
+            r2[((size_t)g * (NB * 16) + blk * 16 + i) * 2 + 1] = pb[blk];
+        }
+        if (i == 0) {
+            r3[g * 5 + VS_P_SAB] = t_sab;
+            r3[g * 5 + VS_P_SA] = t_sa;
+            r3[g * 5 + VS_P_SB] = t_sb;
+            r3[g * 5 + VS_P_S1] = t_s1;
+            r3[g * 5 + VS_P_S2] = t_s2;
+        }
+        __syncthreads();
+        double* rec = A.first_partials + (size_t)blockIdx.x * VS_PLEN(k);
+        for (int e = tid; e < NB * 16 * 2; e += 256) {
+            const int m = e >> 1, which = e & 1;
+            double sum = 0.0;
+            for (int gg = 0; gg < 16; ++gg) sum += r2[((size_t)gg * (NB * 16) + m) * 2 + which];
+            if (m < 2 * k) {
+                // record layout: head, ac[k], bd[k], ad[k], bc[k]
+                const int j = m < k ? m : m - k;
+                const int slot = m < k ? (which == 0 ? 0 : 3) : (which == 0 ? 2 : 1);
+                rec[VS_P_HEAD + (size_t)slot * k + j] = sum;
+            }
+        }
+        if (tid < VS_P_HEAD) {
+            double sum = 0.0;
+            for (int gg = 0; gg < 16; ++gg) sum += r3[gg * 5 + tid];
+            rec[tid] = sum;
+        }
+    }
 }
 
 // Off-diagonal super-block pairs (SI < SJ): all 16 block pairs are needed.  Eight waves share the
@@ -456,6 +564,7 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     A.nsuper = nsuper;
     A.slab_wgs = slab_wgs;
     A.partials = ctx->partials;
+    A.first_partials = nullptr;
     A.keep = nullptr;
     A.counters = ctx->counters;
     vs_gram_fold_args F;
@@ -486,7 +595,7 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
             const int nb = nsuper > 1 ? 4 : (2 * K + 15) / 16;
 #define VS2_LAUNCH_WAVE2(NBV, MK, AL) \
-    hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, MK, AL>), grid_diag, dim3(256), lds_w, ctx->stream, A)
+    hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, MK, AL, false>), grid_diag, dim3(256), lds_w, ctx->stream, A)
 #define VS2_LAUNCH_WAVE(NBV)                                        \
     do {                                                            \
         if (masked && aligned) VS2_LAUNCH_WAVE2(NBV, true, true);   \
@@ -515,6 +624,87 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
         }
         VS_HIP(hipGetLastError());
     }
+    return VS_OK;
+}
+
+extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
+                                            int flags, int rank, int max_ranks, double* acc_dev,
+                                            double* gram_dev) {
+    VS_REQUIRE(ctx && acc_dev && gram_dev, "null argument");
+    VS_REQUIRE(k >= 1 && l >= 1, "k and l must be positive");
+    VS_REQUIRE(max_ranks >= 1 && rank >= 0 && rank < max_ranks, "rank %d not in [0,%d)", rank, max_ranks);
+    VS_REQUIRE(rows <= 0xfffffff0ull, "rows per GPU must stay below 2^32");
+    VS_REQUIRE(rows == 0 || f_dev, "f_dev is null");
+    const char* env = getenv("VS_REDUCE_BOTH");
+    const bool combined = l == 1 && 2 * k <= VS2_SUPER && !(flags & VS_REDUCE_NAN_TRIM) && rows >= 1 &&
+                          !(env && *env == '0');
+    if (!combined) {
+        int rc = vs_reduce_first_order(ctx, f_dev, rows, k, l, flags, rank, max_ranks, acc_dev);
+        if (rc) return rc;
+        return vs_reduce_second_order(ctx, f_dev, rows, k, l, flags, gram_dev);
+    }
+    const int K = k;
+    const uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    const char* pc = getenv("VS_GRAM_WGS_PER_CU");
+    const uint64_t want = (uint64_t)cus * (pc && *pc ? atoi(pc) : 2);  // two waves per SIMD
+    const uint32_t P = (uint32_t)(nchunks < want ? nchunks : want);
+    const size_t plen = VS_PLEN(k);
+    // workspace: first-order records [P][plen] + folded [plen] (vs_fold_partials' layout), then Gram partials
+    size_t first_doubles = (size_t)P * plen + plen;
+    first_doubles = (first_doubles + 1) & ~(size_t)1;
+    int rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + (size_t)P * VS2_TILE_OUT));
+    if (rc) return rc;
+    VS_HIP(hipMemsetAsync(gram_dev, 0, sizeof(double) * 3 * (size_t)K * K, ctx->stream));
+    vs_gram_args A;
+    A.f = f_dev;
+    A.rows = rows;
+    A.k = k;
+    A.l = 1;
+    A.K = K;
+    A.nsuper = 1;
+    A.slab_wgs = P;
+    A.partials = ctx->partials + first_doubles;
+    A.first_partials = ctx->partials;
+    A.keep = nullptr;
+    A.counters = ctx->counters;
+    const bool aligned = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
+    const size_t lds_w = sizeof(double) * 4 * VS2_SUPER * VS2_WPITCH;
+    const int nb = (2 * K + 15) / 16;
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
+#define VS2_LAUNCH_BOTH(NBV)                                                                                           \
+    do {                                                                                                               \
+        if (aligned) hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, false, true, true>), dim3(P), dim3(256), lds_w,    \
+                                        ctx->stream, A);                                                               \
+        else hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, false, false, true>), dim3(P), dim3(256), lds_w,           \
+                                ctx->stream, A);                                                                       \
+    } while (0)
+        switch (nb) {
+            case 1: VS2_LAUNCH_BOTH(1); break;
+            case 2: VS2_LAUNCH_BOTH(2); break;
+            case 3: VS2_LAUNCH_BOTH(3); break;
+            default: VS2_LAUNCH_BOTH(4); break;
+        }
+#undef VS2_LAUNCH_BOTH
+    }
+    VS_HIP(hipGetLastError());
+    rc = vs_fold_partials(ctx, P, k, 1, rows, nullptr, f_dev, rank, max_ranks, acc_dev);
+    if (rc) return rc;
+    vs_gram_fold_args F;
+    F.partials = A.partials;
+    F.P = P;
+    F.K = K;
+    F.nsuper = 1;
+    F.npairs = 1;
+    F.gram = gram_dev;
+    F.counters = ctx->counters;
+    F.masked = 0;
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_SECOND_FOLD);
+        hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)(VS2_TILE_OUT / 64)), dim3(VS2_FOLD_THREADS), 0, ctx->stream, F);
+    }
+    VS_HIP(hipGetLastError());
     return VS_OK;
 }
 

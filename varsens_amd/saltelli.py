@@ -531,6 +531,10 @@ class Varsens(object):
             ctx.eval_reduce_first_order(obj.sample._design, handle, obj._row_begin, obj._rows, acc, rank, world)
             ctx.sync()
             handle.free()
+        elif self._second_order:
+            # both reductions read the same blocks: one pass where the shape allows (k <= 32, one output)
+            gram = ctx.alloc(8 * 3 * k * l * k * l)
+            ctx.reduce_first_second_order(obj._values(), obj._rows, k, l, acc, gram, flags, rank, world)
         else:
             ctx.reduce_first_order(obj._values(), obj._rows, k, l, acc, flags, rank, world)
         if world > 1:
@@ -548,8 +552,6 @@ class Varsens(object):
 
         if self._second_order:
             K = k * l
-            gram = ctx.alloc(8 * 3 * K * K)
-            ctx.reduce_second_order(obj._values(), obj._rows, k, l, gram, flags)
             if world > 1:
                 self._comm.allreduce(gram, 3 * K * K)
             s2 = ctx.alloc(8 * K * K)
