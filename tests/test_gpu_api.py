@@ -484,3 +484,27 @@ def test_export_files_are_byte_identical_to_the_reference(vs, golden, tmp_path):
     for name in os.listdir(d):
         with open(os.path.join(d, name), "rb") as fh:
             assert fh.read() == bytes(g["file_" + name.replace(".", "_")]), name
+
+
+@pytest.mark.parametrize("second_order", [True, False])
+@pytest.mark.parametrize("case", ["g6", "lin32", "double_g", "ishigami"])
+def test_streamed_row_ranges_equal_the_resident_run(vs, case, second_order):
+    """rows_per_pass: the f-values go through one HBM buffer in row ranges (designs larger than the
+    GPU's memory); every estimator equals the all-resident run."""
+    if case == "g6":
+        k, n, obj, sc, R = 6, 5000, vs.objectives.GFunction(model), vs.scale.Identity(), 777
+    elif case == "lin32":
+        k, n, obj, sc, R = 32, 20001, vs.objectives.Linear(numpy.arange(1.0, 33.0)), vs.scale.Identity(), 4096
+    elif case == "double_g":
+        k, n, obj, sc, R = 6, 3000, vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 1000
+    else:
+        k, n, obj, sc, R = 3, 4096, vs.objectives.Ishigami(7.0, 0.1), vs.scale.Linear(-numpy.pi, numpy.pi), 64
+    a = vs.Varsens(obj, sc, k, n, verbose=False, second_order=second_order, rows_per_pass=None, fused=False)
+    b = vs.Varsens(obj, sc, k, n, verbose=False, second_order=second_order, rows_per_pass=R)
+    for name in ("E_2", "var_y", "U_j", "U_nj"):
+        numpy.testing.assert_allclose(getattr(b, name), getattr(a, name), rtol=1e-13, atol=1e-15, err_msg=name)
+    for name in ("sens", "sens_t") + (("sens_2", "sens_2n") if second_order else ()):
+        numpy.testing.assert_allclose(getattr(b, name), getattr(a, name), rtol=1e-10, atol=1e-13, err_msg=name)
+    assert b.accumulators[0] == n          # rows kept, summed over the ranges
+    with pytest.raises(Exception):
+        vs.Varsens(obj, sc, k, n, verbose=False, rows_per_pass=R, bogus=1)

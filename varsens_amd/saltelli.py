@@ -475,6 +475,9 @@ class Varsens(object):
         vectorized = extra.pop('vectorized', False)  # host callable takes a (rows,k) block (extension)
         ctx = extra.pop('context', None)
         shard = extra.pop('shard', None)
+        # device objectives: evaluate and reduce this many draws at a time instead of holding all
+        # 2n(k+1) values in HBM ('auto': only when they would not fit comfortably)
+        self._rows_per_pass = extra.pop('rows_per_pass', 'auto')
         if extra:
             raise TypeError("unexpected keyword arguments: %s" % sorted(extra))
         if isinstance(sample, Sample):
@@ -497,7 +500,8 @@ class Varsens(object):
             kw = dict(shard=shard) if shard is not None else {}
             if vectorized:
                 kw['vectorized'] = True
-            if self._fused_eligible(objective):
+            self._stream_rows = self._streaming_rows(objective, shard, ctx)
+            if self._fused_eligible(objective) or self._stream_rows:
                 kw['lazy'] = True   # the values are only produced if somebody asks for them
             elif self._fused is True:
                 raise Exception("fused=True needs first order only (second_order=False) and a single-output "
@@ -505,6 +509,26 @@ class Varsens(object):
             self.objective = Objective(self.k, self.n, self.sample, objective, verbose=verbose, **kw)
         self._ctx = self.objective._ctx
         self.compute_varsens()
+
+    _stream_rows = 0
+
+    def _streaming_rows(self, objective, shard, ctx):
+        """Draws per pass when the f-values are to be streamed through HBM in row ranges, else 0."""
+        if not isinstance(objective, _objectives.DeviceObjective) or self._rows_per_pass in (None, 0, False):
+            return 0
+        k = int(self.k)
+        rows = _shard_rows(int(self.n), shard)[1]
+        per_row = 8 * 2 * (k + 1) * int(objective.outputs(k))
+        if self._rows_per_pass != 'auto':
+            r = int(self._rows_per_pass)
+            return r if 0 < r < rows else 0
+        hbm = (ctx or self.sample._ctx).info()['hbm_bytes']
+        if per_row * rows <= 0.5 * hbm:
+            return 0
+        # passes of at most 8 GiB: large enough to fill the GPU many times over, small enough that the
+        # allocator never leaves its fast path (the first 64-GiB hipMalloc of a process takes seconds)
+        r = int(min(0.25 * hbm, 8 << 30) // per_row)
+        return max(64, r - r % 64)
 
     def _fused_eligible(self, objective):
         if self._fused is False or self._second_order:
@@ -523,6 +547,9 @@ class Varsens(object):
         rank = self._comm.rank if self._comm is not None else 0
         flags = _native.REDUCE_NAN_TRIM if obj._nan_trim else 0
 
+        if self._stream_rows and obj._f is None and obj._rows > 0:
+            return self._compute_streamed(self._stream_rows)
+
         nacc = _native.acc_len(k, l, world)
         acc = ctx.alloc(8 * nacc)
         if obj._f is None and obj._rows > 0 and self._fused_eligible(obj.objective_func):
@@ -537,10 +564,17 @@ class Varsens(object):
             ctx.reduce_first_second_order(obj._values(), obj._rows, k, l, acc, gram, flags, rank, world)
         else:
             ctx.reduce_first_order(obj._values(), obj._rows, k, l, acc, flags, rank, world)
+        self._finish(acc, nacc, gram if self._second_order else None, world)
+
+    def _finish(self, acc, nacc, gram, slots):
+        """Exchange, finishing kernels and the result attributes; `slots` = variance slots in the record."""
+        ctx, obj = self._ctx, self.objective
+        k, n, l = int(self.k), int(self.n), int(obj._l)
+        world = self._comm.world if self._comm is not None else 1
         if world > 1:
             self._comm.allreduce(acc, nacc)
         first = ctx.alloc(8 * _native.first_order_len(k, l))
-        ctx.finish_first_order(acc, n, k, l, first, world)
+        ctx.finish_first_order(acc, n, k, l, first, slots)
         r = ctx.download(first, (2 + 4 * k, l))
         self.accumulators = ctx.download(acc, (nacc,))
         self.E_2 = r[0].copy()
@@ -563,3 +597,43 @@ class Varsens(object):
                 b.free()
         acc.free()
         first.free()
+
+
+    def _compute_streamed(self, rows_per_pass):
+        """The same estimators with the f-values streamed through one HBM buffer in row ranges:
+        every range is a variance slot of the record (as a rank is), the records and Gram matrices
+        add up.  For designs whose 2n(k+1) values exceed the memory of the GPU."""
+        ctx, obj = self._ctx, self.objective
+        k, n, l = int(self.k), int(self.n), int(obj._l)
+        world = self._comm.world if self._comm is not None else 1
+        rank = self._comm.rank if self._comm is not None else 0
+        R = int(rows_per_pass)
+        per_rank = -(-n // world)                 # the same pass count on every rank
+        passes = max(1, -(-per_rank // R))
+        slots = passes * world
+        nacc = _native.acc_len(k, l, slots)
+        K = k * l
+        acc = ctx.alloc(8 * nacc)
+        gram = ctx.alloc(8 * 3 * K * K) if self._second_order else None
+        total = numpy.zeros(nacc)
+        gram_total = numpy.zeros(3 * K * K)
+        f = ctx.alloc(8 * 2 * (k + 1) * min(R, obj._rows) * l)
+        handle = obj._device_objective()
+        for c in range(passes):
+            begin = c * R
+            count = min(R, obj._rows - begin)
+            if count <= 0:
+                break
+            ctx.eval(obj.sample._design, handle, obj._row_begin + begin, count, f)
+            if self._second_order:
+                ctx.reduce_first_second_order(f, count, k, l, acc, gram, 0, rank * passes + c, slots)
+                gram_total += ctx.download(gram, (3 * K * K,))
+            else:
+                ctx.reduce_first_order(f, count, k, l, acc, 0, rank * passes + c, slots)
+            total += ctx.download(acc, (nacc,))
+        handle.free()
+        f.free()
+        ctx.upload_into(acc, total)
+        if gram is not None:
+            ctx.upload_into(gram, gram_total)
+        self._finish(acc, nacc, gram, slots)
