@@ -1,3 +1,4 @@
+"""hipMalloc / first-touch / hipFree latency by buffer size (why streamed passes are capped at 8 GiB)."""
 import sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from varsens_amd import _native
