@@ -51,7 +51,7 @@ def cpu_baseline(k, f_small, n_small, cores):
     (b) compute_varsens with the reference's numpy formulas (saltelli.py:572-622)."""
     from oracle import saltelli_oracle as orc
     c = np.arange(1, k + 1, dtype=float)
-    n_eval = 4096
+    n_eval = 32768 if n_small > (1 << 16) else 4096   # ~2 M reference-style calls: a second or two
     S = orc.build_sample(k, n_eval)
     t0 = time.perf_counter()
     F = orc.evaluate_callable(lambda x: float(np.dot(c, x)), *S)
@@ -251,7 +251,7 @@ def main():
                          "avg_launch_ms": avg["reduce_first"]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            n_small = min(rows, 1 << 20)
+            n_small = min(rows, 1 << 22)   # the whole pass at the default size: 2.2 GB over PCIe, ~2 s of numpy
             blocks = np.empty((2 * k + 2, n_small, l))
             for b in range(2 * k + 2):
                 blocks[b] = ctx.download(f, (n_small, l), byte_offset=8 * b * rows * l)
