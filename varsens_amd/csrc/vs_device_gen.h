@@ -191,6 +191,9 @@ struct vs_eval_args {
 // ---------------------------------------------------------------------------
 #define VS_CHAINS 8                                 // chains per thread and pass
 #define VS_PASS (VS_EVAL_WAVES * VS_CHAINS)         // blocks i handled per pass
+#ifndef VS_TILE_AHEAD
+#define VS_TILE_AHEAD 4                             // columns whose tile reads are in flight ahead of their folds
+#endif
 
 
 
@@ -220,22 +223,50 @@ __device__ __forceinline__ void vs_chain_pass(const double* F1, const double* F2
                                               double (&cj)[VS_PASS / W], double (&dj)[VS_PASS / W]) {
     constexpr int T = VS_EVAL_ROWS;
     constexpr int CH = VS_PASS / W;
+    // The tile reads run VS_TILE_AHEAD columns ahead of the folds that use them (left to itself the
+    // compiler issues each pair of reads right in front of its folds, and the wave sits out the LDS
+    // latency once per column); the scheduling barrier keeps the reads of the next batch in front
+    // of the folds of this one.
+    constexpr int B = VS_TILE_AHEAD;
+    double na[B], nb[B];
 #pragma unroll
-    for (int j = 0; j < VS_PASS; ++j) {
-        const double ta = vs_tile_ld<SCRATCH>(F1 + (size_t)(i0 + j) * T);
-        const double tb = vs_tile_ld<SCRATCH>(F2 + (size_t)(i0 + j) * T);
+    for (int t = 0; t < B; ++t) {
+        na[t] = vs_tile_ld<SCRATCH>(F1 + (size_t)(i0 + t) * T);
+        nb[t] = vs_tile_ld<SCRATCH>(F2 + (size_t)(i0 + t) * T);
+    }
 #pragma unroll
-        for (int m = 0; m < CH; ++m) {
-            if (Q + W * m < j) {
-                cj[m] = vs_fold<KIND>(cj[m], tb);
-                dj[m] = vs_fold<KIND>(dj[m], ta);
-            } else if (Q + W * m == j) {
-                cj[m] = vs_fold<KIND>(pb, ta);  // N_j[i0+j]: M_2 with column i0+j from M_1
-                dj[m] = vs_fold<KIND>(pa, tb);  // N_nj[i0+j]: M_1 with column i0+j from M_2
+    for (int j0 = 0; j0 < VS_PASS; j0 += B) {
+        double ca[B], cb[B];
+#pragma unroll
+        for (int t = 0; t < B; ++t) {
+            ca[t] = na[t];
+            cb[t] = nb[t];
+        }
+        if (j0 + B < VS_PASS) {
+#pragma unroll
+            for (int t = 0; t < B; ++t) {
+                na[t] = vs_tile_ld<SCRATCH>(F1 + (size_t)(i0 + j0 + B + t) * T);
+                nb[t] = vs_tile_ld<SCRATCH>(F2 + (size_t)(i0 + j0 + B + t) * T);
             }
         }
-        pa = vs_fold<KIND>(pa, ta);
-        pb = vs_fold<KIND>(pb, tb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < B; ++t) {
+            const int j = j0 + t;
+            const double ta = ca[t], tb = cb[t];
+#pragma unroll
+            for (int m = 0; m < CH; ++m) {
+                if (Q + W * m < j) {
+                    cj[m] = vs_fold<KIND>(cj[m], tb);
+                    dj[m] = vs_fold<KIND>(dj[m], ta);
+                } else if (Q + W * m == j) {
+                    cj[m] = vs_fold<KIND>(pb, ta);  // N_j[i0+j]: M_2 with column i0+j from M_1
+                    dj[m] = vs_fold<KIND>(pa, tb);  // N_nj[i0+j]: M_1 with column i0+j from M_2
+                }
+            }
+            pa = vs_fold<KIND>(pa, ta);
+            pb = vs_fold<KIND>(pb, tb);
+        }
     }
 }
 
