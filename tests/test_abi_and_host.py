@@ -162,3 +162,21 @@ def test_bench_cpu_baseline_leg():
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["unit"] == "GSamples/s" and cpu["value"] > 0
     assert R["sens"].shape == (k, 1)
     assert bench.pmc_traffic("void reduce_first_kernel", 32, 22) is None or bench.pmc_traffic("void reduce_first_kernel", 32, 22) > 2.2e9
+
+
+def test_header_is_plain_c_and_a_c_program_links(native, tmp_path):
+    """include/varsens_hip.h compiles as ISO C99; examples/c_abi_demo.c (no Python, no C++) links against
+    the library.  Without a GPU the program must stop at vs_context_create with the no-fallback message."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    libdir = os.path.dirname(os.environ.get("VARSENS_HIP_LIB") or native.LIB_PATH)
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L", libdir, "-lvarsens_hip",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    if r.returncode != 0:   # no GPU here: the only acceptable failure is the loud one at context creation
+        assert r.returncode == 1 and "vs_context_create" in r.stderr and "no host fallback" in r.stderr

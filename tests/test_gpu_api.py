@@ -508,3 +508,32 @@ def test_streamed_row_ranges_equal_the_resident_run(vs, case, second_order):
     assert b.accumulators[0] == n          # rows kept, summed over the ranges
     with pytest.raises(Exception):
         vs.Varsens(obj, sc, k, n, verbose=False, rows_per_pass=R, bogus=1)
+
+
+def test_c_program_over_the_abi_reproduces_the_reference(vs, golden, tmp_path):
+    """examples/c_abi_demo.c: config 1 from plain C99 through the C ABI, no Python in the data path."""
+    import os
+    import subprocess
+    from varsens_amd import _native
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(os.environ.get("VARSENS_HIP_LIB") or _native.LIB_PATH)
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.check_call([gcc, "-std=c99", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_abi_demo.c"), "-L", libdir, "-lvarsens_hip",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    vals = {}
+    for line in r.stdout.splitlines():
+        parts = line.split()
+        for name, v in zip(parts[0::2], parts[1::2]):
+            vals[name] = float(v)
+    g = golden("g1_gfunc_k6_n1024")
+    assert abs(vals["E_2"] - g["E_2"][0]) <= 1e-13 * abs(g["E_2"][0])
+    assert abs(vals["var_y"] - g["var_y"][0]) <= 1e-13 * abs(g["var_y"][0])
+    for j in range(6):
+        assert abs(vals["sens[%d]" % j] - g["sens"][j, 0]) <= 1e-10 * abs(g["sens"][j, 0]) + 1e-13
+        assert abs(vals["sens_t[%d]" % j] - g["sens_t"][j, 0]) <= 1e-10 * abs(g["sens_t"][j, 0]) + 1e-13
