@@ -537,3 +537,26 @@ def test_c_program_over_the_abi_reproduces_the_reference(vs, golden, tmp_path):
     for j in range(6):
         assert abs(vals["sens[%d]" % j] - g["sens"][j, 0]) <= 1e-10 * abs(g["sens"][j, 0]) + 1e-13
         assert abs(vals["sens_t[%d]" % j] - g["sens_t"][j, 0]) <= 1e-10 * abs(g["sens_t"][j, 0]) + 1e-13
+
+
+def test_sobol_large_design_uses_every_byte_table(vs):
+    """n = 2^23 + 3: sequence indices pass 2^24, so the design kernels read all four byte tables of the
+    direction integers; flat rows at the start, across the M_1/M_2 seam and at the end of M_2 against
+    the oracle's bit loop."""
+    from varsens_amd.saltelli import sobol_directions, seed1_permutation
+    k, n = 3, (1 << 23) + 3
+    s = vs.Sample(k, n, vs.scale.Identity(), verbose=False, generator='sobol')
+    d = sobol_directions(k)
+    perm = seed1_permutation(n)
+    head = s._rows(0, 4)                       # M_1 rows 0..3: indices 4096..
+    assert numpy.array_equal(head, orc.sobol(k, 4096, 4, d))
+    seam = s._rows(n - 2, 4)                   # last two rows of M_1, first two of M_2
+    assert numpy.array_equal(seam[:2], orc.sobol(k, 4096 + n - 2, 2, d))
+    for r in range(2):
+        assert numpy.array_equal(seam[2 + r], orc.sobol(k, 4096 + n + int(perm[r]), 1, d)[0])
+    tail = s._rows(2 * n - 2, 2)               # last rows of M_2
+    for r in range(2):
+        assert numpy.array_equal(tail[r], orc.sobol(k, 4096 + n + int(perm[n - 2 + r]), 1, d)[0])
+    top = int(perm.argmax())                   # the row of M_2 that holds the largest sequence index of all
+    assert numpy.array_equal(s._rows(n + top, 1)[0], orc.sobol(k, 4096 + 2 * n - 1, 1, d)[0])
+    assert 4096 + 2 * n - 1 >= 1 << 24

@@ -52,6 +52,7 @@ struct vs_design {
     uint32_t* perm = nullptr;  // device, n or null
     double* raw = nullptr;     // device (2n,k) or null
     uint32_t* dirs = nullptr;  // device (k,32) or null
+    uint32_t* sobol_tabs = nullptr;  // device (k,4,256): XOR of the direction integers selected by each byte value
     uint32_t* bases = nullptr; // device, k x {base, magic, shift, pad}
 };
 

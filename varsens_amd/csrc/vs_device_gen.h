@@ -141,6 +141,17 @@ __device__ __attribute__((noinline)) double vs_sobol_point(vs_u64 i, const vs_u3
     return (double)x * (1.0 / 4294967296.0);
 }
 
+// The same point from per-column byte tables (built once per design on the host): tab[b][v] is the
+// XOR of the direction integers selected by the bits of byte value v at byte position b of the Gray
+// code -- three or four cached 4-byte reads and XORs instead of ~3 vector instructions per bit.
+__device__ __forceinline__ double vs_sobol_point_tab(vs_u64 i, const vs_u32* __restrict__ tab, int nbits) {
+    const vs_u32 g = (vs_u32)(i ^ (i >> 1));
+    vs_u32 x = tab[g & 255u] ^ tab[256 + ((g >> 8) & 255u)];
+    if (nbits > 16) x ^= tab[512 + ((g >> 16) & 255u)];
+    if (nbits > 24) x ^= tab[768 + (g >> 24)];
+    return (double)x * (1.0 / 4294967296.0);
+}
+
 struct vs_design_dev {
     int generator, k, scale_mode;
     int sobol_bits;  // Gray-code bits in use (VS_GEN_SOBOL)
@@ -150,6 +161,7 @@ struct vs_design_dev {
     const vs_u32* perm;
     const double* raw;
     const vs_u32* dirs;
+    const vs_u32* sobol_tabs;
     const vs_base* bases;
 };
 
@@ -157,7 +169,7 @@ struct vs_design_dev {
 // M_1, second half M_2 before the shuffle).
 __device__ __forceinline__ double vs_unit_point(const vs_design_dev& D, vs_u64 seq_row, int c) {
     if (D.generator == VS_GEN_HALTON) return vs_radical_inverse(D.first_index + seq_row, D.bases[c]);
-    if (D.generator == VS_GEN_SOBOL) return vs_sobol_point(D.first_index + seq_row, D.dirs + 32 * c, D.sobol_bits);
+    if (D.generator == VS_GEN_SOBOL) return vs_sobol_point_tab(D.first_index + seq_row, D.sobol_tabs + 1024 * c, D.sobol_bits);
     return D.raw[seq_row * (vs_u64)D.k + c];
 }
 

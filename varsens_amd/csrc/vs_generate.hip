@@ -37,6 +37,7 @@ static vs_design_dev to_dev(const vs_design* g) {
     D.perm = g->perm;
     D.raw = g->raw;
     D.dirs = g->dirs;
+    D.sobol_tabs = g->sobol_tabs;
     D.bases = (const vs_base*)g->bases;
     return D;
 }
@@ -188,6 +189,7 @@ extern "C" int vs_design_destroy(vs_context* ctx, vs_design* g) {
     if (g->perm) hipFree(g->perm);
     if (g->raw) hipFree(g->raw);
     if (g->dirs) hipFree(g->dirs);
+    if (g->sobol_tabs) hipFree(g->sobol_tabs);
     if (g->bases) hipFree(g->bases);
     delete g;
     return VS_OK;
@@ -254,6 +256,18 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
         VS_TRY(hipMalloc(&g->dirs, sizeof(uint32_t) * 32 * k));
         VS_TRY(hipMemcpyAsync(g->dirs, desc->sobol_directions, sizeof(uint32_t) * 32 * k,
                               hipMemcpyHostToDevice, ctx->stream));
+        // byte tables of the direction integers (vs_sobol_point_tab)
+        std::vector<uint32_t> tabs((size_t)k * 1024);
+        for (int c = 0; c < k; ++c)
+            for (int b = 0; b < 4; ++b)
+                for (int v = 0; v < 256; ++v) {
+                    uint32_t x = 0;
+                    for (int j = 0; j < 8; ++j)
+                        if ((v >> j) & 1) x ^= desc->sobol_directions[(size_t)c * 32 + 8 * b + j];
+                    tabs[((size_t)c * 4 + b) * 256 + v] = x;
+                }
+        VS_TRY(hipMalloc(&g->sobol_tabs, sizeof(uint32_t) * tabs.size()));
+        VS_TRY(hipMemcpy(g->sobol_tabs, tabs.data(), sizeof(uint32_t) * tabs.size(), hipMemcpyHostToDevice));
     }
     if (desc->generator == VS_GEN_HALTON) {
         uint32_t largest = 0;
