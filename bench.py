@@ -84,8 +84,8 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: 2^log2n draws IN TOTAL, split over the GPUs (default: weak, 2^log2n per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prewarm-seconds", type=float, default=0.3,
-                    help="untimed passes before the warm-up steps, to get the GPU off its idle clock")
+    ap.add_argument("--prewarm-steps", type=int, default=320,
+                    help="untimed passes (~0.3 s) before the warm-up steps, to get the GPU off its idle clock")
     ap.add_argument("--exchange", choices=["rccl", "host"], default="rccl",
                     help="host = rehearsal of the multi-rank flow without RCCL (records cross the host over gloo)")
     ap.add_argument("--shared-device", action="store_true",
@@ -158,11 +158,10 @@ def main():
 
     # DVFS: a GPU that was idle needs ~0.2 s of work to reach its sustained clock; bring it there
     # before the W warm-up steps so that the K timed steps do not depend on how small K and W are
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_seconds:
-        for _ in range(8):
-            step()
-        ctx.sync()
+    # (a fixed COUNT, not a wall-clock loop: every rank must issue the same number of all-reduces)
+    for _ in range(args.prewarm_steps):
+        step()
+    ctx.sync()
     for _ in range(args.warmup):
         step()
     ctx.sync()
