@@ -184,3 +184,28 @@ def test_config5_shard_polynomial_k128(ctx):
     total, S, ST = orc.product_form_indices(V)
     np.testing.assert_allclose(fin[1, 0], total, rtol=2e-2)
     np.testing.assert_allclose(fin[2 + 2 * k:2 + 3 * k, 0], S, atol=5e-3)
+
+
+def test_model_study_shape_k100_l10():
+    """A shape like the reference's model studies: k=100 parameters, l=10 outputs, n=20000 draws, a user
+    objective compiled by hiprtc.  First and second order (k*l = 1000 index rows, 528 super-block pairs)
+    against the oracle's numpy arithmetic on the same f-values."""
+    import varsens_amd as vs
+    k, l, n = 100, 10, 20000
+    body = """
+    for (int o = 0; o < %d; ++o) {
+        double s = 0.0;
+        for (int c = 0; c < k; ++c) s += p[(o * 7 + c) %% k] * x[c] * (1.0 + 0.01 * o * x[(c + o + 1) %% k]);
+        out[o] = s;
+    }""" % l
+    obj = vs.objectives.Expression(body, outputs=l, params=1.0 / (1.0 + np.arange(k)))
+    s = vs.Sample(k, n, vs.scale.Linear(-1.0, 2.0), verbose=False)
+    o = vs.Objective(k, n, s, obj, verbose=False)
+    v = vs.Varsens(o, verbose=False)
+    R = orc.compute_varsens(o.fM_1, o.fM_2, o.fN_j, o.fN_nj, n)
+    assert v.sens_2.shape == (k, l, k, l)
+    for name in ("E_2", "var_y", "U_j", "U_nj"):
+        np.testing.assert_allclose(getattr(v, name), R[name], rtol=1e-12, err_msg=name)
+    for name in ("sens", "sens_t", "sens_2", "sens_2n"):
+        a, b = getattr(v, name), R[name]
+        assert np.abs(a - b).max() <= 1e-10 * np.abs(b).max(), name
