@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--host-exchange", action="store_true")
     ap.add_argument("--shared-device", action="store_true")
     ap.add_argument("--out", default=None, help="rank 0 saves the result arrays here (.npz)")
+    ap.add_argument("--rows-per-pass", type=int, default=0,
+                    help="stream every rank's shard through HBM in row ranges of this many draws")
     args = ap.parse_args()
 
     group = dist.HostGroup()
@@ -34,8 +36,13 @@ def main():
     a = np.array([0, 0.5, 3, 9, 99, 99], dtype=float)[:args.k] if args.k <= 6 else np.linspace(0, 9, args.k)
     sample = vs.Sample(args.k, args.n, vs.scale.Identity(), verbose=False, context=ctx)
     shard = dist.shard_rows(args.n, group.world, group.rank)
-    objective = vs.Objective(args.k, args.n, sample, vs.objectives.GFunction([a, a[::-1]]), verbose=False, shard=shard)
-    v = vs.Varsens(objective, verbose=False, comm=comm)
+    if args.rows_per_pass:
+        v = vs.Varsens(vs.objectives.GFunction([a, a[::-1]]), sample=sample, verbose=False, comm=comm, shard=shard,
+                       rows_per_pass=args.rows_per_pass)
+    else:
+        objective = vs.Objective(args.k, args.n, sample, vs.objectives.GFunction([a, a[::-1]]), verbose=False,
+                                 shard=shard)
+        v = vs.Varsens(objective, verbose=False, comm=comm)
     if group.rank == 0:
         print("ranks=%d rows/rank=%d sens[:,0]=%s" % (group.world, shard[1], np.array2string(v.sens[:, 0], precision=6)))
         if args.out:

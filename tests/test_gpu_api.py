@@ -407,7 +407,8 @@ def test_fused_first_order_through_api(vs, golden):
 
 # ---------------------------------------------------------------- multi-process flow (rehearsal on one GPU)
 
-def test_two_process_sharded_run_equals_single_process(vs, tmp_path):
+@pytest.mark.parametrize("rows_per_pass", [0, 3000])
+def test_two_process_sharded_run_equals_single_process(vs, tmp_path, rows_per_pass):
     """examples/multi_gpu.py with 2 ranks sharing GPU 0 and the records crossing the host (gloo): the
     sharded Objective + Varsens(comm=...) flow gives the single-process result.  The RCCL exchange
     itself needs >= 2 GPUs and is exercised by the driver's scaling runs."""
@@ -423,7 +424,8 @@ def test_two_process_sharded_run_equals_single_process(vs, tmp_path):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "examples", "multi_gpu.py"), "--k", "6",
-                                       "--n", "20001", "--host-exchange", "--shared-device", "--out", out],
+                                       "--n", "20001", "--host-exchange", "--shared-device", "--out", out,
+                                       "--rows-per-pass", str(rows_per_pass)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for p in procs:
         o, _ = p.communicate(timeout=300)
