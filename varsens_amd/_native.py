@@ -126,6 +126,10 @@ SIGNATURES = {
     "vs_comm_destroy": (C.c_int, [C.c_void_p]),
 }
 
+# dmabuf IPC is the only mode this pool's driver supports; RCCL between processes needs it, and the
+# runtime reads the variable when it initialises (first HIP call), so it is set before the library loads
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 _lib = None
 
 
