@@ -82,6 +82,10 @@ int vs_free(vs_context* ctx, void* dptr);
 int vs_upload(vs_context* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int vs_download(vs_context* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int vs_memset(vs_context* ctx, void* dst_dev, int byte, size_t bytes);
+/* dst_dev[i] += src_dev[i] for `count` doubles on the context's stream: sums the accumulator records
+ * and Gram sums of successive row ranges on the device (no reference counterpart: numpy.sum over the
+ * whole arrays, varsens/saltelli.py:577,591-596,612-619, here taken range by range). */
+int vs_accumulate(vs_context* ctx, double* dst_dev, const double* src_dev, size_t count);
 
 /* Per-launch timing.  Between begin and end every kernel launched through
  * this context is bracketed by HIP events on the context's stream (no host
@@ -242,9 +246,14 @@ int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint64_t rows, i
 
 /* Fused path: evaluates the shard's 2(k+1)*row_count points and reduces them in registers --
  * no f-values are written or read (the record equals vs_eval + vs_reduce_first_order's up to
- * summation order).  Covers single-output G_FUNCTION / POLYNOMIAL / LINEAR objectives with
- * k <= 32; returns VS_ERR_ARG otherwise (callers then use the two-kernel path).  NaN values
- * propagate (as on the reference's live-evaluation route, saltelli.py:329-355). */
+ * summation order and, for separable objectives, the association order of the k-term folds:
+ * rounding-level differences, <= ~2e-13 relative on the record).  Covers G_FUNCTION / POLYNOMIAL /
+ * LINEAR objectives (any number of outputs) and separable source objectives with k <= 128 on
+ * designs with identity or linear scaling, and ISHIGAMI; returns VS_ERR_ARG otherwise (callers then
+ * use the two-kernel path; vs_eval_reduce_supported tells in advance: *supported = 1 or 0).  NaN
+ * values propagate (as on the reference's live-evaluation route, saltelli.py:329-355).
+ * Replaces saltelli.py:329-355 + :577,583,591-596 in one kernel. */
+int vs_eval_reduce_supported(vs_context* ctx, const vs_design* design, const vs_objective* obj, int* supported);
 int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                                uint64_t row_begin, uint64_t row_count, int rank, int max_ranks,
                                double* acc_dev);

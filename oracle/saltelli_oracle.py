@@ -249,6 +249,105 @@ def polynomial_rows(X, beta):
 
 
 # ----------------------------------------------------------------------------
+# separable objectives in segmented-scan order (varsens_amd/csrc/vs_device_scan.h)
+#
+# For k >= 33 columns the HIP engine folds the per-coordinate terms of a separable objective in a
+# fixed REASSOCIATED order (O(k) work per design row instead of O(k^2)); the fused evaluate+reduce
+# kernels use that order for every k.  The reference has no counterpart: it calls an arbitrary
+# Python function row by row (varsens/saltelli.py:329-355), for which any association order of a
+# product / sum is as legitimate as numpy.prod's.  The order is restated here exactly, so that the
+# device values can be compared bit for bit; against the strict left-to-right folds above they
+# differ by rounding only (asserted by the tests at <= 1e-15 relative).
+# ----------------------------------------------------------------------------
+
+SCAN_SUB = 4
+
+
+def scan_shape(k, fused=False):
+    """(L, W): columns per segment and segments, as the kernels choose them (vs_scan.hip)."""
+    if k <= 8: return 2, 4
+    if k <= 16: return 4, 4
+    if k <= 32: return 8, 4
+    if k <= 64: return 8, 8
+    if k <= 128: return (8, 16) if fused else (16, 8)
+    if k <= 256 and not fused: return 16, 16
+    raise ValueError("k=%d is outside the scan kernels" % k)
+
+
+def separable_terms(kind, X, params):
+    """Per-coordinate terms t_c(x_c) of the built-in separable objectives, same operations as vs_term."""
+    X = np.asarray(X, dtype=np.float64)
+    p = np.asarray(params, dtype=np.float64)
+    if kind == "g_function":
+        return (np.abs(4.0 * X - 2.0) + p) / (1.0 + p)
+    if kind == "polynomial":
+        return 1.0 + p * (X - 0.5)
+    if kind == "linear":
+        return p * X
+    raise ValueError(kind)
+
+
+def separable_scan(ta, tb, shape, add=False):
+    """a, b (rows,), c, d (k, rows) from term arrays ta, tb (rows, k) in the kernels' order:
+    segment totals left to right; prefixes over earlier segments left to right from the identity;
+    suffixes over later segments and inside a segment right to left; c_i = (pb . ta_i) . sb_i."""
+    L, W = shape
+    rows, k = ta.shape
+    ident = 0.0 if add else 1.0
+    op = (lambda x, y: x + y) if add else (lambda x, y: x * y)
+    pad = np.full((rows, L * W - k), ident)
+    ta = np.concatenate([ta, pad], axis=1)
+    tb = np.concatenate([tb, pad], axis=1)
+    full = np.full(rows, ident)
+    Ta, Tb = [], []
+    for q in range(W):
+        x, y = full.copy(), full.copy()
+        for j in range(L):
+            x = op(x, ta[:, q * L + j])
+            y = op(y, tb[:, q * L + j])
+        Ta.append(x); Tb.append(y)
+    a, b = full.copy(), full.copy()
+    for q in range(W):
+        a = op(a, Ta[q]); b = op(b, Tb[q])
+    c = np.empty((k, rows)); d = np.empty((k, rows))
+    for q in range(W):
+        Pa, Pb = full.copy(), full.copy()
+        for w in range(q):
+            Pa = op(Pa, Ta[w]); Pb = op(Pb, Tb[w])
+        Sa, Sb = full.copy(), full.copy()
+        for w in range(W - 1, q, -1):
+            Sa = op(Ta[w], Sa); Sb = op(Tb[w], Sb)
+        sa = [None] * L; sb = [None] * L          # fold of the terms AFTER column j
+        sa[L - 1], sb[L - 1] = Sa, Sb
+        for j in range(L - 2, -1, -1):
+            sa[j] = op(ta[:, q * L + j + 1], sa[j + 1])
+            sb[j] = op(tb[:, q * L + j + 1], sb[j + 1])
+        pa, pb = Pa, Pb
+        for j in range(L):
+            i = q * L + j
+            if i < k:
+                c[i] = op(op(pb, ta[:, i]), sb[j])     # N_j[i]: M_2 with column i from M_1
+                d[i] = op(op(pa, tb[:, i]), sa[j])     # N_nj[i]: M_1 with column i from M_2
+            pa = op(pa, ta[:, i]); pb = op(pb, tb[:, i])
+    return a, b, c, d
+
+
+def evaluate_scan(kind, params, M_1, M_2, fused=False):
+    """fM_1, fM_2 (n,l), fN_j, fN_nj (k,n,l) of a built-in separable objective in the scan kernels'
+    order; params (k,) or (l,k)."""
+    P = np.atleast_2d(np.asarray(params, dtype=np.float64))
+    n, k = M_1.shape
+    l = P.shape[0]
+    fM_1 = np.empty((n, l)); fM_2 = np.empty((n, l))
+    fN_j = np.empty((k, n, l)); fN_nj = np.empty((k, n, l))
+    for o in range(l):
+        a, b, c, d = separable_scan(separable_terms(kind, M_1, P[o]), separable_terms(kind, M_2, P[o]),
+                                    scan_shape(k, fused), add=(kind == "linear"))
+        fM_1[:, o], fM_2[:, o], fN_j[:, :, o], fN_nj[:, :, o] = a, b, c, d
+    return fM_1, fM_2, fN_j, fN_nj
+
+
+# ----------------------------------------------------------------------------
 # a6: Objective evaluation, a7: loading pre-computed values
 # ----------------------------------------------------------------------------
 

@@ -239,11 +239,49 @@ def wire_formats():
     save("g14_wire_formats_k3_n4", k=k, n=n, **out)
 
 
+def nan_fm_only():
+    """G6b: the only NaNs sit in fM_1 / fM_2 rows (blocks the second-order products never read);
+    the reference still trims those rows from fN_j / fN_nj (saltelli.py:474-492)."""
+    ref, rscale = load_reference()
+    rng = np.random.RandomState(20260102)
+    k, n, l = 4, 96, 1
+    vals = 1.0 + rng.rand(2 * n * (k + 1), l)
+    vals[11, 0] = np.nan          # fM_1 row 11
+    vals[n + 70, 0] = np.nan      # fM_2 row 70
+    o = ref.Objective(k, n, objective_vals=vals.copy(), verbose=False)
+    v = ref.Varsens(o, verbose=False)
+    save("g6b_nantrim_fm_only_k4_n96", k=k, n=n, l=l, vals=vals, kept=o.fM_1.shape[0], **result_fields(v))
+
+
+def config2():
+    """G15: BASELINE configs[1] -- Sobol g-function, k=6, n=2^20 -- through the reference's own
+    3-step route (14.7 M calls of the objective: a few minutes in the build container).  Only the
+    results go into the fixture, plus checksums / a head of the f-values the reference produced."""
+    ref, rscale = load_reference()
+    a6 = [0, 0.5, 3, 9, 99, 99]
+    arr = np.array(a6, dtype=float)
+
+    def g_obj(x):  # the same arithmetic as g_obj in main(): per-factor terms, numpy.prod over 6 values
+        return np.prod((np.abs(4.0 * x - 2.0) + arr) / (1.0 + arr))
+
+    n = 1 << 20
+    s, o, v = run3(ref, 6, n, lambda x: x, g_obj)
+    save("g15_gfunc_k6_n1048576", k=6, n=n, a=arr,
+         M_1_head=s.M_1[:8], M_2_head=s.M_2[:8],
+         fM_1_head=o.fM_1[:8], fM_2_head=o.fM_2[:8], fN_j_head=o.fN_j[:, :4], fN_nj_head=o.fN_nj[:, :4],
+         fvals_sha=sha(o.flat()), **result_fields(v))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference checkout not found at %s" % REF)
     if "--only-wire" in sys.argv:
         wire_formats()
+    elif "--nan-fm" in sys.argv:
+        nan_fm_only()
+    elif "--config2" in sys.argv:   # minutes of reference time: generated on its own
+        config2()
     else:
         main()
+        nan_fm_only()
         wire_formats()

@@ -180,3 +180,49 @@ def test_header_is_plain_c_and_a_c_program_links(native, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     if r.returncode != 0:   # no GPU here: the only acceptable failure is the loud one at context creation
         assert r.returncode == 1 and "vs_context_create" in r.stderr and "no host fallback" in r.stderr
+
+
+# ---- streamed mode: every decision comes from the LARGEST shard, so all ranks agree -----------
+
+def test_stream_plan_is_rank_invariant():
+    from varsens_amd import dist
+    from varsens_amd.saltelli import stream_passes, stream_rows_per_pass
+    # shards differing by two rows: a per-rank decision would split the ranks for R between the sizes
+    n, world = 1003, 4
+    shards = [dist.shard_rows(n, world, r)[1] for r in range(world)]
+    assert sum(shards) == n and max(shards) - min(shards) <= 3
+    biggest = max(shards)
+    for R in (min(shards), min(shards) + 1, biggest - 1):
+        assert stream_rows_per_pass(R, biggest, 100, None) == R          # everybody streams ...
+        passes = stream_passes(biggest, R)
+        assert all(passes * R >= rows for rows in shards)                # ... and covers its rows
+    assert stream_rows_per_pass(biggest, biggest, 100, None) == 0        # one pass holds the largest shard: resident
+    assert stream_rows_per_pass(0, biggest, 100, None) == 0 and stream_rows_per_pass(None, biggest, 100, None) == 0
+    # 'auto': resident while the largest shard takes at most half of HBM, else <= 8 GiB ranges of whole 64-row blocks
+    hbm = 288 << 30
+    assert stream_rows_per_pass('auto', 1 << 22, 8 * 66, hbm) == 0
+    r = stream_rows_per_pass('auto', 1 << 27, 8 * 258, hbm)
+    assert r % 64 == 0 and 0 < r * 8 * 258 <= (8 << 30)
+
+
+def test_varsens_takes_the_stream_plan_from_the_largest_shard():
+    """Varsens._max_rows_over_ranks: communicator max() when there is one, else the standard split."""
+    from varsens_amd import dist
+    from varsens_amd.saltelli import Varsens
+
+    class Comm(object):
+        world, rank = 4, 1
+
+    v = Varsens.__new__(Varsens)
+    v._comm, v.n = Comm(), 1003
+    mine = dist.shard_rows(1003, 4, 1)[1]
+    assert v._max_rows_over_ranks(mine) == max(dist.shard_rows(1003, 4, r)[1] for r in range(4)) > mine
+
+    class CommMax(Comm):
+        def max(self, value):
+            return 777.0
+
+    v._comm = CommMax()
+    assert v._max_rows_over_ranks(mine) == 777
+    v._comm = None
+    assert v._max_rows_over_ranks(mine) == mine

@@ -281,6 +281,19 @@ def test_nan_trim(vs, golden, capsys):
     assert numpy.isnan(v.sens[:, 1]).all()
 
 
+def test_nan_trim_fm_only(vs, golden):
+    """NaNs only in fM_1 / fM_2 (blocks the Gram kernel never reads) still trim the second-order
+    sums, as the reference does (varsens/saltelli.py:474-492)."""
+    g = golden("g6b_nantrim_fm_only_k4_n96")
+    o = vs.Objective(4, 96, objective_vals=g["vals"], verbose=False)
+    assert o.fM_1.shape == (94, 1) and o.fN_j.shape == (4, 94, 1)
+    v = vs.Varsens(o, verbose=False)
+    for f in ("E_2", "var_y", "U_j", "U_nj"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-13)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-10, atol=1e-12)
+
+
 # ---------------------------------------------------------------- varsens/tests/test_import_export.py
 
 def test_import_export(vs):
@@ -401,13 +414,43 @@ def test_fused_first_order_through_api(vs, golden):
     numpy.testing.assert_allclose(v.sens, v2.sens, rtol=1e-10, atol=1e-14)
     # the values are still there for whoever asks (evaluated on first access)
     assert v.objective.fM_1.shape == (51200, 1) and numpy.array_equal(v.objective.fM_1, v2.objective.fM_1)
+    # what the fused kernels do not cover takes the two-kernel path by itself, or says so when fused=True was asked
+    with pytest.raises(Exception, match="fused=True"):
+        vs.Varsens(vs.objectives.Invert(), vs.scale.Identity(), 3, 64, verbose=False, second_order=False, fused=True)
     with pytest.raises(Exception, match="fused=True needs"):
-        vs.Varsens(vs.objectives.Ishigami(), vs.scale.Identity(), 3, 64, verbose=False, second_order=False, fused=True)
+        vs.Varsens(vs.objectives.GFunction(model), vs.scale.Identity(), 6, 64, verbose=False, fused=True)  # second order
+    vi = vs.Varsens(vs.objectives.Invert(), vs.scale.Identity(), 3, 64, verbose=False, second_order=False)
+    assert vi.sens.shape == (3, 3)
+
+
+def test_fused_through_api_wider_shapes(vs):
+    """Ishigami, two outputs, k = 64 and a user-written separable objective through Varsens(second_order=False):
+    no f-values are written, results equal the two-kernel route's."""
+    cases = [
+        (vs.objectives.Ishigami(), vs.scale.Linear(-numpy.pi, numpy.pi), 3, 20000),
+        (vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 30001),
+        (vs.objectives.Polynomial(1.0 / (1.0 + numpy.arange(64) / 8.0)), vs.scale.Linear(0.0, 1.5), 64, 5000),
+        (vs.objectives.SeparableExpression("return p[c] * x * x;", params=numpy.arange(1.0, 41.0), fold="sum"),
+         vs.scale.Identity(), 40, 3000),
+    ]
+    for obj, sc, k, n in cases:
+        a = vs.Varsens(obj, sc, k, n, verbose=False, second_order=False)
+        assert a.objective._f is None, type(obj).__name__
+        b = vs.Varsens(obj, sc, k, n, verbose=False, second_order=False, fused=False)
+        assert b.objective._f is not None
+        for f in ("E_2", "var_y", "U_j", "U_nj"):
+            numpy.testing.assert_allclose(getattr(a, f), getattr(b, f), rtol=1e-12, err_msg=f)
+        for f in ("sens", "sens_t"):
+            numpy.testing.assert_allclose(getattr(a, f), getattr(b, f), rtol=1e-9, atol=1e-11, err_msg=f)
+    # power scaling is left to the two-kernel route
+    p = vs.Varsens(vs.objectives.Linear(numpy.ones(5)), vs.scale.Power(1.0, 10.0), 5, 1000, verbose=False,
+                   second_order=False)
+    assert p.objective._f is not None
 
 
 # ---------------------------------------------------------------- multi-process flow (rehearsal on one GPU)
 
-@pytest.mark.parametrize("rows_per_pass", [0, 3000])
+@pytest.mark.parametrize("rows_per_pass", [0, 3000, 10000])   # 10000 = rank 0's shard, one less than rank 1's
 def test_two_process_sharded_run_equals_single_process(vs, tmp_path, rows_per_pass):
     """examples/multi_gpu.py with 2 ranks sharing GPU 0 and the records crossing the host (gloo): the
     sharded Objective + Varsens(comm=...) flow gives the single-process result.  The RCCL exchange

@@ -92,6 +92,54 @@ def test_config2_gfunction_k6_n2pow20(ctx):
     assert np.array_equal(rec, rec2) and np.array_equal(fin, fin2)
 
 
+def test_config2_against_the_reference_run(ctx, golden, capsys):
+    """BASELINE configs[1] against fixture G15 = the reference's own 3-step run at k=6, n=2^20 (14.7 M calls
+    of its Python objective, tests/golden/make_golden.py --config2).  The device f-values ARE the
+    reference's (same SHA-256 over all 14 680 064 of them); raw sums are held to exactly rounded sums,
+    the indices to their evaluation from those sums (north-star bar 1e-10), and the reference's own
+    distance to that evaluation -- its summation noise, SURVEY.md section 7 -- is printed beside it."""
+    import hashlib
+    from varsens_amd import _native
+    g = golden("g15_gfunc_k6_n1048576")
+    k, n = 6, 1 << 20
+    a = [0, 0.5, 3, 9, 99, 99]
+    f = device_eval(ctx, k, n, _native.OBJ_G_FUNCTION, a)
+    blocks = _native.from_planar(ctx.download(f, (1, 2 * k + 2, n)))          # [2k+2][n][1], flat order
+    assert hashlib.sha256(np.ascontiguousarray(blocks.reshape(-1, 1)).tobytes()).hexdigest() == str(g["fvals_sha"])
+    assert np.array_equal(blocks[0][:8], g["fM_1_head"]) and np.array_equal(blocks[2:2 + k, :4], g["fN_j_head"])
+    rec, fin = first_order(ctx, f, n, n, k)
+    F = (blocks[0], blocks[1], blocks[2:2 + k], blocks[2 + k:])
+    ex = orc.exact_accumulators(*F)
+    per = _native.acc_per_output(k)
+    body = rec[4:4 + per]
+    np.testing.assert_allclose(body[0], ex["sab"][0], rtol=1e-13)
+    for q, name in enumerate(("ac", "bd", "ad", "bc")):
+        np.testing.assert_allclose(body[3 + q * k:3 + (q + 1) * k], ex[name][:, 0], rtol=1e-13, err_msg=name)
+    want = orc.indices_from_accumulators(ex, n)
+    for row, name in ((0, "E_2"), (1, "var_y")):
+        np.testing.assert_allclose(fin[row, 0], want[name][0], rtol=1e-13, err_msg=name)
+        np.testing.assert_allclose(fin[row, 0], g[name][0], rtol=1e-13, err_msg=name)     # the reference's value
+    sens, sens_t = fin[2 + 2 * k:2 + 3 * k, 0], fin[2 + 3 * k:2 + 4 * k, 0]
+    np.testing.assert_allclose(sens, want["sens"][:, 0], rtol=1e-10, atol=0)
+    np.testing.assert_allclose(sens_t, want["sens_t"][:, 0], rtol=1e-10, atol=0)
+    # the reference against the same exact evaluation: its own rounding noise (S_5, S_6 are small differences)
+    ref_dist = np.abs(g["sens"][:, 0] - want["sens"][:, 0]) / np.abs(want["sens"][:, 0])
+    gpu_dist = np.abs(sens - want["sens"][:, 0]) / np.abs(want["sens"][:, 0])
+    with capsys.disabled():
+        print("\nconfig 2, relative distance of sens to the exactly summed evaluation: reference %s | GPU %s"
+              % (np.array2string(ref_dist, precision=1), np.array2string(gpu_dist, precision=1)))
+    assert gpu_dist.max() <= max(ref_dist.max(), 1e-12)
+    np.testing.assert_allclose(sens, g["sens"][:, 0], rtol=2e-9)              # within the reference's own noise
+    np.testing.assert_allclose(sens_t, g["sens_t"][:, 0], rtol=2e-9, atol=1e-12)
+    # second order against the reference's tensordot results
+    gram = ctx.alloc(8 * 3 * k * k)
+    ctx.reduce_second_order(f, n, k, 1, gram)
+    s2, s2n = ctx.alloc(8 * k * k), ctx.alloc(8 * k * k)
+    ctx.finish_second_order(gram, ctx.upload(fin), n, k, 1, s2, s2n)
+    np.testing.assert_allclose(ctx.download(s2, (k, 1, k, 1)), g["sens_2"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ctx.download(s2n, (k, 1, k, 1)), g["sens_2n"], rtol=1e-9, atol=1e-12)
+
+
 def test_config3_ishigami_k3_n2pow22(ctx):
     from varsens_amd import _native
     k, n = 3, 1 << 22
@@ -178,12 +226,71 @@ def test_config5_shard_polynomial_k128(ctx):
     local = np.array([0, 1, count // 2, count - 1])
     got = spot(ctx, f, k, count, 1, local)
     want = oracle_rows(k, n, begin + local, lambda X: orc.polynomial_rows(X, beta))
-    assert np.array_equal(got, want)
+    assert np.max(np.abs(got - want) / np.abs(want)) <= 4e-15      # scan kernels: reassociated product of 128 factors
     rec, fin = first_order(ctx, f, count, count, k)       # the shard alone is a valid (smaller) design
     V = beta ** 2 / 12.0
     total, S, ST = orc.product_form_indices(V)
     np.testing.assert_allclose(fin[1, 0], total, rtol=2e-2)
     np.testing.assert_allclose(fin[2 + 2 * k:2 + 3 * k, 0], S, atol=5e-3)
+
+
+def test_config5_whole_polynomial_k128_n2pow24(ctx):
+    """configs[4] whole on ONE MI355X: k=128, n=2^24, 34.6 GB of f-values -- evaluation (scan kernels, k >= 33),
+    first order, second order.  Spot rows against the oracle (bit-exact in the kernels' association order,
+    rounding-close to the strict left-to-right product), analytic S_i / ST_i, and the 8-rank row split:
+    shard records and shard Gram sums add up to the whole."""
+    from varsens_amd import _native
+    from varsens_amd.dist import shard_rows
+    k, n = 128, 1 << 24
+    beta = 1.0 / (1.0 + np.arange(k) / 8.0)
+    f = device_eval(ctx, k, n, _native.OBJ_POLYNOMIAL, beta)
+    rows = pick_rows(n, 5, 26)
+    got = spot(ctx, f, k, n, 1, rows)
+    perm = orc.seed1_permutation(n)
+    first = orc.halton_skip(k)
+    M1 = np.concatenate([orc.halton(k, first + int(r), 1) for r in rows], axis=0)
+    M2 = np.concatenate([orc.halton(k, first + n + int(perm[r]), 1) for r in rows], axis=0)
+    F = orc.evaluate_scan("polynomial", beta, M1, M2)
+    assert np.array_equal(got, np.concatenate([F[0][None], F[1][None], F[2], F[3]], axis=0))
+    strict = oracle_rows(k, n, rows, lambda X: orc.polynomial_rows(X, beta))
+    assert np.max(np.abs(got - strict) / np.abs(strict)) <= 4e-15
+    rec, fin = first_order(ctx, f, n, n, k)
+    V = beta ** 2 / 12.0
+    total, S, ST = orc.product_form_indices(V)
+    np.testing.assert_allclose(fin[1, 0], total, rtol=2e-3)
+    np.testing.assert_allclose(fin[0, 0], 1.0, rtol=1e-4)
+    np.testing.assert_allclose(fin[2 + 2 * k:2 + 3 * k, 0], S, atol=1e-3)      # builder's full-size run: 3e-4 / 8e-4
+    np.testing.assert_allclose(fin[2 + 3 * k:2 + 4 * k, 0], ST, atol=2e-3)
+    # second order on the whole: closed pair indices (V_i + V_j + V_i V_j) / V of a product form
+    gram = ctx.alloc(8 * 3 * k * k)
+    ctx.reduce_second_order(f, n, k, 1, gram)
+    G = ctx.download(gram, (3, k, k))
+    s2, s2n = ctx.alloc(8 * k * k), ctx.alloc(8 * k * k)
+    ctx.finish_second_order(gram, ctx.upload(fin), n, k, 1, s2, s2n)
+    sens_2 = ctx.download(s2, (k, k))
+    pair = (V[:, None] + V[None, :] + V[:, None] * V[None, :]) / total
+    off = ~np.eye(k, dtype=bool)
+    np.testing.assert_allclose(sens_2[off], pair[off], atol=3e-3)
+    np.testing.assert_allclose(sens_2, sens_2.T, rtol=1e-12, atol=1e-15)
+    f.free()
+    # the 8-rank row split (what the 8-GPU run does, one shard at a time here): records and Gram sums add up
+    world = 8
+    nacc = _native.acc_len(k, 1, world)
+    total_rec, total_gram = np.zeros(nacc), np.zeros((3, k, k))
+    for rank in range(world):
+        b, cnt = shard_rows(n, world, rank)
+        fs = device_eval(ctx, k, n, _native.OBJ_POLYNOMIAL, beta, begin=b, count=cnt)
+        acc, gs = ctx.alloc(8 * nacc), ctx.alloc(8 * 3 * k * k)
+        ctx.reduce_first_second_order(fs, cnt, k, 1, acc, gs, 0, rank, world)
+        total_rec += ctx.download(acc, (nacc,))
+        total_gram += ctx.download(gs, (3, k, k))
+        fs.free()
+    out = ctx.alloc(8 * _native.first_order_len(k, 1))
+    ctx.finish_first_order(ctx.upload(total_rec), n, k, 1, out, world)
+    fin8 = ctx.download(out, (2 + 4 * k, 1))
+    np.testing.assert_allclose(fin8[:2 + 2 * k], fin[:2 + 2 * k], rtol=1e-13)
+    np.testing.assert_allclose(fin8[2 + 2 * k:], fin[2 + 2 * k:], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(total_gram, G, rtol=1e-12)
 
 
 def test_model_study_shape_k100_l10():

@@ -1,0 +1,288 @@
+"""The segmented-scan kernels (varsens_amd/csrc/vs_device_scan.h, vs_scan.hip) against the oracle, through
+the C ABI.  GPU only.
+
+* evaluation (vs_eval, k >= 33 by itself; forced at small k through VS_EVAL_MODE=2): bit-exact against the
+  oracle's restatement of the kernels' association order (orc.evaluate_scan), rounding-close (<= 4e-15
+  relative) to the strict left-to-right folds the chain kernel and the reference's numpy.prod produce;
+* fused evaluate + first-order reduce (vs_eval_reduce_first_order): its accumulator record against the
+  exactly rounded sums of the oracle's values in the fused kernels' order, and against the two-kernel path
+  (<= 2e-13 relative), for k in {33, 64, 128}, l in {1, 2, 3}, Ishigami and separable source objectives.
+"""
+import numpy as np
+import pytest
+
+from oracle import saltelli_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+KINDS = {"g_function": 1, "linear": 3, "polynomial": 4}
+STRICT = {"g_function": orc.g_function_rows, "linear": orc.linear_rows, "polynomial": orc.polynomial_rows}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from varsens_amd import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def scan_ctx():
+    """A context whose vs_eval takes the scan kernels at every k they cover (VS_EVAL_MODE=2, read once at
+    context creation)."""
+    import os
+    from varsens_amd import _native
+    os.environ["VS_EVAL_MODE"] = "2"
+    try:
+        c = _native.Context(0)
+    finally:
+        del os.environ["VS_EVAL_MODE"]
+    yield c
+    c.close()
+
+
+def same(a, b):
+    assert a.shape == b.shape
+    assert np.array_equal(a, b, equal_nan=True), "max |d| = %g" % np.nanmax(np.abs(a - b))
+
+
+def params_for(kind, k, l, seed):
+    rng = np.random.RandomState(seed)
+    if kind == "g_function":
+        P = rng.rand(l, k) * 9.0
+    elif kind == "linear":
+        P = np.arange(1, k + 1, dtype=float)[None, :] * (1.0 + np.arange(l))[:, None]
+    else:
+        P = (1.0 / (1.0 + np.arange(k) / 8.0))[None, :] * (1.0 - 0.25 * np.arange(l))[:, None]
+    return np.ascontiguousarray(P)
+
+
+def design(ctx, k, n, mode=0, lo=None, hi=None, raw=None, generator=None, dirs=None, first=None):
+    from varsens_amd import _native
+    perm = orc.seed1_permutation(n).astype(np.uint32)
+    if raw is not None:
+        return ctx.design_create(_native.GEN_RAW, k, n, 0, mode, lo, hi, perm, raw)
+    if generator == "sobol":
+        return ctx.design_create(_native.GEN_SOBOL, k, n, 4096 if first is None else first, mode, lo, hi, perm, None, dirs)
+    return ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k) if first is None else first, mode, lo, hi, perm)
+
+
+def device_blocks(ctx, d, kind, k, l, P, n, begin=0, count=None):
+    from varsens_amd._native import from_planar
+    count = n if count is None else count
+    obj = ctx.objective_create(KINDS[kind], k, l, P)
+    f = ctx.alloc(8 * 2 * (k + 1) * count * l)
+    ctx.eval(d, obj, begin, count, f)
+    return f, obj, from_planar(ctx.download(f, (l, 2 * k + 2, count)))
+
+
+def blocks_of(F):
+    return np.concatenate([F[0][None], F[1][None], F[2], F[3]], axis=0)
+
+
+def strict_blocks(kind, P, S):
+    return blocks_of(orc.evaluate_rows(lambda X: np.stack([STRICT[kind](X, p) for p in P], axis=-1), *S))
+
+
+# ------------------------------------------------------------------ evaluation
+
+@pytest.mark.parametrize("kind", ["g_function", "linear", "polynomial"])
+@pytest.mark.parametrize("k,n,l", [(33, 300, 1), (40, 1000, 1), (64, 129, 1), (65, 64, 1), (100, 333, 2), (128, 500, 1),
+                                   (129, 70, 1), (200, 100, 1), (256, 65, 3)])
+def test_scan_eval_default_route(ctx, kind, k, n, l):
+    P = params_for(kind, k, l, k + n)
+    S = orc.build_sample(k, n)
+    _, _, got = device_blocks(ctx, design(ctx, k, n), kind, k, l, P, n)
+    same(got, blocks_of(orc.evaluate_scan(kind, P, S[0], S[1])))
+    strict = strict_blocks(kind, P, S)
+    assert np.max(np.abs(got - strict) / np.maximum(np.abs(strict), 1e-300)) <= 4e-15
+
+
+@pytest.mark.parametrize("kind,k,n,l", [("g_function", 6, 1024, 1), ("g_function", 6, 1000, 2), ("linear", 1, 7, 1),
+                                        ("polynomial", 2, 64, 1), ("g_function", 9, 65, 1), ("linear", 16, 1, 1),
+                                        ("polynomial", 17, 4097, 1), ("linear", 32, 500, 1), ("g_function", 31, 200, 3)])
+def test_scan_eval_forced_at_small_k(scan_ctx, kind, k, n, l):
+    P = params_for(kind, k, l, 7 * k + n)
+    S = orc.build_sample(k, n)
+    _, _, got = device_blocks(scan_ctx, design(scan_ctx, k, n), kind, k, l, P, n)
+    same(got, blocks_of(orc.evaluate_scan(kind, P, S[0], S[1])))
+    strict = strict_blocks(kind, P, S)
+    assert np.max(np.abs(got - strict) / np.maximum(np.abs(strict), 1e-300)) <= 2e-15
+
+
+def test_scan_eval_row_shards_and_scalings(ctx):
+    """A row shard evaluates to the same values; linear and power scaling, raw points and Sobol points go
+    through the same kernels (compact generator paths)."""
+    from varsens_amd import _native
+    from varsens_amd.saltelli import sobol_directions
+    k, n = 48, 777
+    P = params_for("g_function", k, 1, 3)
+    lo, hi = np.linspace(-1.0, 0.5, k), np.linspace(1.0, 3.0, k)
+    S = orc.build_sample(k, n, lambda x: orc.scale_linear(x, lo, hi))
+    d = design(ctx, k, n, _native.SCALE_LINEAR, lo, hi)
+    _, _, whole = device_blocks(ctx, d, "g_function", k, 1, P, n)
+    same(whole, blocks_of(orc.evaluate_scan("g_function", P, S[0], S[1])))
+    _, _, part = device_blocks(ctx, d, "g_function", k, 1, P, n, begin=130, count=211)
+    same(part, whole[:, 130:341])
+    # power scaling: device pow within a few ulp of libm's
+    plo, phi = np.full(k, 0.5), np.linspace(2.0, 50.0, k)
+    Sp = orc.build_sample(k, n, lambda x: orc.scale_power(x, plo, phi))
+    _, _, got = device_blocks(ctx, design(ctx, k, n, _native.SCALE_POWER, plo, phi), "polynomial", k, 1,
+                              params_for("polynomial", k, 1, 0), n)
+    want = blocks_of(orc.evaluate_scan("polynomial", params_for("polynomial", k, 1, 0), Sp[0], Sp[1]))
+    np.testing.assert_allclose(got, want, rtol=1e-13)
+    # raw points
+    rng = np.random.RandomState(5)
+    raw = rng.rand(2 * n, k)
+    Sr = orc.build_sample(k, n, raw=raw)
+    _, _, got = device_blocks(ctx, design(ctx, k, n, raw=raw), "linear", k, 1, params_for("linear", k, 1, 0), n)
+    same(got, blocks_of(orc.evaluate_scan("linear", params_for("linear", k, 1, 0), Sr[0], Sr[1])))
+    # Sobol points
+    dirs = sobol_directions(k)
+    pts = orc.sobol(k, 4096, 2 * n, dirs)
+    Ss = orc.build_sample(k, n, raw=pts)
+    _, _, got = device_blocks(ctx, design(ctx, k, n, generator="sobol", dirs=dirs), "g_function", k, 1, P, n)
+    same(got, blocks_of(orc.evaluate_scan("g_function", P, Ss[0], Ss[1])))
+
+
+# ------------------------------------------------------------------ fused evaluate + reduce
+
+def record_parts(rec, k, l):
+    from varsens_amd import _native
+    per = _native.acc_per_output(k)
+    body = rec[4:4 + l * per].reshape(l, per)
+    return dict(rows=rec[0], sab=body[:, 0], sa=body[:, 1], sb=body[:, 2], ac=body[:, 3:3 + k].T,
+                bd=body[:, 3 + k:3 + 2 * k].T, ad=body[:, 3 + 2 * k:3 + 3 * k].T, bc=body[:, 3 + 3 * k:3 + 4 * k].T,
+                slots=rec[4 + l * per:])
+
+
+def check_record(rec, F, k, l, rtol=1e-13):
+    ex = orc.exact_accumulators(*F)
+    got = record_parts(rec, k, l)
+    assert got["rows"] == F[0].shape[0]
+    for name in ("sab", "sa", "sb", "ac", "bd", "ad", "bc"):
+        np.testing.assert_allclose(got[name], ex[name], rtol=rtol, err_msg=name)
+    cnt, mean, m2 = got["slots"][0], got["slots"][1:1 + l], got["slots"][1 + l:1 + 2 * l]
+    assert cnt == 2 * F[0].shape[0]
+    np.testing.assert_allclose(mean, ex["mean"], rtol=1e-13)
+    np.testing.assert_allclose(m2, ex["m2"], rtol=1e-11)       # sum of squared deviations: conditioned by sigma/mean
+
+
+@pytest.mark.parametrize("kind", ["g_function", "linear", "polynomial"])
+@pytest.mark.parametrize("k,n,l", [(6, 5000, 1), (1, 64, 1), (16, 333, 1), (31, 1, 1), (32, 20001, 1), (33, 4000, 1),
+                                   (64, 3000, 1), (128, 2049, 1), (33, 700, 2), (64, 650, 3), (128, 300, 2), (7, 900, 3)])
+def test_fused_record(ctx, kind, k, n, l):
+    from varsens_amd import _native
+    P = params_for(kind, k, l, 11 * k + n + l)
+    d = design(ctx, k, n)
+    f, obj, _ = device_blocks(ctx, d, kind, k, l, P, n)
+    nacc = _native.acc_len(k, l, 1)
+    acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
+    assert ctx.eval_reduce_supported(d, obj)
+    ctx.reduce_first_order(f, n, k, l, acc1)
+    ctx.eval_reduce_first_order(d, obj, 0, n, acc2)
+    r1, r2 = ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,))
+    # against exact sums of the oracle's values in the fused kernels' association order
+    S = orc.build_sample(k, n)
+    check_record(r2, orc.evaluate_scan(kind, P, S[0], S[1], fused=True), k, l)
+    # against the two-kernel path (whose f-values differ by the association order of the folds only)
+    per = _native.acc_per_output(k)
+    np.testing.assert_allclose(r2[4:4 + l * per], r1[4:4 + l * per], rtol=2e-13)
+    if n > 1:
+        out1, out2 = ctx.alloc(8 * _native.first_order_len(k, l)), ctx.alloc(8 * _native.first_order_len(k, l))
+        ctx.finish_first_order(acc1, n, k, l, out1)
+        ctx.finish_first_order(acc2, n, k, l, out2)
+        a, b = ctx.download(out1, (2 + 4 * k, l)), ctx.download(out2, (2 + 4 * k, l))
+        np.testing.assert_allclose(b[:2 + 2 * k], a[:2 + 2 * k], rtol=1e-12)
+        np.testing.assert_allclose(b[2 + 2 * k:], a[2 + 2 * k:], rtol=1e-9, atol=1e-11)
+
+
+def test_fused_shard_slot_and_linear_scaling(ctx):
+    """A rank's shard: rows [begin, begin+count) of a bigger design, its own variance slot of 3."""
+    from varsens_amd import _native
+    k, n, l = 40, 5000, 1
+    lo, hi = np.full(k, -2.0), np.linspace(1.0, 4.0, k)
+    P = params_for("polynomial", k, l, 1)
+    d = design(ctx, k, n, _native.SCALE_LINEAR, lo, hi)
+    obj = ctx.objective_create(KINDS["polynomial"], k, l, P)
+    begin, count = 1234, 2001
+    nacc = _native.acc_len(k, l, 3)
+    acc = ctx.alloc(8 * nacc)
+    ctx.eval_reduce_first_order(d, obj, begin, count, acc, rank=1, max_ranks=3)
+    rec = ctx.download(acc, (nacc,))
+    S = orc.build_sample(k, n, lambda x: orc.scale_linear(x, lo, hi))
+    F = orc.evaluate_scan("polynomial", P, S[0][begin:begin + count], S[1][begin:begin + count], fused=True)
+    parts = record_parts(rec, k, l)
+    slots = parts["slots"].reshape(3, 3)
+    assert slots[0, 0] == 0 and slots[2, 0] == 0 and slots[1, 0] == 2 * count
+    parts["slots"] = slots[1]
+    ex = orc.exact_accumulators(*F)
+    for name in ("sab", "sa", "sb", "ac", "bd", "ad", "bc"):
+        np.testing.assert_allclose(parts[name], ex[name], rtol=1e-13, err_msg=name)
+    np.testing.assert_allclose(slots[1, 1], ex["mean"][0], rtol=1e-13)
+
+
+def test_fused_ishigami(ctx):
+    from varsens_amd import _native
+    n = 100003
+    lo, hi = np.full(3, -np.pi), np.full(3, np.pi)
+    d = design(ctx, 3, n, _native.SCALE_LINEAR, lo, hi)
+    obj = ctx.objective_create(_native.OBJ_ISHIGAMI, 3, 1, [7.0, 0.1])
+    assert ctx.eval_reduce_supported(d, obj)
+    nacc = _native.acc_len(3, 1, 1)
+    f = ctx.alloc(8 * 8 * n)
+    ctx.eval(d, obj, 0, n, f)
+    acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
+    ctx.reduce_first_order(f, n, 3, 1, acc1)
+    ctx.eval_reduce_first_order(d, obj, 0, n, acc2)
+    r1, r2 = ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,))
+    np.testing.assert_allclose(r2[:4 + 15], r1[:4 + 15], rtol=2e-13)       # same operations per value, other summation order
+    np.testing.assert_allclose(r2[4 + 15:], r1[4 + 15:], rtol=1e-11)
+    out = ctx.alloc(8 * _native.first_order_len(3, 1))
+    ctx.finish_first_order(acc2, n, 3, 1, out)
+    fin = ctx.download(out, (14, 1))
+    V, S, ST = orc.ishigami_truth()
+    np.testing.assert_allclose(fin[8:11, 0], S, atol=2e-2)
+    np.testing.assert_allclose(fin[11:14, 0], ST, atol=2e-2)
+
+
+@pytest.mark.parametrize("k,n", [(6, 3000), (32, 2000), (50, 1500), (128, 600)])
+def test_fused_separable_source_objective(ctx, k, n):
+    """A user-written separable objective (hiprtc) takes the same scan kernels as the built-in of the same
+    formula: identical f-values and an identical fused record."""
+    from varsens_amd import _native
+    a = np.linspace(0.0, 9.0, k)
+    d = design(ctx, k, n)
+    user = ctx.objective_create_separable(k, "return (fabs(4.0 * x - 2.0) + p[c]) / (1.0 + p[c]);", False, a)
+    builtin = ctx.objective_create(_native.OBJ_G_FUNCTION, k, 1, a)
+    f1, f2 = ctx.alloc(8 * 2 * (k + 1) * n), ctx.alloc(8 * 2 * (k + 1) * n)
+    ctx.eval(d, user, 0, n, f1)
+    ctx.eval(d, builtin, 0, n, f2)
+    same(ctx.download(f1, (2 * k + 2, n)), ctx.download(f2, (2 * k + 2, n)))
+    assert ctx.eval_reduce_supported(d, user)
+    nacc = _native.acc_len(k, 1, 1)
+    acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
+    ctx.eval_reduce_first_order(d, user, 0, n, acc1)
+    ctx.eval_reduce_first_order(d, builtin, 0, n, acc2)
+    same(ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,)))
+    # and a sum-separable one against the built-in linear objective
+    c = 1.0 + np.arange(k)
+    lin_user = ctx.objective_create_separable(k, "return p[c] * x;", True, c)
+    lin = ctx.objective_create(_native.OBJ_LINEAR, k, 1, c)
+    ctx.eval_reduce_first_order(d, lin_user, 0, n, acc1)
+    ctx.eval_reduce_first_order(d, lin, 0, n, acc2)
+    same(ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,)))
+
+
+def test_fused_is_bit_reproducible(ctx):
+    from varsens_amd import _native
+    k, n = 64, 40000
+    d = design(ctx, k, n)
+    obj = ctx.objective_create(_native.OBJ_G_FUNCTION, k, 1, np.linspace(0, 5, k))
+    nacc = _native.acc_len(k, 1, 1)
+    acc = ctx.alloc(8 * nacc)
+    ctx.eval_reduce_first_order(d, obj, 0, n, acc)
+    first = ctx.download(acc, (nacc,))
+    ctx.eval_reduce_first_order(d, obj, 0, n, acc)
+    same(ctx.download(acc, (nacc,)), first)

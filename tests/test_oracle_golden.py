@@ -45,6 +45,26 @@ def test_gfunction(golden, name, n):
         same(R[f], g[f])
 
 
+def test_config2_gfunction_n2pow20(golden):
+    """BASELINE configs[1] (k=6, n=2^20) as the reference itself computed it (fixture G15): the oracle's
+    f-values are the reference's bit for bit, and so is every estimator -- including the reference's own
+    rounding noise on the two smallest indices, which the GPU test measures against exact sums."""
+    g = golden("g15_gfunc_k6_n1048576")
+    n = 1 << 20
+    S, F, R = run(6, n, None, lambda X: orc.g_function_rows(X, A6))
+    same(S[0][:8], g["M_1_head"]); same(S[1][:8], g["M_2_head"])
+    same(F[0][:8], g["fM_1_head"]); same(F[2][:, :4], g["fN_j_head"])
+    assert sha(orc.flat_objective(*F)) == str(g["fvals_sha"])
+    for f in FIELDS:
+        same(R[f], g[f])
+    # analytic values (varsens/tests/test_g_function.py:21-50) at the quasi-Monte Carlo error of n = 2^20
+    V = orc.g_partial_variances(A6)
+    total, St, STt = orc.product_form_indices(V)
+    assert abs(g["var_y"][0] - total) < 2e-3 and abs(g["E_2"][0] - 1.0) < 1e-3
+    np.testing.assert_allclose(g["sens"][:, 0], St, atol=2e-3)
+    np.testing.assert_allclose(g["sens_t"][:, 0], STt, atol=2e-3)
+
+
 def test_gfunction_known_answers(golden):
     """varsens/tests/test_g_function.py:52-73, places=2, on the reference's n=51200 output."""
     g = golden("g2_gfunc_k6_n51200")
@@ -110,6 +130,17 @@ def test_nan_trim(golden):
     for f in FIELDS:
         same(R[f], g[f])
     assert np.isnan(R["sens"][:, 1]).all() and np.isfinite(R["sens"][:, 0]).all()
+
+
+def test_nan_trim_fm_only(golden):
+    """NaNs only in fM_1 / fM_2: the rows leave fN_j / fN_nj too (sens_2 / sens_2n change)."""
+    g = golden("g6b_nantrim_fm_only_k4_n96")
+    k, n = int(g["k"]), int(g["n"])
+    fM_1, fM_2, fN_j, fN_nj, dropped = orc.load_objective(g["vals"], k, n)
+    assert dropped == 2 and fM_1.shape[0] == int(g["kept"]) == 94 and fN_j.shape[1] == 94
+    R = orc.compute_varsens(fM_1, fM_2, fN_j, fN_nj, n)
+    for f in FIELDS:
+        same(R[f], g[f])
 
 
 def test_seed1_permutation(golden):

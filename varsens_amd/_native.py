@@ -92,6 +92,7 @@ SIGNATURES = {
     "vs_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vs_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vs_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "vs_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vs_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "vs_profile_end": (C.c_int, [C.c_void_p, C.POINTER(ProfileRecord), C.c_int, C.POINTER(C.c_int)]),
     "vs_halton_fill": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
@@ -110,6 +111,7 @@ SIGNATURES = {
     "vs_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "vs_reduce_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_void_p]),
+    "vs_eval_reduce_supported": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "vs_eval_reduce_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int,
                                              C.c_int, C.c_void_p]),
     "vs_finish_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
@@ -279,6 +281,12 @@ class Context(object):
     def memset(self, buf, byte=0):
         _check(self.lib.vs_memset(self.handle, C.c_void_p(buf.ptr), int(byte), buf.nbytes))
 
+    def accumulate(self, dst_buf, src_buf, count):
+        """dst[i] += src[i] for `count` doubles, on the device."""
+        if 8 * int(count) > min(dst_buf.nbytes, src_buf.nbytes):
+            raise VarsensHipError("accumulate exceeds a device buffer")
+        _check(self.lib.vs_accumulate(self.handle, C.c_void_p(dst_buf.ptr), C.c_void_p(src_buf.ptr), int(count)))
+
     def profile_begin(self, capacity=4096):
         self._prof_capacity = int(capacity)
         _check(self.lib.vs_profile_begin(self.handle, self._prof_capacity))
@@ -376,6 +384,12 @@ class Context(object):
     def reduce_first_order(self, f_buf, rows, k, l, acc_buf, flags=0, rank=0, max_ranks=1):
         _check(self.lib.vs_reduce_first_order(self.handle, C.c_void_p(f_buf.ptr), int(rows), int(k), int(l),
                                               int(flags), int(rank), int(max_ranks), C.c_void_p(acc_buf.ptr)))
+
+    def eval_reduce_supported(self, design, objective):
+        """True when the fused evaluate+reduce kernels cover this (design, objective)."""
+        flag = C.c_int(0)
+        _check(self.lib.vs_eval_reduce_supported(self.handle, design.h, objective.h, C.byref(flag)))
+        return bool(flag.value)
 
     def eval_reduce_first_order(self, design, objective, row_begin, row_count, acc_buf, rank=0, max_ranks=1):
         _check(self.lib.vs_eval_reduce_first_order(self.handle, design.h, objective.h, int(row_begin), int(row_count),

@@ -12,10 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvarsens_hip.so")
-SOURCES = ["vs_api.hip", "vs_generate.hip", "vs_reduce.hip", "vs_second.hip", "vs_comm.hip", "vs_rtc.hip"]
+SOURCES = ["vs_api.hip", "vs_generate.hip", "vs_scan.hip", "vs_reduce.hip", "vs_second.hip", "vs_comm.hip", "vs_rtc.hip"]
 # device sources hiprtc needs at run time, embedded into the library as C++ raw strings
-EMBED = {"vs_device_gen.h": "vs_rtc_embed_gen.inc", "vs_rtc_kernel.h": "vs_rtc_embed_kernel.inc",
-         "vs_rtc_kernel_sep.h": "vs_rtc_embed_kernel_sep.inc"}
+EMBED = {"vs_device_gen.h": "vs_rtc_embed_gen.inc", "vs_device_scan.h": "vs_rtc_embed_scan.inc",
+         "vs_rtc_kernel.h": "vs_rtc_embed_kernel.inc", "vs_rtc_kernel_sep.h": "vs_rtc_embed_kernel_sep.inc"}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          # numpy-exact arithmetic: no implicit fma contraction; fmas are written out
          "-ffp-contract=off",
@@ -49,15 +49,49 @@ def embed_sources():
                 fh.write(out)
 
 
+def _deps_newer(target):
+    if not os.path.isfile(target):
+        return True
+    t = os.path.getmtime(target)
+    deps = glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
 def build(force=False, verbose=True):
+    """One object per source (compiled side by side), then one link.  The library is written to a
+    temporary name and renamed into place under a file lock, so that the ranks of a multi-process
+    job that all find it missing never load a half-written file."""
     if not force and not needs_build():
         return OUT
-    embed_sources()
-    cmd = [_hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-o", OUT] + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-L/opt/rocm/lib", "-lhiprtc"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    import fcntl
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():     # another process built it while this one waited
+            return OUT
+        embed_sources()
+        hipcc = _hipcc()
+        cflags = [f for f in FLAGS if f != "-shared"]
+
+        def compile_one(src):
+            obj = os.path.join(objdir, src.replace(".hip", ".o"))
+            if force or _deps_newer(obj):
+                cmd = [hipcc] + cflags + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.check_call(cmd)
+            return obj
+
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        tmp = OUT + ".tmp.%d" % os.getpid()
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-L/opt/rocm/lib", "-lhiprtc"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(tmp, OUT)
     return OUT
 
 

@@ -1,4 +1,6 @@
 // Context, memory, error and profiling plumbing of libvarsens_hip.so.
+#include <cstdlib>
+
 #include "vs_common.h"
 
 static thread_local char g_err[8192] = "";
@@ -55,6 +57,23 @@ extern "C" int vs_context_create(int device, vs_context** out) {
         return vs_fail(VS_ERR_HIP, "hipStreamCreate failed");
     }
     ctx->stream = ctx->streams[0];
+    {   // the only place the environment is read
+        auto env_long = [](const char* name, long dflt) {
+            const char* v = getenv(name);
+            return v && *v ? strtol(v, nullptr, 0) : dflt;
+        };
+        vs_tuning& t = ctx->tune;
+        t.reduce_nv = (int)env_long("VS_REDUCE_NV", t.reduce_nv);
+        t.reduce_wgs_per_cu = (int)env_long("VS_REDUCE_WGS_PER_CU", t.reduce_wgs_per_cu);
+        t.eval_scratch = (int)env_long("VS_EVAL_SCRATCH", t.eval_scratch);
+        t.eval_waves = (int)env_long("VS_EVAL_WAVES_PER_WG", t.eval_waves);
+        t.eval_mode = (int)env_long("VS_EVAL_MODE", t.eval_mode);
+        t.fused_wgs_per_cu = (int)env_long("VS_FUSED_WGS_PER_CU", t.fused_wgs_per_cu);
+        t.fused_variant = (int)env_long("VS_FUSED_VARIANT", t.fused_variant);
+        t.gram_wgs_per_cu = (int)env_long("VS_GRAM_WGS_PER_CU", t.gram_wgs_per_cu);
+        t.reduce_both = (int)env_long("VS_REDUCE_BOTH", t.reduce_both);
+        t.profile_mask = env_long("VS_PROFILE_MASK", t.profile_mask);
+    }
     for (int i = 0; i < 8; ++i)
         if (hipEventCreateWithFlags(&ctx->events[i], hipEventDisableTiming) != hipSuccess) {
             delete ctx;
@@ -170,6 +189,23 @@ extern "C" int vs_memset(vs_context* ctx, void* dst_dev, int byte, size_t bytes)
     VS_REQUIRE(ctx && (bytes == 0 || dst_dev), "null argument");
     if (!bytes) return VS_OK;
     VS_HIP(hipMemsetAsync(dst_dev, byte, bytes, ctx->stream));
+    return VS_OK;
+}
+
+// dst[i] += src[i]: sums the accumulator records / Gram sums of streamed row ranges on the device
+__global__ void __launch_bounds__(256) accumulate_kernel(double* __restrict__ dst, const double* __restrict__ src,
+                                                         size_t count) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] += src[i];
+}
+
+extern "C" int vs_accumulate(vs_context* ctx, double* dst_dev, const double* src_dev, size_t count) {
+    VS_REQUIRE(ctx && (count == 0 || (dst_dev && src_dev)), "null argument");
+    if (!count) return VS_OK;
+    const size_t blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, ctx->stream,
+                       dst_dev, src_dev, count);
+    VS_HIP(hipGetLastError());
     return VS_OK;
 }
 
@@ -317,8 +353,7 @@ extern "C" int vs_profile_end(vs_context* ctx, vs_profile_record* out, int capac
 
 vs_launch_scope::vs_launch_scope(vs_context* c, int kernel_id) : ctx(c) {
     if (!ctx->profiling || ctx->prof.size() >= ctx->prof_capacity) return;
-    static const long mask = getenv("VS_PROFILE_MASK") ? strtol(getenv("VS_PROFILE_MASK"), nullptr, 0) : -1L;
-    if (!((mask >> kernel_id) & 1)) return;  // tuning aid: bracket only some kernel ids
+    if (!((ctx->tune.profile_mask >> kernel_id) & 1)) return;  // tuning aid: bracket only some kernel ids
     slot = (int)ctx->prof.size();
     vs_prof_slot s = ctx->prof_pool[slot];
     s.kernel_id = kernel_id;

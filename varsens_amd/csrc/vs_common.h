@@ -16,8 +16,24 @@ struct vs_prof_slot {
     hipEvent_t start, stop;
 };
 
+// Measurement knobs of the tools/ scripts (launch shapes, kernel variants).  Read from the
+// environment ONCE, when the context is created; product code never calls getenv afterwards.
+struct vs_tuning {
+    int reduce_nv = 4;           // VS_REDUCE_NV: 16-byte loads per thread and block (2, 4, 8)
+    int reduce_wgs_per_cu = 1;   // VS_REDUCE_WGS_PER_CU
+    int eval_scratch = 0;        // VS_EVAL_SCRATCH=1: chain kernel with its tile in HBM scratch (tests force it at small k)
+    int eval_waves = 0;          // VS_EVAL_WAVES_PER_WG: 4 or 8 (0 = by tile size)
+    int eval_mode = 0;           // VS_EVAL_MODE: 0 = by k, 1 = chain scheme (strict left-to-right folds), 2 = segmented scan
+    int fused_wgs_per_cu = 0;    // VS_FUSED_WGS_PER_CU (0 = by kernel)
+    int fused_variant = 0;       // VS_FUSED_VARIANT=1: 64 < k <= 128 fused as 8 waves x 16 columns instead of 16 x 8
+    int gram_wgs_per_cu = 0;     // VS_GRAM_WGS_PER_CU (0 = by shape)
+    int reduce_both = 1;         // VS_REDUCE_BOTH=0: never take the combined first+second-order kernel
+    long profile_mask = -1;      // VS_PROFILE_MASK: bracket only these kernel ids with events
+};
+
 struct vs_context {
     int device = -1;
+    vs_tuning tune;
     hipStream_t stream = nullptr;      // the stream launches currently go to (streams[selected])
     hipStream_t streams[2] = {nullptr, nullptr};  // 0 = main, 1 = auxiliary (exchange / finishing)
     hipEvent_t events[8] = {};         // cross-stream ordering slots (vs_event_record / vs_stream_wait_event)
@@ -64,6 +80,12 @@ struct vs_objective {
     size_t nparams = 0;
     void* module = nullptr;    // hipModule_t of a run-time compiled objective
     void* function = nullptr;  // hipFunction_t (vs_user_eval)
+    void* fused_function = nullptr;  // hipFunction_t (vs_user_fused): separable source objectives with k <= 128
+    bool eval_scan = false;    // vs_user_eval is the scan kernel (separable, k >= 33): one 64-row block per workgroup
+    int eval_threads = 256;    // launch shape of vs_user_eval / vs_user_fused
+    size_t eval_lds = 0;       //   (eval_lds = 0: the 2k x 64 tile of the chain / general kernels)
+    int fused_threads = 0;
+    size_t fused_lds = 0;
     bool scratch_tile = false; // compiled for the HBM scratch tile (k beyond the LDS budget)
 };
 
@@ -71,6 +93,11 @@ int vs_rtc_build(vs_context* ctx, vs_objective* o, const char* body, int fold);
 void vs_rtc_release(vs_objective* o);
 int vs_rtc_launch(vs_context* ctx, const vs_objective* o, const void* eval_args, size_t eval_args_bytes,
                   unsigned blocks, size_t lds);
+int vs_rtc_launch_fused(vs_context* ctx, const vs_objective* o, const void* eval_args, size_t eval_args_bytes,
+                        unsigned P, const double* shift_dev);
+// launch shape of the scan kernels for k columns (vs_scan.hip); false: k is outside them
+bool vs_scan_shape(int k, bool fused, int* L, int* W, int* tlds, size_t* lds_bytes);
+#define VS_SCAN_MIN_K 33   // first k at which vs_eval takes the scan kernels by itself (measured crossover)
 
 int vs_fail(int code, const char* fmt, ...);
 
@@ -100,7 +127,7 @@ int vs_workspace_keep(vs_context* ctx, size_t bytes);
 int vs_workspace_scratch(vs_context* ctx, size_t bytes);
 
 int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, const double* shift_dev,
-                     const double* f_dev, int rank, int max_ranks, double* acc_dev);
+                     int shift_stride, const double* f_dev, int rank, int max_ranks, double* acc_dev);
 
 // partial record of one workgroup for one output: 5 head values + 4 per block j
 #define VS_P_SAB 0
@@ -111,49 +138,7 @@ int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, c
 #define VS_P_HEAD 5
 #define VS_PLEN(k) (VS_P_HEAD + 4 * (size_t)(k))
 
-// ---- device helpers -------------------------------------------------------
+// ---- device helpers (wave sums, variance shift): vs_device_gen.h, shared with the hiprtc kernels
 #ifdef __HIPCC__
-// wave-wide sum with DPP; total valid in lanes 48..63
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double vs_dpp_add(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    return v + __hiloint2double(thi, tlo);
-}
-
-__device__ __forceinline__ double vs_wave_sum_dpp(double v) {
-    v = vs_dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-    v = vs_dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-    v = vs_dpp_add<0x141, 0xf>(v);  // row_half_mirror
-    v = vs_dpp_add<0x140, 0xf>(v);  // row_mirror: every lane holds its row's sum
-    v = vs_dpp_add<0x142, 0xa>(v);  // row_bcast15 into rows 1,3
-    v = vs_dpp_add<0x143, 0xc>(v);  // row_bcast31 into rows 2,3
-    return v;                       // rows 3 (lanes 48..63): sum of all 64 lanes
-}
-
-
-// Common shift of the one-pass variance sums: the mean of the first min(rows, 1024) values of a
-// block, summed in a fixed order by ONE wave (every lane returns the same bits, and every wave or
-// kernel that calls it gets the same bits).  A sample mean is within a small fraction of sigma of the
-// true mean, so sum (x-s)^2 - (sum (x-s))^2/N loses nothing to cancellation, and one outlier among
-// the leading values moves it by outlier/1024 only.
-__device__ __forceinline__ double vs_shift_estimate(const double* a, uint64_t rows);
-
-// Sum over the 64 lanes of a wavefront; result valid in every lane.
-__device__ __forceinline__ double vs_wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ double vs_shift_estimate(const double* a, uint64_t rows) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t m = rows < 1024 ? rows : 1024;
-    double s = 0.0;
-    for (uint64_t i = lane; i < m; i += 64) s += a[i];
-    s = vs_wave_sum_dpp(s);  // total in lanes 48..63
-    const int lo = __builtin_amdgcn_readlane(__double2loint(s), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(s), 63);
-    return m ? __hiloint2double(hi, lo) / (double)m : 0.0;
-}
+#include "vs_device_gen.h"
 #endif

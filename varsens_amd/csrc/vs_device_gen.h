@@ -15,14 +15,57 @@ enum { VS_OBJ_G_FUNCTION = 1, VS_OBJ_ISHIGAMI = 2, VS_OBJ_LINEAR = 3, VS_OBJ_POL
        VS_OBJ_SOURCE = 6 };
 #endif
 
+// ---------------------------------------------------------------------------
+// wave-level sums
+// ---------------------------------------------------------------------------
+// wave-wide sum with DPP; total valid in lanes 48..63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double vs_dpp_add(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(thi, tlo);
+}
+
+__device__ __forceinline__ double vs_wave_sum_dpp(double v) {
+    v = vs_dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = vs_dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = vs_dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = vs_dpp_add<0x140, 0xf>(v);  // row_mirror: every lane holds its row's sum
+    v = vs_dpp_add<0x142, 0xa>(v);  // row_bcast15 into rows 1,3
+    v = vs_dpp_add<0x143, 0xc>(v);  // row_bcast31 into rows 2,3
+    return v;                       // rows 3 (lanes 48..63): sum of all 64 lanes
+}
+
+
+// Common shift of the one-pass variance sums: the mean of the first min(rows, 1024) values of a
+// block, summed in a fixed order by ONE wave (every lane returns the same bits, and every wave or
+// kernel that calls it gets the same bits).  A sample mean is within a small fraction of sigma of the
+// true mean, so sum (x-s)^2 - (sum (x-s))^2/N loses nothing to cancellation, and one outlier among
+// the leading values moves it by outlier/1024 only.
+__device__ __forceinline__ double vs_shift_estimate(const double* a, vs_u64 rows);
+
+// Sum over the 64 lanes of a wavefront; result valid in every lane.
+__device__ __forceinline__ double vs_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double vs_shift_estimate(const double* a, vs_u64 rows) {
+    const int lane = threadIdx.x & 63;
+    const vs_u64 m = rows < 1024 ? rows : 1024;
+    double s = 0.0;
+    for (vs_u64 i = lane; i < m; i += 64) s += a[i];
+    s = vs_wave_sum_dpp(s);  // total in lanes 48..63
+    const int lo = __builtin_amdgcn_readlane(__double2loint(s), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(s), 63);
+    return m ? __hiloint2double(hi, lo) / (double)m : 0.0;
+}
+
 #define VS_EVAL_ROWS 64
 #define VS_EVAL_WAVES 4
 
-#ifndef VS_NO_NT_STORE
 #define VS_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define VS_STORE(p, v) (*(p) = (v))
-#endif
 
 // ---------------------------------------------------------------------------
 // Halton radical inverse
@@ -212,6 +255,14 @@ struct vs_eval_args {
 template <int KIND>
 __device__ __forceinline__ double vs_fold(double acc, double t) {
     return KIND == VS_OBJ_LINEAR ? acc + t : acc * t;
+}
+
+// per-coordinate terms of the built-in separable objectives (include/varsens_hip.h)
+template <int KIND>
+__device__ __forceinline__ double vs_term(double x, double p) {
+    if (KIND == VS_OBJ_G_FUNCTION) return (fabs(4.0 * x - 2.0) + p) / (1.0 + p);
+    if (KIND == VS_OBJ_POLYNOMIAL) return 1.0 + p * (x - 0.5);
+    return p * x;  // VS_OBJ_LINEAR
 }
 
 // Tile reads.  The coordinate / term tile normally lives in LDS.  For k too large for LDS it

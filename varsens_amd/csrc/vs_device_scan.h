@@ -1,0 +1,307 @@
+// Segmented-scan form of the separable objectives: O(k) folds per design row instead of the
+// O(k^2) of the chain scheme (vs_device_gen.h).  Device code shared by the precompiled kernels
+// (vs_scan.hip) and by the kernels hiprtc builds for user separable objectives (vs_rtc.hip embeds
+// this file as text after vs_device_gen.h).
+//
+// Reference counterpart: the four evaluation loops of Objective.__init__
+// (varsens/saltelli.py:329-355) for an objective f(x) = t_0(x_0) op t_1(x_1) op ... op t_{k-1}(x_{k-1}).
+//
+// With ta_c = t_c(M_1[r][c]) and tb_c = t_c(M_2[r][c]) the 2k+2 values of design row r are
+//   a   = ta_0 op ... op ta_{k-1}                     f(M_1[r])
+//   b   = tb_0 op ... op tb_{k-1}                     f(M_2[r])
+//   c_i = tb_0 .. tb_{i-1} op ta_i op tb_{i+1} ..     f(N_j[i][r])   (M_2 with column i from M_1)
+//   d_i = ta_0 .. ta_{i-1} op tb_i op ta_{i+1} ..     f(N_nj[i][r])
+// i.e. c_i = PB_i op ta_i op SB_{i+1} with PB the prefix and SB the suffix folds of the tb's.  A
+// workgroup of W waves owns 64 design rows (row = lane) and cuts the k columns into W contiguous
+// segments of L columns; wave q generates the coordinates and terms of its segment into REGISTERS
+// (no LDS tile: the only shared data are the 2W segment totals per row), then
+//   1. folds its segment totals TA_q, TB_q (left to right) and publishes them in LDS;
+//   2. after ONE workgroup barrier folds the totals of the segments before it (left to right,
+//      from the identity) into PA_q, PB_q and of the segments after it (right to left) into
+//      SA_q, SB_q -- and all W totals into a and b (every wave, same order, same bits);
+//   3. walks its segment backwards for the in-segment suffixes, forwards for the prefixes and
+//      emits c_i = (pb op ta_j) op sb_j, d_i = (pa op tb_j) op sa_j.
+// The association order is fixed by (L, W) alone and restated on the CPU by the test-side checker
+// (evaluate_scan), so parity with it is bit-exact; against the
+// strict left-to-right fold the values differ by reassociation only (<= ~k/2 ulp, typically 1-2).
+// Serial depth per wave: L + W dependent operations instead of k, in four independent chains.
+#ifndef VS_DEVICE_SCAN_H
+#define VS_DEVICE_SCAN_H
+
+// The unit-cube pair (coordinate c of the sequence rows behind M_1[r] and M_2[r]) for the scan kernels,
+// whose column loop is unrolled L times: only the compact generator paths are inlined (Halton below
+// 2^32 -- the host sends designs whose indices reach 2^32 to the chain kernel --, Sobol byte tables,
+// raw points), and pow() of the power scaling sits behind one out-of-line copy.
+__device__ __forceinline__ void vs_unit_pair(const vs_design_dev& D, vs_u64 r, vs_u64 src2, int c, double& x1,
+                                             double& x2) {
+    if (D.generator == VS_GEN_HALTON) {
+        vs_radical_inverse_pair((vs_u32)(D.first_index + r), (vs_u32)(D.first_index + src2), D.bases[c], x1, x2);
+    } else if (D.generator == VS_GEN_SOBOL) {
+        x1 = vs_sobol_point_tab(D.first_index + r, D.sobol_tabs + 1024 * c, D.sobol_bits);
+        x2 = vs_sobol_point_tab(D.first_index + src2, D.sobol_tabs + 1024 * c, D.sobol_bits);
+    } else {
+        x1 = D.raw[r * (vs_u64)D.k + c];
+        x2 = D.raw[src2 * (vs_u64)D.k + c];
+    }
+}
+
+__device__ __attribute__((noinline, const)) double vs_scale_power(double lower, double ratio, double p) {
+    return lower * pow(ratio, p);  // scale.py:62
+}
+
+// POWER = false (the fused kernels): no power scaling in the kernel at all -- a call in a kernel that
+// carries 4L sums in registers costs spills around every call site; the host sends power-scaled
+// designs through vs_eval + vs_reduce_first_order instead.
+template <bool POWER>
+__device__ __forceinline__ double vs_apply_scale_compact(const vs_design_dev& D, double p, int c) {
+    if (D.scale_mode == VS_SCALE_LINEAR) return p * D.width[c] + D.lower[c];   // scale.py:33
+    if (POWER && D.scale_mode == VS_SCALE_POWER) return vs_scale_power(D.lower[c], D.width[c], p);
+    return p;
+}
+
+// Per-wave state carried across the row blocks of a persistent workgroup (fused reduce only).
+template <int L>
+struct vs_scan_acc {
+    double v[L][4];   // ac, bd, ad, bc of the wave's L columns
+    double sab, sa, sb, s1, s2;
+};
+
+// One 64-row block.  Term::eval(x, c, params) is the per-coordinate term; FOLD is VS_OBJ_LINEAR
+// (sum) or anything else (product).  `tot` is this block's LDS slab [2][W][64].
+// FUSED = false: stores the 2k+2 values (planar f-values, non-temporal); FUSED = true: adds the
+// products a*c_i, b*d_i, a*d_i, b*c_i and the head sums into `acc` and stores nothing.
+// TLDS: the 2L terms of the wave live in a wave-private LDS slab `tl` ([2][L][64], conflict-free)
+// instead of registers -- the shape for k > 64 in the fused kernel, whose 4L register sums leave no
+// room for them.
+// The in-segment suffixes are kept for VS_SCAN_SUB columns at a time: a backward walk over the
+// segment leaves one checkpoint per sub-block (the fold of everything after it), and the output walk
+// rebuilds the sub-block's suffixes from its checkpoint -- the same right-to-left chain, so the same
+// bits as keeping all L suffixes, with 2(L/SUB + SUB) registers instead of 2L.
+#define VS_SCAN_SUB 4
+
+template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS>
+__device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const double* __restrict__ params,
+                                              int q, int lane, vs_u64 rb, double* __restrict__ tot,
+                                              double* __restrict__ tl, double* __restrict__ fplane, double shift,
+                                              vs_scan_acc<L>& acc) {
+    constexpr int T = VS_EVAL_ROWS;
+    constexpr int SUB = L < VS_SCAN_SUB ? L : VS_SCAN_SUB;
+    constexpr int NSUB = L / SUB;
+    // q is loop-invariant in the persistent walk; tied to the block index here, or the optimiser hoists
+    // every column's addresses and masks (all derived from q) out of that loop and spills scalars for
+    // them.  (Not `volatile`: a volatile asm counts as a memory clobber and turns every scalar load of
+    // design constants behind it into a vector load.)
+    {
+        const vs_u32 rb_lo = (vs_u32)rb;
+        asm("" : "+s"(q) : "s"(rb_lo));
+    }
+    const int k = A.D.k;
+    const vs_u64 rows = A.rows;
+    const vs_u64 lr = rb * T + lane;
+    const bool valid = lr < rows;
+    const vs_u64 r = A.row_begin + (valid ? lr : rows - 1);  // clamp: loads stay in range, stores are guarded
+    const double ident = FOLD == VS_OBJ_LINEAR ? 0.0 : 1.0;
+    const vs_u64 src2 = A.D.perm ? (vs_u64)A.D.perm[r] : r;  // row of the un-shuffled second half behind M_2[r]
+
+    // ---- terms of this wave's segment (registers, or the wave's LDS slab) and their totals
+    double ta[TLDS ? 1 : L], tb[TLDS ? 1 : L];
+#define VS_TA(j) (TLDS ? tl[(size_t)(j) * T] : ta[TLDS ? 0 : (j)])
+#define VS_TB(j) (TLDS ? tl[(size_t)(L + (j)) * T] : tb[TLDS ? 0 : (j)])
+    double Ta = ident, Tb = ident;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int c = q * L + j;  // wave-uniform
+        double t1 = ident, t2 = ident;
+        if (c < k) {
+            double x1, x2;
+            vs_unit_pair(A.D, r, A.D.n + src2, c, x1, x2);
+            t1 = Term::eval(vs_apply_scale_compact<!FUSED>(A.D, x1, c), c, params);
+            t2 = Term::eval(vs_apply_scale_compact<!FUSED>(A.D, x2, c), c, params);
+        }
+        if (TLDS) {
+            tl[(size_t)j * T] = t1;
+            tl[(size_t)(L + j) * T] = t2;
+        } else {
+            ta[TLDS ? 0 : j] = t1;
+            tb[TLDS ? 0 : j] = t2;
+        }
+        Ta = vs_fold<FOLD>(Ta, t1);
+        Tb = vs_fold<FOLD>(Tb, t2);
+        // one column at a time: left alone the scheduler hoists the scalar loads of all L columns'
+        // base constants to the top and spills scalars into vector lanes
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    tot[(0 * W + q) * T + lane] = Ta;
+    tot[(1 * W + q) * T + lane] = Tb;
+    __syncthreads();
+    // ---- folds over the other segments: prefix (left to right), suffix (right to left), whole row
+    double Pa = ident, Pb = ident, Sa = ident, Sb = ident, a = ident, b = ident;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const double ua = tot[(0 * W + w) * T + lane], ub = tot[(1 * W + w) * T + lane];
+        a = vs_fold<FOLD>(a, ua);
+        b = vs_fold<FOLD>(b, ub);
+        if (w < q) {
+            Pa = vs_fold<FOLD>(Pa, ua);
+            Pb = vs_fold<FOLD>(Pb, ub);
+        }
+    }
+#pragma unroll
+    for (int w = W - 1; w > 0; --w) {
+        if (w > q) {
+            Sa = vs_fold<FOLD>(tot[(0 * W + w) * T + lane], Sa);
+            Sb = vs_fold<FOLD>(tot[(1 * W + w) * T + lane], Sb);
+        }
+    }
+    // ---- checkpoints of the right-to-left suffix chain: ca[m] = fold of the a-terms after sub-block m
+    double ca[NSUB], cb[NSUB];
+    {
+        double ra = Sa, rb2 = Sb;
+#pragma unroll
+        for (int m = NSUB - 1; m >= 0; --m) {
+            ca[m] = ra;
+            cb[m] = rb2;
+            if (m > 0) {
+#pragma unroll
+                for (int j = SUB - 1; j >= 0; --j) {
+                    ra = vs_fold<FOLD>(VS_TA(m * SUB + j), ra);
+                    rb2 = vs_fold<FOLD>(VS_TB(m * SUB + j), rb2);
+                }
+            }
+        }
+    }
+    // ---- outputs, sub-block by sub-block
+    double* f = FUSED ? nullptr : fplane + rb * T + lane;
+    double pa = Pa, pb = Pb;
+#pragma unroll
+    for (int m = 0; m < NSUB; ++m) {
+        double ua[SUB], ub[SUB], sa[SUB], sb[SUB];  // the sub-block's terms and the suffixes AFTER each column
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            ua[j] = VS_TA(m * SUB + j);
+            ub[j] = VS_TB(m * SUB + j);
+        }
+        sa[SUB - 1] = ca[m];
+        sb[SUB - 1] = cb[m];
+#pragma unroll
+        for (int j = SUB - 2; j >= 0; --j) {
+            sa[j] = vs_fold<FOLD>(ua[j + 1], sa[j + 1]);
+            sb[j] = vs_fold<FOLD>(ub[j + 1], sb[j + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            const int jj = m * SUB + j;
+            const int i = q * L + jj;
+            const double cj = vs_fold<FOLD>(vs_fold<FOLD>(pb, ua[j]), sb[j]);  // N_j[i]: M_2 with column i from M_1
+            const double dj = vs_fold<FOLD>(vs_fold<FOLD>(pa, ub[j]), sa[j]);  // N_nj[i]: M_1 with column i from M_2
+            pa = vs_fold<FOLD>(pa, ua[j]);
+            pb = vs_fold<FOLD>(pb, ub[j]);
+            if (FUSED) {
+                if (valid) {  // columns beyond k hold the identity; their sums are dropped at the end
+                    acc.v[jj][0] = fma(a, cj, acc.v[jj][0]);
+                    acc.v[jj][1] = fma(b, dj, acc.v[jj][1]);
+                    acc.v[jj][2] = fma(a, dj, acc.v[jj][2]);
+                    acc.v[jj][3] = fma(b, cj, acc.v[jj][3]);
+                }
+            } else if (i < k && valid) {
+                VS_STORE(f + (vs_u64)(2 + i) * rows, cj);
+                VS_STORE(f + (vs_u64)(2 + k + i) * rows, dj);
+            }
+        }
+    }
+#undef VS_TA
+#undef VS_TB
+    if (q == 0 && valid) {
+        if (FUSED) {
+            const double dx = a - shift, dy = b - shift;
+            acc.sab = fma(a, b, acc.sab);
+            acc.sa += a;
+            acc.sb += b;
+            acc.s1 += dx + dy;
+            acc.s2 = fma(dx, dx, acc.s2);
+            acc.s2 = fma(dy, dy, acc.s2);
+        } else {
+            VS_STORE(f, a);
+            VS_STORE(f + rows, b);
+        }
+    }
+}
+
+// LDS doubles a workgroup of the scan kernels needs: totals slabs (two, or one when the terms take
+// the room) + the wave-private term slabs
+template <int L, int W, bool TLDS>
+struct vs_scan_lds {
+    static constexpr int slabs = TLDS ? 1 : 2;
+    static constexpr int totals = slabs * 2 * W * VS_EVAL_ROWS;
+    static constexpr int doubles = totals + (TLDS ? 2 * L * W * VS_EVAL_ROWS : 0);
+};
+
+// The whole kernel body.  grid.x workgroups walk the 64-row blocks (FUSED: persistent; else one block
+// per workgroup, grid.x = number of blocks), grid.y = output
+// (every output is its own plane of f-values / its own record; params + o*k are its parameters).
+// FUSED: one partial record per workgroup and output, layout and fold of reduce_first_kernel
+// (partials[(blockIdx.x * l + o) * VS_PLEN(k)], VS_PLEN = 5 + 4k).
+template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS>
+__device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __restrict__ lds,
+                                             const double* __restrict__ shift_src, double* __restrict__ partials) {
+    constexpr int T = VS_EVAL_ROWS;
+    const int k = A.D.k;
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index, provably uniform
+    const int o = blockIdx.y;
+    const double* params = A.params + (size_t)o * k;
+    double* fplane = FUSED ? nullptr : A.f + (vs_u64)o * (2 * (vs_u64)k + 2) * A.rows;
+    const double shift = FUSED ? shift_src[(size_t)o * (2 * (size_t)k + 2)] : 0.0;  // f_o(M_1[row]) of a one-row evaluation
+    double* tl = lds + vs_scan_lds<L, W, TLDS>::totals + (size_t)q * (2 * L * T) + lane;
+    vs_scan_acc<L> acc;
+    if (FUSED) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) acc.v[j][0] = acc.v[j][1] = acc.v[j][2] = acc.v[j][3] = 0.0;
+        acc.sab = acc.sa = acc.sb = acc.s1 = acc.s2 = 0.0;
+    }
+    const vs_u64 nblocks = (A.rows + T - 1) / T;
+    int parity = 0;
+    // two totals slabs: a wave may publish the totals of block n+1 while slower waves still read
+    // those of block n; it cannot reach block n+2 before everybody passed the barrier of n+1.
+    // (one slab: a second barrier closes the block instead.)
+    if (FUSED) {
+        for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+            vs_scan_block<Term, FOLD, L, W, FUSED, TLDS>(A, params, q, lane, rb, lds + parity * (2 * W * T), tl,
+                                                         fplane, shift, acc);
+            if (TLDS) __syncthreads();
+            else parity ^= 1;
+        }
+    } else {
+        // one block per workgroup: every load of design constants then precedes every store of the
+        // kernel, so the compiler may take them through the scalar cache (a persistent walk makes them
+        // "possibly clobbered" and turns them into vector loads with a wait per column)
+        vs_scan_block<Term, FOLD, L, W, FUSED, TLDS>(A, params, q, lane, blockIdx.x, lds, tl, fplane, shift, acc);
+    }
+    if (FUSED) {
+        const size_t plen = 5 + 4 * (size_t)k;
+        double* out = partials + ((size_t)blockIdx.x * gridDim.y + o) * plen;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int i = q * L + j;
+#pragma unroll
+            for (int z = 0; z < 4; ++z) {
+                const double v = vs_wave_sum_dpp(acc.v[j][z]);
+                if (lane == 63 && i < k) out[5 + (size_t)z * k + i] = v;
+            }
+        }
+        if (q == 0) {
+            const double t0 = vs_wave_sum_dpp(acc.sab), t1 = vs_wave_sum_dpp(acc.sa),
+                         t2 = vs_wave_sum_dpp(acc.sb), t3 = vs_wave_sum_dpp(acc.s1),
+                         t4 = vs_wave_sum_dpp(acc.s2);
+            if (lane == 63) {
+                out[0] = t0;
+                out[1] = t1;
+                out[2] = t2;
+                out[3] = t3;
+                out[4] = t4;
+            }
+        }
+    }
+}
+
+#endif  // VS_DEVICE_SCAN_H

@@ -468,12 +468,6 @@ extern "C" int vs_objective_create_separable(vs_context* ctx, int k, const char*
 //
 // Output index: f[((o*(2k+2) + block)*rows + (r-row_begin)] (planar, see varsens_hip.h).
 
-template <int KIND>
-__device__ __forceinline__ double vs_term(double x, double p) {
-    if (KIND == VS_OBJ_G_FUNCTION) return (fabs(4.0 * x - 2.0) + p) / (1.0 + p);
-    if (KIND == VS_OBJ_POLYNOMIAL) return 1.0 + p * (x - 0.5);
-    return p * x;  // VS_OBJ_LINEAR
-}
 
 #ifndef VS_EVAL_MIN_WAVES
 #define VS_EVAL_MIN_WAVES 1
@@ -697,16 +691,14 @@ static int launch_eval(vs_context* ctx, const vs_eval_args& A, int tiles) {
     const size_t lds = sizeof(double) * (size_t)tiles * k * VS_EVAL_ROWS;
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
-    const char* force = getenv("VS_EVAL_SCRATCH");
-    const bool scratch = lds > 160 * 1024 || (force && *force == '1');
+    const bool scratch = lds > 160 * 1024 || ctx->tune.eval_scratch == 1;
     constexpr bool SEPARABLE = KIND == VS_OBJ_G_FUNCTION || KIND == VS_OBJ_POLYNOMIAL || KIND == VS_OBJ_LINEAR;
     // waves per workgroup: with a big tile only one or two workgroups fit a CU, and eight waves
     // sharing the tile keep the SIMDs busier than four (measured: k=48 4 waves 0.72 / 8 waves 0.79 ms,
     // k=64 1.12 / 0.98, k=96 2.79 / 2.07, k=128 9.0 / 6.9; sixteen waves were never better)
     int W = 4;
     if (SEPARABLE && !scratch && lds > 56 * 1024) W = 8;
-    const char* wenv = getenv("VS_EVAL_WAVES_PER_WG");
-    if (SEPARABLE && wenv && *wenv) W = atoi(wenv) == 8 ? 8 : 4;
+    if (SEPARABLE && ctx->tune.eval_waves) W = ctx->tune.eval_waves == 8 ? 8 : 4;
     if (SEPARABLE && W == 8) return launch_eval_w<KIND, 8>(ctx, A, tiles, lds, blocks, scratch);
     return launch_eval_w<KIND, 4>(ctx, A, tiles, lds, blocks, scratch);
 }
@@ -861,9 +853,49 @@ fused_first_kernel(vs_eval_args A, const double* shift_src, double* partials, ui
 template <int KIND>
 static int launch_fused(vs_context* ctx, const vs_eval_args& A, uint32_t P, const double* shift_dev) {
     const size_t lds = sizeof(double) * 2 * (size_t)A.D.k * VS_EVAL_ROWS;
-    vs_launch_scope scope(ctx, VS_KERNEL_FUSED);
-    hipLaunchKernelGGL(fused_first_kernel<KIND>, dim3(P), dim3(VS_EVAL_ROWS * VS_EVAL_WAVES), lds, ctx->stream, A,
-                       shift_dev, ctx->partials, ctx->counters);
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_FUSED);
+        hipLaunchKernelGGL(fused_first_kernel<KIND>, dim3(P), dim3(VS_EVAL_ROWS * VS_EVAL_WAVES), lds, ctx->stream, A,
+                           shift_dev, ctx->partials, ctx->counters);
+    }
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+// vs_scan.hip
+bool vs_scan_covers(int kind, int k, bool fused);
+int vs_scan_eval(vs_context* ctx, const vs_eval_args& A);
+unsigned vs_scan_fused_workgroups(vs_context* ctx, int k, int l, uint64_t rows);
+int vs_scan_fused(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev);
+unsigned vs_fused_ishigami_workgroups(vs_context* ctx, uint64_t rows);
+int vs_fused_ishigami(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev);
+
+// The scan kernels inline only the compact generator paths: Halton indices must stay below 2^32
+// (per-column constant digit counts), which every design with n < 2^31 - first_index/2 meets.
+static bool design_compact(const vs_design* g) {
+    return g->d.generator != VS_GEN_HALTON || g->d.first_index + 2 * g->d.n - 1 < (1ull << 32);
+}
+
+enum fused_route { FUSED_NONE = 0, FUSED_CHAIN, FUSED_SCAN, FUSED_ISHIGAMI, FUSED_USER };
+
+// which fused kernel serves (design, objective): the chain-scheme kernel (k <= 32, one output; strict
+// left-to-right folds) only when asked for (VS_EVAL_MODE=1); else the scan kernels, Ishigami's own,
+// or a run-time compiled one.  The scan kernels leave power scaling to the two-kernel path.
+static fused_route fused_route_for(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
+    const int k = obj->k, l = obj->l;
+    const bool separable = obj->kind == VS_OBJ_G_FUNCTION || obj->kind == VS_OBJ_POLYNOMIAL || obj->kind == VS_OBJ_LINEAR;
+    const bool scan_ok = design_compact(design) && design->d.scale_mode != VS_SCALE_POWER;
+    if (separable && ctx->tune.eval_mode == 1 && l == 1 && k <= VS_PASS) return FUSED_CHAIN;
+    if (separable && scan_ok && vs_scan_covers(obj->kind, k, true)) return FUSED_SCAN;
+    if (obj->kind == VS_OBJ_ISHIGAMI) return FUSED_ISHIGAMI;
+    if (obj->kind == VS_OBJ_SOURCE && obj->fused_function && scan_ok) return FUSED_USER;
+    return FUSED_NONE;
+}
+
+extern "C" int vs_eval_reduce_supported(vs_context* ctx, const vs_design* design, const vs_objective* obj,
+                                        int* supported) {
+    VS_REQUIRE(ctx && design && obj && supported, "null argument");
+    *supported = (obj->k == design->d.k && fused_route_for(ctx, design, obj) != FUSED_NONE) ? 1 : 0;
     return VS_OK;
 }
 
@@ -874,40 +906,59 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
     VS_REQUIRE(obj->k == design->d.k, "objective has k=%d, design has k=%d", obj->k, design->d.k);
     VS_REQUIRE(row_begin <= design->d.n && row_count <= design->d.n - row_begin, "rows exceed n");
     VS_REQUIRE(max_ranks >= 1 && rank >= 0 && rank < max_ranks, "rank %d not in [0,%d)", rank, max_ranks);
-    const bool separable = obj->kind == VS_OBJ_G_FUNCTION || obj->kind == VS_OBJ_POLYNOMIAL || obj->kind == VS_OBJ_LINEAR;
-    VS_REQUIRE(separable && obj->l == 1 && obj->k <= VS_PASS && row_count >= 1,
-               "the fused path covers single-output g-function / polynomial / linear objectives with k <= %d; "
-               "use vs_eval + vs_reduce_first_order", VS_PASS);
-    const int k = obj->k;
-    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    VS_REQUIRE(row_count >= 1, "the fused path needs at least one row");
+    VS_HIP(hipSetDevice(ctx->device));
+    const int k = obj->k, l = obj->l;
+    const fused_route route = fused_route_for(ctx, design, obj);
+    if (route == FUSED_NONE)
+        return vs_fail(VS_ERR_ARG, "the fused path covers G_FUNCTION / POLYNOMIAL / LINEAR objectives and separable "
+                                   "source objectives with k <= 128 (identity or linear scaling), and ISHIGAMI; "
+                                   "use vs_eval + vs_reduce_first_order (vs_eval_reduce_supported tells)");
+    unsigned P = 1;
     const uint64_t blocks = (row_count + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
-    const char* env = getenv("VS_FUSED_WGS_PER_CU");
-    uint64_t Pw = (uint64_t)cus * (env && *env ? atoi(env) : 2);  // 2 resident workgroups per CU (204 VGPRs)
-    if (Pw > blocks) Pw = blocks;
-    const uint32_t P = (uint32_t)Pw;
-    const size_t plen = VS_PLEN(k);
-    // workspace: [P][plen] partials + [plen] folded + 8 doubles for the shift row's f-values (2k+2)
-    int rc = vs_workspace_partials(ctx, sizeof(double) * ((size_t)P * plen + plen + 2 * (size_t)k + 2));
+    if (route == FUSED_CHAIN) {
+        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        uint64_t Pw = (uint64_t)cus * (ctx->tune.fused_wgs_per_cu > 0 ? ctx->tune.fused_wgs_per_cu : 2);
+        P = (unsigned)(Pw > blocks ? blocks : Pw);
+    } else if (route == FUSED_ISHIGAMI) {
+        P = vs_fused_ishigami_workgroups(ctx, row_count);
+    } else if (route == FUSED_USER) {
+        P = vs_scan_fused_workgroups(ctx, k, 1, row_count);
+    } else {
+        P = vs_scan_fused_workgroups(ctx, k, l, row_count);
+    }
+    const size_t plen = VS_PLEN(k), width = (size_t)l * plen;
+    // workspace: [P][l][plen] partials + [l][plen] folded + the f-values of one design row (l planes of 2k+2)
+    const size_t shift_stride = 2 * (size_t)k + 2;
+    int rc = vs_workspace_partials(ctx, sizeof(double) * ((size_t)P * width + width + (size_t)l * shift_stride));
     if (rc) return rc;
-    double* shift_buf = ctx->partials + (size_t)P * plen + plen;
-    // the variance shift is f(M_1[row_begin]): one-row launch of the ordinary evaluation kernel
+    double* shift_buf = ctx->partials + (size_t)P * width + width;
+    // the variance shift of output o is f_o(M_1[row_begin]): a one-row launch of the ordinary evaluation
     rc = vs_eval(ctx, design, obj, row_begin, 1, shift_buf);
     if (rc) return rc;
     vs_eval_args A;
     A.D = to_dev(design);
     A.kind = obj->kind;
-    A.l = 1;
+    A.l = l;
     A.params = obj->params;
     A.row_begin = row_begin;
     A.rows = row_count;
     A.f = nullptr;
-    switch (obj->kind) {
-        case VS_OBJ_G_FUNCTION: launch_fused<VS_OBJ_G_FUNCTION>(ctx, A, P, shift_buf); break;
-        case VS_OBJ_POLYNOMIAL: launch_fused<VS_OBJ_POLYNOMIAL>(ctx, A, P, shift_buf); break;
-        default: launch_fused<VS_OBJ_LINEAR>(ctx, A, P, shift_buf); break;
+    switch (route) {
+        case FUSED_CHAIN:
+            switch (obj->kind) {
+                case VS_OBJ_G_FUNCTION: rc = launch_fused<VS_OBJ_G_FUNCTION>(ctx, A, P, shift_buf); break;
+                case VS_OBJ_POLYNOMIAL: rc = launch_fused<VS_OBJ_POLYNOMIAL>(ctx, A, P, shift_buf); break;
+                default: rc = launch_fused<VS_OBJ_LINEAR>(ctx, A, P, shift_buf); break;
+            }
+            break;
+        case FUSED_SCAN: rc = vs_scan_fused(ctx, A, P, shift_buf); break;
+        case FUSED_ISHIGAMI: rc = vs_fused_ishigami(ctx, A, P, shift_buf); break;
+        case FUSED_USER: rc = vs_rtc_launch_fused(ctx, obj, &A, sizeof(A), P, shift_buf); break;
+        default: break;
     }
-    VS_HIP(hipGetLastError());
-    return vs_fold_partials(ctx, P, k, 1, row_count, shift_buf, nullptr, rank, max_ranks, acc_dev);
+    if (rc) return rc;
+    return vs_fold_partials(ctx, P, k, l, row_count, shift_buf, (int)shift_stride, nullptr, rank, max_ranks, acc_dev);
 }
 
 extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,
@@ -927,7 +978,13 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
     A.row_begin = row_begin;
     A.rows = row_count;
     A.f = f_dev;
+    VS_HIP(hipSetDevice(ctx->device));
     const int sep_tiles = obj->l > 1 ? 4 : 2;
+    // separable built-ins: the chain scheme (strict left-to-right folds, O(k^2)) for small k, the
+    // segmented scan (O(k), reassociated folds) from VS_SCAN_MIN_K columns on; VS_EVAL_MODE overrides
+    if (vs_scan_covers(obj->kind, obj->k, false) && design_compact(design) && ctx->tune.eval_scratch != 1 &&
+        (ctx->tune.eval_mode == 2 || (ctx->tune.eval_mode == 0 && obj->k >= VS_SCAN_MIN_K)))
+        return vs_scan_eval(ctx, A);
     switch (obj->kind) {
         case VS_OBJ_G_FUNCTION: return launch_eval<VS_OBJ_G_FUNCTION>(ctx, A, sep_tiles);
         case VS_OBJ_POLYNOMIAL: return launch_eval<VS_OBJ_POLYNOMIAL>(ctx, A, sep_tiles);
@@ -935,9 +992,11 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
         case VS_OBJ_ISHIGAMI: return launch_eval<VS_OBJ_ISHIGAMI>(ctx, A, 2);
         case VS_OBJ_INVERT: return launch_eval<VS_OBJ_INVERT>(ctx, A, 2);
         case VS_OBJ_SOURCE: {
-            const size_t lds = sizeof(double) * 2 * (size_t)design->d.k * VS_EVAL_ROWS;
+            const size_t lds = obj->eval_scan ? obj->eval_lds : sizeof(double) * 2 * (size_t)design->d.k * VS_EVAL_ROWS;
             const uint64_t blocks = (row_count + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
             VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
+            VS_REQUIRE(!obj->eval_scan || design_compact(design),
+                       "separable source objectives with k >= %d need Halton indices below 2^32", VS_SCAN_MIN_K);
             return vs_rtc_launch(ctx, obj, &A, sizeof(A), (unsigned)blocks, lds);
         }
     }

@@ -46,7 +46,6 @@ struct vs_reduce_args {
     double* partials;   // [tile_wgs][l][VS_PLEN(k)]
     const uint8_t* keep;      // MASKED: 1 = row kept
     const uint32_t* counters; // MASKED: early exit + shift row
-    int reverse;        // walk the tiles from the last row down (see vs_reduce_first_order)
 };
 
 template <int VEC>
@@ -55,13 +54,9 @@ template <>
 struct vs_vec<2> {
     double v[2];
     __device__ __forceinline__ void load(const double* p) {
-#ifndef VS_NO_NT_LOAD
-        double2 t;
+        double2 t;  // read once: non-temporal (one global_load_dwordx4 ... nt)
         t.x = __builtin_nontemporal_load(p);
         t.y = __builtin_nontemporal_load(p + 1);
-#else
-        double2 t = *reinterpret_cast<const double2*>(p);
-#endif
         v[0] = t.x;
         v[1] = t.y;
     }
@@ -120,7 +115,7 @@ reduce_first_kernel(vs_reduce_args A) {
     double t_sab = 0, t_sa = 0, t_sb = 0, t_s1 = 0, t_s2 = 0;
 
     for (uint64_t t = wg; t < ntiles; t += A.tile_wgs) {
-        const uint64_t tile = A.reverse ? ntiles - 1 - t : t;
+        const uint64_t tile = t;
         const uint64_t base = tile * TILE + (uint64_t)tid * VEC;
         bool ok[NV];
         double keepf[NV][VEC];
@@ -288,7 +283,8 @@ struct vs_fold_args {
     int k, l;
     uint64_t rows;
     const double* f;    // for the shift value (block 0, row shift_row of each output plane) ...
-    const double* shift_values;  // ... or, when non-null, l explicit shift values (fused path: no f-values exist)
+    const double* shift_values;  // ... or, when non-null, explicit shift values (fused path: no f-values exist):
+    int shift_stride;            //     output o's is shift_values[o * shift_stride]
     double* acc;        // record (device)
     int rank, max_ranks;
     uint32_t* counters;
@@ -390,7 +386,7 @@ fold_first_kernel(vs_fold_args A, double* folded /* [l*plen] scratch */) {
         double mean = 0.0, m2 = 0.0;
         if (kept > 0) {
             const double* a_block = A.f ? A.f + (uint64_t)o * (2 * (uint64_t)k + 2) * A.rows : nullptr;
-            const double shift = A.shift_values ? A.shift_values[o]
+            const double shift = A.shift_values ? A.shift_values[(size_t)o * A.shift_stride]
                                  : (A.masked ? (shift_row < A.rows ? a_block[shift_row] : 0.0)
                                              : vs_shift_estimate(a_block, A.rows));
             const double s1 = ld(o * plen + VS_P_S1), s2 = ld(o * plen + VS_P_S2);
@@ -471,12 +467,6 @@ static int launch_reduce(vs_context* ctx, const vs_reduce_args& A, dim3 grid, si
     return VS_OK;
 }
 
-// rows per thread per tile on the fast path; overridable for tuning runs
-static int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return s && *s ? atoi(s) : dflt;
-}
-
 extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                                      int flags, int rank, int max_ranks, double* acc_dev) {
     VS_REQUIRE(ctx && acc_dev, "null argument");
@@ -487,12 +477,12 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     const size_t plen = VS_PLEN(k);
     const size_t width = (size_t)l * plen;
     const bool fast = (rows % 2 == 0) && (((uintptr_t)f_dev & 15) == 0);
-    const int nv = fast ? env_int("VS_REDUCE_NV", 4) : 8;
+    const int nv = fast ? ctx->tune.reduce_nv : 8;
     const uint64_t tile = (uint64_t)VS_WG * nv * (fast ? 2 : 1);
     uint64_t ntiles = (rows + tile - 1) / tile;
     if (ntiles < 1) ntiles = 1;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    uint64_t cap = (uint64_t)cus * env_int("VS_REDUCE_WGS_PER_CU", 1);
+    uint64_t cap = (uint64_t)cus * (ctx->tune.reduce_wgs_per_cu > 0 ? ctx->tune.reduce_wgs_per_cu : 1);
     if (l > 1) cap = (cap + l - 1) / l;
     const uint32_t tile_wgs = (uint32_t)(ntiles < cap ? ntiles : cap);
     const int jchunk = k < VS_JCHUNK ? k : VS_JCHUNK;
@@ -513,7 +503,6 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     A.partials = ctx->partials;
     A.keep = nullptr;
     A.counters = ctx->counters;
-    A.reverse = env_int("VS_REDUCE_REVERSE", 0);
     const dim3 grid(tile_wgs * l, jblocks);
     const size_t lds = sizeof(double) * VS_WAVES * (VS_P_HEAD + 4 * (size_t)jchunk);
 
@@ -525,6 +514,7 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     F.rows = rows;
     F.f = f_dev;
     F.shift_values = nullptr;
+    F.shift_stride = 1;
     F.acc = acc_dev;
     F.rank = rank;
     F.max_ranks = max_ranks;
@@ -578,9 +568,10 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
 // accumulator record.  Used by the fused evaluate+reduce kernel (vs_generate.hip) and by the
 // combined first+second-order kernel (vs_second.hip), whose records have the layout of
 // reduce_first_kernel's.  The variance shift comes from shift_dev (l values) or, when that is
-// null, from the leading a-values of f_dev as in the first-order pass.
+// null, from the leading a-values of f_dev as in the first-order pass (output o's shift is
+// shift_dev[o * shift_stride]).
 int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, const double* shift_dev,
-                     const double* f_dev, int rank, int max_ranks, double* acc_dev) {
+                     int shift_stride, const double* f_dev, int rank, int max_ranks, double* acc_dev) {
     const size_t width = (size_t)l * VS_PLEN(k);
     vs_fold_args F;
     F.partials = ctx->partials;
@@ -590,6 +581,7 @@ int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, c
     F.rows = rows;
     F.f = f_dev;
     F.shift_values = shift_dev;
+    F.shift_stride = shift_stride;
     F.acc = acc_dev;
     F.rank = rank;
     F.max_ranks = max_ranks;

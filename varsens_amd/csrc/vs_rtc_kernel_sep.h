@@ -7,6 +7,38 @@
 // eval_kernel (prefix sharing, 8+8 chains per thread, per-wave static schedule for full passes),
 // so a user model of this shape runs at the speed of the built-in g-function / linear kernels.
 
+// From 33 columns on (VS_USER_EVAL_SCAN) the evaluation takes the segmented-scan form of
+// vs_device_scan.h instead (O(k) folds per row), and for k <= 128 a fused evaluate+reduce kernel
+// vs_user_fused is built beside it (VS_USER_FUSED); shapes VS_USER_*_L / _W / _TLDS come from the host.
+struct vs_user_term_t {
+    static __device__ __forceinline__ double eval(double x, int c, const double* __restrict__ p) {
+        return vs_user_term(x, c, p);
+    }
+};
+
+#if VS_USER_FUSED
+extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_USER_FUSED_W)
+vs_user_fused(vs_eval_args A, const double* shift_src, double* partials, unsigned* counters) {
+    extern __shared__ double lds[];
+    vs_scan_body<vs_user_term_t, VS_USER_FOLD_KIND, VS_USER_FUSED_L, VS_USER_FUSED_W, true, VS_USER_FUSED_TLDS>(
+        A, lds, shift_src, partials);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the fold that follows (see scan_kernel)
+        counters[0] = 0;
+        counters[1] = 0xffffffffu;
+        counters[2] = 0;
+        counters[3] = 0;
+        counters[4] = 0;
+    }
+}
+#endif
+
+#if VS_USER_EVAL_SCAN
+extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_USER_EVAL_W) vs_user_eval(vs_eval_args A, double* scratch) {
+    extern __shared__ double lds[];
+    vs_scan_body<vs_user_term_t, VS_USER_FOLD_KIND, VS_USER_EVAL_L, VS_USER_EVAL_W, false, false>(A, lds, nullptr,
+                                                                                                 nullptr);
+}
+#else
 extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_user_eval(vs_eval_args A, double* scratch) {
     extern __shared__ double lds[];
     constexpr int T = VS_EVAL_ROWS;
@@ -89,3 +121,4 @@ extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_use
         VS_STORE(f + rows, pb);
     }
 }
+#endif  // VS_USER_EVAL_SCAN

@@ -1,0 +1,237 @@
+// Separable objectives in segmented-scan form (vs_device_scan.h): the evaluation kernel for larger k
+// and the fused evaluate + first-order-reduce kernel that never writes f-values.
+//
+// Reference counterparts (paths relative to the reference checkout):
+//   Objective evaluation loops         varsens/saltelli.py:329-355
+//   E_2, var_y, U_j, U_nj sums         varsens/saltelli.py:577,583,591-596 (fused kernel)
+//
+// Built with -ffp-contract=off (see vs_generate.hip).
+#include <cmath>
+
+#include "vs_common.h"
+
+#include "vs_device_scan.h"
+
+template <int KIND>
+struct builtin_term {
+    static __device__ __forceinline__ double eval(double x, int c, const double* __restrict__ p) {
+        return vs_term<KIND>(x, p[c]);
+    }
+};
+
+template <int KIND, int L, int W, bool FUSED, bool TLDS>
+__global__ void __launch_bounds__(VS_EVAL_ROWS* W)
+scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
+    extern __shared__ double scan_lds[];  // totals slabs [2 families][W][64] (+ term slabs), vs_scan_lds
+    vs_scan_body<builtin_term<KIND>, KIND, L, W, FUSED, TLDS>(A, scan_lds, shift_src, partials);
+    // counters of the fold that follows (see reduce_first_kernel).  At the END of the kernel: a global
+    // store in front of the row loop would make every load of design constants "possibly clobbered"
+    // and keep it out of the scalar cache.
+    if (FUSED && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        counters[0] = 0;
+        counters[1] = 0xffffffffu;
+        counters[2] = 0;
+        counters[3] = 0;
+        counters[4] = 0;
+    }
+}
+
+// Ishigami (k = 3, not separable): thread = design row, 8 values per row, 4*3 + 5 register sums.
+__global__ void __launch_bounds__(256)
+fused_ishigami_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
+    __shared__ double wsum[4][17];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counters[0] = 0;
+        counters[1] = 0xffffffffu;
+        counters[2] = 0;
+        counters[3] = 0;
+        counters[4] = 0;
+    }
+    const double pa_ = A.params[0], pb_ = A.params[1];
+    const double shift = shift_src[0];
+    double acc[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) acc[i] = 0.0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t lr = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lr < A.rows; lr += stride) {
+        const uint64_t r = A.row_begin + lr;
+        double s[2][2], p4[2];
+        s[0][0] = sin(vs_m1(A.D, r, 0));
+        s[1][0] = sin(vs_m2(A.D, r, 0));
+        s[0][1] = sin(vs_m1(A.D, r, 1));
+        s[1][1] = sin(vs_m2(A.D, r, 1));
+        const double x3a = vs_m1(A.D, r, 2), x3b = vs_m2(A.D, r, 2);
+        p4[0] = (x3a * x3a) * (x3a * x3a);
+        p4[1] = (x3b * x3b) * (x3b * x3b);
+        auto val = [&](int u0, int u1, int u2) {  // same operation order as eval_kernel<VS_OBJ_ISHIGAMI>
+            const double s1 = s[u0][0], s2 = s[u1][1];
+            return (s1 + pa_ * (s2 * s2)) + (pb_ * p4[u2]) * s1;
+        };
+        const double a = val(0, 0, 0), b = val(1, 1, 1);
+        const double c[3] = {val(0, 1, 1), val(1, 0, 1), val(1, 1, 0)};  // N_j[i]: M_2 except column i
+        const double d[3] = {val(1, 0, 0), val(0, 1, 0), val(0, 0, 1)};  // N_nj[i]: M_1 except column i
+        const double dx = a - shift, dy = b - shift;
+        acc[VS_P_SAB] = fma(a, b, acc[VS_P_SAB]);
+        acc[VS_P_SA] += a;
+        acc[VS_P_SB] += b;
+        acc[VS_P_S1] += dx + dy;
+        acc[VS_P_S2] = fma(dx, dx, acc[VS_P_S2]);
+        acc[VS_P_S2] = fma(dy, dy, acc[VS_P_S2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            acc[VS_P_HEAD + 0 * 3 + i] = fma(a, c[i], acc[VS_P_HEAD + 0 * 3 + i]);
+            acc[VS_P_HEAD + 1 * 3 + i] = fma(b, d[i], acc[VS_P_HEAD + 1 * 3 + i]);
+            acc[VS_P_HEAD + 2 * 3 + i] = fma(a, d[i], acc[VS_P_HEAD + 2 * 3 + i]);
+            acc[VS_P_HEAD + 3 * 3 + i] = fma(b, c[i], acc[VS_P_HEAD + 3 * 3 + i]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+        const double v = vs_wave_sum_dpp(acc[i]);
+        if (lane == 63) wsum[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 17)
+        partials[(size_t)blockIdx.x * 17 + threadIdx.x] =
+            ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------
+// launch shapes
+// ---------------------------------------------------------------------------
+//   k <=   8: 4 waves x 2 columns      k <=  64: 8 waves x  8 columns      k <= 256: 16 waves x 16 columns
+//   k <=  16: 4 waves x 4 columns      k <= 128: 8 waves x 16 columns
+//   k <=  32: 4 waves x 8 columns
+// (registers: 4L doubles of terms and suffixes, +4L sums in the fused kernel)
+struct scan_shape {
+    int L, W;
+};
+
+// variant 1 (VS_FUSED_VARIANT=1, measurements): the fused kernel for 64 < k <= 128 as 8 waves x 16 columns
+static bool scan_shape_for(int k, bool fused, scan_shape* s, int variant = 0) {
+    if (k <= 8) *s = {2, 4};
+    else if (k <= 16) *s = {4, 4};
+    else if (k <= 32) *s = {8, 4};
+    else if (k <= 64) *s = {8, 8};
+    else if (k <= 128) *s = (fused && variant == 0) ? scan_shape{8, 16} : scan_shape{16, 8};
+    else if (k <= 256 && !fused) *s = {16, 16};
+    else return false;
+    return true;
+}
+
+bool vs_scan_shape(int k, bool fused, int* L, int* W, int* tlds, size_t* lds_bytes) {
+    scan_shape s;
+    if (!scan_shape_for(k, fused, &s)) return false;
+    const bool t = fused && s.L * s.W > 64;   // terms in LDS
+    *L = s.L;
+    *W = s.W;
+    *tlds = t ? 1 : 0;
+    const int slabs = t ? 1 : 2;
+    *lds_bytes = sizeof(double) * ((size_t)slabs * 2 * s.W * VS_EVAL_ROWS + (t ? 2 * (size_t)s.L * s.W * VS_EVAL_ROWS : 0));
+    return true;
+}
+
+bool vs_scan_covers(int kind, int k, bool fused) {
+    scan_shape s;
+    const bool separable = kind == VS_OBJ_G_FUNCTION || kind == VS_OBJ_POLYNOMIAL || kind == VS_OBJ_LINEAR;
+    return separable && scan_shape_for(k, fused, &s);
+}
+
+template <int KIND, int L, int W, bool FUSED, bool TLDS>
+static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev, int kid) {
+    const size_t lds = sizeof(double) * vs_scan_lds<L, W, TLDS>::doubles;
+    if (lds > 64 * 1024)
+        VS_HIP(hipFuncSetAttribute((const void*)scan_kernel<KIND, L, W, FUSED, TLDS>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        vs_launch_scope scope(ctx, kid);
+        hipLaunchKernelGGL((scan_kernel<KIND, L, W, FUSED, TLDS>), dim3(P, (unsigned)A.l), dim3(VS_EVAL_ROWS * W), lds,
+                           ctx->stream, A, shift_dev, ctx->partials, ctx->counters);
+    }
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+template <int KIND, bool FUSED>
+static int launch_scan_kind(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned P, const double* shift_dev) {
+    const int kid = FUSED ? VS_KERNEL_FUSED : VS_KERNEL_EVAL;
+#define VS_SCAN_CASE(LL, WW, TL) \
+    if (s.L == LL && s.W == WW) return launch_scan_lw<KIND, LL, WW, FUSED, TL>(ctx, A, P, shift_dev, kid)
+    VS_SCAN_CASE(2, 4, false);
+    VS_SCAN_CASE(4, 4, false);
+    VS_SCAN_CASE(8, 4, false);
+    VS_SCAN_CASE(8, 8, false);
+    if constexpr (FUSED) {
+        VS_SCAN_CASE(8, 16, true);
+        VS_SCAN_CASE(16, 8, true);
+    } else {
+        VS_SCAN_CASE(16, 8, false);
+        VS_SCAN_CASE(16, 16, false);
+    }
+#undef VS_SCAN_CASE
+    return vs_fail(VS_ERR_ARG, "no scan kernel for L=%d W=%d", s.L, s.W);
+}
+
+template <bool FUSED>
+static int launch_scan(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned P, const double* shift_dev) {
+    switch (A.kind) {
+        case VS_OBJ_G_FUNCTION: return launch_scan_kind<VS_OBJ_G_FUNCTION, FUSED>(ctx, A, s, P, shift_dev);
+        case VS_OBJ_POLYNOMIAL: return launch_scan_kind<VS_OBJ_POLYNOMIAL, FUSED>(ctx, A, s, P, shift_dev);
+        case VS_OBJ_LINEAR: return launch_scan_kind<VS_OBJ_LINEAR, FUSED>(ctx, A, s, P, shift_dev);
+    }
+    return vs_fail(VS_ERR_ARG, "objective kind %d is not separable", A.kind);
+}
+
+// workgroups of a persistent launch: enough to fill every CU at the kernel's occupancy
+static unsigned scan_workgroups(vs_context* ctx, uint64_t blocks, int W, bool fused, int l) {
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    int per_cu = fused ? (W <= 4 ? 2 : 1) : (W <= 4 ? 8 : (W <= 8 ? 4 : 2));
+    if (fused && ctx->tune.fused_wgs_per_cu > 0) per_cu = ctx->tune.fused_wgs_per_cu;
+    uint64_t P = (uint64_t)cus * per_cu;
+    if (l > 1) P = (P + l - 1) / l;  // grid.y = l planes share the chip
+    if (P > blocks) P = blocks;
+    if (P < 1) P = 1;
+    return (unsigned)P;
+}
+
+// vs_eval for a separable built-in in scan form (called by vs_eval, vs_generate.hip)
+int vs_scan_eval(vs_context* ctx, const vs_eval_args& A) {
+    scan_shape s;
+    if (!scan_shape_for(A.D.k, false, &s)) return vs_fail(VS_ERR_ARG, "k=%d is outside the scan kernels", A.D.k);
+    const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
+    VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
+    return launch_scan<false>(ctx, A, s, (unsigned)blocks, nullptr);  // one 64-row block per workgroup
+}
+
+unsigned vs_scan_fused_workgroups(vs_context* ctx, int k, int l, uint64_t rows) {
+    scan_shape s;
+    if (!scan_shape_for(k, true, &s, ctx->tune.fused_variant)) return 1;
+    return scan_workgroups(ctx, (rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS, s.W, true, l);
+}
+
+// The fused path: P workgroups leave [P][l][plen] partial records in ctx->partials (sized by the
+// caller), folded like reduce_first_kernel's.  shift_dev: the f-values of one design row, l planes
+// of 2k+2 doubles; the variance shift of output o is shift_dev[o*(2k+2)] = f_o(M_1[row]).
+int vs_scan_fused(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev) {
+    scan_shape s;
+    if (!scan_shape_for(A.D.k, true, &s, ctx->tune.fused_variant))
+        return vs_fail(VS_ERR_ARG, "k=%d is outside the fused kernels", A.D.k);
+    return launch_scan<true>(ctx, A, s, P, shift_dev);
+}
+
+unsigned vs_fused_ishigami_workgroups(vs_context* ctx, uint64_t rows) {
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    uint64_t P = (uint64_t)cus * 4;
+    const uint64_t blocks = (rows + 255) / 256;
+    if (P > blocks) P = blocks;
+    return (unsigned)(P < 1 ? 1 : P);
+}
+
+int vs_fused_ishigami(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev) {
+    vs_launch_scope scope(ctx, VS_KERNEL_FUSED);
+    hipLaunchKernelGGL(fused_ishigami_kernel, dim3(P), dim3(256), 0, ctx->stream, A, shift_dev, ctx->partials,
+                       ctx->counters);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}

@@ -404,6 +404,21 @@ gram_offdiag_kernel(vs_gram_args A) {
     }
 }
 
+// NaN probe of the two blocks the Gram matrix never sees: fM_1 and fM_2 of output 0 (planes 0, 1).
+// The reference drops row r from fN_j / fN_nj when ANY of the 2k+2 blocks holds a NaN at r
+// (saltelli.py:474-492); a NaN in blocks 2..2k+1 poisons a Gram total and gram_fold_kernel raises the
+// flag, a NaN in block 0 or 1 is caught here.  2/(2k+2) of the data: cheap beside the Gram pass.
+__global__ void __launch_bounds__(256)
+nan_probe_kernel(const double* __restrict__ f, uint64_t count, uint32_t* counters) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
+        const double x = f[e];
+        bad |= (x != x);
+    }
+    if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(&counters[CNT_NANFLAG], 1u);
+}
+
 // keep mask for the second-order pass (same rule as the first-order one)
 __global__ void __launch_bounds__(256)
 nan_mask2_kernel(const double* __restrict__ f, uint64_t rows, int k, int l, uint8_t* __restrict__ keep,
@@ -541,10 +556,9 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
     if (nchunks < 1) nchunks = 1;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    const char* env = getenv("VS_GRAM_WGS_PER_CU");
     // 16-byte loads need an even row count: planar blocks start at multiples of `rows` doubles
     const bool aligned = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
-    const int per_cu = env && *env ? atoi(env) : (npairs == 1 ? 3 : 8);  // measured (tools/gram_only.py)
+    const int per_cu = ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu : (npairs == 1 ? 3 : 8);  // measured (tools/gram_only.py)
     uint64_t want = ((uint64_t)cus * per_cu + npairs - 1) / npairs;
     if (want < 1) want = 1;
     const uint32_t slab_wgs = (uint32_t)(nchunks < want ? nchunks : want);
@@ -580,6 +594,14 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     VS_HIP(hipFuncSetAttribute((const void*)gram_offdiag_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     VS_HIP(hipFuncSetAttribute((const void*)gram_offdiag_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     const dim3 grid_diag(slab_wgs, nsuper), grid_off(slab_wgs, npairs - nsuper);
+    if ((flags & VS_REDUCE_NAN_TRIM) && rows > 0) {
+        const uint64_t count = 2 * rows;  // blocks 0 and 1 of output 0 are contiguous
+        const uint64_t want_blocks = (count + 255) / 256;
+        vs_launch_scope scope(ctx, VS_KERNEL_NAN_MASK);
+        hipLaunchKernelGGL(nan_probe_kernel, dim3((unsigned)(want_blocks < 2048 ? want_blocks : 2048)), dim3(256), 0,
+                           ctx->stream, f_dev, count, ctx->counters);
+        VS_HIP(hipGetLastError());
+    }
     for (int pass = 0; pass < 2; ++pass) {
         const bool masked = pass == 1;
         if (masked) {
@@ -635,9 +657,8 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     VS_REQUIRE(max_ranks >= 1 && rank >= 0 && rank < max_ranks, "rank %d not in [0,%d)", rank, max_ranks);
     VS_REQUIRE(rows <= 0xfffffff0ull, "rows per GPU must stay below 2^32");
     VS_REQUIRE(rows == 0 || f_dev, "f_dev is null");
-    const char* env = getenv("VS_REDUCE_BOTH");
     const bool combined = l == 1 && 2 * k <= VS2_SUPER && !(flags & VS_REDUCE_NAN_TRIM) && rows >= 1 &&
-                          !(env && *env == '0');
+                          ctx->tune.reduce_both != 0;
     if (!combined) {
         int rc = vs_reduce_first_order(ctx, f_dev, rows, k, l, flags, rank, max_ranks, acc_dev);
         if (rc) return rc;
@@ -646,8 +667,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     const int K = k;
     const uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    const char* pc = getenv("VS_GRAM_WGS_PER_CU");
-    const uint64_t want = (uint64_t)cus * (pc && *pc ? atoi(pc) : 2);  // two waves per SIMD
+    const uint64_t want = (uint64_t)cus * (ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu : 2);  // two waves per SIMD
     const uint32_t P = (uint32_t)(nchunks < want ? nchunks : want);
     const size_t plen = VS_PLEN(k);
     // workspace: first-order records [P][plen] + folded [plen] (vs_fold_partials' layout), then Gram partials
@@ -689,7 +709,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
 #undef VS2_LAUNCH_BOTH
     }
     VS_HIP(hipGetLastError());
-    rc = vs_fold_partials(ctx, P, k, 1, rows, nullptr, f_dev, rank, max_ranks, acc_dev);
+    rc = vs_fold_partials(ctx, P, k, 1, rows, nullptr, 1, f_dev, rank, max_ranks, acc_dev);
     if (rc) return rc;
     vs_gram_fold_args F;
     F.partials = A.partials;

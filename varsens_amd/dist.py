@@ -102,6 +102,7 @@ class RcclComm(object):
 
     def __init__(self, ctx, group):
         self.ctx = ctx
+        self.group = group
         self.world = group.world
         self.rank = group.rank
         if self.world > 1:
@@ -117,6 +118,10 @@ class RcclComm(object):
     def allreduce(self, buf, count):
         if self.world > 1:
             self.ctx.comm_allreduce(buf, count)
+
+    def max(self, value):
+        """Largest `value` over the ranks (host side; planning decisions that must agree on every rank)."""
+        return self.group.max(value)
 
     def close(self):
         if self.world > 1:
@@ -136,6 +141,9 @@ class HostExchange(object):
             self.ctx.sync()
             total = self.group.sum_array(self.ctx.download(buf, (int(count),)))
             self.ctx.upload_into(buf, total)
+
+    def max(self, value):
+        return self.group.max(value)
 
     def close(self):
         pass

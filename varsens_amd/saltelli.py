@@ -452,6 +452,27 @@ class Objective(object):
                   (lost, 2 * n * (1 + k), 100.0 * lost / (2 * n * (1 + k))))
 
 
+def stream_rows_per_pass(request, max_rows, bytes_per_row, hbm_bytes):
+    """Draws per streamed pass (0 = hold all f-values in HBM) for a job whose LARGEST shard has
+    `max_rows` draws.  Pure host logic, identical on every rank by construction."""
+    if request in (None, 0, False):
+        return 0
+    if request != 'auto':
+        r = int(request)
+        return r if 0 < r < max_rows else 0
+    if bytes_per_row * max_rows <= 0.5 * hbm_bytes:
+        return 0
+    # passes of at most 8 GiB: large enough to fill the GPU many times over, small enough that the
+    # allocator never leaves its fast path (the first 64-GiB hipMalloc of a process takes seconds)
+    r = int(min(0.25 * hbm_bytes, 8 << 30) // bytes_per_row)
+    return max(64, r - r % 64)
+
+
+def stream_passes(max_rows, rows_per_pass):
+    """Passes every rank walks (ranks with fewer rows leave their last slots empty)."""
+    return max(1, -(-int(max_rows) // int(rows_per_pass)))
+
+
 class Varsens(object):
     """Variance-based sensitivity by the method of Saltelli (2002).
 
@@ -501,42 +522,43 @@ class Varsens(object):
             if vectorized:
                 kw['vectorized'] = True
             self._stream_rows = self._streaming_rows(objective, shard, ctx)
-            if self._fused_eligible(objective) or self._stream_rows:
+            if self._fused_candidate(objective) or self._stream_rows:
                 kw['lazy'] = True   # the values are only produced if somebody asks for them
             elif self._fused is True:
-                raise Exception("fused=True needs first order only (second_order=False) and a single-output "
-                                "GFunction / Polynomial / Linear device objective with k <= 32")
+                raise Exception("fused=True needs first order only (second_order=False) and a device objective")
             self.objective = Objective(self.k, self.n, self.sample, objective, verbose=verbose, **kw)
         self._ctx = self.objective._ctx
         self.compute_varsens()
 
     _stream_rows = 0
 
+    def _max_rows_over_ranks(self, rows):
+        """The largest shard of the job: every streaming decision is taken from it, so that all ranks
+        stream (or none does) with the same pass count -- the all-reduce sizes depend on both."""
+        comm = self._comm
+        if comm is None or comm.world == 1:
+            return int(rows)
+        if hasattr(comm, 'max'):
+            return int(comm.max(rows))
+        from .dist import shard_rows      # a communicator without max(): the standard row split
+        return max(int(rows), max(shard_rows(int(self.n), comm.world, r)[1] for r in range(comm.world)))
+
     def _streaming_rows(self, objective, shard, ctx):
-        """Draws per pass when the f-values are to be streamed through HBM in row ranges, else 0."""
+        """Draws per pass when the f-values are to be streamed through HBM in row ranges, else 0.
+        Rank-invariant: computed from the largest shard over the ranks."""
         if not isinstance(objective, _objectives.DeviceObjective) or self._rows_per_pass in (None, 0, False):
             return 0
         k = int(self.k)
-        rows = _shard_rows(int(self.n), shard)[1]
-        per_row = 8 * 2 * (k + 1) * int(objective.outputs(k))
-        if self._rows_per_pass != 'auto':
-            r = int(self._rows_per_pass)
-            return r if 0 < r < rows else 0
-        hbm = (ctx or self.sample._ctx).info()['hbm_bytes']
-        if per_row * rows <= 0.5 * hbm:
-            return 0
-        # passes of at most 8 GiB: large enough to fill the GPU many times over, small enough that the
-        # allocator never leaves its fast path (the first 64-GiB hipMalloc of a process takes seconds)
-        r = int(min(0.25 * hbm, 8 << 30) // per_row)
-        return max(64, r - r % 64)
+        rows = self._max_rows_over_ranks(_shard_rows(int(self.n), shard)[1])
+        self._max_rows = rows
+        hbm = None if self._rows_per_pass != 'auto' else (ctx or self.sample._ctx).info()['hbm_bytes']
+        return stream_rows_per_pass(self._rows_per_pass, rows, 8 * 2 * (k + 1) * int(objective.outputs(k)), hbm)
 
-    def _fused_eligible(self, objective):
-        if self._fused is False or self._second_order:
-            return False
-        if not isinstance(objective, _objectives.DeviceObjective):
-            return False
-        separable = objective.kind in (_native.OBJ_G_FUNCTION, _native.OBJ_POLYNOMIAL, _native.OBJ_LINEAR)
-        return separable and int(self.k) <= 32 and objective.outputs(int(self.k)) == 1
+    def _fused_candidate(self, objective):
+        """First order only and a device objective: the engine is asked whether its fused
+        evaluate+reduce kernels cover the (design, objective) pair (vs_eval_reduce_supported)."""
+        return (self._fused is not False and not self._second_order and
+                isinstance(objective, _objectives.DeviceObjective))
 
     def compute_varsens(self):
         """E_2, var_y, U_j, U_nj, sens, sens_t, sens_2, sens_2n (varsens/saltelli.py:572-622)."""
@@ -552,12 +574,20 @@ class Varsens(object):
 
         nacc = _native.acc_len(k, l, world)
         acc = ctx.alloc(8 * nacc)
-        if obj._f is None and obj._rows > 0 and self._fused_eligible(obj.objective_func):
-            # evaluate and reduce in one kernel: the 2n(k+1) values never reach HBM
+        fused = False
+        if obj._f is None and obj._rows > 0 and self._fused_candidate(obj.objective_func):
             handle = obj._device_objective()
-            ctx.eval_reduce_first_order(obj.sample._design, handle, obj._row_begin, obj._rows, acc, rank, world)
-            ctx.sync()
+            fused = ctx.eval_reduce_supported(obj.sample._design, handle)
+            if fused:
+                # evaluate and reduce in one kernel: the 2n(k+1) values never reach HBM
+                ctx.eval_reduce_first_order(obj.sample._design, handle, obj._row_begin, obj._rows, acc, rank, world)
+                ctx.sync()
             handle.free()
+            if not fused and self._fused is True:
+                raise Exception("fused=True: the fused kernels do not cover this design / objective "
+                                "(see vs_eval_reduce_first_order in include/varsens_hip.h)")
+        if fused:
+            pass
         elif self._second_order:
             # both reductions read the same blocks: one pass where the shape allows (k <= 32, one output)
             gram = ctx.alloc(8 * 3 * k * l * k * l)
@@ -602,21 +632,26 @@ class Varsens(object):
     def _compute_streamed(self, rows_per_pass):
         """The same estimators with the f-values streamed through one HBM buffer in row ranges:
         every range is a variance slot of the record (as a rank is), the records and Gram matrices
-        add up.  For designs whose 2n(k+1) values exceed the memory of the GPU."""
+        add up on the device.  For designs whose 2n(k+1) values exceed the memory of the GPU."""
         ctx, obj = self._ctx, self.objective
         k, n, l = int(self.k), int(self.n), int(obj._l)
         world = self._comm.world if self._comm is not None else 1
         rank = self._comm.rank if self._comm is not None else 0
         R = int(rows_per_pass)
-        per_rank = -(-n // world)                 # the same pass count on every rank
-        passes = max(1, -(-per_rank // R))
+        passes = stream_passes(getattr(self, '_max_rows', obj._rows), R)   # the same on every rank
+        if passes * R < obj._rows:
+            raise Exception("streamed passes (%d x %d rows) do not cover this rank's %d rows" % (passes, R, obj._rows))
         slots = passes * world
         nacc = _native.acc_len(k, l, slots)
         K = k * l
         acc = ctx.alloc(8 * nacc)
-        gram = ctx.alloc(8 * 3 * K * K) if self._second_order else None
-        total = numpy.zeros(nacc)
-        gram_total = numpy.zeros(3 * K * K)
+        total = ctx.alloc(8 * nacc)
+        ctx.memset(total, 0)
+        gram = gram_total = None
+        if self._second_order:
+            gram = ctx.alloc(8 * 3 * K * K)
+            gram_total = ctx.alloc(8 * 3 * K * K)
+            ctx.memset(gram_total, 0)
         f = ctx.alloc(8 * 2 * (k + 1) * min(R, obj._rows) * l)
         handle = obj._device_objective()
         for c in range(passes):
@@ -627,13 +662,14 @@ class Varsens(object):
             ctx.eval(obj.sample._design, handle, obj._row_begin + begin, count, f)
             if self._second_order:
                 ctx.reduce_first_second_order(f, count, k, l, acc, gram, 0, rank * passes + c, slots)
-                gram_total += ctx.download(gram, (3 * K * K,))
+                ctx.accumulate(gram_total, gram, 3 * K * K)
             else:
                 ctx.reduce_first_order(f, count, k, l, acc, 0, rank * passes + c, slots)
-            total += ctx.download(acc, (nacc,))
+            ctx.accumulate(total, acc, nacc)
+        ctx.sync()
         handle.free()
         f.free()
-        ctx.upload_into(acc, total)
+        acc.free()
         if gram is not None:
-            ctx.upload_into(gram, gram_total)
-        self._finish(acc, nacc, gram, slots)
+            gram.free()
+        self._finish(total, nacc, gram_total, slots)
