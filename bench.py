@@ -12,8 +12,15 @@ One step = one pass of the whole path over one batch, everything in HBM:
 Workload (BASELINE.json configs[3], weak-scaling form): linear objective f = sum c_i x_i,
 c_i = i+1, identity scaling, k = 32, n = 2^22 draws PER GPU (global n = N * 2^22, rows sharded).
 `value` = samples (= model evaluations) generated, evaluated and reduced per second over all
-GPUs.  `roofline` is the sens/sens_t reduction kernel alone, timed with HIP events on the
-engine's stream inside the timed region.
+GPUs.
+
+Cache-proof schedule: the f-values rotate through THREE 2.2 GB buffers and the reduction of a
+step reads the batch the PREVIOUS step evaluated (software pipeline by one batch; every step still
+runs one full evaluation and one full reduction).  Between the write of a buffer and its read lie
+2.2 GB of other writes and 2.2 GB of other reads, so none of its lines can still sit in the 256 MB
+Infinity Cache: `roofline` -- the sens/sens_t reduction kernel alone, timed with HIP events on the
+engine's stream inside the timed region -- is an HBM number.  The same-batch schedule on one buffer
+(round 1's) is timed afterwards and reported as `single_buffer`.
 """
 import argparse
 import json
@@ -26,23 +33,31 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "bench_pmc_fetch_write.json")
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # data-sheet fp64 matrix rate (the guide lists no fp64 figure); see DESIGN.md 4.3 for the measured issue rate
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "bench_pmc.json")
+F_BUFFERS = 3
 
 
-def pmc_traffic(kernel_prefix, k, log2n):
-    """HBM bytes per launch of the reduction kernel from the committed rocprofv3 PMC passes
-    (collected on this exact workload; FETCH_SIZE doubled per the gfx950 correction), or None."""
+def pmc_kernel(prefix, k, log2n):
+    """Counters per launch from the committed rocprofv3 PMC passes (collected on this exact workload), or None."""
     if (k, log2n) != (32, 22) or not os.path.isfile(PMC_SUMMARY):
         return None
     try:
-        kernels = json.load(open(PMC_SUMMARY))["kernels"]
-        for name, c in kernels.items():
-            if name.startswith(kernel_prefix):
-                return (2.0 * c["FETCH_SIZE_KB_avg_per_launch"] + c["WRITE_SIZE_KB_avg_per_launch"]) * 1024.0
+        for name, c in json.load(open(PMC_SUMMARY))["kernels"].items():
+            if name.startswith(prefix):
+                return c
     except Exception:
         return None
     return None
+
+
+def pmc_traffic(prefix, k, log2n):
+    """HBM bytes per launch: FETCH_SIZE doubled per the gfx950 wide-load correction, plus WRITE_SIZE (both KB)."""
+    c = pmc_kernel(prefix, k, log2n)
+    if not c or "FETCH_SIZE_avg_per_launch" not in c:
+        return None
+    return (2.0 * c["FETCH_SIZE_avg_per_launch"] + c.get("WRITE_SIZE_avg_per_launch", 0.0)) * 1024.0
 
 
 def cpu_baseline(k, f_small, n_small, cores):
@@ -74,6 +89,13 @@ def cpu_baseline(k, f_small, n_small, cores):
     }, R
 
 
+def averages(recs):
+    per = {}
+    for name, ms in recs:
+        per.setdefault(name, []).append(ms)
+    return {name: float(np.mean(v)) for name, v in per.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,18 +123,20 @@ def main():
     ctx = _native.Context(0 if args.shared_device else group.local_rank)
     world, rank = group.world, group.rank
     exchange = "none (single GPU)" if world == 1 else "rccl all-reduce (xGMI)"
+    host_fallback = False
     try:
         if args.exchange == "host" and world > 1:
             raise RuntimeError("--exchange host requested")
         comm = dist.RcclComm(ctx, group)
         failed = 0.0
-    except Exception as exc:   # keep the scaling run alive, but say so in the result line
+    except Exception as exc:   # keep the scaling run alive, but say so in the result line and in the exit code
         comm, failed, why = None, 1.0, str(exc)
         sys.stderr.write("rank %d: RCCL communicator failed (%s); falling back to a host exchange\n" % (rank, why))
     if group.max(failed) > 0.0:
         if comm is not None:
             comm.close()
         comm = dist.HostExchange(ctx, group)
+        host_fallback = args.exchange != "host"
         exchange = ("host exchange over gloo (requested: rehearsal)" if args.exchange == "host" else
                     "HOST FALLBACK over gloo (RCCL init failed on at least one rank)")
 
@@ -128,25 +152,20 @@ def main():
     N_local = 2 * (k + 1) * rows
     N_total = 2 * (k + 1) * n
 
-    perm = seed1_permutation(n)
-    design = ctx.design_create(_native.GEN_HALTON, k, n, 1 + 20 * k, _native.SCALE_IDENTITY, None, None, perm)
+    # every rank computes the global seed-1 shuffle (12 ns per row on the host) but uploads its own slice only
+    perm = seed1_permutation(n)[begin:begin + rows]
+    design = ctx.design_create(_native.GEN_HALTON, k, n, 1 + 20 * k, _native.SCALE_IDENTITY, None, None, perm,
+                               perm_begin=begin)
     objective = ctx.objective_create(_native.OBJ_LINEAR, k, l, np.arange(1, k + 1, dtype=float))
-    f = ctx.alloc(8 * N_local)
+    fbuf = [ctx.alloc(8 * N_local) for _ in range(F_BUFFERS)]
     nacc = _native.acc_len(k, l, world)
     accs = [ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)]
     outs = [ctx.alloc(8 * _native.first_order_len(k, l)) for _ in range(2)]
     counter = [0]
 
-    def step():
-        """eval + reduce on the main stream; the exchange and the finishing kernel of this pass go to
-        the auxiliary stream so that they run beside the NEXT pass's evaluation (records and result
-        buffers alternate; events order the two streams)."""
-        b = counter[0] & 1
-        counter[0] += 1
-        ctx.stream_select(0)
-        ctx.eval(design, objective, begin, rows, f)
-        ctx.stream_wait_event(0, b)             # pass i-2 is done with record b
-        ctx.reduce_first_order(f, rows, k, l, accs[b], 0, rank, world)
+    def finish_on_aux(b):
+        """exchange + finishing kernel of this pass on the auxiliary stream, beside the NEXT pass's evaluation
+        (records and result buffers alternate; events order the two streams)"""
         ctx.event_record(2 + b, 0)
         ctx.stream_wait_event(1, 2 + b)
         ctx.stream_select(1)
@@ -156,67 +175,80 @@ def main():
         ctx.stream_select(0)
         return outs[b]
 
+    def step():
+        """evaluate batch i into buffer i mod 3, reduce batch i-1 from the buffer the previous step wrote"""
+        i = counter[0]
+        b = i & 1
+        counter[0] += 1
+        ctx.stream_select(0)
+        ctx.eval(design, objective, begin, rows, fbuf[i % F_BUFFERS])
+        ctx.stream_wait_event(0, b)             # pass i-2 is done with record b
+        ctx.reduce_first_order(fbuf[(i - 1) % F_BUFFERS], rows, k, l, accs[b], 0, rank, world)
+        return finish_on_aux(b)
+
+    def step_single_buffer():
+        """round 1's schedule: evaluate and reduce the same batch through one buffer"""
+        b = counter[0] & 1
+        counter[0] += 1
+        ctx.stream_select(0)
+        ctx.eval(design, objective, begin, rows, fbuf[0])
+        ctx.stream_wait_event(0, b)
+        ctx.reduce_first_order(fbuf[0], rows, k, l, accs[b], 0, rank, world)
+        return finish_on_aux(b)
+
+    def fused_step():
+        """the same job through the fused evaluate+reduce kernel: no f-values in HBM"""
+        b = counter[0] & 1
+        counter[0] += 1
+        ctx.stream_select(0)
+        ctx.stream_wait_event(0, b)
+        ctx.eval_reduce_first_order(design, objective, begin, rows, accs[b], rank, world)
+        return finish_on_aux(b)
+
+    def timed(fn, steps, warmup, profile=False):
+        for _ in range(warmup):
+            fn()
+        ctx.sync()
+        group.barrier()
+        if profile:
+            ctx.profile_begin(10 * steps + 8)
+        t0 = time.perf_counter()
+        res = None
+        for _ in range(steps):
+            res = fn()
+        ctx.sync()
+        group.barrier()
+        dt = time.perf_counter() - t0
+        recs = ctx.profile_end() if profile else []
+        return group.max(dt), recs, res
+
+    ctx.eval(design, objective, begin, rows, fbuf[F_BUFFERS - 1])   # batch "-1" of the pipeline
     # DVFS: a GPU that was idle needs ~0.2 s of work to reach its sustained clock; bring it there
     # before the W warm-up steps so that the K timed steps do not depend on how small K and W are
     # (a fixed COUNT, not a wall-clock loop: every rank must issue the same number of all-reduces)
     for _ in range(args.prewarm_steps):
         step()
     ctx.sync()
-    for _ in range(args.warmup):
-        step()
-    ctx.sync()
-    group.barrier()
-    ctx.profile_begin(8 * args.steps + 8)
-    t0 = time.perf_counter()
-    out = None
-    for _ in range(args.steps):
-        out = step()
-    ctx.sync()
-    group.barrier()
-    elapsed = time.perf_counter() - t0
-    recs = ctx.profile_end()
-    elapsed = group.max(elapsed)
+    elapsed, recs, out = timed(step, args.steps, args.warmup, profile=True)
+    avg = averages(recs)
+    result = ctx.download(out, (2 + 4 * k, l))
 
-    # the same job through the fused evaluate+reduce kernel (no f-values in HBM): reported beside the
-    # headline, never instead of it -- the graded kernel is the HBM reduction above
-    def fused_step():
-        b = counter[0] & 1
-        counter[0] += 1
-        ctx.stream_select(0)
-        ctx.stream_wait_event(0, b)
-        ctx.eval_reduce_first_order(design, objective, begin, rows, accs[b], rank, world)
-        ctx.event_record(2 + b, 0)
-        ctx.stream_wait_event(1, 2 + b)
-        ctx.stream_select(1)
-        comm.allreduce(accs[b], nacc)
-        ctx.finish_first_order(accs[b], n, k, l, outs[b], world)
-        ctx.event_record(b, 1)
-        ctx.stream_select(0)
-        return outs[b]
-
+    # secondary legs, reported beside the headline and never instead of it
+    t_single, recs_single, _ = timed(step_single_buffer, args.steps, args.warmup, profile=True)
+    avg_single = averages(recs_single)
     fused = None
-    if k <= 32:
-        for _ in range(args.warmup):
-            fused_step()
-        ctx.sync()
-        group.barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            fout = fused_step()
-        ctx.sync()
-        group.barrier()
-        t_fused = group.max(time.perf_counter() - t1)
+    if ctx.eval_reduce_supported(design, objective):
+        t_fused, recs_fused, fout = timed(fused_step, args.steps, args.warmup, profile=True)
         fres = ctx.download(fout, (2 + 4 * k, l))
         fused = {"value": N_total / (t_fused / args.steps) / 1e9, "unit": "GSamples/s",
-                 "ms_per_step": 1e3 * t_fused / args.steps,
+                 "ms_per_step": 1e3 * t_fused / args.steps, "kernel_ms": averages(recs_fused).get("fused"),
                  "max_abs_diff_sens_vs_two_kernel_path": float(np.max(np.abs(
-                     fres[2 + 2 * k:2 + 3 * k] - ctx.download(out, (2 + 4 * k, l))[2 + 2 * k:2 + 3 * k])))}
-
-    per = {}
-    for name, ms in recs:
-        per.setdefault(name, []).append(ms)
-    avg = {name: float(np.mean(v)) for name, v in per.items()}
-    result = ctx.download(out, (2 + 4 * k, l))
+                     fres[2 + 2 * k:2 + 3 * k] - result[2 + 2 * k:2 + 3 * k])))}
+    # second order (sens_2 / sens_2n Gram sums on the fp64 matrix cores), on its own: a few launches
+    gram = ctx.alloc(8 * 3 * k * k)
+    so_steps = max(3, min(args.steps, 20))
+    t_so, recs_so, _ = timed(lambda: ctx.reduce_second_order(fbuf[0], rows, k, l, gram), so_steps, 2, profile=True)
+    avg_so = averages(recs_so)
 
     # analytic check of the finished indices (linear objective: S_i = c_i^2 / sum c^2)
     c = np.arange(1, k + 1, dtype=float)
@@ -224,10 +256,19 @@ def main():
     sens = result[2 + 2 * k:2 + 3 * k, 0]
     max_err = float(np.max(np.abs(sens - truth)))
 
+    per_rank = group.gather_objects({"rank": rank, "stages_ms": avg}) if world > 1 else None
+
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         t_red = avg["reduce_first"] * 1e-3
         achieved = 8.0 * N_local / t_red / 1e9
+        t_eval = avg["eval"] * 1e-3
+        eval_gbs = 8.0 * N_local / t_eval / 1e9
+        eval_pmc = pmc_kernel("void scan_kernel", k, args.log2n) or {}
+        # issued MFMA work of the Gram kernels: 16x16 tiles on and above the diagonal of the 2K x 2K Gram matrix
+        nb = (2 * k * l + 15) // 16
+        mfma_flops = nb * (nb + 1) / 2 * (rows / 4.0) * (2 * 16 * 16 * 4)
+        so_ms = avg_so.get("second_order")
         line = {
             # BASELINE.json's metric string; every sample is one model evaluation, generated, evaluated and
             # reduced inside the step, so the one rate is both "model-evals/sec" and "GSamples/s"
@@ -241,28 +282,57 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[3] weak-scaling form: linear objective c_i=i+1, identity scaling, "
                                    "Halton design, k=%d, n=2^%d draws per GPU (global n=%d), rows sharded, "
-                                   "one RCCL all-reduce of %d doubles per step" % (k, args.log2n, n, nacc),
+                                   "one RCCL all-reduce of %d doubles per step; f-values rotate through %d buffers, "
+                                   "each step evaluates batch i and reduces batch i-1"
+                                   % (k, args.log2n, n, nacc, F_BUFFERS),
                        "k": k, "n_per_gpu": rows, "n_global": n, "l": l,
                        "samples_per_step": N_total, "sharding": "rows/%d" % world},
             "exchange": exchange,
             "stages_ms": avg,
-            "model_evals_per_s": N_total / (avg["eval"] * 1e-3),  # rank 0's kernel time, all ranks' evaluations
+            "stages_ms_per_rank": per_rank,
+            "allreduce_ms": avg.get("allreduce"),
+            "model_evals_per_s": N_total / t_eval,  # rank 0's kernel time, all ranks' evaluations
             "reduce_gsamples_per_s_per_gpu": N_local / t_red / 1e9,
             "max_abs_err_sens_vs_analytic": max_err,
             "fused_path": fused,
+            "single_buffer": {"value": N_total / (t_single / args.steps) / 1e9, "unit": "GSamples/s",
+                              "ms_per_step": 1e3 * t_single / args.steps, "stages_ms": avg_single,
+                              "reduce_frac_of_hbm_peak": 8.0 * N_local / (avg_single["reduce_first"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": "evaluate and reduce the same batch through one buffer: the reduction may find "
+                                      "the tail of the evaluation's writes in the Infinity Cache"},
             "roofline": {"kernel": "reduce_first_kernel (sens/sens_t streaming reduction)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic("void reduce_first_kernel", k, args.log2n),
-                         "traffic_source": "profiles/r01/bench_pmc_fetch_write.json (separate rocprofv3 --pmc passes)",
+                         "traffic_source": "profiles/r02/bench_pmc.json (separate rocprofv3 --pmc passes)",
                          "algorithmic_bytes_per_launch": 8 * N_local,
-                         "avg_launch_ms": avg["reduce_first"]},
+                         "avg_launch_ms": avg["reduce_first"],
+                         "input_last_written": "one step earlier (3 rotating buffers): not an Infinity-Cache number"},
+            "roofline_eval": {"kernel": "scan_kernel (Halton -> scale -> column swap -> evaluate, 8 B written per evaluation)",
+                              "bound": "hbm", "achieved": eval_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": eval_gbs / HBM_PEAK_GBS,
+                              "traffic": (eval_pmc.get("WRITE_SIZE_avg_per_launch") or 0) * 1024.0 or None,
+                              "algorithmic_bytes_per_launch": 8 * N_local, "avg_launch_ms": avg["eval"],
+                              "write_stream_ceiling_gbs": 5600.0,
+                              "frac_of_write_ceiling": eval_gbs / 5600.0,
+                              "valu_busy_frac": eval_pmc.get("valu_busy_frac"),
+                              "note": "store-only kernel of the same shape sustains 5.6 TB/s (tools/write_bw.hip)"},
+            "roofline_second_order": None if not so_ms else {
+                "kernel": "gram_diag_wave_kernel (sens_2 / sens_2n Gram sums, v_mfma_f64_16x16x4_f64)",
+                "bound": "mfma", "achieved": mfma_flops / (so_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": mfma_flops / (so_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": pmc_traffic("void gram_diag_wave_kernel", k, args.log2n),
+                "avg_launch_ms": so_ms, "mfma_flops_per_launch": mfma_flops,
+                "algorithmic_hbm_gbs": 16.0 * k * l * rows / (so_ms * 1e-3) / 1e9,
+                "measured_fp64_mfma_issue_ceiling_tflops": 48.0,
+                "note": "issued MFMA flops (upper-triangle 16x16 tiles); peak = data-sheet fp64 matrix rate, a bare "
+                        "issue loop sustains 47-49 TFLOP/s on this chip (tools/mfma_f64_peak.hip)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             n_small = min(rows, 1 << 22)   # the whole pass at the default size: 2.2 GB over PCIe, ~2 s of numpy
             blocks = np.empty((2 * k + 2, n_small, l))
             for b in range(2 * k + 2):
-                blocks[b] = ctx.download(f, (n_small, l), byte_offset=8 * b * rows * l)
+                blocks[b] = ctx.download(fbuf[0], (n_small, l), byte_offset=8 * b * rows * l)
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
             cpu, _ = cpu_baseline(k, blocks, n_small, cores)
             line["cpu_baseline"] = cpu
@@ -270,6 +340,10 @@ def main():
     comm.close()
     ctx.close()
     group.close()
+    if host_fallback:
+        sys.stderr.write("bench.py: --gpus %d ended on the HOST FALLBACK exchange (RCCL did not initialise); the "
+                         "line above is not a scaling number\n" % world)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

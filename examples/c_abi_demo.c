@@ -44,6 +44,8 @@ int main(void) {
     d.perm = perm;
     d.raw = NULL;
     d.sobol_directions = NULL;
+    d.perm_begin = 0;                                 /* the whole shuffle (a rank of a multi-GPU job passes its slice) */
+    d.perm_count = n;
     CHECK(vs_design_create(ctx, &d, &design));
     CHECK(vs_objective_create(ctx, VS_OBJ_G_FUNCTION, K, L, a, K, &objective));
     CHECK(vs_alloc(ctx, sizeof(double) * 2 * (K + 1) * n * L, &f));

@@ -3,8 +3,8 @@
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/multi_gpu.py
 
-Every rank generates, evaluates and reduces its own row shard; the accumulator record (and the Gram
-sums of the second order) are summed once over RCCL; every rank ends with the full result.
+Every rank generates, evaluates and reduces its own row shard; the accumulator record and the Gram
+sums of the second order cross the GPUs in ONE RCCL all-reduce; every rank ends with the full result.
 `--host-exchange --shared-device` rehearses the same flow on a single GPU (records cross the host).
 """
 import argparse
@@ -34,8 +34,9 @@ def main():
     comm = dist.HostExchange(ctx, group) if args.host_exchange else dist.RcclComm(ctx, group)
 
     a = np.array([0, 0.5, 3, 9, 99, 99], dtype=float)[:args.k] if args.k <= 6 else np.linspace(0, 9, args.k)
-    sample = vs.Sample(args.k, args.n, vs.scale.Identity(), verbose=False, context=ctx)
     shard = dist.shard_rows(args.n, group.world, group.rank)
+    # shard=: only this rank's slice of the seed-1 shuffle goes to its GPU
+    sample = vs.Sample(args.k, args.n, vs.scale.Identity(), verbose=False, context=ctx, shard=shard)
     if args.rows_per_pass:
         v = vs.Varsens(vs.objectives.GFunction([a, a[::-1]]), sample=sample, verbose=False, comm=comm, shard=shard,
                        rows_per_pass=args.rows_per_pass)

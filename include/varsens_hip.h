@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 1
+#define VS_ABI_VERSION 2
 
 typedef enum vs_status {
     VS_OK = 0,
@@ -67,6 +67,17 @@ int vs_context_create(int device, vs_context** out);
 int vs_context_destroy(vs_context* ctx);
 int vs_context_info(vs_context* ctx, vs_device_info* out);
 int vs_sync(vs_context* ctx);   /* waits for both streams */
+
+/* Association order of the k-term products / sums of the separable objectives (G_FUNCTION, POLYNOMIAL,
+ * LINEAR, separable source objectives).  The reference evaluates whatever Python callable it is given
+ * (varsens/saltelli.py:329-355); its own tests multiply the factors with numpy.prod, i.e. left to right.
+ *   VS_ORDER_FAST   (default) segmented-scan kernels: O(k) operations per design row, fixed reassociated
+ *                   order (csrc/vs_device_scan.h) -- values within a few ulp of the left-to-right fold
+ *   VS_ORDER_STRICT strictly left to right: bit-identical to numpy.prod / a Python loop, O(k^2) per row;
+ *                   the fused evaluate+reduce path is not available for separable objectives
+ * Applies to objectives created and evaluated afterwards. */
+enum { VS_ORDER_FAST = 0, VS_ORDER_STRICT = 1 };
+int vs_context_set_eval_order(vs_context* ctx, int order);
 
 /* A context owns two HIP streams: 0 = main (default), 1 = auxiliary.  vs_stream_select routes
  * every following launch / collective of this context to that stream; vs_event_record marks a
@@ -108,7 +119,8 @@ enum {
     VS_KERNEL_NAN_MASK = 8,
     VS_KERNEL_SECOND_ORDER = 9,
     VS_KERNEL_SECOND_FOLD = 10,
-    VS_KERNEL_FUSED = 11
+    VS_KERNEL_FUSED = 11,
+    VS_KERNEL_ALLREDUCE = 12    /* the RCCL all-reduce of vs_comm_allreduce (events around the collective) */
 };
 
 int vs_profile_begin(vs_context* ctx, int capacity);
@@ -144,11 +156,16 @@ typedef struct vs_design_desc {
     int32_t reserved;
     const double* lower;   /* host, k entries (LINEAR/POWER) */
     const double* upper;   /* host, k entries (LINEAR/POWER) */
-    const uint32_t* perm;  /* host, n entries: M_2[r] = second_half[perm[r]]
-                              (the seed-1 shuffle, saltelli.py:100-101); NULL = identity */
+    const uint32_t* perm;  /* host: M_2[r] = second_half[perm[r - perm_begin]] for the rows
+                              [perm_begin, perm_begin + perm_count) (the seed-1 shuffle, saltelli.py:100-101);
+                              NULL = identity.  perm_count = 0 means all n rows from row 0.  A rank of a
+                              multi-GPU job passes its own shard's slice only; vs_eval then accepts rows of
+                              that slice, and vs_sample_flat needs the whole shuffle. */
     const double* raw;     /* host (2n,k) unit-cube points for VS_GEN_RAW
                               (Sample(raw=...), saltelli.py:69-73), uploaded */
     const uint32_t* sobol_directions; /* host (k,32) for VS_GEN_SOBOL, uploaded */
+    uint64_t perm_begin;   /* first design row `perm` covers */
+    uint64_t perm_count;   /* entries in `perm` (0: n) */
 } vs_design_desc;
 
 /* Host helper (no GPU involved): out[r] = index of the row that numpy.random.seed(1);

@@ -268,9 +268,11 @@ def scan_shape(k, fused=False):
     if k <= 8: return 2, 4
     if k <= 16: return 4, 4
     if k <= 32: return 8, 4
+    if k <= 48: return 12, 4
     if k <= 64: return 8, 8
+    if k <= 96: return 12, 8
     if k <= 128: return (8, 16) if fused else (16, 8)
-    if k <= 256 and not fused: return 16, 16
+    if k <= 256 and not fused: return 32, 8
     raise ValueError("k=%d is outside the scan kernels" % k)
 
 
@@ -345,6 +347,19 @@ def evaluate_scan(kind, params, M_1, M_2, fused=False):
                                     scan_shape(k, fused), add=(kind == "linear"))
         fM_1[:, o], fM_2[:, o], fN_j[:, :, o], fN_nj[:, :, o] = a, b, c, d
     return fM_1, fM_2, fN_j, fN_nj
+
+
+def evaluate_engine_order(kind, params, M_1, M_2, strict=False):
+    """A built-in separable objective in the order the engine's vs_eval uses by default: the scan
+    order for k <= 256 (VS_ORDER_FAST), strictly left to right beyond that or when ``strict``
+    (VS_ORDER_STRICT, = numpy.prod over the factors as in the reference's tests)."""
+    P = np.atleast_2d(np.asarray(params, dtype=np.float64))
+    k = M_1.shape[1]
+    if k <= 256 and not strict:
+        return evaluate_scan(kind, P, M_1, M_2)
+    one = {"g_function": g_function_rows, "linear": linear_rows, "polynomial": polynomial_rows}[kind]
+    return evaluate_rows(lambda X: np.stack([one(X, p) for p in P], axis=-1), M_1, M_2,
+                         column_swap(M_2, M_1), column_swap(M_1, M_2))
 
 
 # ----------------------------------------------------------------------------

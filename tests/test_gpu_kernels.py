@@ -101,10 +101,9 @@ def oracle_blocks(F):
 @pytest.mark.parametrize("k,n,l", [(6, 1024, 1), (6, 1024, 2), (1, 7, 1), (33, 300, 1), (70, 129, 1),
                                    (197, 700, 1), (100, 200, 2), (300, 70, 1)])
 def test_eval_gfunction_bit_exact(ctx, k, n, l):
-    """Up to 32 columns the chain kernel folds strictly left to right (the oracle's *_rows order); from
-    33 to 256 columns the scan kernels fold in the segmented order the oracle restates in
-    evaluate_scan -- bit-exact against that, rounding-close to the strict order.  k = 300 exceeds both the
-    scan kernels and the LDS tile: chain kernel with its tile in an HBM scratch slice."""
+    """Up to 256 columns the scan kernels fold in the segmented order the oracle restates in evaluate_scan --
+    bit-exact against that, rounding-close to the strict left-to-right product.  k = 300 exceeds both the
+    scan kernels and the LDS tile: chain kernel (strict order) with its tile in an HBM scratch slice."""
     from varsens_amd import _native
     rng = np.random.RandomState(k)
     a = np.array(A6, dtype=float) if k == 6 else rng.rand(k) * 10
@@ -112,13 +111,35 @@ def test_eval_gfunction_bit_exact(ctx, k, n, l):
     d = make_design(ctx, k, n)
     _, got = eval_dev(ctx, d, _native.OBJ_G_FUNCTION, k, l, A, n)
     S = orc.build_sample(k, n)
-    strict = oracle_blocks(orc.evaluate_rows(
-        lambda X: np.stack([orc.g_function_rows(X, A[o]) for o in range(l)], axis=-1), *S))
-    if 33 <= k <= 256:
-        same(got, oracle_blocks(orc.evaluate_scan("g_function", A, S[0], S[1])))
-        assert np.max(np.abs(got - strict) / np.abs(strict)) <= 4e-15      # reassociation of <= 256 factors
-    else:
-        same(got, strict)
+    strict = oracle_blocks(orc.evaluate_engine_order("g_function", A, S[0], S[1], strict=True))
+    same(got, oracle_blocks(orc.evaluate_engine_order("g_function", A, S[0], S[1])))
+    assert np.max(np.abs(got - strict) / np.abs(strict)) <= 6e-15      # reassociation of <= 256 factors
+
+
+@pytest.fixture(scope="module")
+def strict_ctx():
+    """A context in strict evaluation order: separable objectives fold left to right (chain kernels), the
+    bits of numpy.prod over the factors, which is what the reference's test objectives compute."""
+    from varsens_amd import _native
+    c = _native.Context(0)
+    c.set_eval_order("strict")
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("k,n,l", [(6, 1024, 1), (6, 1024, 2), (1, 7, 1), (33, 300, 1), (70, 129, 1), (100, 200, 2)])
+def test_eval_strict_order_bit_exact(strict_ctx, k, n, l):
+    from varsens_amd import _native
+    rng = np.random.RandomState(k)
+    a = np.array(A6, dtype=float) if k == 6 else rng.rand(k) * 10
+    A = np.stack([a, a[::-1]])[:l]
+    _, got = eval_dev(strict_ctx, make_design(strict_ctx, k, n), _native.OBJ_G_FUNCTION, k, l, A, n)
+    S = orc.build_sample(k, n)
+    same(got, oracle_blocks(orc.evaluate_rows(
+        lambda X: np.stack([orc.g_function_rows(X, A[o]) for o in range(l)], axis=-1), *S)))
+    d = make_design(strict_ctx, k, n)
+    obj = strict_ctx.objective_create(_native.OBJ_G_FUNCTION, k, l, A)
+    assert not strict_ctx.eval_reduce_supported(d, obj)      # the fused kernels fold in scan order
 
 
 def tuned_context(monkeypatch, **env):
@@ -133,18 +154,19 @@ def tuned_context(monkeypatch, **env):
     return c
 
 
-def test_eval_scratch_tile_path_forced(ctx, monkeypatch):
-    """The HBM-scratch tile variant on a size that also fits LDS: identical bits, several blocks per workgroup."""
+def test_eval_scratch_tile_path_forced(strict_ctx, monkeypatch):
+    """The HBM-scratch tile variant of the chain kernel on a size that also fits LDS: identical bits, several
+    blocks per workgroup."""
     from varsens_amd import _native
     k, n = 12, 300000
     a = np.linspace(0.1, 9.0, k)
-    _, want = eval_dev(ctx, make_design(ctx, k, n), _native.OBJ_G_FUNCTION, k, 1, a, n)
+    _, want = eval_dev(strict_ctx, make_design(strict_ctx, k, n), _native.OBJ_G_FUNCTION, k, 1, a, n)
     c2 = tuned_context(monkeypatch, VS_EVAL_SCRATCH=1)
     d2 = make_design(c2, k, n)
     _, got = eval_dev(c2, d2, _native.OBJ_G_FUNCTION, k, 1, a, n)
     same(got, want)
     _, got = eval_dev(c2, d2, _native.OBJ_INVERT, k, k, None, 5000)
-    _, want = eval_dev(ctx, make_design(ctx, k, n), _native.OBJ_INVERT, k, k, None, 5000)
+    _, want = eval_dev(strict_ctx, make_design(strict_ctx, k, n), _native.OBJ_INVERT, k, k, None, 5000)
     same(got, want)
     d2.free()
     c2.close()
@@ -157,10 +179,10 @@ def test_eval_linear_polynomial_bit_exact(ctx):
     S = orc.build_sample(k, n)
     c = np.arange(1, k + 1, dtype=float)
     _, got = eval_dev(ctx, d, _native.OBJ_LINEAR, k, 1, c, n)
-    same(got, oracle_blocks(orc.evaluate_rows(lambda X: orc.linear_rows(X, c), *S)))
+    same(got, oracle_blocks(orc.evaluate_engine_order("linear", c, S[0], S[1])))
     beta = 1.0 / (1.0 + np.arange(k) / 8.0)
     _, got = eval_dev(ctx, d, _native.OBJ_POLYNOMIAL, k, 1, beta, n)
-    same(got, oracle_blocks(orc.evaluate_rows(lambda X: orc.polynomial_rows(X, beta), *S)))
+    same(got, oracle_blocks(orc.evaluate_engine_order("polynomial", beta, S[0], S[1])))
 
 
 def test_eval_ishigami(ctx):
@@ -629,3 +651,37 @@ def test_very_large_k(ctx):
     same(got, want)
     rec, fin = reduce_dev(ctx, got, n)
     check_against_exact(rec, fin, got, n)
+
+
+def test_design_with_a_slice_of_the_shuffle(ctx):
+    """A rank of a multi-GPU job uploads only the seed-1 shuffle entries of its own rows (vs_design_desc.perm_begin /
+    perm_count): same values as the whole design on those rows, other rows refused."""
+    from varsens_amd import _native
+    k, n = 9, 5001
+    begin, count = 1250, 1250
+    perm = orc.seed1_permutation(n).astype(np.uint32)
+    whole = ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 0, None, None, perm)
+    part = ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 0, None, None, perm[begin:begin + count],
+                             perm_begin=begin)
+    a = np.linspace(0.0, 4.0, k)
+    _, want = eval_dev(ctx, whole, _native.OBJ_G_FUNCTION, k, 1, a, n, begin=begin, count=count)
+    _, got = eval_dev(ctx, part, _native.OBJ_G_FUNCTION, k, 1, a, n, begin=begin, count=count)
+    same(got, want)
+    _, got = eval_dev(ctx, part, _native.OBJ_INVERT, k, k, None, n, begin=begin + 7, count=100)       # chain kernel
+    _, want = eval_dev(ctx, whole, _native.OBJ_INVERT, k, k, None, n, begin=begin + 7, count=100)
+    same(got, want)
+    obj = ctx.objective_create(_native.OBJ_G_FUNCTION, k, 1, a)
+    nacc = _native.acc_len(k, 1, 1)
+    acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
+    ctx.eval_reduce_first_order(whole, obj, begin, count, acc1)
+    ctx.eval_reduce_first_order(part, obj, begin, count, acc2)
+    same(ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,)))
+    f = ctx.alloc(8 * 2 * (k + 1) * 10)
+    with pytest.raises(_native.VarsensHipError, match="shuffle slice"):
+        ctx.eval(part, obj, begin - 1, 10, f)
+    with pytest.raises(_native.VarsensHipError, match="shuffle slice"):
+        ctx.eval_reduce_first_order(part, obj, begin + count - 5, 10, acc1)
+    with pytest.raises(_native.VarsensHipError, match="whole shuffle"):
+        ctx.sample_flat(part, 0, 10, f)
+    with pytest.raises(_native.VarsensHipError, match="exceeds n|perm must hold"):
+        ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 0, None, None, perm[:100], perm_begin=n - 50)

@@ -84,9 +84,11 @@ def test_evaluation_any_shape(k, n, kind, l, discard, begin_frac, mode):
         P = 0.5 + rng.rand(l, k)
         params = P
         code = {"g": _native.OBJ_G_FUNCTION, "lin": _native.OBJ_LINEAR, "poly": _native.OBJ_POLYNOMIAL}[kind]
-        one = {"g": orc.g_function_rows, "lin": orc.linear_rows, "poly": orc.polynomial_rows}[kind]
-        rows_func = lambda X: np.stack([one(X, P[o]) for o in range(l)], axis=-1)
-    want = orc.evaluate_rows(rows_func, *S)
+        rows_func = None
+    if rows_func is None:     # separable built-ins: the engine's default (scan) association order
+        want = orc.evaluate_engine_order({"g": "g_function", "lin": "linear", "poly": "polynomial"}[kind], P, S[0], S[1])
+    else:
+        want = orc.evaluate_rows(rows_func, *S)
     want = np.concatenate([want[0][None], want[1][None], want[2], want[3]], axis=0)
     begin = int(begin_frac * (n - 1))
     count = n - begin

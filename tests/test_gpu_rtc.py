@@ -23,12 +23,19 @@ def vs():
 def test_expression_equals_builtin_gfunction_bit_for_bit(vs):
     k, n = 6, 4096
     s = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
-    o1 = vs.Objective(k, n, s, vs.objectives.GFunction(A6), verbose=False)
+    s._ctx.set_eval_order("strict")     # the built-in then multiplies left to right, like the user's loop
+    try:
+        o1 = vs.Objective(k, n, s, vs.objectives.GFunction(A6), verbose=False)
+    finally:
+        s._ctx.set_eval_order("fast")
     o2 = vs.Objective(k, n, s, vs.objectives.Expression(G_BODY, params=A6), verbose=False)
     assert np.array_equal(o1.flat(), o2.flat())
     S = orc.build_sample(k, n)
     F = orc.evaluate_rows(lambda X: orc.g_function_rows(X, A6), *S)
     assert np.array_equal(o2.flat(), orc.flat_objective(*F))
+    o3 = vs.Objective(k, n, s, vs.objectives.GFunction(A6), verbose=False)      # default order: scan kernels
+    assert np.array_equal(o3.flat(), orc.flat_objective(*orc.evaluate_engine_order("g_function", A6, S[0], S[1])))
+    assert np.max(np.abs(o3.flat() - o2.flat()) / o2.flat()) <= 1e-15
 
 
 def test_expression_ishigami_matches_builtin_and_truth(vs):
@@ -69,7 +76,11 @@ def test_expression_beyond_lds_budget(vs):
     k, n = 200, 150
     a = np.linspace(0.0, 50.0, k)
     s = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
-    o1 = vs.Objective(k, n, s, vs.objectives.GFunction(a), verbose=False)
+    s._ctx.set_eval_order("strict")     # the built-in multiplies left to right, like the user's loop
+    try:
+        o1 = vs.Objective(k, n, s, vs.objectives.GFunction(a), verbose=False)
+    finally:
+        s._ctx.set_eval_order("fast")
     o2 = vs.Objective(k, n, s, vs.objectives.Expression(G_BODY, params=a), verbose=False)
     assert np.array_equal(o1.flat(), o2.flat())
 

@@ -2,7 +2,7 @@
 the C ABI.  GPU only.
 
 * evaluation (vs_eval, k >= 33 by itself; forced at small k through VS_EVAL_MODE=2): bit-exact against the
-  oracle's restatement of the kernels' association order (orc.evaluate_scan), rounding-close (<= 4e-15
+  oracle's restatement of the kernels' association order (orc.evaluate_scan), rounding-close (<= 6e-15
   relative) to the strict left-to-right folds the chain kernel and the reference's numpy.prod produce;
 * fused evaluate + first-order reduce (vs_eval_reduce_first_order): its accumulator record against the
   exactly rounded sums of the oracle's values in the fused kernels' order, and against the two-kernel path
@@ -96,7 +96,7 @@ def test_scan_eval_default_route(ctx, kind, k, n, l):
     _, _, got = device_blocks(ctx, design(ctx, k, n), kind, k, l, P, n)
     same(got, blocks_of(orc.evaluate_scan(kind, P, S[0], S[1])))
     strict = strict_blocks(kind, P, S)
-    assert np.max(np.abs(got - strict) / np.maximum(np.abs(strict), 1e-300)) <= 4e-15
+    assert np.max(np.abs(got - strict) / np.maximum(np.abs(strict), 1e-300)) <= 6e-15
 
 
 @pytest.mark.parametrize("kind,k,n,l", [("g_function", 6, 1024, 1), ("g_function", 6, 1000, 2), ("linear", 1, 7, 1),

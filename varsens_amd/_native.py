@@ -12,17 +12,18 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARSENS_HIP_LIB") or os.path.join(_HERE, "libvarsens_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 COMM_ID_BYTES = 128
 
 GEN_HALTON, GEN_SOBOL, GEN_RAW = 0, 1, 2
 SCALE_IDENTITY, SCALE_LINEAR, SCALE_POWER = 0, 1, 2
 OBJ_G_FUNCTION, OBJ_ISHIGAMI, OBJ_LINEAR, OBJ_POLYNOMIAL, OBJ_INVERT, OBJ_SOURCE = 1, 2, 3, 4, 5, 6
 REDUCE_NAN_TRIM = 1
+ORDER_FAST, ORDER_STRICT = 0, 1
 
 KERNEL_NAMES = {
     1: "halton_fill", 2: "sobol_fill", 3: "sample_flat", 4: "eval", 5: "reduce_first",
-    6: "fold", 7: "finish", 8: "nan_mask", 9: "second_order", 10: "second_fold", 11: "fused",
+    6: "fold", 7: "finish", 8: "nan_mask", 9: "second_order", 10: "second_fold", 11: "fused", 12: "allreduce",
 }
 
 ACC_HEADER = 4
@@ -72,7 +73,7 @@ class DesignDesc(C.Structure):
     _fields_ = [("generator", C.c_int32), ("k", C.c_int32), ("n", C.c_uint64), ("first_index", C.c_uint64),
                 ("scale_mode", C.c_int32), ("reserved", C.c_int32),
                 ("lower", C.c_void_p), ("upper", C.c_void_p), ("perm", C.c_void_p), ("raw", C.c_void_p),
-                ("sobol_directions", C.c_void_p)]
+                ("sobol_directions", C.c_void_p), ("perm_begin", C.c_uint64), ("perm_count", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/varsens_hip.h declares
@@ -84,6 +85,7 @@ SIGNATURES = {
     "vs_context_destroy": (C.c_int, [C.c_void_p]),
     "vs_context_info": (C.c_int, [C.c_void_p, C.POINTER(DeviceInfo)]),
     "vs_sync": (C.c_int, [C.c_void_p]),
+    "vs_context_set_eval_order": (C.c_int, [C.c_void_p, C.c_int]),
     "vs_stream_select": (C.c_int, [C.c_void_p, C.c_int]),
     "vs_event_record": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "vs_stream_wait_event": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
@@ -213,6 +215,25 @@ class DeviceBuffer(object):
             pass
 
 
+class DeviceView(object):
+    """A window [byte_offset, byte_offset + nbytes) of a DeviceBuffer; accepted wherever a buffer is.
+    (The accumulator record and the second-order Gram sums live in ONE buffer so that a rank makes one
+    all-reduce call; the kernels see two windows of it.)"""
+
+    def __init__(self, buf, byte_offset, nbytes):
+        if byte_offset < 0 or byte_offset + nbytes > buf.nbytes:
+            raise VarsensHipError("view exceeds the device buffer")
+        self.base, self.ctx = buf, buf.ctx
+        self.ptr = buf.ptr + int(byte_offset)
+        self.nbytes = int(nbytes)
+
+    def at(self, byte_offset):
+        return C.c_void_p(self.ptr + int(byte_offset))
+
+    def free(self):
+        pass    # the parent buffer owns the memory
+
+
 class Context(object):
     """One GPU + one HIP stream (vs_context)."""
 
@@ -246,6 +267,13 @@ class Context(object):
 
     def sync(self):
         _check(self.lib.vs_sync(self.handle))
+
+    def set_eval_order(self, order):
+        """'fast' (default): scan kernels, reassociated k-term folds; 'strict': left-to-right folds, bit-identical
+        to numpy.prod over the factors (include/varsens_hip.h, vs_context_set_eval_order)."""
+        if order not in ("fast", "strict"):
+            raise VarsensHipError("order must be 'fast' or 'strict'")
+        _check(self.lib.vs_context_set_eval_order(self.handle, ORDER_STRICT if order == "strict" else ORDER_FAST))
 
     def stream_select(self, which):
         _check(self.lib.vs_stream_select(self.handle, int(which)))
@@ -314,7 +342,9 @@ class Context(object):
 
     # -- design / objective handles
     def design_create(self, generator, k, n, first_index=0, scale_mode=SCALE_IDENTITY, lower=None, upper=None,
-                      perm=None, raw=None, sobol_directions=None):
+                      perm=None, raw=None, sobol_directions=None, perm_begin=0):
+        """``perm``: the whole seed-1 permutation (n entries), or -- with ``perm_begin`` -- the entries of a
+        rank's own rows [perm_begin, perm_begin + len(perm)) only."""
         keep = []
 
         def ptr(a, dtype, shape=None):
@@ -333,7 +363,12 @@ class Context(object):
         desc.scale_mode = int(scale_mode)
         desc.lower = ptr(lower, np.float64, (k,))
         desc.upper = ptr(upper, np.float64, (k,))
-        desc.perm = ptr(perm, np.uint32, (n,))
+        desc.perm = ptr(perm, np.uint32)
+        if perm is not None:
+            count = keep[-1].size
+            if keep[-1].ndim != 1 or perm_begin < 0 or perm_begin + count > n or (perm_begin == 0 and count == 0):
+                raise VarsensHipError("perm must hold the shuffle entries of rows [perm_begin, perm_begin+len) of n")
+            desc.perm_begin, desc.perm_count = int(perm_begin), int(count)
         desc.raw = ptr(raw, np.float64, (2 * n, k))
         desc.sobol_directions = ptr(sobol_directions, np.uint32, (k, 32))
         h = C.c_void_p()

@@ -70,6 +70,7 @@ extern "C" int vs_context_create(int device, vs_context** out) {
         t.eval_mode = (int)env_long("VS_EVAL_MODE", t.eval_mode);
         t.fused_wgs_per_cu = (int)env_long("VS_FUSED_WGS_PER_CU", t.fused_wgs_per_cu);
         t.fused_variant = (int)env_long("VS_FUSED_VARIANT", t.fused_variant);
+        t.scan_shape = (int)env_long("VS_SCAN_SHAPE", t.scan_shape);
         t.gram_wgs_per_cu = (int)env_long("VS_GRAM_WGS_PER_CU", t.gram_wgs_per_cu);
         t.reduce_both = (int)env_long("VS_REDUCE_BOTH", t.reduce_both);
         t.profile_mask = env_long("VS_PROFILE_MASK", t.profile_mask);
@@ -121,6 +122,13 @@ extern "C" int vs_context_info(vs_context* ctx, vs_device_info* out) {
     out->lds_bytes_per_cu = (int32_t)ctx->prop.maxSharedMemoryPerMultiProcessor;
     out->clock_mhz = ctx->prop.clockRate / 1000;
     out->hbm_bytes = ctx->prop.totalGlobalMem;
+    return VS_OK;
+}
+
+extern "C" int vs_context_set_eval_order(vs_context* ctx, int order) {
+    VS_REQUIRE(ctx, "ctx is null");
+    VS_REQUIRE(order == VS_ORDER_FAST || order == VS_ORDER_STRICT, "order must be VS_ORDER_FAST or VS_ORDER_STRICT");
+    ctx->tune.eval_mode = order == VS_ORDER_STRICT ? 1 : 0;
     return VS_OK;
 }
 

@@ -78,6 +78,7 @@ extern "C" int vs_comm_init(vs_context* ctx, const void* id, int nranks, int ran
 extern "C" int vs_comm_allreduce(vs_context* ctx, double* buf_dev, size_t count) {
     VS_REQUIRE(ctx && buf_dev, "null argument");
     if (!ctx->comm) return vs_fail(VS_ERR_STATE, "vs_comm_init has not been called on this context");
+    vs_launch_scope scope(ctx, VS_KERNEL_ALLREDUCE);
     VS_NCCL(g_rccl.AllReduce(buf_dev, buf_dev, count, ncclFloat64, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
     return VS_OK;
 }

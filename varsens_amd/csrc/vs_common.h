@@ -23,9 +23,10 @@ struct vs_tuning {
     int reduce_wgs_per_cu = 1;   // VS_REDUCE_WGS_PER_CU
     int eval_scratch = 0;        // VS_EVAL_SCRATCH=1: chain kernel with its tile in HBM scratch (tests force it at small k)
     int eval_waves = 0;          // VS_EVAL_WAVES_PER_WG: 4 or 8 (0 = by tile size)
-    int eval_mode = 0;           // VS_EVAL_MODE: 0 = by k, 1 = chain scheme (strict left-to-right folds), 2 = segmented scan
+    int eval_mode = 0;           // vs_context_set_eval_order / VS_EVAL_MODE: 0 = scan kernels where they apply, 1 = strict order (chain scheme)
     int fused_wgs_per_cu = 0;    // VS_FUSED_WGS_PER_CU (0 = by kernel)
-    int fused_variant = 0;       // VS_FUSED_VARIANT=1: 64 < k <= 128 fused as 8 waves x 16 columns instead of 16 x 8
+    int scan_shape = 0;          // VS_SCAN_SHAPE=L*100+W: force the evaluation scan kernel's shape (must be instantiated)
+    int fused_variant = 0;       // VS_FUSED_VARIANT=1 or L*100+W: 64 < k <= 128 fused as 8 waves x 16 columns instead of 16 x 8
     int gram_wgs_per_cu = 0;     // VS_GRAM_WGS_PER_CU (0 = by shape)
     int reduce_both = 1;         // VS_REDUCE_BOTH=0: never take the combined first+second-order kernel
     long profile_mask = -1;      // VS_PROFILE_MASK: bracket only these kernel ids with events
@@ -81,7 +82,7 @@ struct vs_objective {
     void* module = nullptr;    // hipModule_t of a run-time compiled objective
     void* function = nullptr;  // hipFunction_t (vs_user_eval)
     void* fused_function = nullptr;  // hipFunction_t (vs_user_fused): separable source objectives with k <= 128
-    bool eval_scan = false;    // vs_user_eval is the scan kernel (separable, k >= 33): one 64-row block per workgroup
+    bool eval_scan = false;    // vs_user_eval is the scan kernel (separable source objective): one 64-row block per workgroup
     int eval_threads = 256;    // launch shape of vs_user_eval / vs_user_fused
     size_t eval_lds = 0;       //   (eval_lds = 0: the 2k x 64 tile of the chain / general kernels)
     int fused_threads = 0;
@@ -97,7 +98,7 @@ int vs_rtc_launch_fused(vs_context* ctx, const vs_objective* o, const void* eval
                         unsigned P, const double* shift_dev);
 // launch shape of the scan kernels for k columns (vs_scan.hip); false: k is outside them
 bool vs_scan_shape(int k, bool fused, int* L, int* W, int* tlds, size_t* lds_bytes);
-#define VS_SCAN_MIN_K 33   // first k at which vs_eval takes the scan kernels by itself (measured crossover)
+int vs_rtc_fused_plan(vs_context* ctx, const vs_objective* o, uint64_t rows, unsigned* P_out);
 
 int vs_fail(int code, const char* fmt, ...);
 

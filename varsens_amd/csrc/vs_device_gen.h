@@ -201,7 +201,8 @@ struct vs_design_dev {
     vs_u64 n, first_index;
     const double* lower;
     const double* width;
-    const vs_u32* perm;
+    const vs_u32* perm;     // entries of rows [perm_begin, perm_begin + perm_count) of the seed-1 shuffle, or null
+    vs_u64 perm_begin;
     const double* raw;
     const vs_u32* dirs;
     const vs_u32* sobol_tabs;
@@ -216,6 +217,11 @@ __device__ __forceinline__ double vs_unit_point(const vs_design_dev& D, vs_u64 s
     return D.raw[seq_row * (vs_u64)D.k + c];
 }
 
+// row of the un-shuffled second half that the seed-1 shuffle moved to row r (r inside the design's slice)
+__device__ __forceinline__ vs_u64 vs_perm_at(const vs_design_dev& D, vs_u64 r) {
+    return D.perm ? (vs_u64)D.perm[r - D.perm_begin] : r;
+}
+
 __device__ __forceinline__ double vs_apply_scale(const vs_design_dev& D, double p, int c) {
     if (D.scale_mode == VS_SCALE_LINEAR) return p * D.width[c] + D.lower[c];   // scale.py:33
     if (D.scale_mode == VS_SCALE_POWER) return D.lower[c] * pow(D.width[c], p); // scale.py:62
@@ -227,7 +233,7 @@ __device__ __forceinline__ double vs_m1(const vs_design_dev& D, vs_u64 r, int c)
     return vs_apply_scale(D, vs_unit_point(D, r, c), c);
 }
 __device__ __forceinline__ double vs_m2(const vs_design_dev& D, vs_u64 r, int c) {
-    vs_u64 src = D.perm ? (vs_u64)D.perm[r] : r;
+    vs_u64 src = vs_perm_at(D, r);
     return vs_apply_scale(D, vs_unit_point(D, D.n + src, c), c);
 }
 

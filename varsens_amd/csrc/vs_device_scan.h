@@ -79,58 +79,19 @@ struct vs_scan_acc {
 // bits as keeping all L suffixes, with 2(L/SUB + SUB) registers instead of 2L.
 #define VS_SCAN_SUB 4
 
-template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS>
-__device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const double* __restrict__ params,
-                                              int q, int lane, vs_u64 rb, double* __restrict__ tot,
-                                              double* __restrict__ tl, double* __restrict__ fplane, double shift,
-                                              vs_scan_acc<L>& acc) {
+// Everything behind the terms of one output: totals exchange, prefixes, suffix checkpoints, outputs.
+// ta/tb: the wave's 2L terms in registers (TLDS: in its LDS slab `tl` instead); Ta/Tb their totals.
+template <int FOLD, int L, int W, bool FUSED, bool TLDS>
+__device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L], const double (&tb)[TLDS ? 1 : L],
+                                               const double* __restrict__ tl, double Ta, double Tb,
+                                               double* __restrict__ tot, int q, int lane, double* __restrict__ f,
+                                               vs_u64 rows, int k, bool valid, double shift, vs_scan_acc<L>& acc) {
     constexpr int T = VS_EVAL_ROWS;
     constexpr int SUB = L < VS_SCAN_SUB ? L : VS_SCAN_SUB;
     constexpr int NSUB = L / SUB;
-    // q is loop-invariant in the persistent walk; tied to the block index here, or the optimiser hoists
-    // every column's addresses and masks (all derived from q) out of that loop and spills scalars for
-    // them.  (Not `volatile`: a volatile asm counts as a memory clobber and turns every scalar load of
-    // design constants behind it into a vector load.)
-    {
-        const vs_u32 rb_lo = (vs_u32)rb;
-        asm("" : "+s"(q) : "s"(rb_lo));
-    }
-    const int k = A.D.k;
-    const vs_u64 rows = A.rows;
-    const vs_u64 lr = rb * T + lane;
-    const bool valid = lr < rows;
-    const vs_u64 r = A.row_begin + (valid ? lr : rows - 1);  // clamp: loads stay in range, stores are guarded
     const double ident = FOLD == VS_OBJ_LINEAR ? 0.0 : 1.0;
-    const vs_u64 src2 = A.D.perm ? (vs_u64)A.D.perm[r] : r;  // row of the un-shuffled second half behind M_2[r]
-
-    // ---- terms of this wave's segment (registers, or the wave's LDS slab) and their totals
-    double ta[TLDS ? 1 : L], tb[TLDS ? 1 : L];
 #define VS_TA(j) (TLDS ? tl[(size_t)(j) * T] : ta[TLDS ? 0 : (j)])
 #define VS_TB(j) (TLDS ? tl[(size_t)(L + (j)) * T] : tb[TLDS ? 0 : (j)])
-    double Ta = ident, Tb = ident;
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-        const int c = q * L + j;  // wave-uniform
-        double t1 = ident, t2 = ident;
-        if (c < k) {
-            double x1, x2;
-            vs_unit_pair(A.D, r, A.D.n + src2, c, x1, x2);
-            t1 = Term::eval(vs_apply_scale_compact<!FUSED>(A.D, x1, c), c, params);
-            t2 = Term::eval(vs_apply_scale_compact<!FUSED>(A.D, x2, c), c, params);
-        }
-        if (TLDS) {
-            tl[(size_t)j * T] = t1;
-            tl[(size_t)(L + j) * T] = t2;
-        } else {
-            ta[TLDS ? 0 : j] = t1;
-            tb[TLDS ? 0 : j] = t2;
-        }
-        Ta = vs_fold<FOLD>(Ta, t1);
-        Tb = vs_fold<FOLD>(Tb, t2);
-        // one column at a time: left alone the scheduler hoists the scalar loads of all L columns'
-        // base constants to the top and spills scalars into vector lanes
-        __builtin_amdgcn_sched_barrier(0);
-    }
     tot[(0 * W + q) * T + lane] = Ta;
     tot[(1 * W + q) * T + lane] = Tb;
     __syncthreads();
@@ -171,7 +132,6 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
         }
     }
     // ---- outputs, sub-block by sub-block
-    double* f = FUSED ? nullptr : fplane + rb * T + lane;
     double pa = Pa, pb = Pb;
 #pragma unroll
     for (int m = 0; m < NSUB; ++m) {
@@ -227,6 +187,92 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     }
 }
 
+// One 64-row block.  MULTI (evaluation only, l > 1): the scaled coordinates of the segment stay in
+// registers and every output o builds its own terms from them (parameters params + o*k, plane o of
+// the f-values; the two totals slabs alternate per output, one barrier each) -- the generator runs
+// once per row whatever l is.  Otherwise one output (`params`, `fplane` are that output's).
+template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI>
+__device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const double* __restrict__ params,
+                                              int q, int lane, vs_u64 rb, double* __restrict__ tot,
+                                              double* __restrict__ tl, double* __restrict__ fplane, double shift,
+                                              vs_scan_acc<L>& acc) {
+    constexpr int T = VS_EVAL_ROWS;
+    // q is loop-invariant in the persistent walk; tied to the block index here, or the optimiser hoists
+    // every column's addresses and masks (all derived from q) out of that loop and spills scalars for
+    // them.  (Not `volatile`: a volatile asm counts as a memory clobber and turns every scalar load of
+    // design constants behind it into a vector load.)
+    {
+        const vs_u32 rb_lo = (vs_u32)rb;
+        asm("" : "+s"(q) : "s"(rb_lo));
+    }
+    const int k = A.D.k;
+    const vs_u64 rows = A.rows;
+    const vs_u64 lr = rb * T + lane;
+    const bool valid = lr < rows;
+    const vs_u64 r = A.row_begin + (valid ? lr : rows - 1);  // clamp: loads stay in range, stores are guarded
+    const double ident = FOLD == VS_OBJ_LINEAR ? 0.0 : 1.0;
+    const vs_u64 src2 = vs_perm_at(A.D, r);  // row of the un-shuffled second half behind M_2[r]
+    double* f = FUSED ? nullptr : fplane + rb * T + lane;
+
+    // ---- this wave's segment: coordinates -> terms (registers, or the wave's LDS slab) and their totals
+    double ta[TLDS ? 1 : L], tb[TLDS ? 1 : L];
+    double Ta = ident, Tb = ident;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const int c = q * L + j;  // wave-uniform
+        double t1 = ident, t2 = ident;
+        if (c < k) {
+            double x1, x2;
+            vs_unit_pair(A.D, r, A.D.n + src2, c, x1, x2);
+            t1 = vs_apply_scale_compact<!FUSED>(A.D, x1, c);
+            t2 = vs_apply_scale_compact<!FUSED>(A.D, x2, c);
+            if (!MULTI) {
+                t1 = Term::eval(t1, c, params);
+                t2 = Term::eval(t2, c, params);
+            }
+        }
+        if (TLDS) {
+            tl[(size_t)j * T] = t1;
+            tl[(size_t)(L + j) * T] = t2;
+        } else {
+            ta[TLDS ? 0 : j] = t1;   // MULTI: the coordinates
+            tb[TLDS ? 0 : j] = t2;
+        }
+        if (!MULTI) {
+            Ta = vs_fold<FOLD>(Ta, t1);
+            Tb = vs_fold<FOLD>(Tb, t2);
+        }
+        // one column at a time: left alone the scheduler hoists the scalar loads of all L columns'
+        // base constants to the top and spills scalars into vector lanes
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (!MULTI) {
+        vs_scan_finish<FOLD, L, W, FUSED, TLDS>(ta, tb, tl, Ta, Tb, tot, q, lane, f, rows, k, valid, shift, acc);
+    } else {
+        const vs_u64 plane = (2 * (vs_u64)k + 2) * rows;
+        for (int o = 0; o < A.l; ++o) {
+            int qo = q;
+            asm("" : "+s"(qo) : "s"(o));  // as above: keep q-derived addresses inside the loop over outputs
+            const double* po = params + (size_t)o * k;
+            double ua[L], ub[L];
+            Ta = Tb = ident;
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                const int c = qo * L + j;
+                ua[j] = ub[j] = ident;
+                if (c < k) {
+                    ua[j] = Term::eval(ta[TLDS ? 0 : j], c, po);
+                    ub[j] = Term::eval(tb[TLDS ? 0 : j], c, po);
+                }
+                Ta = vs_fold<FOLD>(Ta, ua[j]);
+                Tb = vs_fold<FOLD>(Tb, ub[j]);
+            }
+            vs_scan_finish<FOLD, L, W, FUSED, false>(ua, ub, tl, Ta, Tb, tot + (o & 1) * (2 * W * T), qo, lane,
+                                                     f + (vs_u64)o * plane, rows, k, valid, shift, acc);
+        }
+    }
+}
+
 // LDS doubles a workgroup of the scan kernels needs: totals slabs (two, or one when the terms take
 // the room) + the wave-private term slabs
 template <int L, int W, bool TLDS>
@@ -241,14 +287,14 @@ struct vs_scan_lds {
 // (every output is its own plane of f-values / its own record; params + o*k are its parameters).
 // FUSED: one partial record per workgroup and output, layout and fold of reduce_first_kernel
 // (partials[(blockIdx.x * l + o) * VS_PLEN(k)], VS_PLEN = 5 + 4k).
-template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS>
+template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI = false>
 __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __restrict__ lds,
                                              const double* __restrict__ shift_src, double* __restrict__ partials) {
     constexpr int T = VS_EVAL_ROWS;
     const int k = A.D.k;
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index, provably uniform
-    const int o = blockIdx.y;
+    const int o = MULTI ? 0 : blockIdx.y;   // MULTI: all outputs inside the block walk
     const double* params = A.params + (size_t)o * k;
     double* fplane = FUSED ? nullptr : A.f + (vs_u64)o * (2 * (vs_u64)k + 2) * A.rows;
     const double shift = FUSED ? shift_src[(size_t)o * (2 * (size_t)k + 2)] : 0.0;  // f_o(M_1[row]) of a one-row evaluation
@@ -266,8 +312,8 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
     // (one slab: a second barrier closes the block instead.)
     if (FUSED) {
         for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-            vs_scan_block<Term, FOLD, L, W, FUSED, TLDS>(A, params, q, lane, rb, lds + parity * (2 * W * T), tl,
-                                                         fplane, shift, acc);
+            vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, false>(A, params, q, lane, rb, lds + parity * (2 * W * T), tl,
+                                                                fplane, shift, acc);
             if (TLDS) __syncthreads();
             else parity ^= 1;
         }
@@ -275,7 +321,7 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
         // one block per workgroup: every load of design constants then precedes every store of the
         // kernel, so the compiler may take them through the scalar cache (a persistent walk makes them
         // "possibly clobbered" and turns them into vector loads with a wait per column)
-        vs_scan_block<Term, FOLD, L, W, FUSED, TLDS>(A, params, q, lane, blockIdx.x, lds, tl, fplane, shift, acc);
+        vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, MULTI>(A, params, q, lane, blockIdx.x, lds, tl, fplane, shift, acc);
     }
     if (FUSED) {
         const size_t plen = 5 + 4 * (size_t)k;

@@ -35,6 +35,7 @@ static vs_design_dev to_dev(const vs_design* g) {
     D.lower = g->lower;
     D.width = g->width;
     D.perm = g->perm;
+    D.perm_begin = g->d.perm_begin;
     D.raw = g->raw;
     D.dirs = g->dirs;
     D.sobol_tabs = g->sobol_tabs;
@@ -129,6 +130,7 @@ static unsigned grid_for(uint64_t total, unsigned block, unsigned cap) {
 
 extern "C" int vs_halton_fill(vs_context* ctx, int k, uint64_t start, uint64_t count, double* out_dev) {
     VS_REQUIRE(ctx, "ctx is null");
+    VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && k <= 65536, "k=%d out of range", k);
     if (count == 0) return VS_OK;
     VS_REQUIRE(out_dev, "out_dev is null");
@@ -155,6 +157,7 @@ extern "C" int vs_halton_fill(vs_context* ctx, int k, uint64_t start, uint64_t c
 extern "C" int vs_sobol_fill(vs_context* ctx, int k, const uint32_t* directions, uint64_t start,
                              uint64_t count, double* out_dev) {
     VS_REQUIRE(ctx && directions, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1, "k=%d out of range", k);
     VS_REQUIRE(start + count <= (1ull << 32), "Sobol indices must stay below 2^32");
     if (count == 0) return VS_OK;
@@ -197,6 +200,7 @@ extern "C" int vs_design_destroy(vs_context* ctx, vs_design* g) {
 
 extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_design** out) {
     VS_REQUIRE(ctx && desc && out, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     *out = nullptr;
     const int k = desc->k;
     const uint64_t n = desc->n;
@@ -213,11 +217,18 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
         VS_REQUIRE(desc->sobol_directions, "direction numbers are required for VS_GEN_SOBOL");
         VS_REQUIRE(desc->first_index + 2 * n <= (1ull << 32), "Sobol indices must stay below 2^32");
     }
-    if (desc->perm)
-        for (uint64_t r = 0; r < n; ++r)
-            VS_REQUIRE(desc->perm[r] < n, "perm[%llu]=%u is not a row of the second half",
-                       (unsigned long long)r, desc->perm[r]);
+    // the shuffle may be given for a slice of rows only (a rank's shard): perm_count entries from row perm_begin
+    const uint64_t perm_count = desc->perm ? (desc->perm_count ? desc->perm_count : n) : 0;
+    if (desc->perm) {
+        VS_REQUIRE(desc->perm_begin <= n && perm_count <= n - desc->perm_begin,
+                   "perm slice [%llu,+%llu) exceeds n=%llu", (unsigned long long)desc->perm_begin,
+                   (unsigned long long)perm_count, (unsigned long long)n);
+        for (uint64_t i = 0; i < perm_count; ++i)
+            VS_REQUIRE(desc->perm[i] < n, "perm[%llu]=%u is not a row of the second half",
+                       (unsigned long long)(desc->perm_begin + i), desc->perm[i]);
+    }
 
+    VS_HIP(hipSetDevice(ctx->device));
     vs_design* g = new vs_design();
     g->d = *desc;
     int rc = VS_OK;
@@ -244,8 +255,12 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
         VS_TRY(hipStreamSynchronize(ctx->stream));
     }
     if (desc->perm) {
-        VS_TRY(hipMalloc(&g->perm, sizeof(uint32_t) * n));
-        VS_TRY(hipMemcpyAsync(g->perm, desc->perm, sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+        VS_TRY(hipMalloc(&g->perm, sizeof(uint32_t) * (perm_count ? perm_count : 1)));
+        VS_TRY(hipMemcpyAsync(g->perm, desc->perm, sizeof(uint32_t) * perm_count, hipMemcpyHostToDevice, ctx->stream));
+        g->d.perm_count = perm_count;
+    } else {
+        g->d.perm_begin = 0;
+        g->d.perm_count = 0;
     }
     if (desc->generator == VS_GEN_RAW) {
         size_t bytes = sizeof(double) * 2 * n * (size_t)k;
@@ -314,12 +329,16 @@ sample_flat_kernel(vs_design_dev D, uint64_t row_begin, uint64_t total, double* 
 extern "C" int vs_sample_flat(vs_context* ctx, const vs_design* design, uint64_t row_begin,
                               uint64_t row_count, double* out_dev) {
     VS_REQUIRE(ctx && design, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     const uint64_t rows_total = 2 * design->d.n * ((uint64_t)design->d.k + 1);
     VS_REQUIRE(row_begin <= rows_total && row_count <= rows_total - row_begin,
                "flat rows [%llu,+%llu) exceed 2n(k+1)=%llu", (unsigned long long)row_begin,
                (unsigned long long)row_count, (unsigned long long)rows_total);
     if (row_count == 0) return VS_OK;
     VS_REQUIRE(out_dev, "out_dev is null");
+    VS_REQUIRE(!design->perm || design->d.perm_count == design->d.n,
+               "vs_sample_flat needs the whole shuffle (this design holds a slice of %llu rows)",
+               (unsigned long long)design->d.perm_count);
     uint64_t total = row_count * (uint64_t)design->d.k;
     {
         vs_launch_scope scope(ctx, VS_KERNEL_SAMPLE_FLAT);
@@ -349,6 +368,7 @@ extern "C" int vs_objective_destroy(vs_context* ctx, vs_objective* obj) {
 extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, const double* params,
                                    size_t nparams, vs_objective** out) {
     VS_REQUIRE(ctx && out, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     *out = nullptr;
     VS_REQUIRE(k >= 1 && l >= 1, "k and l must be positive");
     switch (kind) {
@@ -389,6 +409,7 @@ extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, cons
 extern "C" int vs_objective_create_source(vs_context* ctx, int k, int l, const char* body, const double* params,
                                           size_t nparams, vs_objective** out) {
     VS_REQUIRE(ctx && out && body, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     *out = nullptr;
     VS_REQUIRE(k >= 1 && l >= 1 && l <= 1024, "k and l must be positive (l <= 1024)");
     VS_REQUIRE(nparams == 0 || params, "params is null");
@@ -418,8 +439,9 @@ extern "C" int vs_objective_create_source(vs_context* ctx, int k, int l, const c
 extern "C" int vs_objective_create_separable(vs_context* ctx, int k, const char* term_body, int fold,
                                              const double* params, size_t nparams, vs_objective** out) {
     VS_REQUIRE(ctx && out && term_body, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     *out = nullptr;
-    VS_REQUIRE(k >= 1 && k <= 160, "a separable source objective needs 1 <= k <= 160 (LDS tile)");
+    VS_REQUIRE(k >= 1 && k <= 256, "a separable source objective needs 1 <= k <= 256");
     VS_REQUIRE(fold == VS_FOLD_PRODUCT || fold == VS_FOLD_SUM, "fold must be VS_FOLD_PRODUCT or VS_FOLD_SUM");
     VS_REQUIRE(nparams == 0 || params, "params is null");
     vs_objective* o = new vs_objective();
@@ -507,7 +529,7 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
     // ---- phase 1: coordinates (for a single-output separable objective: terms)
     const bool terms_now = SEPARABLE && l == 1;
     const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
-    const uint64_t src2 = A.D.n + (A.D.perm ? (uint64_t)A.D.perm[r] : r);  // sequence row behind M_2[r]
+    const uint64_t src2 = A.D.n + vs_perm_at(A.D, r);  // sequence row behind M_2[r]
     for (int c = q; c < k; c += W) {
         double x1, x2;
         if (halton_fast) {
@@ -704,171 +726,21 @@ static int launch_eval(vs_context* ctx, const vs_eval_args& A, int tiles) {
 }
 
 // ---------------------------------------------------------------------------
-// fused evaluate + first-order reduce: no f-values are written
+// fused evaluate + first-order reduce: no f-values are written (kernels: vs_scan.hip, vs_rtc.hip)
 // ---------------------------------------------------------------------------
-//
-// Same two phases as eval_kernel for a single-output separable objective with k <= 32 (one chain
-// pass).  After phase 2 a thread holds a = f(M_1[r]), b = f(M_2[r]) and the values c_i, d_i of the
-// blocks i = q, q+4, .. it owns; their four products go straight into 32 register accumulators
-// that live for the whole kernel (persistent workgroups walk the row blocks).  Block i belongs to
-// exactly one wave, so the only reduction left at the end is the DPP wave sum; one partial record
-// per workgroup, same layout and same fold as reduce_first_kernel's.
-
-// The whole persistent walk of one wave, specialised on its index Q in the workgroup: the chain
-// schedule (which chain starts at which column) is then a compile-time constant in straight-line
-// code, and the accumulators never move between registers.
-template <int KIND, int Q>
-__device__ __forceinline__ void fused_rows(const vs_eval_args& A, double shift, double* lds, double* partials) {
-    constexpr int T = VS_EVAL_ROWS;
-    const int k = A.D.k;  // <= VS_PASS
-    const int lane = threadIdx.x & 63;
-    const uint64_t rows = A.rows;
-    double* X1 = lds + lane;
-    double* X2 = lds + (size_t)k * T + lane;
-    const double ident = KIND == VS_OBJ_LINEAR ? 0.0 : 1.0;
-    const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
-
-    double acc[VS_CHAINS][4];
-#pragma unroll
-    for (int m = 0; m < VS_CHAINS; ++m) acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0.0;
-    double t_sab = 0, t_sa = 0, t_sb = 0, t_s1 = 0, t_s2 = 0;
-
-    const uint64_t nblocks = (rows + T - 1) / T;
-    for (uint64_t rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-        const uint64_t lr = rb * T + lane;
-        const bool valid = lr < rows;
-        const uint64_t r = A.row_begin + (valid ? lr : rows - 1);
-        const uint64_t src2 = A.D.n + (A.D.perm ? (uint64_t)A.D.perm[r] : r);
-        for (int c = Q; c < k; c += VS_EVAL_WAVES) {
-            double x1, x2;
-            if (halton_fast) {
-                vs_radical_inverse_pair((uint32_t)(A.D.first_index + r), (uint32_t)(A.D.first_index + src2),
-                                        A.D.bases[c], x1, x2);
-            } else {
-                x1 = vs_unit_point(A.D, r, c);
-                x2 = vs_unit_point(A.D, src2, c);
-            }
-            const double p = A.params[c];
-            X1[(size_t)c * T] = vs_term<KIND>(vs_apply_scale(A.D, x1, c), p);
-            X2[(size_t)c * T] = vs_term<KIND>(vs_apply_scale(A.D, x2, c), p);
-        }
-        __syncthreads();
-
-        double pa = ident, pb = ident;
-        double cj[VS_CHAINS], dj[VS_CHAINS];
-#pragma unroll
-        for (int m = 0; m < VS_CHAINS; ++m) cj[m] = dj[m] = ident;
-        if (k == VS_PASS) {
-            vs_chain_pass<KIND, Q, false>(X1, X2, 0, pa, pb, cj, dj);
-        } else {
-            // k < 32: same schedule with run-time bounds (chain m of this wave starts at column Q+4m)
-            for (int c = 0; c < k; ++c) {
-                const double ta = X1[(size_t)c * T], tb = X2[(size_t)c * T];
-#pragma unroll
-                for (int m = 0; m < VS_CHAINS; ++m) {
-                    const int start = Q + VS_EVAL_WAVES * m;
-                    if (c > start) {
-                        cj[m] = vs_fold<KIND>(cj[m], tb);
-                        dj[m] = vs_fold<KIND>(dj[m], ta);
-                    } else if (c == start) {
-                        cj[m] = vs_fold<KIND>(pb, ta);
-                        dj[m] = vs_fold<KIND>(pa, tb);
-                    }
-                }
-                pa = vs_fold<KIND>(pa, ta);
-                pb = vs_fold<KIND>(pb, tb);
-            }
-        }
-        if (valid) {  // a = pa, b = pb, c_i = cj, d_i = dj
-#pragma unroll
-            for (int m = 0; m < VS_CHAINS; ++m) {
-                acc[m][0] = fma(pa, cj[m], acc[m][0]);  // a.c_i   (chains beyond k hold the identity and are dropped below)
-                acc[m][1] = fma(pb, dj[m], acc[m][1]);  // b.d_i
-                acc[m][2] = fma(pa, dj[m], acc[m][2]);  // a.d_i
-                acc[m][3] = fma(pb, cj[m], acc[m][3]);  // b.c_i
-            }
-            if (Q == 0) {
-                const double dx = pa - shift, dy = pb - shift;
-                t_sab = fma(pa, pb, t_sab);
-                t_sa += pa;
-                t_sb += pb;
-                t_s1 += dx + dy;
-                t_s2 = fma(dx, dx, t_s2);
-                t_s2 = fma(dy, dy, t_s2);
-            }
-        }
-        __syncthreads();  // the tile is rewritten by the next block
-    }
-
-    double* out = partials + (size_t)blockIdx.x * VS_PLEN(k);
-#pragma unroll
-    for (int m = 0; m < VS_CHAINS; ++m) {
-        const int i = Q + VS_EVAL_WAVES * m;
-#pragma unroll
-        for (int z = 0; z < 4; ++z) {
-            const double v = vs_wave_sum_dpp(acc[m][z]);
-            if (lane == 63 && i < k) out[VS_P_HEAD + (size_t)z * k + i] = v;
-        }
-    }
-    if (Q == 0) {
-        t_sab = vs_wave_sum_dpp(t_sab);
-        t_sa = vs_wave_sum_dpp(t_sa);
-        t_sb = vs_wave_sum_dpp(t_sb);
-        t_s1 = vs_wave_sum_dpp(t_s1);
-        t_s2 = vs_wave_sum_dpp(t_s2);
-        if (lane == 63) {
-            out[VS_P_SAB] = t_sab;
-            out[VS_P_SA] = t_sa;
-            out[VS_P_SB] = t_sb;
-            out[VS_P_S1] = t_s1;
-            out[VS_P_S2] = t_s2;
-        }
-    }
-}
-
-#ifndef VS_FUSED_MIN_WAVES
-#define VS_FUSED_MIN_WAVES 1
-#endif
-template <int KIND>
-__global__ void __launch_bounds__(VS_EVAL_ROWS * VS_EVAL_WAVES, VS_FUSED_MIN_WAVES)
-fused_first_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
-    extern __shared__ double lds[];
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the fold that follows (see reduce_first_kernel)
-        counters[0] = 0;
-        counters[1] = 0xffffffffu;
-        counters[2] = 0;
-        counters[3] = 0;
-        counters[4] = 0;
-    }
-    const double shift = *shift_src;
-    switch (q) {  // wave-uniform: one straight-line specialisation per wave index
-        case 0: fused_rows<KIND, 0>(A, shift, lds, partials); break;
-        case 1: fused_rows<KIND, 1>(A, shift, lds, partials); break;
-        case 2: fused_rows<KIND, 2>(A, shift, lds, partials); break;
-        default: fused_rows<KIND, 3>(A, shift, lds, partials); break;
-    }
-}
-
-template <int KIND>
-static int launch_fused(vs_context* ctx, const vs_eval_args& A, uint32_t P, const double* shift_dev) {
-    const size_t lds = sizeof(double) * 2 * (size_t)A.D.k * VS_EVAL_ROWS;
-    {
-        vs_launch_scope scope(ctx, VS_KERNEL_FUSED);
-        hipLaunchKernelGGL(fused_first_kernel<KIND>, dim3(P), dim3(VS_EVAL_ROWS * VS_EVAL_WAVES), lds, ctx->stream, A,
-                           shift_dev, ctx->partials, ctx->counters);
-    }
-    VS_HIP(hipGetLastError());
-    return VS_OK;
-}
 
 // vs_scan.hip
 bool vs_scan_covers(int kind, int k, bool fused);
 int vs_scan_eval(vs_context* ctx, const vs_eval_args& A);
-unsigned vs_scan_fused_workgroups(vs_context* ctx, int k, int l, uint64_t rows);
+int vs_scan_fused_plan(vs_context* ctx, const vs_eval_args& A, unsigned* P);
 int vs_scan_fused(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev);
 unsigned vs_fused_ishigami_workgroups(vs_context* ctx, uint64_t rows);
 int vs_fused_ishigami(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev);
+
+static bool rows_in_perm_slice(const vs_design* g, uint64_t row_begin, uint64_t row_count) {
+    if (!g->perm) return true;
+    return row_begin >= g->d.perm_begin && row_begin + row_count <= g->d.perm_begin + g->d.perm_count;
+}
 
 // The scan kernels inline only the compact generator paths: Halton indices must stay below 2^32
 // (per-column constant digit counts), which every design with n < 2^31 - first_index/2 meets.
@@ -876,17 +748,16 @@ static bool design_compact(const vs_design* g) {
     return g->d.generator != VS_GEN_HALTON || g->d.first_index + 2 * g->d.n - 1 < (1ull << 32);
 }
 
-enum fused_route { FUSED_NONE = 0, FUSED_CHAIN, FUSED_SCAN, FUSED_ISHIGAMI, FUSED_USER };
+enum fused_route { FUSED_NONE = 0, FUSED_SCAN, FUSED_ISHIGAMI, FUSED_USER };
 
-// which fused kernel serves (design, objective): the chain-scheme kernel (k <= 32, one output; strict
-// left-to-right folds) only when asked for (VS_EVAL_MODE=1); else the scan kernels, Ishigami's own,
-// or a run-time compiled one.  The scan kernels leave power scaling to the two-kernel path.
+// which fused kernel serves (design, objective): the scan kernels, Ishigami's own, or a run-time
+// compiled one.  The scan kernels leave power scaling to the two-kernel path; a context in strict
+// evaluation order (vs_context_set_eval_order) has no fused path for separable objectives -- the fused
+// kernels fold in scan order.
 static fused_route fused_route_for(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
-    const int k = obj->k, l = obj->l;
     const bool separable = obj->kind == VS_OBJ_G_FUNCTION || obj->kind == VS_OBJ_POLYNOMIAL || obj->kind == VS_OBJ_LINEAR;
-    const bool scan_ok = design_compact(design) && design->d.scale_mode != VS_SCALE_POWER;
-    if (separable && ctx->tune.eval_mode == 1 && l == 1 && k <= VS_PASS) return FUSED_CHAIN;
-    if (separable && scan_ok && vs_scan_covers(obj->kind, k, true)) return FUSED_SCAN;
+    const bool scan_ok = design_compact(design) && design->d.scale_mode != VS_SCALE_POWER && ctx->tune.eval_mode != 1;
+    if (separable && scan_ok && vs_scan_covers(obj->kind, obj->k, true)) return FUSED_SCAN;
     if (obj->kind == VS_OBJ_ISHIGAMI) return FUSED_ISHIGAMI;
     if (obj->kind == VS_OBJ_SOURCE && obj->fused_function && scan_ok) return FUSED_USER;
     return FUSED_NONE;
@@ -895,6 +766,7 @@ static fused_route fused_route_for(const vs_context* ctx, const vs_design* desig
 extern "C" int vs_eval_reduce_supported(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                                         int* supported) {
     VS_REQUIRE(ctx && design && obj && supported, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     *supported = (obj->k == design->d.k && fused_route_for(ctx, design, obj) != FUSED_NONE) ? 1 : 0;
     return VS_OK;
 }
@@ -907,6 +779,7 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
     VS_REQUIRE(row_begin <= design->d.n && row_count <= design->d.n - row_begin, "rows exceed n");
     VS_REQUIRE(max_ranks >= 1 && rank >= 0 && rank < max_ranks, "rank %d not in [0,%d)", rank, max_ranks);
     VS_REQUIRE(row_count >= 1, "the fused path needs at least one row");
+    VS_REQUIRE(rows_in_perm_slice(design, row_begin, row_count), "rows lie outside the design's shuffle slice");
     VS_HIP(hipSetDevice(ctx->device));
     const int k = obj->k, l = obj->l;
     const fused_route route = fused_route_for(ctx, design, obj);
@@ -914,28 +787,6 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
         return vs_fail(VS_ERR_ARG, "the fused path covers G_FUNCTION / POLYNOMIAL / LINEAR objectives and separable "
                                    "source objectives with k <= 128 (identity or linear scaling), and ISHIGAMI; "
                                    "use vs_eval + vs_reduce_first_order (vs_eval_reduce_supported tells)");
-    unsigned P = 1;
-    const uint64_t blocks = (row_count + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
-    if (route == FUSED_CHAIN) {
-        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-        uint64_t Pw = (uint64_t)cus * (ctx->tune.fused_wgs_per_cu > 0 ? ctx->tune.fused_wgs_per_cu : 2);
-        P = (unsigned)(Pw > blocks ? blocks : Pw);
-    } else if (route == FUSED_ISHIGAMI) {
-        P = vs_fused_ishigami_workgroups(ctx, row_count);
-    } else if (route == FUSED_USER) {
-        P = vs_scan_fused_workgroups(ctx, k, 1, row_count);
-    } else {
-        P = vs_scan_fused_workgroups(ctx, k, l, row_count);
-    }
-    const size_t plen = VS_PLEN(k), width = (size_t)l * plen;
-    // workspace: [P][l][plen] partials + [l][plen] folded + the f-values of one design row (l planes of 2k+2)
-    const size_t shift_stride = 2 * (size_t)k + 2;
-    int rc = vs_workspace_partials(ctx, sizeof(double) * ((size_t)P * width + width + (size_t)l * shift_stride));
-    if (rc) return rc;
-    double* shift_buf = ctx->partials + (size_t)P * width + width;
-    // the variance shift of output o is f_o(M_1[row_begin]): a one-row launch of the ordinary evaluation
-    rc = vs_eval(ctx, design, obj, row_begin, 1, shift_buf);
-    if (rc) return rc;
     vs_eval_args A;
     A.D = to_dev(design);
     A.kind = obj->kind;
@@ -944,14 +795,22 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
     A.row_begin = row_begin;
     A.rows = row_count;
     A.f = nullptr;
+    unsigned P = 1;
+    int rc = VS_OK;
+    if (route == FUSED_ISHIGAMI) P = vs_fused_ishigami_workgroups(ctx, row_count);
+    else if (route == FUSED_USER) rc = vs_rtc_fused_plan(ctx, obj, row_count, &P);
+    else rc = vs_scan_fused_plan(ctx, A, &P);
+    if (rc) return rc;
+    const size_t plen = VS_PLEN(k), width = (size_t)l * plen;
+    // workspace: [P][l][plen] partials + [l][plen] folded + the f-values of one design row (l planes of 2k+2)
+    const size_t shift_stride = 2 * (size_t)k + 2;
+    rc = vs_workspace_partials(ctx, sizeof(double) * ((size_t)P * width + width + (size_t)l * shift_stride));
+    if (rc) return rc;
+    double* shift_buf = ctx->partials + (size_t)P * width + width;
+    // the variance shift of output o is f_o(M_1[row_begin]): a one-row launch of the ordinary evaluation
+    rc = vs_eval(ctx, design, obj, row_begin, 1, shift_buf);
+    if (rc) return rc;
     switch (route) {
-        case FUSED_CHAIN:
-            switch (obj->kind) {
-                case VS_OBJ_G_FUNCTION: rc = launch_fused<VS_OBJ_G_FUNCTION>(ctx, A, P, shift_buf); break;
-                case VS_OBJ_POLYNOMIAL: rc = launch_fused<VS_OBJ_POLYNOMIAL>(ctx, A, P, shift_buf); break;
-                default: rc = launch_fused<VS_OBJ_LINEAR>(ctx, A, P, shift_buf); break;
-            }
-            break;
         case FUSED_SCAN: rc = vs_scan_fused(ctx, A, P, shift_buf); break;
         case FUSED_ISHIGAMI: rc = vs_fused_ishigami(ctx, A, P, shift_buf); break;
         case FUSED_USER: rc = vs_rtc_launch_fused(ctx, obj, &A, sizeof(A), P, shift_buf); break;
@@ -964,12 +823,17 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
 extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                        uint64_t row_begin, uint64_t row_count, double* f_dev) {
     VS_REQUIRE(ctx && design && obj, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(obj->k == design->d.k, "objective has k=%d, design has k=%d", obj->k, design->d.k);
     VS_REQUIRE(row_begin <= design->d.n && row_count <= design->d.n - row_begin,
                "rows [%llu,+%llu) exceed n=%llu", (unsigned long long)row_begin,
                (unsigned long long)row_count, (unsigned long long)design->d.n);
     if (row_count == 0) return VS_OK;
     VS_REQUIRE(f_dev, "f_dev is null");
+    VS_REQUIRE(rows_in_perm_slice(design, row_begin, row_count),
+               "rows [%llu,+%llu) lie outside the design's shuffle slice [%llu,+%llu)", (unsigned long long)row_begin,
+               (unsigned long long)row_count, (unsigned long long)design->d.perm_begin,
+               (unsigned long long)design->d.perm_count);
     vs_eval_args A;
     A.D = to_dev(design);
     A.kind = obj->kind;
@@ -980,10 +844,11 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
     A.f = f_dev;
     VS_HIP(hipSetDevice(ctx->device));
     const int sep_tiles = obj->l > 1 ? 4 : 2;
-    // separable built-ins: the chain scheme (strict left-to-right folds, O(k^2)) for small k, the
-    // segmented scan (O(k), reassociated folds) from VS_SCAN_MIN_K columns on; VS_EVAL_MODE overrides
+    // separable built-ins: the segmented scan (O(k) folds per row, association order of
+    // vs_device_scan.h) wherever it applies; the chain scheme (strict left-to-right folds, O(k^2)) beyond
+    // 256 columns, for Halton indices beyond 2^32, and when the context asks for the strict order
     if (vs_scan_covers(obj->kind, obj->k, false) && design_compact(design) && ctx->tune.eval_scratch != 1 &&
-        (ctx->tune.eval_mode == 2 || (ctx->tune.eval_mode == 0 && obj->k >= VS_SCAN_MIN_K)))
+        ctx->tune.eval_mode != 1)
         return vs_scan_eval(ctx, A);
     switch (obj->kind) {
         case VS_OBJ_G_FUNCTION: return launch_eval<VS_OBJ_G_FUNCTION>(ctx, A, sep_tiles);
@@ -996,7 +861,7 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
             const uint64_t blocks = (row_count + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
             VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
             VS_REQUIRE(!obj->eval_scan || design_compact(design),
-                       "separable source objectives with k >= %d need Halton indices below 2^32", VS_SCAN_MIN_K);
+                       "separable source objectives need Halton indices below 2^32 (or a context in strict evaluation order)");
             return vs_rtc_launch(ctx, obj, &A, sizeof(A), (unsigned)blocks, lds);
         }
     }

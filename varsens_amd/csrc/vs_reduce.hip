@@ -470,6 +470,7 @@ static int launch_reduce(vs_context* ctx, const vs_reduce_args& A, dim3 grid, si
 extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                                      int flags, int rank, int max_ranks, double* acc_dev) {
     VS_REQUIRE(ctx && acc_dev, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && l >= 1, "k and l must be positive");
     VS_REQUIRE(max_ranks >= 1 && rank >= 0 && rank < max_ranks, "rank %d not in [0,%d)", rank, max_ranks);
     VS_REQUIRE(rows <= 0xfffffff0ull, "rows per GPU must stay below 2^32");
@@ -600,6 +601,7 @@ int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, c
 extern "C" int vs_finish_first_order(vs_context* ctx, const double* acc_dev, uint64_t n, int k, int l,
                                      int max_ranks, double* out_dev) {
     VS_REQUIRE(ctx && acc_dev && out_dev, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && l >= 1 && max_ranks >= 1 && n >= 2, "bad dimensions");
     {
         vs_launch_scope scope(ctx, VS_KERNEL_FINISH);

@@ -29,7 +29,7 @@ extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_use
     const vs_u64 plane = (2 * (vs_u64)k + 2) * rows;
 
     const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
-    const vs_u64 src2 = A.D.n + (A.D.perm ? (vs_u64)A.D.perm[r] : r);
+    const vs_u64 src2 = A.D.n + vs_perm_at(A.D, r);
     for (int c = q; c < k; c += VS_EVAL_WAVES) {
         double x1, x2;
         if (halton_fast) {

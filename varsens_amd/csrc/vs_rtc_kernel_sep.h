@@ -7,9 +7,10 @@
 // eval_kernel (prefix sharing, 8+8 chains per thread, per-wave static schedule for full passes),
 // so a user model of this shape runs at the speed of the built-in g-function / linear kernels.
 
-// From 33 columns on (VS_USER_EVAL_SCAN) the evaluation takes the segmented-scan form of
-// vs_device_scan.h instead (O(k) folds per row), and for k <= 128 a fused evaluate+reduce kernel
-// vs_user_fused is built beside it (VS_USER_FUSED); shapes VS_USER_*_L / _W / _TLDS come from the host.
+// By default (VS_USER_EVAL_SCAN) the evaluation takes the segmented-scan form of vs_device_scan.h
+// instead (O(k) folds per row), and for k <= 128 a fused evaluate+reduce kernel vs_user_fused is built
+// beside it (VS_USER_FUSED); shapes VS_USER_*_L / _W / _TLDS come from the host.  The chain-scheme kernel
+// below serves contexts in strict evaluation order.
 struct vs_user_term_t {
     static __device__ __forceinline__ double eval(double x, int c, const double* __restrict__ p) {
         return vs_user_term(x, c, p);
@@ -55,7 +56,7 @@ extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_use
     double* f = A.f + (vs_u64)blockIdx.x * T + lane;  // planar f-values, one output
 
     const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
-    const vs_u64 src2 = A.D.n + (A.D.perm ? (vs_u64)A.D.perm[r] : r);
+    const vs_u64 src2 = A.D.n + vs_perm_at(A.D, r);
     for (int c = q; c < k; c += VS_EVAL_WAVES) {
         double x1, x2;
         if (halton_fast) {

@@ -19,11 +19,11 @@ struct builtin_term {
     }
 };
 
-template <int KIND, int L, int W, bool FUSED, bool TLDS>
+template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
 __global__ void __launch_bounds__(VS_EVAL_ROWS* W)
 scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
     extern __shared__ double scan_lds[];  // totals slabs [2 families][W][64] (+ term slabs), vs_scan_lds
-    vs_scan_body<builtin_term<KIND>, KIND, L, W, FUSED, TLDS>(A, scan_lds, shift_src, partials);
+    vs_scan_body<builtin_term<KIND>, KIND, L, W, FUSED, TLDS, MULTI>(A, scan_lds, shift_src, partials);
     // counters of the fold that follows (see reduce_first_kernel).  At the END of the kernel: a global
     // store in front of the row loop would make every load of design constants "possibly clobbered"
     // and keep it out of the scalar cache.
@@ -98,32 +98,40 @@ fused_ishigami_kernel(vs_eval_args A, const double* shift_src, double* partials,
 }
 
 // ---------------------------------------------------------------------------
-// launch shapes
+// launch shapes (measured on MI355X, tools/scan_sweep.py; registers: 2L doubles of terms, 2(L/4 + 4) of
+// suffixes, +4L sums in the fused kernel, whose terms move to LDS beyond 96 columns)
 // ---------------------------------------------------------------------------
-//   k <=   8: 4 waves x 2 columns      k <=  64: 8 waves x  8 columns      k <= 256: 16 waves x 16 columns
-//   k <=  16: 4 waves x 4 columns      k <= 128: 8 waves x 16 columns
-//   k <=  32: 4 waves x 8 columns
-// (registers: 4L doubles of terms and suffixes, +4L sums in the fused kernel)
+//   k <=  8: 4 waves x  2 columns     k <= 48: 4 waves x 12     k <= 128: 8 waves x 16
+//   k <= 16: 4 waves x  4             k <= 64: 8 waves x  8     k <= 256: 8 waves x 32 (evaluation only)
+//   k <= 32: 4 waves x  8             k <= 96: 8 waves x 12
 struct scan_shape {
     int L, W;
 };
 
-// variant 1 (VS_FUSED_VARIANT=1, measurements): the fused kernel for 64 < k <= 128 as 8 waves x 16 columns
+// variant (VS_SCAN_SHAPE / VS_FUSED_VARIANT = L*100+W, measurements only): another instantiated shape
 static bool scan_shape_for(int k, bool fused, scan_shape* s, int variant = 0) {
+    if (variant >= 100) {
+        *s = {variant / 100, variant % 100};
+        return s->L * s->W >= k;
+    }
     if (k <= 8) *s = {2, 4};
     else if (k <= 16) *s = {4, 4};
     else if (k <= 32) *s = {8, 4};
+    else if (k <= 48) *s = {12, 4};
     else if (k <= 64) *s = {8, 8};
-    else if (k <= 128) *s = (fused && variant == 0) ? scan_shape{8, 16} : scan_shape{16, 8};
-    else if (k <= 256 && !fused) *s = {16, 16};
+    else if (k <= 96) *s = {12, 8};
+    else if (k <= 128) *s = {16, 8};
+    else if (k <= 256 && !fused) *s = {32, 8};
     else return false;
     return true;
 }
 
+static bool scan_terms_in_lds(scan_shape s, bool fused) { return fused && s.L * s.W > 96; }
+
 bool vs_scan_shape(int k, bool fused, int* L, int* W, int* tlds, size_t* lds_bytes) {
     scan_shape s;
     if (!scan_shape_for(k, fused, &s)) return false;
-    const bool t = fused && s.L * s.W > 64;   // terms in LDS
+    const bool t = scan_terms_in_lds(s, fused);
     *L = s.L;
     *W = s.W;
     *tlds = t ? 1 : 0;
@@ -138,86 +146,106 @@ bool vs_scan_covers(int kind, int k, bool fused) {
     return separable && scan_shape_for(k, fused, &s);
 }
 
-template <int KIND, int L, int W, bool FUSED, bool TLDS>
-static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev, int kid) {
+// Workgroups of the persistent fused launch: twice what is resident at the kernel's occupancy (the
+// second half takes over CU by CU as the first drains; measured better than an exact fit).
+unsigned vs_persistent_workgroups(vs_context* ctx, const void* kernel, int threads, size_t lds, uint64_t blocks, int l) {
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    int resident = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kernel, threads, lds) != hipSuccess || resident < 1)
+        resident = 1;
+    int per_cu = 2 * resident;
+    if (ctx->tune.fused_wgs_per_cu > 0) per_cu = ctx->tune.fused_wgs_per_cu;
+    uint64_t P = (uint64_t)cus * per_cu;
+    if (l > 1) P = (P + l - 1) / l;  // grid.y = l outputs share the chip
+    if (P > blocks) P = blocks;
+    return (unsigned)(P < 1 ? 1 : P);
+}
+
+template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
+static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
     const size_t lds = sizeof(double) * vs_scan_lds<L, W, TLDS>::doubles;
-    if (lds > 64 * 1024)
-        VS_HIP(hipFuncSetAttribute((const void*)scan_kernel<KIND, L, W, FUSED, TLDS>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void* fn = (const void*)scan_kernel<KIND, L, W, FUSED, TLDS, MULTI>;
+    if (lds > 64 * 1024) VS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
+    if (plan_only) {
+        *P_io = FUSED ? vs_persistent_workgroups(ctx, fn, VS_EVAL_ROWS * W, lds, blocks, A.l) : (unsigned)blocks;
+        return VS_OK;
+    }
     {
-        vs_launch_scope scope(ctx, kid);
-        hipLaunchKernelGGL((scan_kernel<KIND, L, W, FUSED, TLDS>), dim3(P, (unsigned)A.l), dim3(VS_EVAL_ROWS * W), lds,
-                           ctx->stream, A, shift_dev, ctx->partials, ctx->counters);
+        vs_launch_scope scope(ctx, FUSED ? VS_KERNEL_FUSED : VS_KERNEL_EVAL);
+        // outputs: grid.y (fused; evaluation without the in-kernel output loop) or inside the block walk (MULTI)
+        hipLaunchKernelGGL((scan_kernel<KIND, L, W, FUSED, TLDS, MULTI>), dim3(*P_io, MULTI ? 1u : (unsigned)A.l),
+                           dim3(VS_EVAL_ROWS * W), lds, ctx->stream, A, shift_dev, ctx->partials, ctx->counters);
     }
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
 
 template <int KIND, bool FUSED>
-static int launch_scan_kind(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned P, const double* shift_dev) {
-    const int kid = FUSED ? VS_KERNEL_FUSED : VS_KERNEL_EVAL;
-#define VS_SCAN_CASE(LL, WW, TL) \
-    if (s.L == LL && s.W == WW) return launch_scan_lw<KIND, LL, WW, FUSED, TL>(ctx, A, P, shift_dev, kid)
-    VS_SCAN_CASE(2, 4, false);
-    VS_SCAN_CASE(4, 4, false);
-    VS_SCAN_CASE(8, 4, false);
-    VS_SCAN_CASE(8, 8, false);
-    if constexpr (FUSED) {
-        VS_SCAN_CASE(8, 16, true);
-        VS_SCAN_CASE(16, 8, true);
-    } else {
-        VS_SCAN_CASE(16, 8, false);
-        VS_SCAN_CASE(16, 16, false);
+static int launch_scan_kind(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned* P_io, const double* shift_dev,
+                            bool plan_only) {
+    // l > 1: the outputs share one generated row inside the kernel (MULTI), except at 32 columns per wave,
+    // where the coordinates no longer fit the registers beside the terms (then: one grid.y plane per output)
+    const bool multi = !FUSED && A.l > 1 && s.L < 32;
+#define VS_SCAN_CASE(LL, WW, TL)                                                                                       \
+    if (s.L == LL && s.W == WW) {                                                                                      \
+        if constexpr (!FUSED && LL < 32) {                                                                             \
+            if (multi) return launch_scan_lw<KIND, LL, WW, false, false, true>(ctx, A, P_io, shift_dev, plan_only);    \
+        }                                                                                                              \
+        return launch_scan_lw<KIND, LL, WW, FUSED, FUSED && TL, false>(ctx, A, P_io, shift_dev, plan_only);            \
+    }
+    VS_SCAN_CASE(2, 4, false)
+    VS_SCAN_CASE(4, 4, false)
+    VS_SCAN_CASE(8, 4, false)
+    VS_SCAN_CASE(12, 4, false)
+    VS_SCAN_CASE(8, 8, false)
+    VS_SCAN_CASE(12, 8, false)
+    VS_SCAN_CASE(16, 8, true)
+    if constexpr (!FUSED) {
+        VS_SCAN_CASE(32, 8, false)
     }
 #undef VS_SCAN_CASE
     return vs_fail(VS_ERR_ARG, "no scan kernel for L=%d W=%d", s.L, s.W);
 }
 
 template <bool FUSED>
-static int launch_scan(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned P, const double* shift_dev) {
+static int launch_scan(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned* P_io, const double* shift_dev,
+                       bool plan_only) {
     switch (A.kind) {
-        case VS_OBJ_G_FUNCTION: return launch_scan_kind<VS_OBJ_G_FUNCTION, FUSED>(ctx, A, s, P, shift_dev);
-        case VS_OBJ_POLYNOMIAL: return launch_scan_kind<VS_OBJ_POLYNOMIAL, FUSED>(ctx, A, s, P, shift_dev);
-        case VS_OBJ_LINEAR: return launch_scan_kind<VS_OBJ_LINEAR, FUSED>(ctx, A, s, P, shift_dev);
+        case VS_OBJ_G_FUNCTION: return launch_scan_kind<VS_OBJ_G_FUNCTION, FUSED>(ctx, A, s, P_io, shift_dev, plan_only);
+        case VS_OBJ_POLYNOMIAL: return launch_scan_kind<VS_OBJ_POLYNOMIAL, FUSED>(ctx, A, s, P_io, shift_dev, plan_only);
+        case VS_OBJ_LINEAR: return launch_scan_kind<VS_OBJ_LINEAR, FUSED>(ctx, A, s, P_io, shift_dev, plan_only);
     }
     return vs_fail(VS_ERR_ARG, "objective kind %d is not separable", A.kind);
 }
 
-// workgroups of a persistent launch: enough to fill every CU at the kernel's occupancy
-static unsigned scan_workgroups(vs_context* ctx, uint64_t blocks, int W, bool fused, int l) {
-    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    int per_cu = fused ? (W <= 4 ? 2 : 1) : (W <= 4 ? 8 : (W <= 8 ? 4 : 2));
-    if (fused && ctx->tune.fused_wgs_per_cu > 0) per_cu = ctx->tune.fused_wgs_per_cu;
-    uint64_t P = (uint64_t)cus * per_cu;
-    if (l > 1) P = (P + l - 1) / l;  // grid.y = l planes share the chip
-    if (P > blocks) P = blocks;
-    if (P < 1) P = 1;
-    return (unsigned)P;
-}
-
-// vs_eval for a separable built-in in scan form (called by vs_eval, vs_generate.hip)
+// vs_eval for a separable built-in in scan form (called by vs_eval, vs_generate.hip): one 64-row block
+// per workgroup, all l outputs inside it
 int vs_scan_eval(vs_context* ctx, const vs_eval_args& A) {
     scan_shape s;
-    if (!scan_shape_for(A.D.k, false, &s)) return vs_fail(VS_ERR_ARG, "k=%d is outside the scan kernels", A.D.k);
+    if (!scan_shape_for(A.D.k, false, &s, ctx->tune.scan_shape))
+        return vs_fail(VS_ERR_ARG, "k=%d is outside the scan kernels", A.D.k);
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
-    return launch_scan<false>(ctx, A, s, (unsigned)blocks, nullptr);  // one 64-row block per workgroup
+    unsigned P = (unsigned)blocks;
+    return launch_scan<false>(ctx, A, s, &P, nullptr, false);
 }
 
-unsigned vs_scan_fused_workgroups(vs_context* ctx, int k, int l, uint64_t rows) {
+// The fused path.  Plan (P workgroups -> the caller sizes ctx->partials for [P][l][plen] records), then
+// launch; the records are folded like reduce_first_kernel's.  shift_dev: the f-values of one design
+// row, l planes of 2k+2 doubles; the variance shift of output o is shift_dev[o*(2k+2)] = f_o(M_1[row]).
+int vs_scan_fused_plan(vs_context* ctx, const vs_eval_args& A, unsigned* P) {
     scan_shape s;
-    if (!scan_shape_for(k, true, &s, ctx->tune.fused_variant)) return 1;
-    return scan_workgroups(ctx, (rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS, s.W, true, l);
+    if (!scan_shape_for(A.D.k, true, &s, ctx->tune.fused_variant))
+        return vs_fail(VS_ERR_ARG, "k=%d is outside the fused kernels", A.D.k);
+    return launch_scan<true>(ctx, A, s, P, nullptr, true);
 }
 
-// The fused path: P workgroups leave [P][l][plen] partial records in ctx->partials (sized by the
-// caller), folded like reduce_first_kernel's.  shift_dev: the f-values of one design row, l planes
-// of 2k+2 doubles; the variance shift of output o is shift_dev[o*(2k+2)] = f_o(M_1[row]).
 int vs_scan_fused(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev) {
     scan_shape s;
     if (!scan_shape_for(A.D.k, true, &s, ctx->tune.fused_variant))
         return vs_fail(VS_ERR_ARG, "k=%d is outside the fused kernels", A.D.k);
-    return launch_scan<true>(ctx, A, s, P, shift_dev);
+    return launch_scan<true>(ctx, A, s, &P, shift_dev, false);
 }
 
 unsigned vs_fused_ishigami_workgroups(vs_context* ctx, uint64_t rows) {

@@ -546,6 +546,7 @@ finish_second_kernel(const double* __restrict__ gram, const double* __restrict__
 extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                                       int flags, double* gram_dev) {
     VS_REQUIRE(ctx && gram_dev, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && l >= 1, "k and l must be positive");
     VS_REQUIRE(rows == 0 || f_dev, "f_dev is null");
     VS_REQUIRE((uint64_t)k * l <= 4096, "k*l=%llu too large for the second-order pass (limit 4096)",
@@ -653,6 +654,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
                                             int flags, int rank, int max_ranks, double* acc_dev,
                                             double* gram_dev) {
     VS_REQUIRE(ctx && acc_dev && gram_dev, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && l >= 1, "k and l must be positive");
     VS_REQUIRE(max_ranks >= 1 && rank >= 0 && rank < max_ranks, "rank %d not in [0,%d)", rank, max_ranks);
     VS_REQUIRE(rows <= 0xfffffff0ull, "rows per GPU must stay below 2^32");
@@ -731,6 +733,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
 extern "C" int vs_finish_second_order(vs_context* ctx, const double* gram_dev, const double* first_dev,
                                       uint64_t n, int k, int l, double* sens2_dev, double* sens2n_dev) {
     VS_REQUIRE(ctx && gram_dev && first_dev && sens2_dev && sens2n_dev, "null argument");
+    VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && l >= 1 && n >= 2, "bad dimensions");
     const size_t total = (size_t)k * l * k * l;
     {

@@ -80,6 +80,14 @@ class HostGroup(object):
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t[0])
 
+    def gather_objects(self, obj):
+        """Every rank's `obj` (picklable), in rank order, on every rank."""
+        if self._dist is None:
+            return [obj]
+        box = [None] * self.world
+        self._dist.all_gather_object(box, obj)
+        return box
+
     def sum_array(self, array):
         """Sum a host float64 array over ranks (host-side checks and CPU tests; the GPU data
         path uses RcclComm.allreduce on device memory instead)."""

@@ -91,7 +91,9 @@ class Sample(object):
     Parameters are those of the reference (varsens/saltelli.py:62):
     ``Sample(k, n, scaling=None, discard=0, verbose=True, raw=None, **loadArgs)``
     plus keyword-only extras: ``generator`` ('halton' default, 'sobol'),
-    ``context`` (a _native.Context).
+    ``context`` (a _native.Context), ``shard=(row_begin, row_count)`` (a rank of a multi-GPU job
+    evaluates only these draws: only their entries of the seed-1 shuffle are uploaded, and the
+    materialising attributes M_1 .. flat() are not available).
 
     ``scaling`` may be a ``scale.Linear/Power/Percentage/Magnitude/Identity``
     spec (applied on the GPU) or any callable on an (n,k) block (applied on the
@@ -101,6 +103,8 @@ class Sample(object):
     def __init__(self, k, n, scaling=None, discard=0, verbose=True, raw=None, **loadArgs):
         generator = loadArgs.pop('generator', 'halton')
         self._ctx = loadArgs.pop('context', None) or default_context()
+        # a rank of a multi-GPU job: only the shuffle entries of its own rows go to its GPU
+        self._shard = loadArgs.pop('shard', None)
         self.k = int(k)
         self.n = int(n)
         self.scaling = scaling
@@ -133,6 +137,10 @@ class Sample(object):
 
         if self.verbose: print("Eliminating correlations")
         perm = seed1_permutation(n)
+        perm_begin = 0
+        if self._shard is not None:
+            perm_begin, count = _shard_rows(n, self._shard)
+            perm = perm[perm_begin:perm_begin + count] if count else None
 
         if generator == 'halton':
             gen, first = _native.GEN_HALTON, 1 + 20 * k + int(discard)   # saltelli.py:83: skip 20k + discard
@@ -143,9 +151,10 @@ class Sample(object):
         if isinstance(self.scaling, _scale.DeviceScale):
             mode, lo, hi = self.scaling.device_spec(k)
             if unit is None:
-                self._design = self._ctx.design_create(gen, k, n, first, mode, lo, hi, perm, None, dirs)
+                self._design = self._ctx.design_create(gen, k, n, first, mode, lo, hi, perm, None, dirs, perm_begin)
             else:
-                self._design = self._ctx.design_create(_native.GEN_RAW, k, n, 0, mode, lo, hi, perm, unit)
+                self._design = self._ctx.design_create(_native.GEN_RAW, k, n, 0, mode, lo, hi, perm, unit, None,
+                                                       perm_begin)
         else:
             # opaque callable: its own Python code has to see the two (n,k) halves (saltelli.py:92,95)
             if unit is None:
@@ -162,7 +171,7 @@ class Sample(object):
             if m1.shape != (n, k) or m2.shape != (n, k):
                 raise Exception("scaling must map an (n,k) block to an (n,k) block")
             self._design = self._ctx.design_create(_native.GEN_RAW, k, n, 0, _native.SCALE_IDENTITY, None, None,
-                                                   perm, numpy.concatenate([m1, m2], axis=0))
+                                                   perm, numpy.concatenate([m1, m2], axis=0), None, perm_begin)
         if self.verbose: print("...Sample Created.")
 
     # -- materialisation on demand --------------------------------------------------------
@@ -509,6 +518,8 @@ class Varsens(object):
             self.k = k
             self.n = n
             kw = dict(context=ctx) if ctx is not None else {}
+            if shard is not None:
+                kw['shard'] = shard
             self.sample = Sample(k, n, scaling_func, verbose=verbose, **kw)
         elif not isinstance(objective, Objective):
             raise ValueError("Must specify sample, (k,n,scaling_func), or Objective object")
@@ -573,7 +584,7 @@ class Varsens(object):
             return self._compute_streamed(self._stream_rows)
 
         nacc = _native.acc_len(k, l, world)
-        acc = ctx.alloc(8 * nacc)
+        acc, gram, whole = self._result_buffers(nacc, k * l)
         fused = False
         if obj._f is None and obj._rows > 0 and self._fused_candidate(obj.objective_func):
             handle = obj._device_objective()
@@ -590,19 +601,27 @@ class Varsens(object):
             pass
         elif self._second_order:
             # both reductions read the same blocks: one pass where the shape allows (k <= 32, one output)
-            gram = ctx.alloc(8 * 3 * k * l * k * l)
             ctx.reduce_first_second_order(obj._values(), obj._rows, k, l, acc, gram, flags, rank, world)
         else:
             ctx.reduce_first_order(obj._values(), obj._rows, k, l, acc, flags, rank, world)
-        self._finish(acc, nacc, gram if self._second_order else None, world)
+        self._finish(acc, nacc, gram, world, whole)
 
-    def _finish(self, acc, nacc, gram, slots):
+    def _result_buffers(self, nacc, K):
+        """The accumulator record and (second order) the 3 K^2 Gram sums as two windows of ONE device
+        buffer: a rank's whole contribution crosses the GPUs in a single all-reduce."""
+        total = nacc + (3 * K * K if self._second_order else 0)
+        whole = self._ctx.alloc(8 * total)
+        acc = _native.DeviceView(whole, 0, 8 * nacc)
+        gram = _native.DeviceView(whole, 8 * nacc, 8 * 3 * K * K) if self._second_order else None
+        return acc, gram, whole
+
+    def _finish(self, acc, nacc, gram, slots, whole):
         """Exchange, finishing kernels and the result attributes; `slots` = variance slots in the record."""
         ctx, obj = self._ctx, self.objective
         k, n, l = int(self.k), int(self.n), int(obj._l)
         world = self._comm.world if self._comm is not None else 1
         if world > 1:
-            self._comm.allreduce(acc, nacc)
+            self._comm.allreduce(whole, whole.nbytes // 8)      # ONE all-reduce: record + Gram sums
         first = ctx.alloc(8 * _native.first_order_len(k, l))
         ctx.finish_first_order(acc, n, k, l, first, slots)
         r = ctx.download(first, (2 + 4 * k, l))
@@ -616,18 +635,15 @@ class Varsens(object):
 
         if self._second_order:
             K = k * l
-            if world > 1:
-                self._comm.allreduce(gram, 3 * K * K)
             s2 = ctx.alloc(8 * K * K)
             s2n = ctx.alloc(8 * K * K)
             ctx.finish_second_order(gram, first, n, k, l, s2, s2n)
             self.sens_2 = ctx.download(s2, (k, l, k, l))
             self.sens_2n = ctx.download(s2n, (k, l, k, l))
-            for b in (gram, s2, s2n):
+            for b in (s2, s2n):
                 b.free()
-        acc.free()
+        whole.free()
         first.free()
-
 
     def _compute_streamed(self, rows_per_pass):
         """The same estimators with the f-values streamed through one HBM buffer in row ranges:
@@ -644,14 +660,11 @@ class Varsens(object):
         slots = passes * world
         nacc = _native.acc_len(k, l, slots)
         K = k * l
-        acc = ctx.alloc(8 * nacc)
-        total = ctx.alloc(8 * nacc)
-        ctx.memset(total, 0)
-        gram = gram_total = None
-        if self._second_order:
-            gram = ctx.alloc(8 * 3 * K * K)
-            gram_total = ctx.alloc(8 * 3 * K * K)
-            ctx.memset(gram_total, 0)
+        # per-pass results and their running totals, each record + Gram sums in one buffer (one add per pass,
+        # one all-reduce at the end)
+        acc, gram, pass_buf = self._result_buffers(nacc, K)
+        total, gram_total, total_buf = self._result_buffers(nacc, K)
+        ctx.memset(total_buf, 0)
         f = ctx.alloc(8 * 2 * (k + 1) * min(R, obj._rows) * l)
         handle = obj._device_objective()
         for c in range(passes):
@@ -662,14 +675,11 @@ class Varsens(object):
             ctx.eval(obj.sample._design, handle, obj._row_begin + begin, count, f)
             if self._second_order:
                 ctx.reduce_first_second_order(f, count, k, l, acc, gram, 0, rank * passes + c, slots)
-                ctx.accumulate(gram_total, gram, 3 * K * K)
             else:
                 ctx.reduce_first_order(f, count, k, l, acc, 0, rank * passes + c, slots)
-            ctx.accumulate(total, acc, nacc)
+            ctx.accumulate(total_buf, pass_buf, total_buf.nbytes // 8)
         ctx.sync()
         handle.free()
         f.free()
-        acc.free()
-        if gram is not None:
-            gram.free()
-        self._finish(total, nacc, gram_total, slots)
+        pass_buf.free()
+        self._finish(total, nacc, gram_total, slots, total_buf)
