@@ -71,6 +71,7 @@ extern "C" int vs_context_create(int device, vs_context** out) {
         t.fused_wgs_per_cu = (int)env_long("VS_FUSED_WGS_PER_CU", t.fused_wgs_per_cu);
         t.fused_variant = (int)env_long("VS_FUSED_VARIANT", t.fused_variant);
         t.scan_shape = (int)env_long("VS_SCAN_SHAPE", t.scan_shape);
+        t.scan_general = (int)env_long("VS_SCAN_GENERAL", t.scan_general);
         t.gram_wgs_per_cu = (int)env_long("VS_GRAM_WGS_PER_CU", t.gram_wgs_per_cu);
         t.reduce_both = (int)env_long("VS_REDUCE_BOTH", t.reduce_both);
         t.profile_mask = env_long("VS_PROFILE_MASK", t.profile_mask);

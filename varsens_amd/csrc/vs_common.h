@@ -25,6 +25,7 @@ struct vs_tuning {
     int eval_waves = 0;          // VS_EVAL_WAVES_PER_WG: 4 or 8 (0 = by tile size)
     int eval_mode = 0;           // vs_context_set_eval_order / VS_EVAL_MODE: 0 = scan kernels where they apply, 1 = strict order (chain scheme)
     int fused_wgs_per_cu = 0;    // VS_FUSED_WGS_PER_CU (0 = by kernel)
+    int scan_general = 0;        // VS_SCAN_GENERAL=1: the scan kernels' general column code also for Halton designs (tests)
     int scan_shape = 0;          // VS_SCAN_SHAPE=L*100+W: force the evaluation scan kernel's shape (must be instantiated)
     int fused_variant = 0;       // VS_FUSED_VARIANT=1 or L*100+W: 64 < k <= 128 fused as 8 waves x 16 columns instead of 16 x 8
     int gram_wgs_per_cu = 0;     // VS_GRAM_WGS_PER_CU (0 = by shape)

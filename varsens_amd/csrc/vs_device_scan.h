@@ -32,10 +32,10 @@
 // whose column loop is unrolled L times: only the compact generator paths are inlined (Halton below
 // 2^32 -- the host sends designs whose indices reach 2^32 to the chain kernel --, Sobol byte tables,
 // raw points), and pow() of the power scaling sits behind one out-of-line copy.
-__device__ __forceinline__ void vs_unit_pair(const vs_design_dev& D, vs_u64 r, vs_u64 src2, int c, double& x1,
-                                             double& x2) {
-    if (D.generator == VS_GEN_HALTON) {
-        vs_radical_inverse_pair((vs_u32)(D.first_index + r), (vs_u32)(D.first_index + src2), D.bases[c], x1, x2);
+__device__ __forceinline__ void vs_unit_pair(const vs_design_dev& D, const vs_base& B, vs_u64 r, vs_u64 src2, int c,
+                                             double& x1, double& x2) {
+    if (D.generator == VS_GEN_HALTON) {  // B = D.bases[c], fetched one column ahead by the caller
+        vs_radical_inverse_pair((vs_u32)(D.first_index + r), (vs_u32)(D.first_index + src2), B, x1, x2);
     } else if (D.generator == VS_GEN_SOBOL) {
         x1 = vs_sobol_point_tab(D.first_index + r, D.sobol_tabs + 1024 * c, D.sobol_bits);
         x2 = vs_sobol_point_tab(D.first_index + src2, D.sobol_tabs + 1024 * c, D.sobol_bits);
@@ -57,6 +57,32 @@ __device__ __forceinline__ double vs_apply_scale_compact(const vs_design_dev& D,
     if (D.scale_mode == VS_SCALE_LINEAR) return p * D.width[c] + D.lower[c];   // scale.py:33
     if (POWER && D.scale_mode == VS_SCALE_POWER) return vs_scale_power(D.lower[c], D.width[c], p);
     return p;
+}
+
+// Per-column constants, all wave-uniform (scalar registers)
+struct vs_scan_col {
+    vs_base B;      // Halton constants of the column
+    double w, lo;   // linear scaling: x * w + lo
+    double pre;     // the term's parameter (Term::pre), when it has one per column
+};
+
+// Term concept: pre(c, params) -> the value eval() needs from memory for column c (0 if none);
+//               eval(x, c, params, pre) -> t_c(x)
+template <class Term, int GENV, bool MULTI>
+__device__ __forceinline__ void vs_scan_col_load(vs_scan_col& C, const vs_design_dev& D, const double* __restrict__ params,
+                                                 int c, int k) {
+    C.B = {2u, 1u, 2.0, 0.5, 0.5};
+    C.w = 1.0;
+    C.lo = 0.0;
+    C.pre = 0.0;
+    if (c < k) {
+        if (GENV != 0 || D.generator == VS_GEN_HALTON) C.B = D.bases[c];
+        if (GENV == 2) {
+            C.w = D.width[c];
+            C.lo = D.lower[c];
+        }
+        if (!MULTI) C.pre = Term::pre(c, params);
+    }
 }
 
 // Per-wave state carried across the row blocks of a persistent workgroup (fused reduce only).
@@ -122,6 +148,9 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
         for (int m = NSUB - 1; m >= 0; --m) {
             ca[m] = ra;
             cb[m] = rb2;
+            // opaque copies: otherwise the compiler recognises the sub-block suffixes below as the values of
+            // this very chain and keeps all 2L of them in registers instead of rebuilding 2*SUB at a time
+            if (NSUB > 1) asm("" : "+v"(ca[m]), "+v"(cb[m]));
             if (m > 0) {
 #pragma unroll
                 for (int j = SUB - 1; j >= 0; --j) {
@@ -164,10 +193,12 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
                     acc.v[jj][3] = fma(b, cj, acc.v[jj][3]);
                 }
             } else if (i < k && valid) {
-                VS_STORE(f + (vs_u64)(2 + i) * rows, cj);
-                VS_STORE(f + (vs_u64)(2 + k + i) * rows, dj);
+                // wave-uniform plane address + lane: scalar base and one vector offset per store
+                VS_STORE(f + (vs_u64)(2 + i) * rows + lane, cj);
+                VS_STORE(f + (vs_u64)(2 + k + i) * rows + lane, dj);
             }
         }
+        if (!FUSED && L >= 16) __builtin_amdgcn_sched_barrier(0);   // one sub-block's suffixes alive at a time
     }
 #undef VS_TA
 #undef VS_TB
@@ -181,8 +212,8 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
             acc.s2 = fma(dx, dx, acc.s2);
             acc.s2 = fma(dy, dy, acc.s2);
         } else {
-            VS_STORE(f, a);
-            VS_STORE(f + rows, b);
+            VS_STORE(f + lane, a);
+            VS_STORE(f + rows + lane, b);
         }
     }
 }
@@ -191,7 +222,7 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
 // registers and every output o builds its own terms from them (parameters params + o*k, plane o of
 // the f-values; the two totals slabs alternate per output, one barrier each) -- the generator runs
 // once per row whatever l is.  Otherwise one output (`params`, `fplane` are that output's).
-template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI>
+template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
 __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const double* __restrict__ params,
                                               int q, int lane, vs_u64 rb, double* __restrict__ tot,
                                               double* __restrict__ tl, double* __restrict__ fplane, double shift,
@@ -212,23 +243,38 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     const vs_u64 r = A.row_begin + (valid ? lr : rows - 1);  // clamp: loads stay in range, stores are guarded
     const double ident = FOLD == VS_OBJ_LINEAR ? 0.0 : 1.0;
     const vs_u64 src2 = vs_perm_at(A.D, r);  // row of the un-shuffled second half behind M_2[r]
-    double* f = FUSED ? nullptr : fplane + rb * T + lane;
+    double* f = FUSED ? nullptr : fplane + rb * T;   // wave-uniform: the block's first row in plane 0
 
     // ---- this wave's segment: coordinates -> terms (registers, or the wave's LDS slab) and their totals
     double ta[TLDS ? 1 : L], tb[TLDS ? 1 : L];
     double Ta = ident, Tb = ident;
+    // Everything a column needs from memory -- the Halton constants, the scaling bounds, the term's
+    // parameter: 14 scalar registers -- is fetched while the column BEFORE it is computed: a scalar load
+    // takes hundreds of cycles, and each column's digit loop starts on these values.
+    // GENV 1 / 2: Halton below 2^32 with identity / linear scaling -- straight-line code per column;
+    // GENV 0: any generator and scaling, decided by (wave-uniform) branches per column.
+    vs_scan_col Cnext;
+    vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, q * L, k);
 #pragma unroll
     for (int j = 0; j < L; ++j) {
         const int c = q * L + j;  // wave-uniform
+        const vs_scan_col C = Cnext;
+        if (j + 1 < L) vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, c + 1, k);
         double t1 = ident, t2 = ident;
         if (c < k) {
             double x1, x2;
-            vs_unit_pair(A.D, r, A.D.n + src2, c, x1, x2);
-            t1 = vs_apply_scale_compact<!FUSED>(A.D, x1, c);
-            t2 = vs_apply_scale_compact<!FUSED>(A.D, x2, c);
+            if (GENV != 0) {
+                vs_radical_inverse_pair((vs_u32)(A.D.first_index + r), (vs_u32)(A.D.first_index + A.D.n + src2), C.B, x1, x2);
+                t1 = GENV == 2 ? x1 * C.w + C.lo : x1;   // scale.py:33
+                t2 = GENV == 2 ? x2 * C.w + C.lo : x2;
+            } else {
+                vs_unit_pair(A.D, C.B, r, A.D.n + src2, c, x1, x2);
+                t1 = vs_apply_scale_compact<!FUSED>(A.D, x1, c);
+                t2 = vs_apply_scale_compact<!FUSED>(A.D, x2, c);
+            }
             if (!MULTI) {
-                t1 = Term::eval(t1, c, params);
-                t2 = Term::eval(t2, c, params);
+                t1 = Term::eval(t1, c, params, C.pre);
+                t2 = Term::eval(t2, c, params, C.pre);
             }
         }
         if (TLDS) {
@@ -243,7 +289,13 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
             Tb = vs_fold<FOLD>(Tb, t2);
         }
         // one column at a time: left alone the scheduler hoists the scalar loads of all L columns'
-        // base constants to the top and spills scalars into vector lanes
+        // constants to the top and spills scalars into vector lanes
+        __builtin_amdgcn_sched_barrier(0);
+        // Scalar loads return out of order, so the only wait there is is "all of them": without this, the
+        // wait for THIS column's constants would sit at the top of the next column, behind the issue of the
+        // next prefetch, and cover that too.  Touching one prefetched value here puts the wait at the end of
+        // this column, where the loads have had its whole arithmetic to land.
+        if (j + 1 < L) asm("" : "+s"(Cnext.B.b));
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (!MULTI) {
@@ -261,8 +313,9 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
                 const int c = qo * L + j;
                 ua[j] = ub[j] = ident;
                 if (c < k) {
-                    ua[j] = Term::eval(ta[TLDS ? 0 : j], c, po);
-                    ub[j] = Term::eval(tb[TLDS ? 0 : j], c, po);
+                    const double pre = Term::pre(c, po);
+                    ua[j] = Term::eval(ta[TLDS ? 0 : j], c, po, pre);
+                    ub[j] = Term::eval(tb[TLDS ? 0 : j], c, po, pre);
                 }
                 Ta = vs_fold<FOLD>(Ta, ua[j]);
                 Tb = vs_fold<FOLD>(Tb, ub[j]);
@@ -287,7 +340,7 @@ struct vs_scan_lds {
 // (every output is its own plane of f-values / its own record; params + o*k are its parameters).
 // FUSED: one partial record per workgroup and output, layout and fold of reduce_first_kernel
 // (partials[(blockIdx.x * l + o) * VS_PLEN(k)], VS_PLEN = 5 + 4k).
-template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI = false>
+template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI = false, int GENV = 0>
 __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __restrict__ lds,
                                              const double* __restrict__ shift_src, double* __restrict__ partials) {
     constexpr int T = VS_EVAL_ROWS;
@@ -312,8 +365,8 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
     // (one slab: a second barrier closes the block instead.)
     if (FUSED) {
         for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-            vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, false>(A, params, q, lane, rb, lds + parity * (2 * W * T), tl,
-                                                                fplane, shift, acc);
+            vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, false, GENV>(A, params, q, lane, rb, lds + parity * (2 * W * T),
+                                                                      tl, fplane, shift, acc);
             if (TLDS) __syncthreads();
             else parity ^= 1;
         }
@@ -321,7 +374,8 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
         // one block per workgroup: every load of design constants then precedes every store of the
         // kernel, so the compiler may take them through the scalar cache (a persistent walk makes them
         // "possibly clobbered" and turns them into vector loads with a wait per column)
-        vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, MULTI>(A, params, q, lane, blockIdx.x, lds, tl, fplane, shift, acc);
+        vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, MULTI, GENV>(A, params, q, lane, blockIdx.x, lds, tl, fplane, shift,
+                                                                  acc);
     }
     if (FUSED) {
         const size_t plen = 5 + 4 * (size_t)k;

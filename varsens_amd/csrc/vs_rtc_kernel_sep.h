@@ -12,7 +12,8 @@
 // beside it (VS_USER_FUSED); shapes VS_USER_*_L / _W / _TLDS come from the host.  The chain-scheme kernel
 // below serves contexts in strict evaluation order.
 struct vs_user_term_t {
-    static __device__ __forceinline__ double eval(double x, int c, const double* __restrict__ p) {
+    static __device__ __forceinline__ double pre(int, const double* __restrict__) { return 0.0; }
+    static __device__ __forceinline__ double eval(double x, int c, const double* __restrict__ p, double) {
         return vs_user_term(x, c, p);
     }
 };

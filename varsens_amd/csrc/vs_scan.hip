@@ -14,16 +14,28 @@
 
 template <int KIND>
 struct builtin_term {
-    static __device__ __forceinline__ double eval(double x, int c, const double* __restrict__ p) {
-        return vs_term<KIND>(x, p[c]);
+    static __device__ __forceinline__ double pre(int c, const double* __restrict__ p) { return p[c]; }
+    static __device__ __forceinline__ double eval(double x, int, const double* __restrict__, double pc) {
+        return vs_term<KIND>(x, pc);
     }
 };
 
-template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
+// 16 columns per wave (k <= 128) without the fused sums: held to 128 registers, so that two workgroups of eight
+// waves share a CU (four waves per SIMD instead of two)
+#ifndef VS_SCAN_NO_MINWAVES
+#define VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI) ((L) == 16 && (W) == 8 && !(FUSED) && !(MULTI) ? 4 : 1)
+#else
+#define VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI) 1
+#endif
+
+// GENV: 1 / 2 = Halton indices below 2^32 with identity / linear scaling (straight-line column code);
+//       0 = any generator and scaling
+template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
 __global__ void __launch_bounds__(VS_EVAL_ROWS* W)
+__attribute__((amdgpu_waves_per_eu(VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI))))
 scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
     extern __shared__ double scan_lds[];  // totals slabs [2 families][W][64] (+ term slabs), vs_scan_lds
-    vs_scan_body<builtin_term<KIND>, KIND, L, W, FUSED, TLDS, MULTI>(A, scan_lds, shift_src, partials);
+    vs_scan_body<builtin_term<KIND>, KIND, L, W, FUSED, TLDS, MULTI, GENV>(A, scan_lds, shift_src, partials);
     // counters of the fold that follows (see reduce_first_kernel).  At the END of the kernel: a global
     // store in front of the row loop would make every load of design constants "possibly clobbered"
     // and keep it out of the scalar cache.
@@ -161,10 +173,10 @@ unsigned vs_persistent_workgroups(vs_context* ctx, const void* kernel, int threa
     return (unsigned)(P < 1 ? 1 : P);
 }
 
-template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
-static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
+template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
+static int launch_scan_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
     const size_t lds = sizeof(double) * vs_scan_lds<L, W, TLDS>::doubles;
-    const void* fn = (const void*)scan_kernel<KIND, L, W, FUSED, TLDS, MULTI>;
+    const void* fn = (const void*)scan_kernel<KIND, L, W, FUSED, TLDS, MULTI, GENV>;
     if (lds > 64 * 1024) VS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     if (plan_only) {
@@ -174,11 +186,23 @@ static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io
     {
         vs_launch_scope scope(ctx, FUSED ? VS_KERNEL_FUSED : VS_KERNEL_EVAL);
         // outputs: grid.y (fused; evaluation without the in-kernel output loop) or inside the block walk (MULTI)
-        hipLaunchKernelGGL((scan_kernel<KIND, L, W, FUSED, TLDS, MULTI>), dim3(*P_io, MULTI ? 1u : (unsigned)A.l),
+        hipLaunchKernelGGL((scan_kernel<KIND, L, W, FUSED, TLDS, MULTI, GENV>), dim3(*P_io, MULTI ? 1u : (unsigned)A.l),
                            dim3(VS_EVAL_ROWS * W), lds, ctx->stream, A, shift_dev, ctx->partials, ctx->counters);
     }
     VS_HIP(hipGetLastError());
     return VS_OK;
+}
+
+// the specialised column code for the common designs: Halton (indices below 2^32: every design the scan
+// kernels accept) with identity or linear scaling; Sobol, raw points and power scaling take the general one
+template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
+static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
+    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0;
+    if (halton && A.D.scale_mode == VS_SCALE_IDENTITY)
+        return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 1>(ctx, A, P_io, shift_dev, plan_only);
+    if (halton && A.D.scale_mode == VS_SCALE_LINEAR)
+        return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 2>(ctx, A, P_io, shift_dev, plan_only);
+    return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 0>(ctx, A, P_io, shift_dev, plan_only);
 }
 
 template <int KIND, bool FUSED>
