@@ -685,3 +685,16 @@ def test_design_with_a_slice_of_the_shuffle(ctx):
         ctx.sample_flat(part, 0, 10, f)
     with pytest.raises(_native.VarsensHipError, match="exceeds n|perm must hold"):
         ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 0, None, None, perm[:100], perm_begin=n - 50)
+
+
+def test_device_halton_against_scipy(ctx):
+    """vs_halton_fill against scipy's unscrambled Halton directly (not through the oracle): <= 2 ulp, k = 128,
+    indices 1.. and across a large offset.  ghalton itself is unavailable: see the oracle header."""
+    from scipy.stats import qmc
+    for k, start, count in ((128, 1, 4096), (32, 123457, 3000)):
+        eng = qmc.Halton(d=k, scramble=False)
+        eng.fast_forward(start)
+        ref = eng.random(count)
+        got = ctx.download(ctx.halton_fill(k, start, count), (count, k))
+        d = np.abs(got - ref) / np.spacing(np.maximum(got, ref))
+        assert d.max() <= (2.0 if start < 100000 else 4.0) and np.percentile(d, 99) <= 2.0 and (d == 0).mean() > 0.45

@@ -328,79 +328,148 @@ gram_diag_wave_kernel(vs_gram_args A) {
     }
 }
 
-// Off-diagonal super-block pairs (SI < SJ): all 16 block pairs are needed.  Eight waves share the
-// two 64x64 LDS tiles and split the OUTPUT: wave w owns tiles (bi = w/2, bj = 2(w%2), 2(w%2)+1) and
-// walks all 16 k-steps of a chunk.  Two accumulator tiles per wave (16 VGPRs) instead of sixteen, so
-// four waves per SIMD stay resident; a tile belongs to one wave, so no cross-wave sum at the end.
-template <bool MASKED>
-__global__ void __launch_bounds__(512)
-gram_offdiag_kernel(vs_gram_args A) {
-    extern __shared__ double tiles[];  // TI, TJ: [64][VS2_PITCH] each
+// More than 64 index rows (k*l > 32): 128-row macro blocks.  One workgroup of eight waves owns a pair
+// (MI <= MJ) of macro blocks and a strided set of 16-sample-row chunks; the chunk of BOTH blocks (256 index
+// rows x 16 sample rows, 32 KiB) is staged once in LDS -- double-buffered, one workgroup barrier per chunk --
+// and feeds all 64 output tiles of the 128 x 128 product: 2*128*128 flop per 8*256 bytes = 16 flop/byte, twice
+// the fp64 matrix pipe's break-even with HBM (64-row blocks sit exactly on it: the pair kernel they had was
+// reading 4.7 TB/s at k = 128).  Wave w owns block row w: its A fragments come from index rows 16w.. of MI,
+// its B fragments from the eight 16-row blocks of MJ; on a diagonal pair (MI == MJ) only the blocks bj >= w
+// are needed (wave-uniform skip; two workgroups share a CU, so the shorter waves leave the pipe to others).
+// LDS tile [256 index rows][16 sample rows], pitch 20 doubles, lane -> sample map and ds_read_b128 fragments
+// exactly as in gram_diag_wave_kernel.
+#define VS2_MACRO 128
+#define VS2_MTILE_OUT (VS2_MACRO * VS2_MACRO)
+
+template <bool MASKED, bool ALIGNED>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+gram_macro_kernel(vs_gram_args A) {
+    extern __shared__ double tiles[];  // [2 buffers][256][VS2_WPITCH]
     if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
-    int SI, SJ;
-    pair_from_index(blockIdx.y + A.nsuper, A.nsuper, SI, SJ);
-    double* TI = tiles;
-    double* TJ = tiles + VS2_SUPER * VS2_PITCH;
+    int MI, MJ;
+    pair_from_index(blockIdx.y, A.nsuper, MI, MJ);   // nsuper = number of macro blocks here
+    const bool diag = MI == MJ;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 = block row of the output
     const int M = 2 * A.K;
     const uint64_t rows = A.rows;
-    const int bi = wave >> 1, bj0 = (wave & 1) * 2;
+    constexpr int BUF = 2 * VS2_MACRO * VS2_WPITCH;  // doubles per buffer
 
-    vs_d4 acc0 = (vs_d4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-
-    // staging: wave w loads index rows w, w+8, .. of both super-blocks (8 + 8 loads of 512 B)
-    constexpr int NR = VS2_SUPER / 8;
-    const double* rowI[NR];
-    const double* rowJ[NR];
-    bool okI[NR], okJ[NR];
+    // staging: thread t loads 16 B (sample rows 2p, 2p+1) of index rows lrow, 64+lrow of MI and of MJ
+    const int lrow = tid >> 3, piece = tid & 7;
+    const double* rp[4];
+    bool ok[4];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int mi = SI * VS2_SUPER + wave + 8 * i, mj = SJ * VS2_SUPER + wave + 8 * i;
-        okI[i] = mi < M;
-        okJ[i] = mj < M;
-        rowI[i] = x_elem(A, okI[i] ? mi : 0, 0);
-        rowJ[i] = x_elem(A, okJ[i] ? mj : 0, 0);
+    for (int j = 0; j < 4; ++j) {
+        const int m = (j < 2 ? MI : MJ) * VS2_MACRO + (j & 1) * 64 + lrow;
+        ok[j] = m < M && !(diag && j >= 2);
+        rp[j] = x_elem(A, ok[j] ? m : 0, 0) + 2 * piece;
     }
-    double vi[NR], vj[NR];
-    auto fetch = [&](uint64_t ch) {
-        const uint64_t r = ch * VS2_CHUNK + lane;
-        const bool rin = r < rows && (!MASKED || A.keep[r]);
+    double* wr = tiles + lrow * VS2_WPITCH + 2 * piece;   // + 64j rows, + buffer
+    // fragments: A = index row 16*wave + (lane&15) of MI's half; B = 16*bj + (lane&15) of MJ's half
+    const double* rdA = tiles + (16 * wave + (lane & 15)) * VS2_WPITCH + 2 * (lane >> 4);
+    const double* rdB = tiles + ((diag ? 0 : VS2_MACRO) + (lane & 15)) * VS2_WPITCH + 2 * (lane >> 4);
+    const int bj0 = diag ? wave : 0;
+
+    vs_d4 acc[8];
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            vi[i] = (rin && okI[i]) ? __builtin_nontemporal_load(rowI[i] + r) : 0.0;
-            vj[i] = (rin && okJ[i]) ? __builtin_nontemporal_load(rowJ[i] + r) : 0.0;
+    for (int i = 0; i < 8; ++i) acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
+
+    const uint64_t nfull = rows / VS2_WCHUNK;
+    const uint64_t nch = nfull + ((rows % VS2_WCHUNK) ? 1 : 0);
+    // a workgroup takes GROUP consecutive chunks per visit (512 contiguous bytes per index row)
+    constexpr uint64_t GROUP = 4;
+    const uint64_t ngroups = (nch + GROUP - 1) / GROUP;
+    uint64_t mine = 0;   // chunks this workgroup walks
+    for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) mine += (g * GROUP + GROUP <= nch) ? GROUP : nch - g * GROUP;
+    auto chunk_of = [&](uint64_t i) {   // the i-th chunk of this workgroup
+        const uint64_t g = blockIdx.x + (i / GROUP) * gridDim.x;
+        return g * GROUP + (i % GROUP);
+    };
+    vs_d2 raw[4];
+    bool k0 = true, k1 = true;
+    auto fetch = [&](uint64_t c) {
+        const uint64_t s0 = c * VS2_WCHUNK;
+        if (c < nfull) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!ok[j]) continue;
+                if (ALIGNED) {
+                    raw[j] = __builtin_nontemporal_load((const vs_d2*)(rp[j] + s0));
+                } else {
+                    raw[j].x = __builtin_nontemporal_load(rp[j] + s0);
+                    raw[j].y = __builtin_nontemporal_load(rp[j] + s0 + 1);
+                }
+            }
+        } else {
+            const uint64_t sm = s0 + 2 * piece;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                raw[j].x = (ok[j] && sm < rows) ? rp[j][s0] : 0.0;
+                raw[j].y = (ok[j] && sm + 1 < rows) ? rp[j][s0 + 1] : 0.0;
+            }
+        }
+        if (MASKED) {
+            const uint64_t sm = s0 + 2 * piece;
+            k0 = sm < rows && A.keep[sm];
+            k1 = sm + 1 < rows && A.keep[sm + 1];
         }
     };
-    const uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
-    if (blockIdx.x < nchunks) fetch(blockIdx.x);
-    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += A.slab_wgs) {
-        __syncthreads();  // previous chunk fully consumed
+    auto stash = [&](int b) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            TI[(wave + 8 * i) * VS2_PITCH + lane] = vi[i];
-            TJ[(wave + 8 * i) * VS2_PITCH + lane] = vj[i];
+        for (int j = 0; j < 4; ++j) {
+            vs_d2 v = raw[j];
+            if (MASKED) {
+                v.x = k0 ? v.x : 0.0;
+                v.y = k1 ? v.y : 0.0;
+            }
+            if (!ok[j]) v = (vs_d2){0.0, 0.0};
+            if (!(diag && j >= 2)) *(vs_d2*)(wr + b * BUF + 64 * j * VS2_WPITCH) = v;
         }
-        if (ch + A.slab_wgs < nchunks) fetch(ch + A.slab_wgs);  // lands while the MFMAs below run
-        __syncthreads();
-        const double* pi = TI + (bi * 16 + (lane & 15)) * VS2_PITCH + (lane >> 4);
-        const double* pj0 = TJ + (bj0 * 16 + (lane & 15)) * VS2_PITCH + (lane >> 4);
-        const double* pj1 = pj0 + 16 * VS2_PITCH;
-#pragma unroll
-        for (int s = 0; s < VS2_CHUNK / 4; ++s) {
-            const double fi = pi[4 * s], f0 = pj0[4 * s], f1 = pj1[4 * s];
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, f0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, f1, acc1, 0, 0, 0);
-        }
+    };
+
+    if (mine > 0) {
+        fetch(chunk_of(0));
+        stash(0);
+        if (mine > 1) fetch(chunk_of(1));
     }
-    const int npairs = A.nsuper * (A.nsuper + 1) / 2;
-    double* out = A.partials + ((size_t)blockIdx.x * npairs + (blockIdx.y + A.nsuper)) * VS2_TILE_OUT;
+    __syncthreads();
+    for (uint64_t i = 0; i < mine; ++i) {
+        const int b = (int)(i & 1);
+        // the next chunk goes into the other buffer (everybody left it at the last barrier) ...
+        if (i + 1 < mine) stash(b ^ 1);
+        if (i + 2 < mine) fetch(chunk_of(i + 2));
+        // ... while this one feeds the matrix pipe
+        vs_d2 fa[2];
+        fa[0] = *(const vs_d2*)(rdA + b * BUF);
+        fa[1] = *(const vs_d2*)(rdA + b * BUF + 8);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int row = (lane >> 4) + 4 * v, col = lane & 15;   // f64 C/D layout
-        out[(bi * 16 + row) * VS2_SUPER + (bj0 * 16 + col)] = acc0[v];
-        out[(bi * 16 + row) * VS2_SUPER + ((bj0 + 1) * 16 + col)] = acc1[v];
+        for (int bj = 0; bj < 8; ++bj) {
+            if (bj >= bj0) {
+                const vs_d2 f0 = *(const vs_d2*)(rdB + b * BUF + 16 * bj * VS2_WPITCH);
+                const vs_d2 f1 = *(const vs_d2*)(rdB + b * BUF + 16 * bj * VS2_WPITCH + 8);
+                acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0][0], f0[0], acc[bj], 0, 0, 0);
+                acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0][1], f0[1], acc[bj], 0, 0, 0);
+                acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1][0], f1[0], acc[bj], 0, 0, 0);
+                acc[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1][1], f1[1], acc[bj], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // a tile belongs to one wave: straight to this workgroup's partial (tiles a diagonal pair skips stay
+    // unwritten; the fold never reads them)
+    const int npairs = A.nsuper * (A.nsuper + 1) / 2;
+    double* out = A.partials + ((size_t)blockIdx.x * npairs + blockIdx.y) * VS2_MTILE_OUT;
+#pragma unroll
+    for (int bj = 0; bj < 8; ++bj) {
+        if (bj >= bj0) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = (lane >> 4) + 4 * v, col = lane & 15;   // f64 C/D layout
+                out[(wave * 16 + row) * VS2_MACRO + (bj * 16 + col)] = acc[bj][v];
+            }
+        }
     }
 }
 
@@ -441,6 +510,7 @@ struct vs_gram_fold_args {
     const double* partials;
     uint32_t P;
     int K, nsuper, npairs;
+    int super;   // index rows per block of the partials: 64 (gram_diag_wave_kernel) or 128 (gram_macro_kernel)
     double* gram;
     uint32_t* counters;
     int masked;
@@ -455,16 +525,18 @@ gram_fold_kernel(vs_gram_fold_args A) {
     __shared__ double s_sum[VS2_FOLD_THREADS / 64][64];
     __shared__ double s_cmp[VS2_FOLD_THREADS / 64][64];
     if (A.masked && A.counters[CNT_NANFLAG] == 0) return;
-    const size_t width = (size_t)A.npairs * VS2_TILE_OUT;
+    const int SB = A.super;
+    const size_t tile_out = (size_t)SB * SB;
+    const size_t width = (size_t)A.npairs * tile_out;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t col = (size_t)blockIdx.x * 64 + lane;   // width is a multiple of 64
-    const int pair = (int)(col / VS2_TILE_OUT);
-    const int e = (int)(col % VS2_TILE_OUT);
+    const int pair = (int)(col / tile_out);
+    const int e = (int)(col % tile_out);
     int SI, SJ;
     pair_from_index(pair, A.nsuper, SI, SJ);
-    const int li = e / VS2_SUPER, lj = e % VS2_SUPER;
+    const int li = e / SB, lj = e % SB;
     const int K = A.K;
-    const int gi = SI * VS2_SUPER + li, gj = SJ * VS2_SUPER + lj;
+    const int gi = SI * SB + li, gj = SJ * SB + lj;
     // entries of mirror blocks (never computed) and of padding rows are skipped
     const bool live = !(SI == SJ && (lj / 16) < (li / 16)) && gi < 2 * K && gj < 2 * K;
     double s = 0.0, comp = 0.0;
@@ -552,18 +624,27 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     VS_REQUIRE((uint64_t)k * l <= 4096, "k*l=%llu too large for the second-order pass (limit 4096)",
                (unsigned long long)k * l);
     const int K = k * l;
-    const int nsuper = (2 * K + VS2_SUPER - 1) / VS2_SUPER;
+    // up to 64 index rows: one 64-row block, wave-private kernel; beyond: 128-row macro blocks
+    const bool macro = 2 * K > VS2_SUPER;
+    const int SB = macro ? VS2_MACRO : VS2_SUPER;
+    const int nsuper = (2 * K + SB - 1) / SB;
     const int npairs = nsuper * (nsuper + 1) / 2;
-    uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
+    uint64_t nchunks = (rows + VS2_WCHUNK - 1) / VS2_WCHUNK;
     if (nchunks < 1) nchunks = 1;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     // 16-byte loads need an even row count: planar blocks start at multiples of `rows` doubles
     const bool aligned = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
-    const int per_cu = ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu : (npairs == 1 ? 3 : 8);  // measured (tools/gram_only.py)
-    uint64_t want = ((uint64_t)cus * per_cu + npairs - 1) / npairs;
+    // workgroups per CU: 3 wave-private ones (measured, tools/gram_only.py); macro ones: 2 are resident (LDS:
+    // 80 KiB each), 6 are launched -- the diagonal pairs finish early and the dispatcher evens it out (measured)
+    const int per_cu = ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu : (macro ? 6 : 3);
+    // grid = want x npairs workgroups: never more than are resident at once (a single workgroup left over
+    // would run a whole extra round on an empty chip)
+    uint64_t want = macro ? ((uint64_t)cus * per_cu) / npairs : ((uint64_t)cus * per_cu + npairs - 1) / npairs;
     if (want < 1) want = 1;
-    const uint32_t slab_wgs = (uint32_t)(nchunks < want ? nchunks : want);
-    const size_t width = (size_t)npairs * VS2_TILE_OUT;
+    const uint64_t units = macro ? (nchunks + 3) / 4 : nchunks;   // the macro kernel walks groups of 4 chunks
+    const uint32_t slab_wgs = (uint32_t)(units < want ? units : want);
+    const size_t tile_out = (size_t)SB * SB;
+    const size_t width = (size_t)npairs * tile_out;
     int rc = vs_workspace_partials(ctx, sizeof(double) * (size_t)slab_wgs * width);
     if (rc) return rc;
 
@@ -588,13 +669,17 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     F.K = K;
     F.nsuper = nsuper;
     F.npairs = npairs;
+    F.super = SB;
     F.gram = gram_dev;
     F.counters = ctx->counters;
-    const size_t lds_w = sizeof(double) * 4 * VS2_SUPER * VS2_WPITCH;  // diagonal: one private tile per wave
-    const size_t lds2 = 2 * sizeof(double) * VS2_SUPER * VS2_PITCH;    // off-diagonal: two shared tiles
-    VS_HIP(hipFuncSetAttribute((const void*)gram_offdiag_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    VS_HIP(hipFuncSetAttribute((const void*)gram_offdiag_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    const dim3 grid_diag(slab_wgs, nsuper), grid_off(slab_wgs, npairs - nsuper);
+    const size_t lds_w = sizeof(double) * 4 * VS2_SUPER * VS2_WPITCH;       // wave-private: one tile per wave
+    const size_t lds_m = sizeof(double) * 2 * 2 * VS2_MACRO * VS2_WPITCH;   // macro: two buffers of 256 rows
+    if (macro) {
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+    }
     if ((flags & VS_REDUCE_NAN_TRIM) && rows > 0) {
         const uint64_t count = 2 * rows;  // blocks 0 and 1 of output 0 are contiguous
         const uint64_t want_blocks = (count + 255) / 256;
@@ -616,7 +701,15 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
         }
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
-            const int nb = nsuper > 1 ? 4 : (2 * K + 15) / 16;
+            if (macro) {
+                const dim3 grid(slab_wgs, npairs);
+                if (masked && aligned) hipLaunchKernelGGL((gram_macro_kernel<true, true>), grid, dim3(512), lds_m, ctx->stream, A);
+                else if (masked) hipLaunchKernelGGL((gram_macro_kernel<true, false>), grid, dim3(512), lds_m, ctx->stream, A);
+                else if (aligned) hipLaunchKernelGGL((gram_macro_kernel<false, true>), grid, dim3(512), lds_m, ctx->stream, A);
+                else hipLaunchKernelGGL((gram_macro_kernel<false, false>), grid, dim3(512), lds_m, ctx->stream, A);
+            } else {
+                const dim3 grid_diag(slab_wgs, 1);
+                const int nb = (2 * K + 15) / 16;
 #define VS2_LAUNCH_WAVE2(NBV, MK, AL) \
     hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, MK, AL, false>), grid_diag, dim3(256), lds_w, ctx->stream, A)
 #define VS2_LAUNCH_WAVE(NBV)                                        \
@@ -626,17 +719,14 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
         else if (aligned) VS2_LAUNCH_WAVE2(NBV, false, true);       \
         else VS2_LAUNCH_WAVE2(NBV, false, false);                   \
     } while (0)
-            switch (nb) {
-                case 1: VS2_LAUNCH_WAVE(1); break;
-                case 2: VS2_LAUNCH_WAVE(2); break;
-                case 3: VS2_LAUNCH_WAVE(3); break;
-                default: VS2_LAUNCH_WAVE(4); break;
-            }
+                switch (nb) {
+                    case 1: VS2_LAUNCH_WAVE(1); break;
+                    case 2: VS2_LAUNCH_WAVE(2); break;
+                    case 3: VS2_LAUNCH_WAVE(3); break;
+                    default: VS2_LAUNCH_WAVE(4); break;
+                }
 #undef VS2_LAUNCH_WAVE
 #undef VS2_LAUNCH_WAVE2
-            if (npairs > nsuper) {
-                if (masked) hipLaunchKernelGGL(gram_offdiag_kernel<true>, grid_off, dim3(512), lds2, ctx->stream, A);
-                else hipLaunchKernelGGL(gram_offdiag_kernel<false>, grid_off, dim3(512), lds2, ctx->stream, A);
             }
         }
         VS_HIP(hipGetLastError());
@@ -719,6 +809,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     F.K = K;
     F.nsuper = 1;
     F.npairs = 1;
+    F.super = VS2_SUPER;
     F.gram = gram_dev;
     F.counters = ctx->counters;
     F.masked = 0;
