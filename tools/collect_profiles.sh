@@ -31,14 +31,22 @@ for sub, name in (("stats", "bench_kernel_stats.csv"), ("stats5", "config5_kerne
 pmc = {}
 for which in ("p_fetch", "p_write", "p_sq1", "p_sq2", "p_grbm"):
     for f in glob.glob(out + "/%s/**/*counter_collection.csv" % which, recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        # full-size launches only: the fused path's one-row evaluation (variance shift) shares a kernel name with
+        # the full evaluation -- keep the launches with the kernel's largest grid
+        biggest = collections.defaultdict(int)
+        for row in rows:
+            biggest[row["Kernel_Name"]] = max(biggest[row["Kernel_Name"]], int(row["Grid_Size"]))
         agg = collections.defaultdict(list)
-        for row in csv.DictReader(open(f)):
-            agg[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
+        for row in rows:
+            if int(row["Grid_Size"]) == biggest[row["Kernel_Name"]]:
+                agg[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
         for (kname, c), v in agg.items():
-            # full-size launches only: the fused path's one-row evaluation (variance shift) shares kernel names
-            big = [x for x in v if x > 0.5 * max(v)] if c in ("WRITE_SIZE", "FETCH_SIZE", "SQ_WAVES") else v
-            pmc.setdefault(kname, {})[c + "_avg_per_launch"] = sum(big) / len(big)
-            pmc[kname]["launches_" + c] = len(big)
+            if kname.startswith("__amd_rocclr"):
+                continue
+            pmc.setdefault(kname, {})[c + "_avg_per_launch"] = sum(v) / len(v)
+            pmc[kname]["launches"] = len(v)
+            pmc[kname]["grid_size"] = biggest[kname]
 for kname, c in pmc.items():
     # share of SIMD cycles with a vector instruction in flight: SQ_ACTIVE_INST_VALU counts quad-cycles summed over
     # the SIMDs, SQ_BUSY_CYCLES sums the busy cycles of the shader engines' SQs (both per launch)

@@ -18,8 +18,8 @@ extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_use
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const vs_u64 rows = A.rows;
     double* lds = VS_USER_SCRATCH ? scratch + (size_t)blockIdx.x * 2 * k * T : lds_tile;
-    const vs_u64 nblocks = (rows + T - 1) / T;
-    for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+    const vs_u64 nrowblocks = (rows + T - 1) / T;
+    for (vs_u64 rb = blockIdx.x; rb < nrowblocks; rb += gridDim.x) {
     const vs_u64 lr = rb * T + lane;
     const bool valid = lr < rows;
     const vs_u64 r = A.row_begin + (valid ? lr : rows - 1);
@@ -44,8 +44,8 @@ extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_use
     }
     __syncthreads();
 
-    const int nblocks = 2 * k + 2;
-    for (int blk = q; blk < nblocks; blk += VS_EVAL_WAVES) {
+    const int npoints = 2 * k + 2;   // evaluation points of a design row = blocks of the f-values
+    for (int blk = q; blk < npoints; blk += VS_EVAL_WAVES) {
         vs_point x;
         if (blk == 0) { x.a = X1; x.b = X1; x.swap = -1; }                    // M_1[r]
         else if (blk == 1) { x.a = X2; x.b = X2; x.swap = -1; }               // M_2[r]
