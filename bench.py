@@ -264,7 +264,7 @@ def main():
         achieved = 8.0 * N_local / t_red / 1e9
         t_eval = avg["eval"] * 1e-3
         eval_gbs = 8.0 * N_local / t_eval / 1e9
-        eval_pmc = pmc_kernel("void scan_kernel", k, args.log2n) or {}
+        eval_pmc = pmc_kernel("void scan_kernel<3, 8, 4, false", k, args.log2n) or {}   # linear objective, evaluation
         # issued MFMA work of the Gram kernels: 16x16 tiles on and above the diagonal of the 2K x 2K Gram matrix
         nb = (2 * k * l + 15) // 16
         mfma_flops = nb * (nb + 1) / 2 * (rows / 4.0) * (2 * 16 * 16 * 4)
