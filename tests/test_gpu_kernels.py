@@ -372,7 +372,8 @@ def test_rccl_single_rank_allreduce(ctx):
 # ------------------------------------------------------------------ second order (fp64 MFMA Gram)
 
 @pytest.mark.parametrize("k,rows,l", [(6, 1000, 1), (32, 5000, 1), (40, 3001, 1), (70, 777, 1), (7, 500, 3),
-                                      (3, 5, 1), (33, 64, 2), (6, 200000, 1), (12, 100003, 1), (24, 65536, 1)])
+                                      (3, 5, 1), (33, 64, 2), (6, 200000, 1), (12, 100003, 1), (24, 65536, 1),
+                                      (64, 4099, 1), (65, 130, 1), (128, 2050, 1), (200, 97, 1), (50, 1000, 3), (129, 15, 1)])
 def test_second_order_gram(ctx, k, rows, l):
     rng = np.random.RandomState(k * 7 + rows + l)
     blocks = 1.0 + rng.randn(2 * k + 2, rows, l)
@@ -446,7 +447,7 @@ def test_one_pass_with_nan_trim_takes_the_separate_kernels(ctx):
     assert np.isnan(ctx.download(acc2, (nacc,))).any() and np.isnan(ctx.download(g2, (3, k, k))).any()
 
 
-@pytest.mark.parametrize("k,rows", [(5, 900), (9, 50001)])
+@pytest.mark.parametrize("k,rows", [(5, 900), (9, 50001), (40, 3001), (70, 1000), (129, 257)])   # k > 32: macro-tile kernel
 def test_second_order_nan_trim(ctx, k, rows):
     from varsens_amd import _native
     rng = np.random.RandomState(9)
@@ -466,7 +467,7 @@ def test_second_order_nan_trim(ctx, k, rows):
 
 
 @pytest.mark.parametrize("block", [0, 1])
-@pytest.mark.parametrize("k,rows,l", [(5, 900, 1), (20, 4097, 1), (3, 700, 2)])
+@pytest.mark.parametrize("k,rows,l", [(5, 900, 1), (20, 4097, 1), (3, 700, 2), (40, 1001, 1), (17, 600, 3)])
 def test_second_order_nan_only_in_fM(ctx, block, k, rows, l):
     """The lone NaN sits in fM_1 or fM_2, blocks the Gram matrix X = [C; D] never reads: the row is
     still dropped from fN_j / fN_nj (varsens/saltelli.py:474-492 trims all four arrays)."""
