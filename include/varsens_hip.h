@@ -293,9 +293,10 @@ int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, 
 /* a8-a10 + a12 in ONE pass over the f-values: Varsens.compute_varsens always needs both
  * (saltelli.py:572-622), and both passes read the same 2k blocks.  Fills acc_dev exactly like
  * vs_reduce_first_order and gram_dev exactly like vs_reduce_second_order.  Single-output
- * designs with k <= 32 and no NaN trimming take the combined kernel (the first-order dot
- * products ride on the Gram kernel's operand fragments); every other shape runs the two
- * separate passes internally, so the call is always valid. */
+ * designs without NaN trimming take one pass: the first-order dot products ride on the Gram
+ * kernels' operand fragments (k <= 32: the wave-private kernel; larger k: the diagonal pairs of
+ * the macro-tile kernel, plus one small pass over fM_1, fM_2 for the scalar sums); every other
+ * shape runs the two separate passes internally, so the call is always valid. */
 int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                                  int flags, int rank, int max_ranks, double* acc_dev, double* gram_dev);
 

@@ -397,10 +397,12 @@ def test_second_order_gram(ctx, k, rows, l):
 
 
 @pytest.mark.parametrize("k,rows,l", [(6, 1000, 1), (32, 5000, 1), (16, 200000, 1), (3, 5, 1), (12, 100003, 1),
-                                      (1, 17, 1), (25, 4096, 1), (40, 3000, 1), (5, 700, 2)])
+                                      (1, 17, 1), (25, 4096, 1), (40, 3000, 1), (5, 700, 2), (33, 2, 1), (64, 4099, 1),
+                                      (65, 777, 1), (128, 10000, 1), (129, 2050, 1), (200, 333, 1), (48, 65536, 1)])
 def test_first_and_second_order_in_one_pass(ctx, k, rows, l):
     """vs_reduce_first_second_order fills the record and the Gram matrices of the two separate passes
-    (k <= 32, l == 1: the combined kernel; other shapes: the separate kernels behind the same call)."""
+    (l == 1: k <= 32 the wave-private kernel, beyond that the macro kernel's diagonal pairs carry the dot
+    products and a small kernel the scalar sums; other shapes: the separate kernels behind the same call)."""
     from varsens_amd import _native
     rng = np.random.RandomState(k * 13 + rows + l)
     blocks = 3.0 + rng.randn(2 * k + 2, rows, l)

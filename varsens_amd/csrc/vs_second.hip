@@ -341,11 +341,27 @@ gram_diag_wave_kernel(vs_gram_args A) {
 #define VS2_MACRO 128
 #define VS2_MTILE_OUT (VS2_MACRO * VS2_MACRO)
 
-template <bool MASKED, bool ALIGNED>
+//
+// FIRST (vs_reduce_first_second_order; one output, no mask): the first-order sums of reduce_first_kernel ride
+// on the DIAGONAL pairs, where every index row of X appears exactly once: a = fM_1 and b = fM_2 of the chunk
+// are staged in the padding of the LDS tile rows, each A fragment element meets them in two fmas (index row
+// m < k is c_m -> a.c, b.c; m >= k is d_{m-k} -> a.d, b.d).  One first-order record per diagonal workgroup,
+// folded like reduce_first_kernel's; sab, sa, sb and the shifted variance sums -- one pass over fM_1, fM_2 only,
+// 1/(k+1) of the data -- come from first_head_kernel's records in the same fold.
+template <bool MASKED, bool ALIGNED, bool FIRST>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 gram_macro_kernel(vs_gram_args A) {
-    extern __shared__ double tiles[];  // [2 buffers][256][VS2_WPITCH]
+    extern __shared__ double tiles[];  // [2 buffers][256][VS2_WPITCH]; FIRST: a, b of the chunk in the row padding
     if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
+    if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        // this kernel opens the call: reset the counters the two folds use (cf. reduce_first_kernel)
+        uint32_t* c = const_cast<uint32_t*>(A.counters);
+        c[0] = 0;
+        c[1] = 0xffffffffu;
+        c[2] = 0;
+        c[3] = 0;
+        c[4] = 0;
+    }
     int MI, MJ;
     pair_from_index(blockIdx.y, A.nsuper, MI, MJ);   // nsuper = number of macro blocks here
     const bool diag = MI == MJ;
@@ -355,6 +371,7 @@ gram_macro_kernel(vs_gram_args A) {
     const int M = 2 * A.K;
     const uint64_t rows = A.rows;
     constexpr int BUF = 2 * VS2_MACRO * VS2_WPITCH;  // doubles per buffer
+    const bool first = FIRST && diag;       // this workgroup also carries first-order dot products
 
     // staging: thread t loads 16 B (sample rows 2p, 2p+1) of index rows lrow, 64+lrow of MI and of MJ
     const int lrow = tid >> 3, piece = tid & 7;
@@ -389,8 +406,23 @@ gram_macro_kernel(vs_gram_args A) {
     };
     vs_d2 raw[4];
     bool k0 = true, k1 = true;
+    // FIRST: threads 0..7 stage a (plane 0), 8..15 b (plane 1) of the chunk: sample pair p goes into the padding
+    // of tile row p (16 of 20 doubles per row are index-row data): a at [16,17], b at [18,19]
+    const bool abth = first && tid < 16;
+    const double* abp = A.f + (tid >= 8 ? rows : 0) + 2 * (tid & 7);
+    vs_d2 rawab = (vs_d2){0.0, 0.0};
+    double pa = 0.0, pb = 0.0;
     auto fetch = [&](uint64_t c) {
         const uint64_t s0 = c * VS2_WCHUNK;
+        if (FIRST && abth) {
+            const uint64_t sm = s0 + 2 * (tid & 7);
+            if (c < nfull && ALIGNED) {
+                rawab = __builtin_nontemporal_load((const vs_d2*)(abp + s0));
+            } else {
+                rawab.x = sm < rows ? abp[s0] : 0.0;
+                rawab.y = sm + 1 < rows ? abp[s0 + 1] : 0.0;
+            }
+        }
         if (c < nfull) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -427,6 +459,7 @@ gram_macro_kernel(vs_gram_args A) {
             if (!ok[j]) v = (vs_d2){0.0, 0.0};
             if (!(diag && j >= 2)) *(vs_d2*)(wr + b * BUF + 64 * j * VS2_WPITCH) = v;
         }
+        if (FIRST && abth) *(vs_d2*)(tiles + b * BUF + (tid & 7) * VS2_WPITCH + 16 + 2 * (tid >> 3)) = rawab;
     };
 
     if (mine > 0) {
@@ -444,6 +477,22 @@ gram_macro_kernel(vs_gram_args A) {
         vs_d2 fa[2];
         fa[0] = *(const vs_d2*)(rdA + b * BUF);
         fa[1] = *(const vs_d2*)(rdA + b * BUF + 8);
+        if (FIRST && first) {
+            // samples 2q, 2q+1 (h = 0) and 8+2q, 8+2q+1 (h = 1) of the lane group q, as in the fragments
+            const double* rdAB = tiles + b * BUF + (lane >> 4) * VS2_WPITCH + 16;
+            vs_d2 av[2], bv[2];
+            av[0] = *(const vs_d2*)(rdAB);
+            av[1] = *(const vs_d2*)(rdAB + 4 * VS2_WPITCH);
+            bv[0] = *(const vs_d2*)(rdAB + 2);
+            bv[1] = *(const vs_d2*)(rdAB + 4 * VS2_WPITCH + 2);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    pa = fma(av[h][t], fa[h][t], pa);
+                    pb = fma(bv[h][t], fa[h][t], pb);
+                }
+        }
 #pragma unroll
         for (int bj = 0; bj < 8; ++bj) {
             if (bj >= bj0) {
@@ -456,6 +505,34 @@ gram_macro_kernel(vs_gram_args A) {
             }
         }
         __syncthreads();
+    }
+    if (FIRST && first) {
+        // the four lane groups of a wave hold the same index rows over different samples
+        pa += __shfl_xor(pa, 16, 64);
+        pa += __shfl_xor(pa, 32, 64);
+        pb += __shfl_xor(pb, 16, 64);
+        pb += __shfl_xor(pb, 32, 64);
+        double* red = tiles;   // the tiles are free: [128 index rows][2]
+        if (lane < 16) {
+            red[(16 * wave + lane) * 2 + 0] = pa;
+            red[(16 * wave + lane) * 2 + 1] = pb;
+        }
+        __syncthreads();
+        // this workgroup's first-order record: its own 128 index rows, zeros elsewhere
+        const int k = A.k, K = A.K;
+        const size_t plen = VS_PLEN(k);
+        double* rec = A.first_partials + ((size_t)blockIdx.x * A.nsuper + MI) * plen;
+        for (size_t e = tid; e < plen; e += 512) {
+            double v = 0.0;
+            if (e >= VS_P_HEAD) {   // the five scalar sums come from first_head_kernel's records
+                // record layout: head, ac[k], bd[k], ad[k], bc[k]; ac/bc come from the c rows (m = j), ad/bd from d (m = K + j)
+                const int slot = (int)((e - VS_P_HEAD) / k), j = (int)((e - VS_P_HEAD) % k);
+                const int m = (slot == 0 || slot == 3) ? j : K + j;
+                const int local = m - MI * VS2_MACRO;
+                if (local >= 0 && local < VS2_MACRO) v = red[local * 2 + ((slot == 0 || slot == 2) ? 0 : 1)];
+            }
+            rec[e] = v;
+        }
     }
     // a tile belongs to one wave: straight to this workgroup's partial (tiles a diagonal pair skips stay
     // unwritten; the fold never reads them)
@@ -471,6 +548,38 @@ gram_macro_kernel(vs_gram_args A) {
             }
         }
     }
+}
+
+// The five scalar sums of the first-order record (sab, sa, sb, shifted s1, s2: varsens/saltelli.py:577,583) for
+// the one-pass route beyond 32 columns: a = fM_1, b = fM_2 only.  One full record per workgroup (zeros in the
+// dot-product part), appended to the macro kernel's records.
+__global__ void __launch_bounds__(256)
+first_head_kernel(const double* __restrict__ f, uint64_t rows, int k, double* __restrict__ records) {
+    __shared__ double wsum[4][5];
+    const double shift = vs_shift_estimate(f, rows);   // wave-wide call; every wave and the fold get the same bits
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+        const double a = __builtin_nontemporal_load(f + r), b = __builtin_nontemporal_load(f + rows + r);
+        const double dx = a - shift, dy = b - shift;
+        v[VS_P_SAB] = fma(a, b, v[VS_P_SAB]);
+        v[VS_P_SA] += a;
+        v[VS_P_SB] += b;
+        v[VS_P_S1] += dx + dy;
+        v[VS_P_S2] = fma(dx, dx, v[VS_P_S2]);
+        v[VS_P_S2] = fma(dy, dy, v[VS_P_S2]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int z = 0; z < 5; ++z) {
+        const double t = vs_wave_sum_dpp(v[z]);
+        if (lane == 63) wsum[wave][z] = t;
+    }
+    __syncthreads();
+    const size_t plen = VS_PLEN(k);
+    double* rec = records + (size_t)blockIdx.x * plen;
+    for (size_t e = threadIdx.x; e < plen; e += 256)
+        rec[e] = e < VS_P_HEAD ? ((wsum[0][e] + wsum[1][e]) + wsum[2][e]) + wsum[3][e] : 0.0;
 }
 
 // NaN probe of the two blocks the Gram matrix never sees: fM_1 and fM_2 of output 0 (planes 0, 1).
@@ -615,8 +724,9 @@ finish_second_kernel(const double* __restrict__ gram, const double* __restrict__
     }
 }
 
-extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
-                                      int flags, double* gram_dev) {
+// with_first (macro kernel, one output, no NaN trimming): also this rank's first-order record into acc_dev
+static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l, int flags,
+                             double* gram_dev, bool with_first, int rank, int max_ranks, double* acc_dev) {
     VS_REQUIRE(ctx && gram_dev, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && l >= 1, "k and l must be positive");
@@ -645,7 +755,14 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     const uint32_t slab_wgs = (uint32_t)(units < want ? units : want);
     const size_t tile_out = (size_t)SB * SB;
     const size_t width = (size_t)npairs * tile_out;
-    int rc = vs_workspace_partials(ctx, sizeof(double) * (size_t)slab_wgs * width);
+    // workspace: [with_first: first-order records of the diagonal workgroups + folded record,] then the Gram partials
+    const size_t plen = VS_PLEN(k);
+    const uint32_t P_diag = with_first ? slab_wgs * (uint32_t)nsuper : 0;                       // macro kernel's records
+    const uint32_t P_head = with_first ? (uint32_t)((rows + 4095) / 4096 < (uint64_t)cus ? (rows + 4095) / 4096 : cus) : 0;
+    const uint32_t P_first = P_diag + P_head;                                                   // + first_head_kernel's
+    size_t first_doubles = with_first ? (size_t)P_first * plen + plen : 0;
+    first_doubles = (first_doubles + 1) & ~(size_t)1;
+    int rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + (size_t)slab_wgs * width));
     if (rc) return rc;
 
     VS_HIP(hipMemsetAsync(ctx->counters + CNT_NANFLAG, 0, sizeof(uint32_t), ctx->stream));
@@ -659,12 +776,12 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     A.K = K;
     A.nsuper = nsuper;
     A.slab_wgs = slab_wgs;
-    A.partials = ctx->partials;
-    A.first_partials = nullptr;
+    A.partials = ctx->partials + first_doubles;
+    A.first_partials = with_first ? ctx->partials : nullptr;
     A.keep = nullptr;
     A.counters = ctx->counters;
     vs_gram_fold_args F;
-    F.partials = ctx->partials;
+    F.partials = A.partials;
     F.P = slab_wgs;
     F.K = K;
     F.nsuper = nsuper;
@@ -675,10 +792,12 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
     const size_t lds_w = sizeof(double) * 4 * VS2_SUPER * VS2_WPITCH;       // wave-private: one tile per wave
     const size_t lds_m = sizeof(double) * 2 * 2 * VS2_MACRO * VS2_WPITCH;   // macro: two buffers of 256 rows
     if (macro) {
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
     }
     if ((flags & VS_REDUCE_NAN_TRIM) && rows > 0) {
         const uint64_t count = 2 * rows;  // blocks 0 and 1 of output 0 are contiguous
@@ -703,10 +822,12 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
             if (macro) {
                 const dim3 grid(slab_wgs, npairs);
-                if (masked && aligned) hipLaunchKernelGGL((gram_macro_kernel<true, true>), grid, dim3(512), lds_m, ctx->stream, A);
-                else if (masked) hipLaunchKernelGGL((gram_macro_kernel<true, false>), grid, dim3(512), lds_m, ctx->stream, A);
-                else if (aligned) hipLaunchKernelGGL((gram_macro_kernel<false, true>), grid, dim3(512), lds_m, ctx->stream, A);
-                else hipLaunchKernelGGL((gram_macro_kernel<false, false>), grid, dim3(512), lds_m, ctx->stream, A);
+                if (with_first && aligned) hipLaunchKernelGGL((gram_macro_kernel<false, true, true>), grid, dim3(512), lds_m, ctx->stream, A);
+                else if (with_first) hipLaunchKernelGGL((gram_macro_kernel<false, false, true>), grid, dim3(512), lds_m, ctx->stream, A);
+                else if (masked && aligned) hipLaunchKernelGGL((gram_macro_kernel<true, true, false>), grid, dim3(512), lds_m, ctx->stream, A);
+                else if (masked) hipLaunchKernelGGL((gram_macro_kernel<true, false, false>), grid, dim3(512), lds_m, ctx->stream, A);
+                else if (aligned) hipLaunchKernelGGL((gram_macro_kernel<false, true, false>), grid, dim3(512), lds_m, ctx->stream, A);
+                else hipLaunchKernelGGL((gram_macro_kernel<false, false, false>), grid, dim3(512), lds_m, ctx->stream, A);
             } else {
                 const dim3 grid_diag(slab_wgs, 1);
                 const int nb = (2 * K + 15) / 16;
@@ -730,6 +851,16 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
             }
         }
         VS_HIP(hipGetLastError());
+        if (with_first && !masked) {
+            {
+                vs_launch_scope scope(ctx, VS_KERNEL_REDUCE_FIRST);
+                hipLaunchKernelGGL(first_head_kernel, dim3(P_head), dim3(256), 0, ctx->stream, f_dev, rows, k,
+                                   ctx->partials + (size_t)P_diag * plen);
+            }
+            VS_HIP(hipGetLastError());
+            rc = vs_fold_partials(ctx, P_first, k, 1, rows, nullptr, 1, f_dev, rank, max_ranks, acc_dev);
+            if (rc) return rc;
+        }
         F.masked = masked ? 1 : 0;
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_FOLD);
@@ -738,6 +869,11 @@ extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint
         VS_HIP(hipGetLastError());
     }
     return VS_OK;
+}
+
+extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
+                                      int flags, double* gram_dev) {
+    return second_order_impl(ctx, f_dev, rows, k, l, flags, gram_dev, false, 0, 1, nullptr);
 }
 
 extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
@@ -749,8 +885,10 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     VS_REQUIRE(max_ranks >= 1 && rank >= 0 && rank < max_ranks, "rank %d not in [0,%d)", rank, max_ranks);
     VS_REQUIRE(rows <= 0xfffffff0ull, "rows per GPU must stay below 2^32");
     VS_REQUIRE(rows == 0 || f_dev, "f_dev is null");
-    const bool combined = l == 1 && 2 * k <= VS2_SUPER && !(flags & VS_REDUCE_NAN_TRIM) && rows >= 1 &&
-                          ctx->tune.reduce_both != 0;
+    const bool one_pass = l == 1 && !(flags & VS_REDUCE_NAN_TRIM) && rows >= 1 && ctx->tune.reduce_both != 0;
+    if (one_pass && 2 * k > VS2_SUPER && (uint64_t)k <= 4096)   // first-order sums ride on the macro kernel's diagonal pairs
+        return second_order_impl(ctx, f_dev, rows, k, 1, 0, gram_dev, true, rank, max_ranks, acc_dev);
+    const bool combined = one_pass && 2 * k <= VS2_SUPER;
     if (!combined) {
         int rc = vs_reduce_first_order(ctx, f_dev, rows, k, l, flags, rank, max_ranks, acc_dev);
         if (rc) return rc;
