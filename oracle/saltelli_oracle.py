@@ -270,8 +270,9 @@ SCAN_SUB = 4
 
 def scan_shape(k, fused=False):
     """(L, W): columns per segment and segments, as the kernels choose them (vs_scan.hip)."""
-    if k <= 8: return 2, 4
-    if k <= 16: return 4, 4
+    if k <= 8: return 8, 1
+    if k <= 16: return 16, 1
+    if k <= 24: return 12, 2
     if k <= 32: return 8, 4
     if k <= 48: return 12, 4
     if k <= 64: return 8, 8

@@ -111,9 +111,9 @@ fused_ishigami_kernel(vs_eval_args A, const double* shift_src, double* partials,
 // launch shapes (measured on MI355X, tools/scan_sweep.py; registers: 2L doubles of terms, 2(L/4 + 4) of
 // suffixes, +4L sums in the fused kernel, whose terms move to LDS beyond 96 columns)
 // ---------------------------------------------------------------------------
-//   k <=  8: 4 waves x  2 columns     k <= 48: 4 waves x 12     k <= 128: 8 waves x 16
-//   k <= 16: 4 waves x  4             k <= 64: 8 waves x  8     k <= 256: 8 waves x 32 (evaluation only)
-//   k <= 32: 4 waves x  8             k <= 96: 8 waves x 12
+//   k <=  8: 1 wave  x  8 columns     k <= 32: 4 waves x  8     k <=  96: 8 waves x 12
+//   k <= 16: 1 wave  x 16             k <= 48: 4 waves x 12     k <= 128: 8 waves x 16
+//   k <= 24: 2 waves x 12             k <= 64: 8 waves x  8     k <= 256: 8 waves x 32 (evaluation only)
 struct scan_shape {
     int L, W;
 };
@@ -124,8 +124,9 @@ static bool scan_shape_for(int k, bool fused, scan_shape* s, int variant = 0) {
         *s = {variant / 100, variant % 100};
         return s->L * s->W >= k;
     }
-    if (k <= 8) *s = {2, 4};
-    else if (k <= 16) *s = {4, 4};
+    if (k <= 8) *s = {8, 1};          // few columns: one wave per 64 rows, nothing to exchange
+    else if (k <= 16) *s = {16, 1};
+    else if (k <= 24) *s = {12, 2};
     else if (k <= 32) *s = {8, 4};
     else if (k <= 48) *s = {12, 4};
     else if (k <= 64) *s = {8, 8};
@@ -216,8 +217,9 @@ static int launch_scan_kind(vs_context* ctx, const vs_eval_args& A, scan_shape s
         }                                                                                                              \
         return launch_scan_lw<KIND, LL, WW, FUSED, FUSED && TL, false>(ctx, A, P_io, shift_dev, plan_only);            \
     }
-    VS_SCAN_CASE(2, 4, false)
-    VS_SCAN_CASE(4, 4, false)
+    VS_SCAN_CASE(8, 1, false)
+    VS_SCAN_CASE(16, 1, false)
+    VS_SCAN_CASE(12, 2, false)
     VS_SCAN_CASE(8, 4, false)
     VS_SCAN_CASE(12, 4, false)
     VS_SCAN_CASE(8, 8, false)
