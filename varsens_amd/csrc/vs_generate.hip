@@ -736,6 +736,7 @@ int vs_scan_fused_plan(vs_context* ctx, const vs_eval_args& A, unsigned* P);
 int vs_scan_fused(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev);
 unsigned vs_fused_ishigami_workgroups(vs_context* ctx, uint64_t rows);
 int vs_fused_ishigami(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev);
+int vs_ishigami_eval(vs_context* ctx, const vs_eval_args& A);
 
 static bool rows_in_perm_slice(const vs_design* g, uint64_t row_begin, uint64_t row_count) {
     if (!g->perm) return true;
@@ -854,7 +855,9 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
         case VS_OBJ_G_FUNCTION: return launch_eval<VS_OBJ_G_FUNCTION>(ctx, A, sep_tiles);
         case VS_OBJ_POLYNOMIAL: return launch_eval<VS_OBJ_POLYNOMIAL>(ctx, A, sep_tiles);
         case VS_OBJ_LINEAR: return launch_eval<VS_OBJ_LINEAR>(ctx, A, sep_tiles);
-        case VS_OBJ_ISHIGAMI: return launch_eval<VS_OBJ_ISHIGAMI>(ctx, A, 2);
+        case VS_OBJ_ISHIGAMI:   // thread-per-row kernel (same operations, same bits); the tile kernel only when forced
+            if (ctx->tune.eval_scratch != 1) return vs_ishigami_eval(ctx, A);
+            return launch_eval<VS_OBJ_ISHIGAMI>(ctx, A, 2);
         case VS_OBJ_INVERT: return launch_eval<VS_OBJ_INVERT>(ctx, A, 2);
         case VS_OBJ_SOURCE: {
             const size_t lds = obj->eval_scan ? obj->eval_lds : sizeof(double) * 2 * (size_t)design->d.k * VS_EVAL_ROWS;

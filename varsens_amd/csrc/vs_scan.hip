@@ -46,7 +46,45 @@ scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t*
     }
 }
 
-// Ishigami (k = 3, not separable): thread = design row, 8 values per row, 4*3 + 5 register sums.
+// Ishigami (k = 3, not separable): thread = design row.  The 8 values of a row -- f(M_1), f(M_2), N_j[0..2],
+// N_nj[0..2] -- from 6 sines; same operation order as eval_kernel<VS_OBJ_ISHIGAMI>, so the same bits.
+__device__ __forceinline__ void ishigami_row(const vs_design_dev& D, uint64_t r, double pa_, double pb_, double (&v)[8]) {
+    double s[2][2], p4[2];
+    s[0][0] = sin(vs_m1(D, r, 0));
+    s[1][0] = sin(vs_m2(D, r, 0));
+    s[0][1] = sin(vs_m1(D, r, 1));
+    s[1][1] = sin(vs_m2(D, r, 1));
+    const double x3a = vs_m1(D, r, 2), x3b = vs_m2(D, r, 2);
+    p4[0] = (x3a * x3a) * (x3a * x3a);
+    p4[1] = (x3b * x3b) * (x3b * x3b);
+    auto val = [&](int u0, int u1, int u2) {  // coordinate c taken from sample u_c in {0 = M_1, 1 = M_2}
+        const double s1 = s[u0][0], s2 = s[u1][1];
+        return (s1 + pa_ * (s2 * s2)) + (pb_ * p4[u2]) * s1;
+    };
+    v[0] = val(0, 0, 0);
+    v[1] = val(1, 1, 1);
+    v[2] = val(0, 1, 1);  // N_j[i]: M_2 except column i
+    v[3] = val(1, 0, 1);
+    v[4] = val(1, 1, 0);
+    v[5] = val(1, 0, 0);  // N_nj[i]: M_1 except column i
+    v[6] = val(0, 1, 0);
+    v[7] = val(0, 0, 1);
+}
+
+// vs_eval for Ishigami: 8 coalesced 512-byte stores per wave
+__global__ void __launch_bounds__(256)
+ishigami_eval_kernel(vs_eval_args A) {
+    const double pa_ = A.params[0], pb_ = A.params[1];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t lr = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lr < A.rows; lr += stride) {
+        double v[8];
+        ishigami_row(A.D, A.row_begin + lr, pa_, pb_, v);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) VS_STORE(A.f + (uint64_t)b * A.rows + lr, v[b]);
+    }
+}
+
+// fused evaluate + first-order reduce for Ishigami: 4*3 + 5 register sums per thread
 __global__ void __launch_bounds__(256)
 fused_ishigami_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
     __shared__ double wsum[4][17];
@@ -64,22 +102,9 @@ fused_ishigami_kernel(vs_eval_args A, const double* shift_src, double* partials,
     for (int i = 0; i < 17; ++i) acc[i] = 0.0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t lr = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lr < A.rows; lr += stride) {
-        const uint64_t r = A.row_begin + lr;
-        double s[2][2], p4[2];
-        s[0][0] = sin(vs_m1(A.D, r, 0));
-        s[1][0] = sin(vs_m2(A.D, r, 0));
-        s[0][1] = sin(vs_m1(A.D, r, 1));
-        s[1][1] = sin(vs_m2(A.D, r, 1));
-        const double x3a = vs_m1(A.D, r, 2), x3b = vs_m2(A.D, r, 2);
-        p4[0] = (x3a * x3a) * (x3a * x3a);
-        p4[1] = (x3b * x3b) * (x3b * x3b);
-        auto val = [&](int u0, int u1, int u2) {  // same operation order as eval_kernel<VS_OBJ_ISHIGAMI>
-            const double s1 = s[u0][0], s2 = s[u1][1];
-            return (s1 + pa_ * (s2 * s2)) + (pb_ * p4[u2]) * s1;
-        };
-        const double a = val(0, 0, 0), b = val(1, 1, 1);
-        const double c[3] = {val(0, 1, 1), val(1, 0, 1), val(1, 1, 0)};  // N_j[i]: M_2 except column i
-        const double d[3] = {val(1, 0, 0), val(0, 1, 0), val(0, 0, 1)};  // N_nj[i]: M_1 except column i
+        double v[8];
+        ishigami_row(A.D, A.row_begin + lr, pa_, pb_, v);
+        const double a = v[0], b = v[1];
         const double dx = a - shift, dy = b - shift;
         acc[VS_P_SAB] = fma(a, b, acc[VS_P_SAB]);
         acc[VS_P_SA] += a;
@@ -89,10 +114,11 @@ fused_ishigami_kernel(vs_eval_args A, const double* shift_src, double* partials,
         acc[VS_P_S2] = fma(dy, dy, acc[VS_P_S2]);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            acc[VS_P_HEAD + 0 * 3 + i] = fma(a, c[i], acc[VS_P_HEAD + 0 * 3 + i]);
-            acc[VS_P_HEAD + 1 * 3 + i] = fma(b, d[i], acc[VS_P_HEAD + 1 * 3 + i]);
-            acc[VS_P_HEAD + 2 * 3 + i] = fma(a, d[i], acc[VS_P_HEAD + 2 * 3 + i]);
-            acc[VS_P_HEAD + 3 * 3 + i] = fma(b, c[i], acc[VS_P_HEAD + 3 * 3 + i]);
+            const double c = v[2 + i], d = v[5 + i];
+            acc[VS_P_HEAD + 0 * 3 + i] = fma(a, c, acc[VS_P_HEAD + 0 * 3 + i]);
+            acc[VS_P_HEAD + 1 * 3 + i] = fma(b, d, acc[VS_P_HEAD + 1 * 3 + i]);
+            acc[VS_P_HEAD + 2 * 3 + i] = fma(a, d, acc[VS_P_HEAD + 2 * 3 + i]);
+            acc[VS_P_HEAD + 3 * 3 + i] = fma(b, c, acc[VS_P_HEAD + 3 * 3 + i]);
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -274,7 +300,7 @@ int vs_scan_fused(vs_context* ctx, const vs_eval_args& A, unsigned P, const doub
 
 unsigned vs_fused_ishigami_workgroups(vs_context* ctx, uint64_t rows) {
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    uint64_t P = (uint64_t)cus * 4;
+    uint64_t P = (uint64_t)cus * 12;   // 3 resident per CU (141 VGPRs), four rounds
     const uint64_t blocks = (rows + 255) / 256;
     if (P > blocks) P = blocks;
     return (unsigned)(P < 1 ? 1 : P);
@@ -284,6 +310,19 @@ int vs_fused_ishigami(vs_context* ctx, const vs_eval_args& A, unsigned P, const 
     vs_launch_scope scope(ctx, VS_KERNEL_FUSED);
     hipLaunchKernelGGL(fused_ishigami_kernel, dim3(P), dim3(256), 0, ctx->stream, A, shift_dev, ctx->partials,
                        ctx->counters);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+// vs_eval for Ishigami (called by vs_eval, vs_generate.hip)
+int vs_ishigami_eval(vs_context* ctx, const vs_eval_args& A) {
+    const uint64_t blocks = (A.rows + 255) / 256;
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    const uint64_t cap = (uint64_t)cus * 32;
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_EVAL);
+        hipLaunchKernelGGL(ishigami_eval_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, ctx->stream, A);
+    }
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
