@@ -95,10 +95,20 @@ typedef double vs_d2 __attribute__((ext_vector_type(2)));
 // index row m < k is c_m (-> ac, bc), m >= k is d_{m-k} (-> ad, bd).  Sixteen lanes hold the same
 // a, b; lane&15 == 0 of each group carries the scalar sums (sab, sa, sb, shifted variance sums).
 // 58 more VGPRs: two waves per SIMD, which still saturates the matrix pipe.
+// Waves per SIMD (= resident workgroups per CU) by the number of live 16-row blocks: with few index rows a wave
+// has little in flight (16 sample rows x 16 NB index rows), so the small shapes -- BASELINE configs[1], [2] have
+// 12 and 6 index rows -- run more waves: they are bound by bytes in flight, not by the matrix pipe.
+#define VS2_WAVES_PER_SIMD(NB, FIRST) ((FIRST) ? ((NB) == 1 ? 5 : (NB) == 2 ? 3 : 2) : ((NB) == 1 ? 8 : (NB) == 2 ? 6 : 3))
+// LDS doubles per workgroup: the four wave tiles (16 NB rows each), and the epilogue's scratch
+#define VS2_WAVE_LDS(NB, FIRST) \
+    ((4 * 16 * (NB) * VS2_WPITCH) > 1024 + ((FIRST) ? 16 * (NB) * 16 * 2 + 80 : 0) \
+         ? (4 * 16 * (NB) * VS2_WPITCH) : 1024 + ((FIRST) ? 16 * (NB) * 16 * 2 + 80 : 0))
+
 template <int NB, bool MASKED, bool ALIGNED, bool FIRST>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FIRST ? 2 : 3, FIRST ? 2 : 3)))
+__global__ void __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(VS2_WAVES_PER_SIMD(NB, FIRST), VS2_WAVES_PER_SIMD(NB, FIRST))))
 gram_diag_wave_kernel(vs_gram_args A) {
-    extern __shared__ double tiles[];  // [4 waves][64][VS2_WPITCH]
+    extern __shared__ double tiles[];  // [4 waves][16 NB][VS2_WPITCH] (VS2_WAVE_LDS doubles)
     if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
     if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) {
         // this kernel opens the call: reset the counters the two folds use (cf. reduce_first_kernel)
@@ -117,7 +127,7 @@ gram_diag_wave_kernel(vs_gram_args A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = 2 * A.K;
     const uint64_t rows = A.rows;
-    double* tile = tiles + wave * (VS2_SUPER * VS2_WPITCH);
+    double* tile = tiles + wave * (16 * NB * VS2_WPITCH);
 
     const int lrow = lane >> 3, piece = lane & 7;
     const double* rp[NJ];
@@ -746,7 +756,9 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const bool aligned = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
     // workgroups per CU: 3 wave-private ones (measured, tools/gram_only.py); macro ones: 2 are resident (LDS:
     // 80 KiB each), 6 are launched -- the diagonal pairs finish early and the dispatcher evens it out (measured)
-    const int per_cu = ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu : (macro ? 6 : 3);
+    const int nb_wave = (2 * K + 15) / 16;   // live 16-row blocks of the wave-private kernel (2K <= 64)
+    const int per_cu = ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu
+                       : (macro ? 6 : (nb_wave <= 4 ? VS2_WAVES_PER_SIMD(nb_wave, false) : 3));
     // grid = want x npairs workgroups: never more than are resident at once (a single workgroup left over
     // would run a whole extra round on an empty chip)
     uint64_t want = macro ? ((uint64_t)cus * per_cu) / npairs : ((uint64_t)cus * per_cu + npairs - 1) / npairs;
@@ -789,7 +801,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     F.super = SB;
     F.gram = gram_dev;
     F.counters = ctx->counters;
-    const size_t lds_w = sizeof(double) * 4 * VS2_SUPER * VS2_WPITCH;       // wave-private: one tile per wave
+    const size_t lds_w = sizeof(double) * (nb_wave <= 4 ? (size_t)VS2_WAVE_LDS(nb_wave, false) : 0);   // wave-private tiles
     const size_t lds_m = sizeof(double) * 2 * 2 * VS2_MACRO * VS2_WPITCH;   // macro: two buffers of 256 rows
     if (macro) {
         VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
@@ -897,7 +909,9 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     const int K = k;
     const uint64_t nchunks = (rows + VS2_CHUNK - 1) / VS2_CHUNK;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    const uint64_t want = (uint64_t)cus * (ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu : 2);  // two waves per SIMD
+    const int nb = (2 * K + 15) / 16;
+    const uint64_t want = (uint64_t)cus * (ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu
+                                                                          : VS2_WAVES_PER_SIMD(nb, true));
     const uint32_t P = (uint32_t)(nchunks < want ? nchunks : want);
     const size_t plen = VS_PLEN(k);
     // workspace: first-order records [P][plen] + folded [plen] (vs_fold_partials' layout), then Gram partials
@@ -919,8 +933,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     A.keep = nullptr;
     A.counters = ctx->counters;
     const bool aligned = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
-    const size_t lds_w = sizeof(double) * 4 * VS2_SUPER * VS2_WPITCH;
-    const int nb = (2 * K + 15) / 16;
+    const size_t lds_w = sizeof(double) * (size_t)VS2_WAVE_LDS(nb, true);
     {
         vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
 #define VS2_LAUNCH_BOTH(NBV)                                                                                           \
