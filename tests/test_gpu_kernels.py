@@ -373,7 +373,10 @@ def test_rccl_single_rank_allreduce(ctx):
 
 @pytest.mark.parametrize("k,rows,l", [(6, 1000, 1), (32, 5000, 1), (40, 3001, 1), (70, 777, 1), (7, 500, 3),
                                       (3, 5, 1), (33, 64, 2), (6, 200000, 1), (12, 100003, 1), (24, 65536, 1),
-                                      (64, 4099, 1), (65, 130, 1), (128, 2050, 1), (200, 97, 1), (50, 1000, 3), (129, 15, 1)])
+                                      (64, 4099, 1), (65, 130, 1), (128, 2050, 1), (200, 97, 1), (50, 1000, 3), (129, 15, 1),
+                                      # 32-sample-row staging (one output, even row count): ragged ends of every kind
+                                      (17, 34, 1), (31, 30, 1), (28, 2, 1), (33, 46, 1), (64, 48, 1), (96, 62, 1),
+                                      (100, 4128, 1), (32, 65598, 1)])
 def test_second_order_gram(ctx, k, rows, l):
     rng = np.random.RandomState(k * 7 + rows + l)
     blocks = 1.0 + rng.randn(2 * k + 2, rows, l)
@@ -398,7 +401,8 @@ def test_second_order_gram(ctx, k, rows, l):
 
 @pytest.mark.parametrize("k,rows,l", [(6, 1000, 1), (32, 5000, 1), (16, 200000, 1), (3, 5, 1), (12, 100003, 1),
                                       (1, 17, 1), (25, 4096, 1), (40, 3000, 1), (5, 700, 2), (33, 2, 1), (64, 4099, 1),
-                                      (65, 777, 1), (128, 10000, 1), (129, 2050, 1), (200, 333, 1), (48, 65536, 1)])
+                                      (65, 777, 1), (128, 10000, 1), (129, 2050, 1), (200, 333, 1), (48, 65536, 1),
+                                      (17, 34, 1), (31, 30, 1), (32, 65598, 1), (33, 46, 1), (64, 48, 1), (96, 62, 1)])
 def test_first_and_second_order_in_one_pass(ctx, k, rows, l):
     """vs_reduce_first_second_order fills the record and the Gram matrices of the two separate passes
     (l == 1: k <= 32 the wave-private kernel, beyond that the macro kernel's diagonal pairs carry the dot
@@ -425,6 +429,32 @@ def test_first_and_second_order_in_one_pass(ctx, k, rows, l):
     ctx.finish_first_order(acc1, rows, k, l, first1)
     np.testing.assert_allclose(ctx.download(first, (2 + 4 * k, l)), ctx.download(first1, (2 + 4 * k, l)),
                                rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("k,rows", [(20, 5000), (32, 100000), (40, 3000), (128, 2050)])
+def test_wide_staging_agrees_with_the_chunk_kernels(ctx, k, rows, monkeypatch):
+    """VS_GRAM_WIDE=0 (read once per context) keeps the 16-sample-row staging for every shape: same sums."""
+    from varsens_amd import _native
+    rng = np.random.RandomState(k + rows)
+    blocks = 2.0 + rng.randn(2 * k + 2, rows, 1)
+    host = _native.to_planar(blocks)
+    nacc = _native.acc_len(k, 1, 1)
+    monkeypatch.setenv("VS_GRAM_WIDE", "0")
+    narrow = _native.Context(0)
+    monkeypatch.delenv("VS_GRAM_WIDE")
+    out = []
+    for c in (ctx, narrow):
+        f = c.upload(host)
+        acc, g1, g2 = c.alloc(8 * nacc), c.alloc(8 * 3 * k * k), c.alloc(8 * 3 * k * k)
+        c.reduce_second_order(f, rows, k, 1, g1)
+        c.reduce_first_second_order(f, rows, k, 1, acc, g2)
+        out.append((c.download(g1, (3, k, k)), c.download(g2, (3, k, k)), c.download(acc, (nacc,))))
+        for b in (f, acc, g1, g2):
+            b.free()
+    narrow.close()
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-13)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-13)
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=2e-13, atol=1e-9)
 
 
 def test_one_pass_with_nan_trim_takes_the_separate_kernels(ctx):

@@ -1,18 +1,29 @@
-// Bare v_mfma_f64_16x16x4_f64 issue loop: what the fp64 matrix pipe sustains on this chip, and
-// at which clock -- the MFMA-side roofline of the second-order Gram kernel.
-// Build+run on the GPU box: hipcc --offload-arch=gfx950 -O3 tools/mfma_f64_peak.hip -o /tmp/mfma && /tmp/mfma
+// Bare v_mfma_f64_16x16x4_f64 issue loop: what the fp64 matrix pipe sustains on this chip, by the number of
+// independent accumulator chains per wave and of waves per SIMD -- the MFMA-side roofline of the second-order
+// Gram kernels.
+//
+// The accumulator register class matters.  Build it twice on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form tools/mfma_f64_peak.hip -o /tmp/mfma_v && /tmp/mfma_v
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_f64_peak.hip -o /tmp/mfma_a && /tmp/mfma_a
+// With the accumulators in VGPRs (what the Gram kernels get: llvm-objdump shows v[..] destinations) one wave
+// with ONE dependent chain already sustains 69 TFLOP/s and anything more 77.6 (the data sheet's 78.6 at 2.4 GHz:
+// one MFMA per 64 clocks per SIMD).  With the accumulators in AGPRs (the compiler's choice for a 256-thread
+// kernel that leaves it the register budget) a single wave per SIMD stops at 35 TFLOP/s, however many chains;
+// two waves per SIMD reach 77.6 again.  Round 1 and early round 2 quoted "47-49 TFLOP/s measured issue
+// ceiling" from the AGPR form: that was this artefact, not a property of the pipe.
+// Operands are constants here, so the loop draws little power and runs at 2.4 GHz; the Gram kernels, streaming
+// HBM beside the matrix pipe, were measured at 2.0-2.1 GHz (clock64 / wall_clock64 inside the kernel).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-template <int NACC>
-__global__ void __launch_bounds__(256) mfma_loop(double* out, long long* clk, int iters, double seed) {
+template <int NACC, int THREADS>
+__global__ void __launch_bounds__(THREADS) mfma_loop(double* out, long long* clk, int iters, double seed) {
     d4 acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = (d4){0, 0, 0, 0};
-    double a = seed * (1.0 + threadIdx.x * 1e-3), b = seed * (1.0 - threadIdx.x * 2e-3);  // seed 0: all-zero operands
+    const double a = seed * (1.0 + threadIdx.x * 1e-3), b = seed * (1.0 - threadIdx.x * 2e-3);
     const long long t0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -23,40 +34,50 @@ __global__ void __launch_bounds__(256) mfma_loop(double* out, long long* clk, in
 #pragma unroll
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if (threadIdx.x == 0) {
-        clk[2 * blockIdx.x] = t1 - t0;
-        clk[2 * blockIdx.x + 1] = w1 - w0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = t1 - t0;
+        clk[1] = w1 - w0;
     }
 }
 
-int main(int argc, char** argv) {
-    const int wgs_per_cu = argc > 1 ? atoi(argv[1]) : 1;
-    const int iters = argc > 2 ? atoi(argv[2]) : 20000;
-    const double scale = argc > 3 ? atof(argv[3]) : 1.0;
+template <int NACC, int THREADS>
+void run(double* out, long long* clk, int wgs, int iters) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((mfma_loop<NACC, THREADS>), dim3(wgs), dim3(THREADS), 0, 0, out, clk, iters, 1.0 + rep);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    long long h[2];
+    (void)hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+    const double flops = (double)iters * NACC * 2048.0 * (THREADS / 64) * wgs;
+    printf("chains/wave=%2d waves/SIMD=%d: %.3f ms  %.1f TFLOP/s fp64  (%.0f MHz shader clock)\n", NACC, THREADS / 256, best,
+           flops / best / 1e9, (double)h[0] / (h[1] * 10.0) * 1e3);
+}
+
+int main() {
     hipDeviceProp_t p;
-    hipGetDeviceProperties(&p, 0);
-    const int wgs = p.multiProcessorCount * wgs_per_cu;
+    (void)hipGetDeviceProperties(&p, 0);
+    const int wgs = p.multiProcessorCount;   // one workgroup per CU
     double* out;
     long long* clk;
-    hipMalloc(&out, sizeof(double) * wgs * 256);
-    hipMalloc(&clk, sizeof(long long) * 2 * wgs);
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    constexpr int NACC = 10;
-    for (int rep = 0; rep < 3; ++rep) {
-        hipEventRecord(e0);
-        hipLaunchKernelGGL(mfma_loop<NACC>, dim3(wgs), dim3(256), 0, 0, out, clk, iters, scale * (1.0 + rep));
-        hipEventRecord(e1);
-        hipEventSynchronize(e1);
-        float ms;
-        hipEventElapsedTime(&ms, e0, e1);
-        std::vector<long long> h(2 * wgs);
-        hipMemcpy(h.data(), clk, sizeof(long long) * 2 * wgs, hipMemcpyDeviceToHost);
-        const double mf = (double)iters * NACC;
-        const double flops = mf * 2048.0 * 4 * wgs;  // 4 waves per workgroup
-        printf("wgs/CU=%d: %.3f ms, %.1f TFLOP/s fp64; per MFMA: %.1f shader clocks (clock64), %.2f ns wall => %.0f MHz effective\n",
-               wgs_per_cu, ms, flops / ms / 1e9, h[0] / mf, h[1] * 10.0 / mf, (h[0] / mf) / (h[1] * 10.0 / mf) * 1e3);
-    }
+    (void)hipMalloc(&out, 8 * wgs * 1024);
+    (void)hipMalloc(&clk, 16);
+    run<1, 256>(out, clk, wgs, 20000);
+    run<2, 256>(out, clk, wgs, 20000);
+    run<4, 256>(out, clk, wgs, 20000);
+    run<10, 256>(out, clk, wgs, 8000);
+    run<1, 512>(out, clk, wgs, 20000);
+    run<4, 512>(out, clk, wgs, 8000);
+    run<10, 512>(out, clk, wgs, 8000);
+    run<10, 768>(out, clk, wgs, 8000);
+    run<4, 1024>(out, clk, wgs, 8000);
     return 0;
 }

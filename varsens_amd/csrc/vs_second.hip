@@ -70,6 +70,49 @@ __device__ __forceinline__ const double* x_elem(const vs_gram_args& A, int m, ui
     return A.f + ((uint64_t)o * (2 * (uint64_t)A.k + 2) + block) * A.rows + r;  // planar f-values
 }
 
+// First-order record of a wave-private workgroup (FIRST): the 16 (wave, lane group) pairs each hold a share of
+// every sum -- pa/pb per 16-row block and index row lane&15, the five scalar sums in the lanes with lane&15 == 0.
+template <int NB>
+__device__ __forceinline__ void gram_first_record(const vs_gram_args& A, double* tiles, const double (&pa)[NB],
+                                                  const double (&pb)[NB], double t_sab, double t_sa, double t_sb,
+                                                  double t_s1, double t_s2) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fq = lane >> 4;
+    const int k = A.k;
+    const int g = wave * 4 + fq, i = lane & 15;
+    double* r2 = tiles;                          // [16][NB*16][2]
+    double* r3 = tiles + 16 * (NB * 16) * 2;     // [16][5]
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        r2[((size_t)g * (NB * 16) + blk * 16 + i) * 2 + 0] = pa[blk];
+        r2[((size_t)g * (NB * 16) + blk * 16 + i) * 2 + 1] = pb[blk];
+    }
+    if (i == 0) {
+        r3[g * 5 + VS_P_SAB] = t_sab;
+        r3[g * 5 + VS_P_SA] = t_sa;
+        r3[g * 5 + VS_P_SB] = t_sb;
+        r3[g * 5 + VS_P_S1] = t_s1;
+        r3[g * 5 + VS_P_S2] = t_s2;
+    }
+    __syncthreads();
+    double* rec = A.first_partials + (size_t)blockIdx.x * VS_PLEN(k);
+    for (int e = tid; e < NB * 16 * 2; e += 256) {
+        const int m = e >> 1, which = e & 1;
+        double sum = 0.0;
+        for (int gg = 0; gg < 16; ++gg) sum += r2[((size_t)gg * (NB * 16) + m) * 2 + which];
+        if (m < 2 * k) {
+            // record layout: head, ac[k], bd[k], ad[k], bc[k]
+            const int j = m < k ? m : m - k;
+            const int slot = m < k ? (which == 0 ? 0 : 3) : (which == 0 ? 2 : 1);
+            rec[VS_P_HEAD + (size_t)slot * k + j] = sum;
+        }
+    }
+    if (tid < VS_P_HEAD) {
+        double sum = 0.0;
+        for (int gg = 0; gg < 16; ++gg) sum += r3[gg * 5 + tid];
+        rec[tid] = sum;
+    }
+}
+
 // Diagonal super-block pairs, wave-private form (the default when the row count is even): no
 // workgroup barrier in the loop.  A wave owns 16-sample-row chunks (the four waves of a
 // workgroup take adjacent chunks: 512 contiguous bytes per index row between them), keeps ALL
@@ -299,43 +342,174 @@ gram_diag_wave_kernel(vs_gram_args A) {
             __syncthreads();
             ++a;
         }
-    if (FIRST) {
-        // first-order record of this workgroup: 16 (wave, q) groups hold a share of every sum
-        const int k = A.k;
-        const int g = wave * 4 + fq, i = lane & 15;
-        double* r2 = tiles;                          // [16][NB*16][2]
-        double* r3 = tiles + 16 * (NB * 16) * 2;     // [16][5]
+    if (FIRST) gram_first_record<NB>(A, tiles, pa, pb, t_sab, t_sa, t_sb, t_s1, t_s2);
+}
+
+// Wide form of the wave-private kernel (one output, even row count, no NaN mask, 2k > 32 index rows): the
+// same accumulators and fragments, but a wave stages 32 sample rows at a time and every load instruction reads
+// 4 index rows x 256 contiguous bytes.  Measured on MI355X (tools/load_patterns.hip): a wave-wide 16-byte load
+// that gathers 8 x 128 B runs from 8 planes sustains 4.9 TB/s however many are in flight; 4 x 256 B runs
+// sustain 6.7 TB/s, 1 x 1 KB 7.0 TB/s.  With one output the index row m is plane 2 + m of f, so the lane's
+// pointer advances by a wave-uniform stride from one load to the next (no pointer per load in registers).
+//   global: load j, lane L: 16 B = sample rows 2(L&15), 2(L&15)+1 of index row 4j + (L>>4);
+//   LDS:    tile [16 NB index rows (+ a, b rows)][32 sample rows], pitch 34 doubles: the 16 lanes of an index
+//           row write 256 contiguous bytes, and the b128 fragment reads (index row = lane&15, stride 272 B)
+//           fall into eight distinct 4-bank groups per 8 lanes;
+//   MFMA:   two 16-sample-row halves x 4 k-steps x NB(NB+1)/2 tiles per staged unit.
+// 64 VGPRs of loads in flight per wave (16 KiB), two waves per SIMD: 128 KiB in flight per CU.
+// FIRST: a = fM_1, b = fM_2 of the unit are one more load (planes 0, 1) into two more tile rows; every lane
+// group reads them back in the fragment layout, as in gram_diag_wave_kernel.
+#define VS2_XCHUNK 32
+#define VS2_XPITCH 34
+#define VS2_WIDE_ROWS(NB, FIRST) (16 * (NB) + ((FIRST) ? 4 : 0))
+#define VS2_WIDE_LDS(NB, FIRST) \
+    ((4 * VS2_WIDE_ROWS(NB, FIRST) * VS2_XPITCH) > 1024 + ((FIRST) ? 16 * (NB) * 16 * 2 + 80 : 0) \
+         ? (4 * VS2_WIDE_ROWS(NB, FIRST) * VS2_XPITCH) : 1024 + ((FIRST) ? 16 * (NB) * 16 * 2 + 80 : 0))
+
+template <int NB, bool FIRST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gram_diag_wide_kernel(vs_gram_args A) {
+    extern __shared__ double tiles[];  // [4 waves][VS2_WIDE_ROWS][VS2_XPITCH] (VS2_WIDE_LDS doubles)
+    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) {
+        // this kernel opens the call: reset the counters the two folds use (cf. reduce_first_kernel)
+        uint32_t* c = const_cast<uint32_t*>(A.counters);
+        c[0] = 0;            // NaN flag
+        c[1] = 0xffffffffu;  // first kept row
+        c[2] = 0;            // kept rows
+        c[3] = 0;            // fold tickets
+        c[4] = 0;
+    }
+    constexpr int NT = NB * (NB + 1) / 2;
+    constexpr int NJ = 4 * NB;          // loads per unit: 4 index rows each
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = 2 * A.K;
+    const uint64_t rows = A.rows;
+    double* tile = tiles + wave * (VS2_WIDE_ROWS(NB, FIRST) * VS2_XPITCH);
+
+    const int mrow = lane >> 4, li = lane & 15;
+    // index row m = plane 2 + m (one output); rows past 2k read row 0 and are zeroed on the way into the tile
+    const double* p0 = A.f + (uint64_t)(2 + mrow) * rows + 2 * li;
+    const uint64_t jstride = 4 * rows;
+    double* wr = tile + mrow * VS2_XPITCH + 2 * li;                          // + 4j rows
+    const double* rd = tile + (lane & 15) * VS2_XPITCH + 2 * (lane >> 4);    // + 16b rows, + 8h, + 16 half
+    // FIRST: lanes 0..15 load a (plane 0), 16..31 b (plane 1), the rest load them again into two spare rows
+    const double* pab = A.f + (uint64_t)(mrow & 1) * rows + 2 * li;
+    double* wrab = tile + (16 * NB + mrow) * VS2_XPITCH + 2 * li;
+    const double* rdab = tile + 16 * NB * VS2_XPITCH + 2 * (lane >> 4);      // a; b one tile row further
+
+    vs_d4 acc[NT];
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            r2[((size_t)g * (NB * 16) + blk * 16 + i) * 2 + 0] = pa[blk];
-            r2[((size_t)g * (NB * 16) + blk * 16 + i) * 2 + 1] = pb[blk];
-        }
-        if (i == 0) {
-            r3[g * 5 + VS_P_SAB] = t_sab;
-            r3[g * 5 + VS_P_SA] = t_sa;
-            r3[g * 5 + VS_P_SB] = t_sb;
-            r3[g * 5 + VS_P_S1] = t_s1;
-            r3[g * 5 + VS_P_S2] = t_s2;
-        }
-        __syncthreads();
-        double* rec = A.first_partials + (size_t)blockIdx.x * VS_PLEN(k);
-        for (int e = tid; e < NB * 16 * 2; e += 256) {
-            const int m = e >> 1, which = e & 1;
-            double sum = 0.0;
-            for (int gg = 0; gg < 16; ++gg) sum += r2[((size_t)gg * (NB * 16) + m) * 2 + which];
-            if (m < 2 * k) {
-                // record layout: head, ac[k], bd[k], ad[k], bc[k]
-                const int j = m < k ? m : m - k;
-                const int slot = m < k ? (which == 0 ? 0 : 3) : (which == 0 ? 2 : 1);
-                rec[VS_P_HEAD + (size_t)slot * k + j] = sum;
+    for (int i = 0; i < NT; ++i) acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
+
+    const uint64_t nfull = rows / VS2_XCHUNK;
+    const uint64_t nun = nfull + ((rows % VS2_XCHUNK) ? 1 : 0);
+    const uint64_t W = (uint64_t)gridDim.x * 4;
+    double pa[NB], pb[NB];   // FIRST: a.x and b.x of index row lane&15 of every block (the five scalar sums of the
+                             // record come from first_head_kernel, as on the macro route)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) pa[b] = pb[b] = 0.0;
+    vs_d2 raw[NJ], rawab = (vs_d2){0.0, 0.0};
+    auto fetch = [&](uint64_t u) {
+        const uint64_t s0 = u * VS2_XCHUNK;
+        if (u < nfull) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bool okj = j < 4 * (NB - 1) || 4 * j + mrow < M;   // only the last 16-row block can be ragged
+                raw[j] = __builtin_nontemporal_load((const vs_d2*)((okj ? p0 + j * jstride : p0) + s0));
+            }
+            if (FIRST) rawab = __builtin_nontemporal_load((const vs_d2*)(pab + s0));
+        } else {  // the ragged last unit
+            const uint64_t s = s0 + 2 * li;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bool okj = 4 * j + mrow < M;
+                const double* q = (okj ? p0 + j * jstride : p0) + s0;
+                raw[j].x = s < rows ? q[0] : 0.0;
+                raw[j].y = s + 1 < rows ? q[1] : 0.0;
+            }
+            if (FIRST) {
+                rawab.x = s < rows ? pab[s0] : 0.0;
+                rawab.y = s + 1 < rows ? pab[s0 + 1] : 0.0;
             }
         }
-        if (tid < VS_P_HEAD) {
-            double sum = 0.0;
-            for (int gg = 0; gg < 16; ++gg) sum += r3[gg * 5 + tid];
-            rec[tid] = sum;
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            vs_d2 v = raw[j];
+            if (j >= 4 * (NB - 1) && 4 * j + mrow >= M) v = (vs_d2){0.0, 0.0};
+            *(vs_d2*)(wr + 4 * j * VS2_XPITCH) = v;
         }
+        if (FIRST) *(vs_d2*)wrab = rawab;
+    };
+
+    uint64_t u = (uint64_t)blockIdx.x * 4 + wave;
+    if (u < nun) fetch(u);
+    for (; u < nun; u += W) {
+        stash();
+        if (u + W < nun) fetch(u + W);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {   // four 8-sample-row quarters of the unit: sample rows 8 hh + 2q, + 1
+            vs_d2 fr[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) fr[b] = *(const vs_d2*)(rd + 16 * b * VS2_XPITCH + 8 * hh);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                int a = 0;
+#pragma unroll
+                for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+                    for (int bj = bi; bj < NB; ++bj) {
+                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[bi][t], fr[bj][t], acc[a], 0, 0, 0);
+                        ++a;
+                    }
+            }
+            if (FIRST) {
+                const vs_d2 av = *(const vs_d2*)(rdab + 8 * hh);
+                const vs_d2 bv = *(const vs_d2*)(rdab + VS2_XPITCH + 8 * hh);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const double a = av[t], b = bv[t];
+#pragma unroll
+                    for (int blk = 0; blk < NB; ++blk) {
+                        pa[blk] = fma(a, fr[blk][t], pa[blk]);
+                        pb[blk] = fma(b, fr[blk][t], pb[blk]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
+    // add the four waves' accumulators through LDS (the tiles are free now), fixed order
+    __syncthreads();
+    double* red = tiles;
+    double* out = A.partials + (size_t)blockIdx.x * VS2_TILE_OUT;
+    int a = 0;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+        for (int bj = bi; bj < NB; ++bj) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = (lane >> 4) + 4 * v, col = lane & 15;   // f64 C/D layout
+                red[(wave * 256) + row * 16 + col] = acc[a][v];
+            }
+            __syncthreads();
+            {
+                const double t = ((red[tid] + red[256 + tid]) + red[512 + tid]) + red[768 + tid];
+                const int row = tid >> 4, col = tid & 15;
+                out[(bi * 16 + row) * VS2_SUPER + (bj * 16 + col)] = t;
+            }
+            __syncthreads();
+            ++a;
+        }
+    if (FIRST) gram_first_record<NB>(A, tiles, pa, pb, 0.0, 0.0, 0.0, 0.0, 0.0);
 }
 
 // More than 64 index rows (k*l > 32): 128-row macro blocks.  One workgroup of eight waves owns a pair
@@ -358,42 +532,51 @@ gram_diag_wave_kernel(vs_gram_args A) {
 // m < k is c_m -> a.c, b.c; m >= k is d_{m-k} -> a.d, b.d).  One first-order record per diagonal workgroup,
 // folded like reduce_first_kernel's; sab, sa, sb and the shifted variance sums -- one pass over fM_1, fM_2 only,
 // 1/(k+1) of the data -- come from first_head_kernel's records in the same fold.
-template <bool MASKED, bool ALIGNED, bool FIRST>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
-gram_macro_kernel(vs_gram_args A) {
-    extern __shared__ double tiles[];  // [2 buffers][256][VS2_WPITCH]; FIRST: a, b of the chunk in the row padding
-    if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
-    if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        // this kernel opens the call: reset the counters the two folds use (cf. reduce_first_kernel)
-        uint32_t* c = const_cast<uint32_t*>(A.counters);
-        c[0] = 0;
-        c[1] = 0xffffffffu;
-        c[2] = 0;
-        c[3] = 0;
-        c[4] = 0;
-    }
-    int MI, MJ;
-    pair_from_index(blockIdx.y, A.nsuper, MI, MJ);   // nsuper = number of macro blocks here
-    const bool diag = MI == MJ;
+// WIDE (one output, even row count): the workgroup stages TWO chunks per fetch -- thread t loads 16 B = sample rows
+// 2(t&15), 2(t&15)+1 of the 32, of index rows (t>>4) + 32j of MI (j < 4) and of MJ, so that a wave-wide load
+// reads 4 index rows x 256 contiguous bytes instead of 8 x 128 (4.9 -> 6.7 TB/s for the pattern alone,
+// tools/load_patterns.hip) -- and the half of the threads that hold a chunk's sample rows write it to the tile.
+// With one output the index row m is plane 2 + m: one pointer per macro block, wave-uniform strides between loads.
+// The body is compiled twice, for diagonal and off-diagonal pairs (a workgroup-uniform branch in the kernel): a
+// diagonal pair stages one macro block only and alone carries the first-order sums, so neither form pays the
+// other's registers.
+template <bool MASKED, bool ALIGNED, bool FIRST, bool WIDE, bool DIAG>
+__device__ __forceinline__ void gram_macro_body(const vs_gram_args& A, const int MI, const int MJ, double* tiles) {
+    constexpr bool diag = DIAG;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 = block row of the output
     const int M = 2 * A.K;
     const uint64_t rows = A.rows;
     constexpr int BUF = 2 * VS2_MACRO * VS2_WPITCH;  // doubles per buffer
-    const bool first = FIRST && diag;       // this workgroup also carries first-order dot products
+    constexpr bool first = FIRST && diag;   // this workgroup also carries first-order dot products
 
     // staging: thread t loads 16 B (sample rows 2p, 2p+1) of index rows lrow, 64+lrow of MI and of MJ
-    const int lrow = tid >> 3, piece = tid & 7;
-    const double* rp[4];
-    bool ok[4];
+    // (WIDE: rows lrow + 32j, j < 4, of MI and of MJ; 16 pieces = 32 sample rows)
+    constexpr int NLD = WIDE ? 8 : 4;
+    const int lrow = WIDE ? tid >> 4 : tid >> 3, piece = WIDE ? tid & 15 : tid & 7;
+    const double* rp[WIDE ? 2 : 4];
+    bool ok[NLD];
+    if (WIDE) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = (j < 2 ? MI : MJ) * VS2_MACRO + (j & 1) * 64 + lrow;
-        ok[j] = m < M && !(diag && j >= 2);
-        rp[j] = x_elem(A, ok[j] ? m : 0, 0) + 2 * piece;
+        for (int j = 0; j < 8; ++j) ok[j] = (j < 4 ? MI : MJ) * VS2_MACRO + (j & 3) * 32 + lrow < M && !(diag && j >= 4);
+        rp[0] = rp[1] = A.f + 2 * piece;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = (j < 2 ? MI : MJ) * VS2_MACRO + (j & 1) * 64 + lrow;
+            ok[j] = m < M && !(diag && j >= 2);
+            rp[j] = x_elem(A, ok[j] ? m : 0, 0) + 2 * piece;
+        }
     }
-    double* wr = tiles + lrow * VS2_WPITCH + 2 * piece;   // + 64j rows, + buffer
+    // WIDE: the address of load j is rebuilt from the index row at every fetch (a handful of integer
+    // instructions) instead of living in registers between fetches: index row m is plane 2 + m, rows past 2k
+    // read index row 0 and are zeroed on the way into the tile
+    auto wide_ptr = [&](int j, int lr) {
+        const int m = (j < 4 ? MI : MJ) * VS2_MACRO + (j & 3) * 32 + lr;
+        return rp[0] + (uint64_t)(2 + (m < M ? m : 0)) * rows;
+    };
+    double* wr = tiles + lrow * VS2_WPITCH + 2 * (piece & 7);   // + 64j (WIDE: 32j) rows, + buffer
     // fragments: A = index row 16*wave + (lane&15) of MI's half; B = 16*bj + (lane&15) of MJ's half
     const double* rdA = tiles + (16 * wave + (lane & 15)) * VS2_WPITCH + 2 * (lane >> 4);
     const double* rdB = tiles + ((diag ? 0 : VS2_MACRO) + (lane & 15)) * VS2_WPITCH + 2 * (lane >> 4);
@@ -408,34 +591,46 @@ gram_macro_kernel(vs_gram_args A) {
     // a workgroup takes GROUP consecutive chunks per visit (512 contiguous bytes per index row)
     constexpr uint64_t GROUP = 4;
     const uint64_t ngroups = (nch + GROUP - 1) / GROUP;
-    uint64_t mine = 0;   // chunks this workgroup walks
-    for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) mine += (g * GROUP + GROUP <= nch) ? GROUP : nch - g * GROUP;
+    uint64_t mine = 0;   // chunks this workgroup walks (WIDE: always whole pairs; a chunk past the end is zeros)
+    for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint64_t here = (g * GROUP + GROUP <= nch) ? GROUP : nch - g * GROUP;
+        mine += WIDE ? (here + 1) & ~(uint64_t)1 : here;
+    }
     auto chunk_of = [&](uint64_t i) {   // the i-th chunk of this workgroup
         const uint64_t g = blockIdx.x + (i / GROUP) * gridDim.x;
         return g * GROUP + (i % GROUP);
     };
-    vs_d2 raw[4];
+    vs_d2 raw[NLD];
     bool k0 = true, k1 = true;
-    // FIRST: threads 0..7 stage a (plane 0), 8..15 b (plane 1) of the chunk: sample pair p goes into the padding
-    // of tile row p (16 of 20 doubles per row are index-row data): a at [16,17], b at [18,19]
-    const bool abth = first && tid < 16;
-    const double* abp = A.f + (tid >= 8 ? rows : 0) + 2 * (tid & 7);
+    // FIRST: threads 0..7 stage a (plane 0), 8..15 b (plane 1) of the chunk (WIDE: 0..15 and 16..31, of the pair
+    // of chunks): sample pair p goes into the padding of tile row p (16 of 20 doubles per row are index-row
+    // data): a at [16,17], b at [18,19]
+    const bool abth = first && tid < (WIDE ? 32 : 16);
+    const double* abp = A.f + (tid >= (WIDE ? 16 : 8) ? rows : 0) + 2 * (WIDE ? tid & 15 : tid & 7);
     vs_d2 rawab = (vs_d2){0.0, 0.0};
     double pa = 0.0, pb = 0.0;
-    auto fetch = [&](uint64_t c) {
+    auto fetch = [&](uint64_t c) {   // WIDE: c is the first chunk of a pair
         const uint64_t s0 = c * VS2_WCHUNK;
+        const bool whole = WIDE ? s0 + 2 * VS2_WCHUNK <= rows : c < nfull;
         if (FIRST && abth) {
-            const uint64_t sm = s0 + 2 * (tid & 7);
-            if (c < nfull && ALIGNED) {
+            const uint64_t sm = s0 + 2 * (WIDE ? tid & 15 : tid & 7);
+            if (whole && ALIGNED) {
                 rawab = __builtin_nontemporal_load((const vs_d2*)(abp + s0));
             } else {
                 rawab.x = sm < rows ? abp[s0] : 0.0;
                 rawab.y = sm + 1 < rows ? abp[s0 + 1] : 0.0;
             }
         }
-        if (c < nfull) {
+        int lr = lrow;
+        if (WIDE) asm volatile("" : "+v"(lr));   // not loop-invariant as far as the compiler can tell
+        if (whole) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NLD; ++j) {
+                if (WIDE) {
+                    if (diag && j >= 4) continue;
+                    raw[j] = __builtin_nontemporal_load((const vs_d2*)(wide_ptr(j, lr) + s0));
+                    continue;
+                }
                 if (!ok[j]) continue;
                 if (ALIGNED) {
                     raw[j] = __builtin_nontemporal_load((const vs_d2*)(rp[j] + s0));
@@ -447,9 +642,10 @@ gram_macro_kernel(vs_gram_args A) {
         } else {
             const uint64_t sm = s0 + 2 * piece;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                raw[j].x = (ok[j] && sm < rows) ? rp[j][s0] : 0.0;
-                raw[j].y = (ok[j] && sm + 1 < rows) ? rp[j][s0 + 1] : 0.0;
+            for (int j = 0; j < NLD; ++j) {
+                const double* q = WIDE ? wide_ptr(j, lr) : rp[j];
+                raw[j].x = (ok[j] && sm < rows) ? q[s0] : 0.0;
+                raw[j].y = (ok[j] && sm + 1 < rows) ? q[s0 + 1] : 0.0;
             }
         }
         if (MASKED) {
@@ -458,31 +654,43 @@ gram_macro_kernel(vs_gram_args A) {
             k1 = sm + 1 < rows && A.keep[sm + 1];
         }
     };
-    auto stash = [&](int b) {
+    auto stash = [&](int b, int half) {   // WIDE: the threads holding sample rows 16 half .. of the pair write
+        if (WIDE && (piece >> 3) != half) return;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NLD; ++j) {
             vs_d2 v = raw[j];
             if (MASKED) {
                 v.x = k0 ? v.x : 0.0;
                 v.y = k1 ? v.y : 0.0;
             }
             if (!ok[j]) v = (vs_d2){0.0, 0.0};
-            if (!(diag && j >= 2)) *(vs_d2*)(wr + b * BUF + 64 * j * VS2_WPITCH) = v;
+            if (WIDE) {
+                if (!(diag && j >= 4)) *(vs_d2*)(wr + b * BUF + ((j >> 2) * VS2_MACRO + (j & 3) * 32) * VS2_WPITCH) = v;
+            } else {
+                if (!(diag && j >= 2)) *(vs_d2*)(wr + b * BUF + 64 * j * VS2_WPITCH) = v;
+            }
         }
-        if (FIRST && abth) *(vs_d2*)(tiles + b * BUF + (tid & 7) * VS2_WPITCH + 16 + 2 * (tid >> 3)) = rawab;
+        if (FIRST && abth) {
+            if (WIDE) *(vs_d2*)(tiles + b * BUF + (tid & 7) * VS2_WPITCH + 16 + 2 * (tid >> 4)) = rawab;
+            else *(vs_d2*)(tiles + b * BUF + (tid & 7) * VS2_WPITCH + 16 + 2 * (tid >> 3)) = rawab;
+        }
     };
 
     if (mine > 0) {
         fetch(chunk_of(0));
-        stash(0);
-        if (mine > 1) fetch(chunk_of(1));
+        stash(0, 0);
+        if (!WIDE && mine > 1) fetch(chunk_of(1));
     }
     __syncthreads();
     for (uint64_t i = 0; i < mine; ++i) {
         const int b = (int)(i & 1);
         // the next chunk goes into the other buffer (everybody left it at the last barrier) ...
-        if (i + 1 < mine) stash(b ^ 1);
-        if (i + 2 < mine) fetch(chunk_of(i + 2));
+        if (i + 1 < mine) stash(b ^ 1, (int)((i + 1) & 1));
+        if (WIDE) {   // ... the registers are free once the second chunk of the pair is in LDS: the next pair
+            if (!(i & 1) && i + 2 < mine) fetch(chunk_of(i + 2));
+        } else {
+            if (i + 2 < mine) fetch(chunk_of(i + 2));
+        }
         // ... while this one feeds the matrix pipe
         vs_d2 fa[2];
         fa[0] = *(const vs_d2*)(rdA + b * BUF);
@@ -490,18 +698,14 @@ gram_macro_kernel(vs_gram_args A) {
         if (FIRST && first) {
             // samples 2q, 2q+1 (h = 0) and 8+2q, 8+2q+1 (h = 1) of the lane group q, as in the fragments
             const double* rdAB = tiles + b * BUF + (lane >> 4) * VS2_WPITCH + 16;
-            vs_d2 av[2], bv[2];
-            av[0] = *(const vs_d2*)(rdAB);
-            av[1] = *(const vs_d2*)(rdAB + 4 * VS2_WPITCH);
-            bv[0] = *(const vs_d2*)(rdAB + 2);
-            bv[1] = *(const vs_d2*)(rdAB + 4 * VS2_WPITCH + 2);
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    pa = fma(av[h][t], fa[h][t], pa);
-                    pb = fma(bv[h][t], fa[h][t], pb);
-                }
+            for (int h = 0; h < 2; ++h) {
+                const vs_d4 ab = *(const vs_d4*)(rdAB + 4 * h * VS2_WPITCH);   // a, a, b, b of two sample rows
+                pa = fma(ab[0], fa[h][0], pa);
+                pb = fma(ab[2], fa[h][0], pb);
+                pa = fma(ab[1], fa[h][1], pa);
+                pb = fma(ab[3], fa[h][1], pb);
+            }
         }
 #pragma unroll
         for (int bj = 0; bj < 8; ++bj) {
@@ -558,6 +762,26 @@ gram_macro_kernel(vs_gram_args A) {
             }
         }
     }
+}
+
+template <bool MASKED, bool ALIGNED, bool FIRST, bool WIDE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+gram_macro_kernel(vs_gram_args A) {
+    extern __shared__ double tiles[];  // [2 buffers][256][VS2_WPITCH]; FIRST: a, b of the chunk in the row padding
+    if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
+    if (FIRST && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        // this kernel opens the call: reset the counters the two folds use (cf. reduce_first_kernel)
+        uint32_t* c = const_cast<uint32_t*>(A.counters);
+        c[0] = 0;
+        c[1] = 0xffffffffu;
+        c[2] = 0;
+        c[3] = 0;
+        c[4] = 0;
+    }
+    int MI, MJ;
+    pair_from_index(blockIdx.y, A.nsuper, MI, MJ);   // nsuper = number of macro blocks here
+    if (MI == MJ) gram_macro_body<MASKED, ALIGNED, FIRST, WIDE, true>(A, MI, MJ, tiles);
+    else gram_macro_body<MASKED, ALIGNED, FIRST, WIDE, false>(A, MI, MJ, tiles);
 }
 
 // The five scalar sums of the first-order record (sab, sa, sb, shifted s1, s2: varsens/saltelli.py:577,583) for
@@ -765,6 +989,12 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     if (want < 1) want = 1;
     const uint64_t units = macro ? (nchunks + 3) / 4 : nchunks;   // the macro kernel walks groups of 4 chunks
     const uint32_t slab_wgs = (uint32_t)(units < want ? units : want);
+    // the wide wave-private kernel (32 sample rows per unit, two workgroups per CU) takes the unmasked pass of
+    // one-output problems with 33..64 index rows
+    const bool wide = !macro && l == 1 && aligned && nb_wave >= 3 && ctx->tune.gram_wide != 0;
+    const uint64_t wide_units = (rows + VS2_XCHUNK - 1) / VS2_XCHUNK;
+    const uint64_t wide_want = (uint64_t)cus * 2;   // all that are resident (LDS)
+    const uint32_t wide_wgs = (uint32_t)(wide_units < 1 ? 1 : wide_units < wide_want ? wide_units : wide_want);
     const size_t tile_out = (size_t)SB * SB;
     const size_t width = (size_t)npairs * tile_out;
     // workspace: [with_first: first-order records of the diagonal workgroups + folded record,] then the Gram partials
@@ -774,7 +1004,8 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const uint32_t P_first = P_diag + P_head;                                                   // + first_head_kernel's
     size_t first_doubles = with_first ? (size_t)P_first * plen + plen : 0;
     first_doubles = (first_doubles + 1) & ~(size_t)1;
-    int rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + (size_t)slab_wgs * width));
+    const uint32_t max_wgs = wide && wide_wgs > slab_wgs ? wide_wgs : slab_wgs;
+    int rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + (size_t)max_wgs * width));
     if (rc) return rc;
 
     VS_HIP(hipMemsetAsync(ctx->counters + CNT_NANFLAG, 0, sizeof(uint32_t), ctx->stream));
@@ -803,13 +1034,17 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     F.counters = ctx->counters;
     const size_t lds_w = sizeof(double) * (nb_wave <= 4 ? (size_t)VS2_WAVE_LDS(nb_wave, false) : 0);   // wave-private tiles
     const size_t lds_m = sizeof(double) * 2 * 2 * VS2_MACRO * VS2_WPITCH;   // macro: two buffers of 256 rows
+    const bool mwide = macro && l == 1 && aligned && ctx->tune.gram_wide != 0;   // two chunks per fetch, 256-byte runs
+    // (MASKED, ALIGNED, FIRST, WIDE) instances the launch below can pick
+#define VS2_MACRO_INSTANCES(X) \
+    X(false, false, false, false) X(false, true, false, false) X(true, false, false, false) X(true, true, false, false) \
+    X(false, false, true, false) X(false, true, true, false) X(false, true, false, true) X(true, true, false, true) \
+    X(false, true, true, true)
     if (macro) {
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+#define VS2_SET_LDS(MK, AL, FI, WI) \
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<MK, AL, FI, WI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS2_MACRO_INSTANCES(VS2_SET_LDS)
+#undef VS2_SET_LDS
     }
     if ((flags & VS_REDUCE_NAN_TRIM) && rows > 0) {
         const uint64_t count = 2 * rows;  // blocks 0 and 1 of output 0 are contiguous
@@ -834,13 +1069,27 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
             if (macro) {
                 const dim3 grid(slab_wgs, npairs);
-                if (with_first && aligned) hipLaunchKernelGGL((gram_macro_kernel<false, true, true>), grid, dim3(512), lds_m, ctx->stream, A);
-                else if (with_first) hipLaunchKernelGGL((gram_macro_kernel<false, false, true>), grid, dim3(512), lds_m, ctx->stream, A);
-                else if (masked && aligned) hipLaunchKernelGGL((gram_macro_kernel<true, true, false>), grid, dim3(512), lds_m, ctx->stream, A);
-                else if (masked) hipLaunchKernelGGL((gram_macro_kernel<true, false, false>), grid, dim3(512), lds_m, ctx->stream, A);
-                else if (aligned) hipLaunchKernelGGL((gram_macro_kernel<false, true, false>), grid, dim3(512), lds_m, ctx->stream, A);
-                else hipLaunchKernelGGL((gram_macro_kernel<false, false, false>), grid, dim3(512), lds_m, ctx->stream, A);
+                bool launched = false;
+#define VS2_LAUNCH_MACRO(MK, AL, FI, WI)                                                                        \
+                if (!launched && masked == MK && aligned == AL && with_first == FI && mwide == WI) {            \
+                    hipLaunchKernelGGL((gram_macro_kernel<MK, AL, FI, WI>), grid, dim3(512), lds_m, ctx->stream, A); \
+                    launched = true;                                                                            \
+                }
+                VS2_MACRO_INSTANCES(VS2_LAUNCH_MACRO)
+#undef VS2_LAUNCH_MACRO
+                if (!launched) return vs_fail(VS_ERR_STATE, "no Gram kernel for this case");   // with_first is never masked
+            } else if (wide && !masked) {
+                const size_t lds_x = sizeof(double) * (size_t)(nb_wave == 3 ? VS2_WIDE_LDS(3, false) : VS2_WIDE_LDS(4, false));
+                A.slab_wgs = F.P = wide_wgs;
+                if (nb_wave == 3) {
+                    VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
+                    hipLaunchKernelGGL((gram_diag_wide_kernel<3, false>), dim3(wide_wgs), dim3(256), lds_x, ctx->stream, A);
+                } else {
+                    VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
+                    hipLaunchKernelGGL((gram_diag_wide_kernel<4, false>), dim3(wide_wgs), dim3(256), lds_x, ctx->stream, A);
+                }
             } else {
+                A.slab_wgs = F.P = slab_wgs;
                 const dim3 grid_diag(slab_wgs, 1);
                 const int nb = (2 * K + 15) / 16;
 #define VS2_LAUNCH_WAVE2(NBV, MK, AL) \
@@ -912,10 +1161,17 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     const int nb = (2 * K + 15) / 16;
     const uint64_t want = (uint64_t)cus * (ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu
                                                                           : VS2_WAVES_PER_SIMD(nb, true));
-    const uint32_t P = (uint32_t)(nchunks < want ? nchunks : want);
+    const bool aligned = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
+    const bool wide = aligned && nb >= 3 && ctx->tune.gram_wide != 0;   // gram_diag_wide_kernel, two workgroups per CU
+    const uint64_t wide_units = (rows + VS2_XCHUNK - 1) / VS2_XCHUNK;
+    const uint64_t wide_want = (uint64_t)cus * 2;   // all that are resident (LDS)
+    const uint32_t P = wide ? (uint32_t)(wide_units < wide_want ? wide_units : wide_want)
+                            : (uint32_t)(nchunks < want ? nchunks : want);
     const size_t plen = VS_PLEN(k);
-    // workspace: first-order records [P][plen] + folded [plen] (vs_fold_partials' layout), then Gram partials
-    size_t first_doubles = (size_t)P * plen + plen;
+    // the wide kernel leaves the five scalar sums of the record to first_head_kernel (P_head more records)
+    const uint32_t P_head = wide ? (uint32_t)((rows + 4095) / 4096 < (uint64_t)cus ? (rows + 4095) / 4096 : cus) : 0;
+    // workspace: first-order records [P + P_head][plen] + folded [plen] (vs_fold_partials' layout), then Gram partials
+    size_t first_doubles = (size_t)(P + P_head) * plen + plen;
     first_doubles = (first_doubles + 1) & ~(size_t)1;
     int rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + (size_t)P * VS2_TILE_OUT));
     if (rc) return rc;
@@ -932,9 +1188,18 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     A.first_partials = ctx->partials;
     A.keep = nullptr;
     A.counters = ctx->counters;
-    const bool aligned = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
     const size_t lds_w = sizeof(double) * (size_t)VS2_WAVE_LDS(nb, true);
-    {
+    if (wide) {
+        const size_t lds_x = sizeof(double) * (size_t)(nb == 3 ? VS2_WIDE_LDS(3, true) : VS2_WIDE_LDS(4, true));
+        vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
+        if (nb == 3) {
+            VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
+            hipLaunchKernelGGL((gram_diag_wide_kernel<3, true>), dim3(P), dim3(256), lds_x, ctx->stream, A);
+        } else {
+            VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
+            hipLaunchKernelGGL((gram_diag_wide_kernel<4, true>), dim3(P), dim3(256), lds_x, ctx->stream, A);
+        }
+    } else {
         vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
 #define VS2_LAUNCH_BOTH(NBV)                                                                                           \
     do {                                                                                                               \
@@ -952,7 +1217,13 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
 #undef VS2_LAUNCH_BOTH
     }
     VS_HIP(hipGetLastError());
-    rc = vs_fold_partials(ctx, P, k, 1, rows, nullptr, 1, f_dev, rank, max_ranks, acc_dev);
+    if (wide) {
+        vs_launch_scope scope(ctx, VS_KERNEL_REDUCE_FIRST);
+        hipLaunchKernelGGL(first_head_kernel, dim3(P_head), dim3(256), 0, ctx->stream, f_dev, rows, k,
+                           ctx->partials + (size_t)P * plen);
+        VS_HIP(hipGetLastError());
+    }
+    rc = vs_fold_partials(ctx, P + P_head, k, 1, rows, nullptr, 1, f_dev, rank, max_ranks, acc_dev);
     if (rc) return rc;
     vs_gram_fold_args F;
     F.partials = A.partials;
