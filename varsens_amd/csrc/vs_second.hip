@@ -8,24 +8,25 @@
 // v_mfma_f64_16x16x4_f64, D(16x16) += A(16x4) B(4x16), where A and B are both
 // "16 index rows x 4 sample rows" fragments of X (one double per lane).
 //
-// The 2K index rows are cut into 64-row super-blocks; a launch covers pairs (SI <= SJ):
-//   diagonal pairs (all of them when k*l <= 32): gram_diag_wave_kernel -- every wave keeps the ten
-//     16x16 accumulator tiles of the super-block and walks its own 16-sample-row chunks through a
-//     private LDS tile, no workgroup barrier in the loop;
-//   off-diagonal pairs: gram_offdiag_kernel -- eight waves share two 64x64 LDS tiles (66-double
-//     pitch) and split the 16 output tiles.
-// One dense 64x64 partial per workgroup and pair goes to HBM; gram_fold_kernel sums the partials
+// Kernels by the number of index rows 2K:
+//   2K <= 64: one 64-row block, wave-private kernels -- every wave keeps the NB(NB+1)/2 accumulator tiles
+//     (16x16 each) of the block and walks its own sample rows through a private LDS tile, no workgroup barrier
+//     in the loop: gram_diag_wave_kernel (16-sample-row chunks; any shape) and gram_diag_wide_kernel
+//     (32-sample-row units; one output, even row count, more than 32 index rows);
+//   2K > 64: gram_macro_kernel -- 128-row macro blocks, a workgroup of eight waves per pair (MI <= MJ) of them.
+// One dense partial per workgroup and pair goes to HBM; gram_fold_kernel sums the partials
 // (compensated) and scatters them into DC, DD, CC.
-// Roofline at k=32, rows=2^22: HBM 16*K*rows bytes = 2.15 GB => 0.31 ms; matrix pipe: 10 tiles x
-// rows/4 MFMAs.  The fp64 MFMA sustains 47-49 TFLOP/s on this chip (99 cycles per 16x16x4 with
-// two or more waves per SIMD; tools/mfma_f64_peak.hip), not the 78.6 of the data sheet, and shares
-// its units with v_fma_f64 (tools/mfma_f64_valu_shadow.hip) => 0.44 ms: the kernel is
-// matrix-pipe-bound.  Reported separately from the first-order pass.
+// Roofline at k=32, rows=2^22: HBM 16*K*rows bytes = 2.15 GB => 0.31 ms at 7 TB/s; matrix pipe: 10 tiles x
+// rows/4 MFMAs of 64 clocks per SIMD => 0.275 ms at 2.4 GHz (77.6 TFLOP/s: tools/mfma_f64_peak.hip, VGPR
+// accumulators; the "47-49 TFLOP/s" quoted in earlier rounds was the AGPR form), 0.32 ms at the 2.05 GHz the
+// kernel actually runs at.  fp64 MFMA and v_fma_f64 share the pipe (tools/mfma_valu_overlap.hip).  What HBM
+// delivers depends on the shape of the wave-wide loads (tools/load_patterns.hip): 8 x 128-byte runs per
+// instruction cap it at 4.9 TB/s, 4 x 256-byte runs reach 6.7 -- hence the 32-sample-row staging.
+// Reported separately from the first-order pass.
 #include "vs_common.h"
 
 #define VS2_SUPER 64                 // index rows per super-block (4 MFMA blocks of 16)
-#define VS2_CHUNK 64                 // sample rows per LDS tile
-#define VS2_PITCH 66                 // doubles per LDS tile row
+#define VS2_CHUNK 64                 // sample rows a workgroup of four waves takes per visit (4 x VS2_WCHUNK)
 #define VS2_TILE_OUT (VS2_SUPER * VS2_SUPER)
 
 typedef double vs_d4 __attribute__((ext_vector_type(4)));
@@ -355,10 +356,12 @@ gram_diag_wave_kernel(vs_gram_args A) {
 //   LDS:    tile [16 NB index rows (+ a, b rows)][32 sample rows], pitch 34 doubles: the 16 lanes of an index
 //           row write 256 contiguous bytes, and the b128 fragment reads (index row = lane&15, stride 272 B)
 //           fall into eight distinct 4-bank groups per 8 lanes;
-//   MFMA:   two 16-sample-row halves x 4 k-steps x NB(NB+1)/2 tiles per staged unit.
+//   MFMA:   four 8-sample-row quarters x 2 k-steps x NB(NB+1)/2 tiles per staged unit.
 // 64 VGPRs of loads in flight per wave (16 KiB), two waves per SIMD: 128 KiB in flight per CU.
 // FIRST: a = fM_1, b = fM_2 of the unit are one more load (planes 0, 1) into two more tile rows; every lane
-// group reads them back in the fragment layout, as in gram_diag_wave_kernel.
+// group reads them back in the fragment layout and meets each fragment element in two fmas (a.c, b.c, a.d, b.d
+// of the record).  The five scalar sums of the record come from first_head_kernel, as on the macro route: they
+// would cost 12 more VGPRs here, and the kernel sits at 256.
 #define VS2_XCHUNK 32
 #define VS2_XPITCH 34
 #define VS2_WIDE_ROWS(NB, FIRST) (16 * (NB) + ((FIRST) ? 4 : 0))
@@ -393,7 +396,7 @@ gram_diag_wide_kernel(vs_gram_args A) {
     const double* p0 = A.f + (uint64_t)(2 + mrow) * rows + 2 * li;
     const uint64_t jstride = 4 * rows;
     double* wr = tile + mrow * VS2_XPITCH + 2 * li;                          // + 4j rows
-    const double* rd = tile + (lane & 15) * VS2_XPITCH + 2 * (lane >> 4);    // + 16b rows, + 8h, + 16 half
+    const double* rd = tile + (lane & 15) * VS2_XPITCH + 2 * (lane >> 4);    // + 16b rows, + 8 per quarter
     // FIRST: lanes 0..15 load a (plane 0), 16..31 b (plane 1), the rest load them again into two spare rows
     const double* pab = A.f + (uint64_t)(mrow & 1) * rows + 2 * li;
     double* wrab = tile + (16 * NB + mrow) * VS2_XPITCH + 2 * li;
