@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-FP64_MFMA_PEAK_TFLOPS = 78.6   # data-sheet fp64 matrix rate (the guide lists no fp64 figure); see DESIGN.md 4.3 for the measured issue rate
+FP64_MFMA_PEAK_TFLOPS = 78.6   # data-sheet fp64 matrix rate (the guide lists no fp64 figure); tools/mfma_f64_peak.hip measures 77.6
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "bench_pmc.json")
 F_BUFFERS = 3
 
@@ -318,15 +318,18 @@ def main():
                               "valu_busy_frac": eval_pmc.get("valu_busy_frac"),
                               "note": "store-only kernel of the same shape sustains 5.6 TB/s (tools/write_bw.hip)"},
             "roofline_second_order": None if not so_ms else {
-                "kernel": "gram_diag_wave_kernel (sens_2 / sens_2n Gram sums, v_mfma_f64_16x16x4_f64)",
+                "kernel": "gram_diag_wide_kernel (sens_2 / sens_2n Gram sums, v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma", "achieved": mfma_flops / (so_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": mfma_flops / (so_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": pmc_traffic("void gram_diag_wave_kernel", k, args.log2n),
+                "traffic": pmc_traffic("void gram_diag_wide_kernel", k, args.log2n)
+                           or pmc_traffic("void gram_diag_wave_kernel", k, args.log2n),
                 "avg_launch_ms": so_ms, "mfma_flops_per_launch": mfma_flops,
                 "algorithmic_hbm_gbs": 16.0 * k * l * rows / (so_ms * 1e-3) / 1e9,
-                "measured_fp64_mfma_issue_ceiling_tflops": 48.0,
-                "note": "issued MFMA flops (upper-triangle 16x16 tiles); peak = data-sheet fp64 matrix rate, a bare "
-                        "issue loop sustains 47-49 TFLOP/s on this chip (tools/mfma_f64_peak.hip)"},
+                "measured_fp64_mfma_rate_tflops": 77.6,
+                "note": "issued MFMA flops (upper-triangle 16x16 tiles); peak = data-sheet fp64 matrix rate; a bare "
+                        "issue loop with VGPR accumulators sustains 77.6 TFLOP/s at 2.4 GHz (tools/mfma_f64_peak.hip), "
+                        "and this kernel, streaming HBM beside the matrix pipe, runs at 2.0-2.1 GHz (~66 TFLOP/s "
+                        "at that clock); HBM side: the same launch reads algorithmic_hbm_gbs"},
         }
         if world == 1 and not args.no_cpu_baseline:
             n_small = min(rows, 1 << 22)   # the whole pass at the default size: 2.2 GB over PCIe, ~2 s of numpy
