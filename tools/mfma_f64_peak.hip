@@ -6,11 +6,12 @@
 //   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form tools/mfma_f64_peak.hip -o /tmp/mfma_v && /tmp/mfma_v
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_f64_peak.hip -o /tmp/mfma_a && /tmp/mfma_a
 // With the accumulators in VGPRs (what the Gram kernels get: llvm-objdump shows v[..] destinations) one wave
-// with ONE dependent chain already sustains 69 TFLOP/s and anything more 77.6 (the data sheet's 78.6 at 2.4 GHz:
-// one MFMA per 64 clocks per SIMD).  With the accumulators in AGPRs (the compiler's choice for a 256-thread
-// kernel that leaves it the register budget) a single wave per SIMD stops at 35 TFLOP/s, however many chains;
-// two waves per SIMD reach 77.6 again.  Round 1 and early round 2 quoted "47-49 TFLOP/s measured issue
-// ceiling" from the AGPR form: that was this artefact, not a property of the pipe.
+// with ONE dependent chain already sustains 69 TFLOP/s and anything more 77.6-78.2 (the data sheet's 78.6 at
+// 2.4 GHz: one MFMA per 64 clocks per SIMD).  With the accumulators in AGPRs -- the compiler's choice for a
+// 256-thread kernel that leaves it the register budget; 512 threads and more get VGPRs by themselves, so only
+// the waves/SIMD=1 rows of the second build differ -- a wave stops at 35 TFLOP/s however many chains it has, and
+// several 256-thread workgroups per CU reach 47-49 (round 1's version of this tool).  That "47-49 TFLOP/s
+// measured issue ceiling" of rounds 1-2 was this artefact, not a property of the pipe.
 // Operands are constants here, so the loop draws little power and runs at 2.4 GHz; the Gram kernels, streaming
 // HBM beside the matrix pipe, were measured at 2.0-2.1 GHz (clock64 / wall_clock64 inside the kernel).
 #include <hip/hip_runtime.h>
