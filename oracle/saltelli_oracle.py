@@ -277,7 +277,7 @@ def scan_shape(k, fused=False):
     if k <= 48: return 12, 4
     if k <= 64: return 8, 8
     if k <= 96: return 12, 8
-    if k <= 128: return (8, 16) if fused else (16, 8)
+    if k <= 128: return 16, 8
     if k <= 256 and not fused: return 32, 8
     raise ValueError("k=%d is outside the scan kernels" % k)
 
@@ -297,7 +297,8 @@ def separable_terms(kind, X, params):
 
 def separable_scan(ta, tb, shape, add=False):
     """a, b (rows,), c, d (k, rows) from term arrays ta, tb (rows, k) in the kernels' order:
-    segment totals left to right; prefixes over earlier segments left to right from the identity;
+    scan position (segment q, place j) holds column j*W + q (VS_SCAN_COLUMN: segments interleave the
+    columns); segment totals left to right; prefixes over earlier segments left to right from the identity;
     suffixes over later segments and inside a segment right to left; c_i = (pb . ta_i) . sb_i."""
     L, W = shape
     rows, k = ta.shape
@@ -306,6 +307,8 @@ def separable_scan(ta, tb, shape, add=False):
     pad = np.full((rows, L * W - k), ident)
     ta = np.concatenate([ta, pad], axis=1)
     tb = np.concatenate([tb, pad], axis=1)
+    column = np.array([j * W + q for q in range(W) for j in range(L)])    # of scan position q*L + j
+    ta, tb = ta[:, column], tb[:, column]                                 # everything below is in scan positions
     full = np.full(rows, ident)
     Ta, Tb = [], []
     for q in range(W):
@@ -332,11 +335,12 @@ def separable_scan(ta, tb, shape, add=False):
             sb[j] = op(tb[:, q * L + j + 1], sb[j + 1])
         pa, pb = Pa, Pb
         for j in range(L):
-            i = q * L + j
+            p = q * L + j
+            i = column[p]
             if i < k:
-                c[i] = op(op(pb, ta[:, i]), sb[j])     # N_j[i]: M_2 with column i from M_1
-                d[i] = op(op(pa, tb[:, i]), sa[j])     # N_nj[i]: M_1 with column i from M_2
-            pa = op(pa, ta[:, i]); pb = op(pb, tb[:, i])
+                c[i] = op(op(pb, ta[:, p]), sb[j])     # N_j[i]: M_2 with column i from M_1
+                d[i] = op(op(pa, tb[:, p]), sa[j])     # N_nj[i]: M_1 with column i from M_2
+            pa = op(pa, ta[:, p]); pb = op(pb, tb[:, p])
     return a, b, c, d
 
 

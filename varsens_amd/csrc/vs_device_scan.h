@@ -104,6 +104,12 @@ struct vs_scan_acc {
 // rebuilds the sub-block's suffixes from its checkpoint -- the same right-to-left chain, so the same
 // bits as keeping all L suffixes, with 2(L/SUB + SUB) registers instead of 2L.
 #define VS_SCAN_SUB 4
+// Scan position (segment q, place j) -> column.  Segments take every W-th column, not L adjacent ones: the cost of
+// a column is its Halton digit count (23 digits in base 2 at 2^23 points, 3 from base 211 on), and the waves of a
+// workgroup meet at a barrier -- with adjacent columns the wave holding the first primes does twice the average
+// work (k = 32: 83 of 188 digits per point in wave 0 of 4; k = 128: 124 of 490 in wave 0 of 8) while the others
+// wait.  Interleaved, every wave gets one column of each run of W primes.  The folds run in scan-position order.
+#define VS_SCAN_COLUMN(q, j, W) ((j) * (W) + (q))
 
 // Everything behind the terms of one output: totals exchange, prefixes, suffix checkpoints, outputs.
 // ta/tb: the wave's 2L terms in registers (TLDS: in its LDS slab `tl` instead); Ta/Tb their totals.
@@ -181,7 +187,7 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
 #pragma unroll
         for (int j = 0; j < SUB; ++j) {
             const int jj = m * SUB + j;
-            const int i = q * L + jj;
+            const int i = VS_SCAN_COLUMN(q, jj, W);
             const double cj = vs_fold<FOLD>(vs_fold<FOLD>(pb, ua[j]), sb[j]);  // N_j[i]: M_2 with column i from M_1
             const double dj = vs_fold<FOLD>(vs_fold<FOLD>(pa, ub[j]), sa[j]);  // N_nj[i]: M_1 with column i from M_2
             pa = vs_fold<FOLD>(pa, ua[j]);
@@ -255,12 +261,12 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     // GENV 1 / 2: Halton below 2^32 with identity / linear scaling -- straight-line code per column;
     // GENV 0: any generator and scaling, decided by (wave-uniform) branches per column.
     vs_scan_col Cnext;
-    vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, q * L, k);
+    vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, VS_SCAN_COLUMN(q, 0, W), k);
 #pragma unroll
     for (int j = 0; j < L; ++j) {
-        const int c = q * L + j;  // wave-uniform
+        const int c = VS_SCAN_COLUMN(q, j, W);  // wave-uniform
         const vs_scan_col C = Cnext;
-        if (j + 1 < L) vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, c + 1, k);
+        if (j + 1 < L) vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, VS_SCAN_COLUMN(q, j + 1, W), k);
         double t1 = ident, t2 = ident;
         if (c < k) {
             double x1, x2;
@@ -311,7 +317,7 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
             Ta = Tb = ident;
 #pragma unroll
             for (int j = 0; j < L; ++j) {
-                const int c = qo * L + j;
+                const int c = VS_SCAN_COLUMN(qo, j, W);
                 ua[j] = ub[j] = ident;
                 if (c < k) {
                     const double pre = Term::pre(c, po);
@@ -383,7 +389,7 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
         double* out = partials + ((size_t)blockIdx.x * gridDim.y + o) * plen;
 #pragma unroll
         for (int j = 0; j < L; ++j) {
-            const int i = q * L + j;
+            const int i = VS_SCAN_COLUMN(q, j, W);
 #pragma unroll
             for (int z = 0; z < 4; ++z) {
                 const double v = vs_wave_sum_dpp(acc.v[j][z]);
