@@ -61,6 +61,46 @@ def test_reduction_any_shape(k, rows, l, seed, offset):
     f.free(); acc.free()
 
 
+GRAM_K = st.one_of(st.integers(13, 34), st.sampled_from([40, 48, 63, 64, 65, 100, 127, 128, 129, 130]))
+
+
+@settings(**dict(COMMON, max_examples=100))
+@given(k=GRAM_K, rows=EDGE_ROWS, seed=st.integers(0, 2 ** 20), trim=st.booleans())
+def test_both_orders_any_shape(k, rows, seed, trim):
+    """vs_reduce_first_second_order (one output) against the two separate passes and against numpy, over the
+    staging variants the row count and k select: 16- and 32-sample-row units, wave-private and macro kernels,
+    ragged ends, the NaN-masked second pass."""
+    from varsens_amd import _native
+    c = ctx()
+    rng = np.random.RandomState(seed)
+    blocks = 1.5 + rng.randn(2 * k + 2, rows, 1)
+    flags = 0
+    keep = np.ones(rows, bool)
+    if trim and rows >= 8:
+        bad = rng.choice(rows, 3, replace=False)
+        blocks[rng.randint(0, 2 * k + 2, 3), bad, 0] = np.nan
+        keep[bad] = False
+        flags = _native.REDUCE_NAN_TRIM
+    f = c.upload(_native.to_planar(blocks))
+    nacc = _native.acc_len(k, 1, 1)
+    acc1, acc2 = c.alloc(8 * nacc), c.alloc(8 * nacc)
+    g1, g2 = c.alloc(8 * 3 * k * k), c.alloc(8 * 3 * k * k)
+    c.reduce_first_order(f, rows, k, 1, acc1, flags=flags)
+    c.reduce_second_order(f, rows, k, 1, g1, flags=flags)
+    c.reduce_first_second_order(f, rows, k, 1, acc2, g2, flags=flags)
+    a1, a2 = c.download(acc1, (nacc,)), c.download(acc2, (nacc,))
+    G1, G2 = c.download(g1, (3, k, k)), c.download(g2, (3, k, k))
+    Cm, Dm = blocks[2:2 + k, keep, 0], blocks[2 + k:, keep, 0]
+    scale = max(1.0, float(np.abs(Cm).max()) ** 2 * rows) if keep.any() else 1.0
+    np.testing.assert_allclose(G1[0], Dm @ Cm.T, rtol=1e-10, atol=1e-12 * scale)
+    np.testing.assert_allclose(G1[2], Cm @ Cm.T, rtol=1e-10, atol=1e-12 * scale)
+    np.testing.assert_allclose(G2, G1, rtol=1e-12, atol=1e-13 * scale)
+    assert np.array_equal(a1[:4], a2[:4])
+    np.testing.assert_allclose(a2, a1, rtol=1e-12, atol=1e-12 * scale)
+    for b in (f, acc1, acc2, g1, g2):
+        b.free()
+
+
 @settings(**COMMON)
 @given(k=EDGE_K, n=st.one_of(st.integers(1, 200), st.sampled_from([63, 64, 65, 128, 1000])),
        kind=st.sampled_from(["g", "lin", "poly", "inv"]), l=st.integers(1, 2), discard=st.integers(0, 50),
