@@ -245,7 +245,7 @@ def main():
                  "max_abs_diff_sens_vs_two_kernel_path": float(np.max(np.abs(
                      fres[2 + 2 * k:2 + 3 * k] - result[2 + 2 * k:2 + 3 * k])))}
     # second order (sens_2 / sens_2n Gram sums on the fp64 matrix cores), on its own: a few launches
-    gram = ctx.alloc(8 * 3 * k * k)
+    gram = ctx.alloc(8 * _native.gram_len(k))
     so_steps = max(3, min(args.steps, 20))
     t_so, recs_so, _ = timed(lambda: ctx.reduce_second_order(fbuf[0], rows, k, l, gram), so_steps, 2, profile=True)
     avg_so = averages(recs_so)

@@ -50,7 +50,7 @@ int main(void) {
     CHECK(vs_objective_create(ctx, VS_OBJ_G_FUNCTION, K, L, a, K, &objective));
     CHECK(vs_alloc(ctx, sizeof(double) * 2 * (K + 1) * n * L, &f));
     CHECK(vs_alloc(ctx, sizeof(double) * VS_ACC_LEN(K, L, 1), &acc));
-    CHECK(vs_alloc(ctx, sizeof(double) * 3 * K * K, &gram));
+    CHECK(vs_alloc(ctx, sizeof(double) * VS_GRAM_LEN(K), &gram));
     CHECK(vs_alloc(ctx, sizeof(double) * VS_FIRST_ORDER_LEN(K, L), &first));
     CHECK(vs_eval(ctx, design, objective, 0, n, (double*)f));
     CHECK(vs_reduce_first_second_order(ctx, (const double*)f, n, K, L, 0, 0, 1, (double*)acc, (double*)gram));

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VS_ABI_VERSION 2
+#define VS_ABI_VERSION 3
 
 typedef enum vs_status {
     VS_OK = 0,
@@ -283,10 +283,16 @@ int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* design, const v
 int vs_finish_first_order(vs_context* ctx, const double* acc_dev, uint64_t n, int k, int l,
                           int max_ranks, double* out_dev);
 
-/* a12: second-order Gram sums over a shard (saltelli.py:612-619).  With
- * C = fN_j, D = fN_nj viewed as (k*l, rows): gram_dev receives three row-major
- * (k*l, k*l) matrices DC = D C^T, DD = D D^T, CC = C C^T (3 (kl)^2 doubles),
- * NaN-trimmed like the first-order pass when VS_REDUCE_NAN_TRIM is set. */
+/* a12: second-order Gram sums over a shard (saltelli.py:612-619).  With C = fN_j,
+ * D = fN_nj viewed as (k*l, rows) matrices, the reference needs only two symmetric
+ * combinations of its four tensordots: D C^T + C D^T (:612-613) and D D^T + C C^T
+ * (:618-619).  With S = C + D and T = C - D these are (S S^T - T T^T) / 2 and
+ * (S S^T + T T^T) / 2: two symmetric (k*l, k*l) products instead of the upper
+ * triangle of the (2kl, 2kl) Gram matrix -- half the matrix-core work.  gram_dev
+ * receives VS_GRAM_LEN(k*l) doubles: SS = S S^T, then TT = T T^T, row-major, both
+ * triangles filled; sums over shards / ranks add entrywise.  NaN-trimmed like the
+ * first-order pass when VS_REDUCE_NAN_TRIM is set. */
+#define VS_GRAM_LEN(K) (2 * (size_t)(K) * (size_t)(K))
 int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                            int flags, double* gram_dev);
 
@@ -300,8 +306,9 @@ int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, 
 int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                                  int flags, int rank, int max_ranks, double* acc_dev, double* gram_dev);
 
-/* sens_2, sens_2n (each (k,l,k,l) row-major) from summed Gram matrices and the
- * finished first-order block (E_2, var_y) (saltelli.py:612-622). */
+/* sens_2, sens_2n (each (k,l,k,l) row-major) from the summed SS, TT of
+ * vs_reduce_second_order and the finished first-order block (E_2, var_y)
+ * (saltelli.py:612-622). */
 int vs_finish_second_order(vs_context* ctx, const double* gram_dev, const double* first_dev,
                            uint64_t n, int k, int l, double* sens2_dev, double* sens2n_dev);
 

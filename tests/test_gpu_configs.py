@@ -149,7 +149,7 @@ def test_config2_against_the_reference_run(ctx, golden, capsys):
     np.testing.assert_allclose(sens, g["sens"][:, 0], rtol=2e-9)              # within the reference's own noise
     np.testing.assert_allclose(sens_t, g["sens_t"][:, 0], rtol=2e-9, atol=1e-12)
     # second order against the reference's tensordot results
-    gram = ctx.alloc(8 * 3 * k * k)
+    gram = ctx.alloc(8 * 2 * k * k)
     ctx.reduce_second_order(f, n, k, 1, gram)
     s2, s2n = ctx.alloc(8 * k * k), ctx.alloc(8 * k * k)
     ctx.finish_second_order(gram, ctx.upload(fin), n, k, 1, s2, s2n)
@@ -179,7 +179,7 @@ def test_config3_ishigami_k3_n2pow22(ctx):
     np.testing.assert_allclose(fin[2 + 2 * k:2 + 3 * k, 0], S, atol=3e-3)
     np.testing.assert_allclose(fin[2 + 3 * k:2 + 4 * k, 0], ST, atol=3e-3)
     # the non-separable pair (x1,x3): closed second-order index V_1 + V_3 + V_13 (sens_2 cross term)
-    gram = ctx.alloc(8 * 3 * k * k)
+    gram = ctx.alloc(8 * 2 * k * k)
     ctx.reduce_second_order(f, n, k, 1, gram)
     from varsens_amd import _native as nat
     first = ctx.upload(fin)
@@ -282,9 +282,9 @@ def test_config5_whole_polynomial_k128_n2pow24(ctx):
     np.testing.assert_allclose(fin[2 + 2 * k:2 + 3 * k, 0], S, atol=1e-3)      # builder's full-size run: 3e-4 / 8e-4
     np.testing.assert_allclose(fin[2 + 3 * k:2 + 4 * k, 0], ST, atol=2e-3)
     # second order on the whole: closed pair indices (V_i + V_j + V_i V_j) / V of a product form
-    gram = ctx.alloc(8 * 3 * k * k)
+    gram = ctx.alloc(8 * 2 * k * k)
     ctx.reduce_second_order(f, n, k, 1, gram)
-    G = ctx.download(gram, (3, k, k))
+    G = ctx.download(gram, (2, k, k))
     s2, s2n = ctx.alloc(8 * k * k), ctx.alloc(8 * k * k)
     ctx.finish_second_order(gram, ctx.upload(fin), n, k, 1, s2, s2n)
     sens_2 = ctx.download(s2, (k, k))
@@ -296,21 +296,21 @@ def test_config5_whole_polynomial_k128_n2pow24(ctx):
     # the 8-rank row split (what the 8-GPU run does, one shard at a time here): records and Gram sums add up
     world = 8
     nacc = _native.acc_len(k, 1, world)
-    total_rec, total_gram = np.zeros(nacc), np.zeros((3, k, k))
+    total_rec, total_gram = np.zeros(nacc), np.zeros((2, k, k))
     for rank in range(world):
         b, cnt = shard_rows(n, world, rank)
         fs = device_eval(ctx, k, n, _native.OBJ_POLYNOMIAL, beta, begin=b, count=cnt)
-        acc, gs = ctx.alloc(8 * nacc), ctx.alloc(8 * 3 * k * k)
+        acc, gs = ctx.alloc(8 * nacc), ctx.alloc(8 * 2 * k * k)
         ctx.reduce_first_second_order(fs, cnt, k, 1, acc, gs, 0, rank, world)
         total_rec += ctx.download(acc, (nacc,))
-        total_gram += ctx.download(gs, (3, k, k))
+        total_gram += ctx.download(gs, (2, k, k))
         fs.free()
     out = ctx.alloc(8 * _native.first_order_len(k, 1))
     ctx.finish_first_order(ctx.upload(total_rec), n, k, 1, out, world)
     fin8 = ctx.download(out, (2 + 4 * k, 1))
     np.testing.assert_allclose(fin8[:2 + 2 * k], fin[:2 + 2 * k], rtol=1e-13)
     np.testing.assert_allclose(fin8[2 + 2 * k:], fin[2 + 2 * k:], rtol=1e-10, atol=1e-13)
-    np.testing.assert_allclose(total_gram, G, rtol=1e-12)
+    np.testing.assert_allclose(total_gram, G, rtol=1e-12, atol=1e-12 * np.abs(G).max())
 
 
 def test_model_study_shape_k100_l10():

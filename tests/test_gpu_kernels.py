@@ -383,19 +383,23 @@ def test_second_order_gram(ctx, k, rows, l):
     from varsens_amd._native import to_planar
     f = ctx.upload(to_planar(blocks))
     K = k * l
-    gram = ctx.alloc(8 * 3 * K * K)
+    gram = ctx.alloc(8 * 2 * K * K)
     ctx.reduce_second_order(f, rows, k, l, gram)
-    G = ctx.download(gram, (3, K, K))
+    G = ctx.download(gram, (2, K, K))
     C = blocks[2:2 + k].transpose(0, 2, 1).reshape(K, rows)
     D = blocks[2 + k:].transpose(0, 2, 1).reshape(K, rows)
-    scale = np.abs(D @ C.T).max()
-    np.testing.assert_allclose(G[0], D @ C.T, rtol=1e-12, atol=1e-12 * scale)
-    np.testing.assert_allclose(G[1], D @ D.T, rtol=1e-12, atol=1e-12 * scale)
-    np.testing.assert_allclose(G[2], C @ C.T, rtol=1e-12, atol=1e-12 * scale)
+    S, T = C + D, C - D          # the interface's sums: SS = S S^T, TT = T T^T (include/varsens_hip.h)
+    scale = np.abs(S @ S.T).max()
+    np.testing.assert_allclose(G[0], S @ S.T, rtol=1e-12, atol=1e-12 * scale)
+    np.testing.assert_allclose(G[1], T @ T.T, rtol=1e-12, atol=1e-12 * scale)
+    assert np.array_equal(G[0], G[0].T) and np.array_equal(G[1], G[1].T)
+    # what the reference forms from its four tensordots (saltelli.py:612-619)
+    np.testing.assert_allclose(0.5 * (G[0] - G[1]), D @ C.T + C @ D.T, rtol=1e-12, atol=2e-12 * scale)
+    np.testing.assert_allclose(0.5 * (G[0] + G[1]), D @ D.T + C @ C.T, rtol=1e-12, atol=2e-12 * scale)
     # exactness spot check against correctly rounded sums
     import math
     for (i, j) in ((0, 0), (K - 1, 0), (K // 2, K - 1)):
-        want = math.fsum((D[i] * C[j]).tolist())
+        want = math.fsum((S[i] * S[j]).tolist())
         assert abs(G[0][i, j] - want) <= 1e-13 * max(1.0, abs(want)) * 10
 
 
@@ -414,15 +418,15 @@ def test_first_and_second_order_in_one_pass(ctx, k, rows, l):
     K = k * l
     nacc = _native.acc_len(k, l, 1)
     acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
-    g1, g2 = ctx.alloc(8 * 3 * K * K), ctx.alloc(8 * 3 * K * K)
+    g1, g2 = ctx.alloc(8 * 2 * K * K), ctx.alloc(8 * 2 * K * K)
     ctx.reduce_first_order(f, rows, k, l, acc1)
     ctx.reduce_second_order(f, rows, k, l, g1)
     ctx.reduce_first_second_order(f, rows, k, l, acc2, g2)
     a1, a2 = ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,))
-    G1, G2 = ctx.download(g1, (3, K, K)), ctx.download(g2, (3, K, K))
+    G1, G2 = ctx.download(g1, (2, K, K)), ctx.download(g2, (2, K, K))
     assert np.array_equal(a1[:4], a2[:4])
     np.testing.assert_allclose(a2, a1, rtol=2e-13, atol=1e-9)
-    np.testing.assert_allclose(G2, G1, rtol=1e-13)
+    np.testing.assert_allclose(G2, G1, rtol=1e-13, atol=1e-13 * np.abs(G1).max())
     first = ctx.alloc(8 * _native.first_order_len(k, l))
     first1 = ctx.alloc(8 * _native.first_order_len(k, l))
     ctx.finish_first_order(acc2, rows, k, l, first)
@@ -445,15 +449,16 @@ def test_wide_staging_agrees_with_the_chunk_kernels(ctx, k, rows, monkeypatch):
     out = []
     for c in (ctx, narrow):
         f = c.upload(host)
-        acc, g1, g2 = c.alloc(8 * nacc), c.alloc(8 * 3 * k * k), c.alloc(8 * 3 * k * k)
+        acc, g1, g2 = c.alloc(8 * nacc), c.alloc(8 * 2 * k * k), c.alloc(8 * 2 * k * k)
         c.reduce_second_order(f, rows, k, 1, g1)
         c.reduce_first_second_order(f, rows, k, 1, acc, g2)
-        out.append((c.download(g1, (3, k, k)), c.download(g2, (3, k, k)), c.download(acc, (nacc,))))
+        out.append((c.download(g1, (2, k, k)), c.download(g2, (2, k, k)), c.download(acc, (nacc,))))
         for b in (f, acc, g1, g2):
             b.free()
     narrow.close()
-    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-13)
-    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-13)
+    scale = np.abs(out[1][0]).max()   # TT = (C - D)(C - D)^T holds sums of zero-mean products: absolute bound
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-13, atol=1e-13 * scale)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-13, atol=1e-13 * scale)
     np.testing.assert_allclose(out[0][2], out[1][2], rtol=2e-13, atol=1e-9)
 
 
@@ -467,16 +472,16 @@ def test_one_pass_with_nan_trim_takes_the_separate_kernels(ctx):
     f = ctx.upload(_native.to_planar(blocks))
     nacc = _native.acc_len(k, 1, 1)
     acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
-    g1, g2 = ctx.alloc(8 * 3 * k * k), ctx.alloc(8 * 3 * k * k)
+    g1, g2 = ctx.alloc(8 * 2 * k * k), ctx.alloc(8 * 2 * k * k)
     ctx.reduce_first_order(f, rows, k, 1, acc1, flags=_native.REDUCE_NAN_TRIM)
     ctx.reduce_second_order(f, rows, k, 1, g1, flags=_native.REDUCE_NAN_TRIM)
     ctx.reduce_first_second_order(f, rows, k, 1, acc2, g2, flags=_native.REDUCE_NAN_TRIM)
     assert np.array_equal(ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,)))
-    assert np.array_equal(ctx.download(g1, (3, k, k)), ctx.download(g2, (3, k, k)))
+    assert np.array_equal(ctx.download(g1, (2, k, k)), ctx.download(g2, (2, k, k)))
     assert ctx.download(acc2, (nacc,))[1] == 2.0     # rows dropped
     # without the flag the combined kernel runs and the NaNs propagate, as in the separate passes
     ctx.reduce_first_second_order(f, rows, k, 1, acc2, g2)
-    assert np.isnan(ctx.download(acc2, (nacc,))).any() and np.isnan(ctx.download(g2, (3, k, k))).any()
+    assert np.isnan(ctx.download(acc2, (nacc,))).any() and np.isnan(ctx.download(g2, (2, k, k))).any()
 
 
 @pytest.mark.parametrize("k,rows", [(5, 900), (9, 50001), (40, 3001), (70, 1000), (129, 257)])   # k > 32: macro-tile kernel
@@ -487,15 +492,15 @@ def test_second_order_nan_trim(ctx, k, rows):
     bad = rng.choice(rows, 11, replace=False)
     blocks[rng.randint(0, 2 * k + 2, 11), bad, 0] = np.nan
     f = ctx.upload(_native.to_planar(blocks))
-    gram = ctx.alloc(8 * 3 * k * k)
+    gram = ctx.alloc(8 * 2 * k * k)
     ctx.reduce_second_order(f, rows, k, 1, gram, flags=_native.REDUCE_NAN_TRIM)
-    G = ctx.download(gram, (3, k, k))
+    G = ctx.download(gram, (2, k, k))
     keep = ~np.isnan(blocks[:, :, 0]).any(axis=0)
     C = blocks[2:2 + k, keep, 0]; D = blocks[2 + k:, keep, 0]
-    np.testing.assert_allclose(G[0], D @ C.T, rtol=1e-12)
-    np.testing.assert_allclose(G[2], C @ C.T, rtol=1e-12)
+    np.testing.assert_allclose(G[0], (C + D) @ (C + D).T, rtol=1e-12)
+    np.testing.assert_allclose(G[1], (C - D) @ (C - D).T, rtol=1e-12, atol=1e-12 * np.abs(G[0]).max())
     ctx.reduce_second_order(f, rows, k, 1, gram)      # without the flag NaNs propagate
-    assert np.isnan(ctx.download(gram, (3, k, k))).any()
+    assert np.isnan(ctx.download(gram, (2, k, k))).any()
 
 
 @pytest.mark.parametrize("block", [0, 1])
@@ -510,23 +515,23 @@ def test_second_order_nan_only_in_fM(ctx, block, k, rows, l):
     blocks[block, r_bad, 0] = np.nan
     f = ctx.upload(_native.to_planar(blocks))
     K = k * l
-    gram = ctx.alloc(8 * 3 * K * K)
+    gram = ctx.alloc(8 * 2 * K * K)
     ctx.reduce_second_order(f, rows, k, l, gram, flags=_native.REDUCE_NAN_TRIM)
-    G = ctx.download(gram, (3, K, K))
+    G = ctx.download(gram, (2, K, K))
     keep = np.ones(rows, bool); keep[r_bad] = False
     C = blocks[2:2 + k][:, keep].transpose(0, 2, 1).reshape(K, -1)      # index row j*l + o
     D = blocks[2 + k:][:, keep].transpose(0, 2, 1).reshape(K, -1)
-    np.testing.assert_allclose(G[0], D @ C.T, rtol=1e-12)
-    np.testing.assert_allclose(G[1], D @ D.T, rtol=1e-12)
-    np.testing.assert_allclose(G[2], C @ C.T, rtol=1e-12)
+    np.testing.assert_allclose(G[0], (C + D) @ (C + D).T, rtol=1e-12)
+    np.testing.assert_allclose(G[1], (C - D) @ (C - D).T, rtol=1e-12, atol=1e-12 * np.abs(G[0]).max())
     # the untrimmed sums differ: the test would not notice a skipped trim otherwise
     Cu = blocks[2:2 + k].transpose(0, 2, 1).reshape(K, -1)
-    assert np.max(np.abs(G[2] - Cu @ Cu.T)) > 0.5
+    Du = blocks[2 + k:].transpose(0, 2, 1).reshape(K, -1)
+    assert np.max(np.abs(G[0] - (Cu + Du) @ (Cu + Du).T)) > 0.5
     # both orders through the one call Varsens uses
     nacc = _native.acc_len(k, l, 1)
-    acc, g2 = ctx.alloc(8 * nacc), ctx.alloc(8 * 3 * K * K)
+    acc, g2 = ctx.alloc(8 * nacc), ctx.alloc(8 * 2 * K * K)
     ctx.reduce_first_second_order(f, rows, k, l, acc, g2, flags=_native.REDUCE_NAN_TRIM)
-    assert np.array_equal(ctx.download(g2, (3, K, K)), G)
+    assert np.array_equal(ctx.download(g2, (2, K, K)), G)
     assert ctx.download(acc, (nacc,))[1] == 1.0
 
 
@@ -630,13 +635,12 @@ def test_reduce_very_wide_k(ctx):
     k2, rows2 = 200, 150
     b2 = rng.randn(2 * k2 + 2, rows2, 1)
     f = ctx.upload(_native.to_planar(b2))
-    gram = ctx.alloc(8 * 3 * k2 * k2)
+    gram = ctx.alloc(8 * 2 * k2 * k2)
     ctx.reduce_second_order(f, rows2, k2, 1, gram)
-    G = ctx.download(gram, (3, k2, k2))
+    G = ctx.download(gram, (2, k2, k2))
     C, D = b2[2:2 + k2, :, 0], b2[2 + k2:, :, 0]
-    np.testing.assert_allclose(G[0], D @ C.T, rtol=1e-11, atol=1e-11)
-    np.testing.assert_allclose(G[1], D @ D.T, rtol=1e-11, atol=1e-11)
-    np.testing.assert_allclose(G[2], C @ C.T, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(G[0], (C + D) @ (C + D).T, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(G[1], (C - D) @ (C - D).T, rtol=1e-11, atol=1e-11)
 
 
 def test_abi_argument_errors(ctx):

@@ -14,7 +14,7 @@ obj = ctx.objective_create(_native.OBJ_POLYNOMIAL, k, 1, beta)
 N = 2 * (k + 1) * n
 f = ctx.alloc(8 * N)
 acc = ctx.alloc(8 * _native.acc_len(k, 1, 1)); out = ctx.alloc(8 * _native.first_order_len(k, 1))
-gram = ctx.alloc(8 * 3 * k * k)
+gram = ctx.alloc(8 * _native.gram_len(k))
 ctx.profile_begin(64)
 for _ in range(2):
     ctx.eval(design, obj, 0, n, f)

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARSENS_HIP_LIB") or os.path.join(_HERE, "libvarsens_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
 
 GEN_HALTON, GEN_SOBOL, GEN_RAW = 0, 1, 2
@@ -39,6 +39,11 @@ def acc_slot(l):
 
 def acc_len(k, l, max_ranks):
     return ACC_HEADER + l * acc_per_output(k) + max_ranks * acc_slot(l)
+
+
+def gram_len(K):
+    """doubles of the second-order sums of vs_reduce_second_order: SS = (C+D)(C+D)^T, TT = (C-D)(C-D)^T, K = k*l"""
+    return 2 * int(K) * int(K)
 
 
 def first_order_len(k, l):

@@ -74,6 +74,7 @@ extern "C" int vs_context_create(int device, vs_context** out) {
         t.scan_general = (int)env_long("VS_SCAN_GENERAL", t.scan_general);
         t.gram_wgs_per_cu = (int)env_long("VS_GRAM_WGS_PER_CU", t.gram_wgs_per_cu);
         t.gram_wide = (int)env_long("VS_GRAM_WIDE", t.gram_wide);
+        t.gram_st = (int)env_long("VS_GRAM_ST", t.gram_st);
         t.reduce_both = (int)env_long("VS_REDUCE_BOTH", t.reduce_both);
         t.profile_mask = env_long("VS_PROFILE_MASK", t.profile_mask);
     }

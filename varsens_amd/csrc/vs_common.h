@@ -29,6 +29,7 @@ struct vs_tuning {
     int scan_shape = 0;          // VS_SCAN_SHAPE=L*100+W: force the evaluation scan kernel's shape (must be instantiated)
     int fused_variant = 0;       // VS_FUSED_VARIANT=1 or L*100+W: 64 < k <= 128 fused as 8 waves x 16 columns instead of 16 x 8
     int gram_wgs_per_cu = 0;     // VS_GRAM_WGS_PER_CU (0 = by shape)
+    int gram_st = 1;             // VS_GRAM_ST=0: 33..128 index rows per half keep the [C; D] macro kernel
     int gram_wide = 1;           // VS_GRAM_WIDE=0: keep gram_diag_wave_kernel for 33..64 index rows
     int reduce_both = 1;         // VS_REDUCE_BOTH=0: never take the combined first+second-order kernel
     long profile_mask = -1;      // VS_PROFILE_MASK: bracket only these kernel ids with events

@@ -72,7 +72,8 @@ __device__ __forceinline__ const double* x_elem(const vs_gram_args& A, int m, ui
 }
 
 // First-order record of a wave-private workgroup (FIRST): the 16 (wave, lane group) pairs each hold a share of
-// every sum -- pa/pb per 16-row block and index row lane&15, the five scalar sums in the lanes with lane&15 == 0.
+// every sum -- pa/pb per 16-row block and tile row lane&15 (a.s_u, b.s_u, a.t_u, b.t_u), the five scalar sums in
+// the lanes with lane&15 == 0.
 template <int NB>
 __device__ __forceinline__ void gram_first_record(const vs_gram_args& A, double* tiles, const double (&pa)[NB],
                                                   const double (&pb)[NB], double t_sab, double t_sa, double t_sb,
@@ -95,17 +96,18 @@ __device__ __forceinline__ void gram_first_record(const vs_gram_args& A, double*
         r3[g * 5 + VS_P_S2] = t_s2;
     }
     __syncthreads();
+    // the tile rows are s_u = c_u + d_u (row u) and t_u = c_u - d_u (row K + u): a.c = (a.s + a.t) / 2, a.d = (a.s - a.t) / 2
     double* rec = A.first_partials + (size_t)blockIdx.x * VS_PLEN(k);
-    for (int e = tid; e < NB * 16 * 2; e += 256) {
-        const int m = e >> 1, which = e & 1;
-        double sum = 0.0;
-        for (int gg = 0; gg < 16; ++gg) sum += r2[((size_t)gg * (NB * 16) + m) * 2 + which];
-        if (m < 2 * k) {
-            // record layout: head, ac[k], bd[k], ad[k], bc[k]
-            const int j = m < k ? m : m - k;
-            const int slot = m < k ? (which == 0 ? 0 : 3) : (which == 0 ? 2 : 1);
-            rec[VS_P_HEAD + (size_t)slot * k + j] = sum;
+    for (int e = tid; e < 4 * k; e += 256) {
+        const int slot = e / k, j = e - slot * k;   // record layout: head, ac[k], bd[k], ad[k], bc[k]
+        const int which = (slot == 0 || slot == 2) ? 0 : 1;   // sums against a (0) or b (1)
+        double xs = 0.0, xt = 0.0;
+        for (int gg = 0; gg < 16; ++gg) {
+            xs += r2[((size_t)gg * (NB * 16) + j) * 2 + which];
+            xt += r2[((size_t)gg * (NB * 16) + A.K + j) * 2 + which];
         }
+        const bool with_c = slot == 0 || slot == 3;
+        rec[VS_P_HEAD + e] = with_c ? 0.5 * (xs + xt) : 0.5 * (xs - xt);
     }
     if (tid < VS_P_HEAD) {
         double sum = 0.0;
@@ -148,7 +150,9 @@ typedef double vs_d2 __attribute__((ext_vector_type(2)));
     ((4 * 16 * (NB) * VS2_WPITCH) > 1024 + ((FIRST) ? 16 * (NB) * 16 * 2 + 80 : 0) \
          ? (4 * 16 * (NB) * VS2_WPITCH) : 1024 + ((FIRST) ? 16 * (NB) * 16 * 2 + 80 : 0))
 
-template <int NB, bool MASKED, bool ALIGNED, bool FIRST>
+// FULL: K == 8 NB exactly (k = 16, 32 with one output): blocks 0 .. NB/2-1 are all S, the rest all T, so the
+// needed tiles are known at compile time and the others cost no registers.
+template <int NB, bool MASKED, bool ALIGNED, bool FIRST, bool FULL>
 __global__ void __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(VS2_WAVES_PER_SIMD(NB, FIRST), VS2_WAVES_PER_SIMD(NB, FIRST))))
 gram_diag_wave_kernel(vs_gram_args A) {
@@ -164,25 +168,41 @@ gram_diag_wave_kernel(vs_gram_args A) {
         c[4] = 0;
     }
     constexpr int NT = NB * (NB + 1) / 2;
-    constexpr int NJ = 2 * NB;          // 8-row groups to load
-    const int S = blockIdx.y;
+    constexpr int NJ = 2 * NB;          // loads per chunk: NB pairs (c row u, d row u), u = 8j + (lane >> 3)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int M = 2 * A.K;
+    const int K = A.K;
     const uint64_t rows = A.rows;
     double* tile = tiles + wave * (16 * NB * VS2_WPITCH);
 
+    // index rows of the tile: s_u = c_u + d_u at row u, t_u = c_u - d_u at row K + u (u < K); rows from 2K on are
+    // padding, zeroed once.  A lane loads c and d of the SAME u and sample rows, so s and t form in registers.
     const int lrow = lane >> 3, piece = lane & 7;
-    const double* rp[NJ];
-    bool ok[NJ];
+    const double* rp[NJ];    // [2j] = c row, [2j + 1] = d row
+    bool ok[NB];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int m = S * VS2_SUPER + 8 * j + lrow;
-        ok[j] = m < M;
-        rp[j] = x_elem(A, ok[j] ? m : 0, 0) + 2 * piece;
+    for (int j = 0; j < NB; ++j) {
+        const int u = 8 * j + lrow;
+        ok[j] = u < K;
+        rp[2 * j] = x_elem(A, ok[j] ? u : 0, 0) + 2 * piece;
+        rp[2 * j + 1] = x_elem(A, K + (ok[j] ? u : 0), 0) + 2 * piece;
     }
-    double* wr = tile + lrow * VS2_WPITCH + 2 * piece;                       // + 8j rows
+    for (int e = 2 * K * VS2_WPITCH + lane; e < 16 * NB * VS2_WPITCH; e += 64) tile[e] = 0.0;
+    double* wr = tile + lrow * VS2_WPITCH + 2 * piece;                       // + 8j rows: s; + K rows more: t
+    double* wrt = wr + K * VS2_WPITCH;
+    // tiles of an S block times a T block are never needed (block b is all S when 16(b+1) <= K, all T when 16b >= K)
+    bool need[NT];
+    {
+        int a = 0;
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+            for (int bj = bi; bj < NB; ++bj) {
+                need[a] = FULL ? (bi < NB / 2) == (bj < NB / 2) : !(16 * (bi + 1) <= K && 16 * bj >= K);
+                ++a;
+            }
+    }
     const double* rd = tile + (lane & 15) * VS2_WPITCH + 2 * (lane >> 4);    // + 16b rows, + 8h
 
     vs_d4 acc[NT];
@@ -251,14 +271,18 @@ gram_diag_wave_kernel(vs_gram_args A) {
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            vs_d2 v = raw[j];
+        for (int j = 0; j < NB; ++j) {
+            vs_d2 c = raw[2 * j], d = raw[2 * j + 1];
             if (MASKED) {
-                v.x = k0 ? v.x : 0.0;
-                v.y = k1 ? v.y : 0.0;
+                c.x = k0 ? c.x : 0.0;
+                c.y = k1 ? c.y : 0.0;
+                d.x = k0 ? d.x : 0.0;
+                d.y = k1 ? d.y : 0.0;
             }
-            if (!ok[j]) v = (vs_d2){0.0, 0.0};
-            *(vs_d2*)(wr + 8 * j * VS2_WPITCH) = v;
+            if (ok[j]) {   // rows u >= K of the s part ARE rows of the t part: nothing may be written for them
+                *(vs_d2*)(wr + 8 * j * VS2_WPITCH) = c + d;
+                *(vs_d2*)(wrt + 8 * j * VS2_WPITCH) = c - d;
+            }
         }
     };
 
@@ -290,7 +314,7 @@ gram_diag_wave_kernel(vs_gram_args A) {
                 for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
                     for (int bj = bi; bj < NB; ++bj) {
-                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[bi][h][t], fr[bj][h][t], acc[a], 0, 0, 0);
+                        if (need[a]) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[bi][h][t], fr[bj][h][t], acc[a], 0, 0, 0);
                         ++a;
                     }
             }
@@ -322,8 +346,7 @@ gram_diag_wave_kernel(vs_gram_args A) {
     // add the four waves' accumulators through LDS (the tiles are free now), fixed order
     __syncthreads();
     double* red = tiles;
-    const int npairs = A.nsuper * (A.nsuper + 1) / 2;
-    double* out = A.partials + ((size_t)blockIdx.x * npairs + S) * VS2_TILE_OUT;
+    double* out = A.partials + (size_t)blockIdx.x * VS2_TILE_OUT;   // one 64-row block
     int a = 0;
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
@@ -369,7 +392,7 @@ gram_diag_wave_kernel(vs_gram_args A) {
     ((4 * VS2_WIDE_ROWS(NB, FIRST) * VS2_XPITCH) > 1024 + ((FIRST) ? 16 * (NB) * 16 * 2 + 80 : 0) \
          ? (4 * VS2_WIDE_ROWS(NB, FIRST) * VS2_XPITCH) : 1024 + ((FIRST) ? 16 * (NB) * 16 * 2 + 80 : 0))
 
-template <int NB, bool FIRST>
+template <int NB, bool FIRST, bool FULL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gram_diag_wide_kernel(vs_gram_args A) {
     extern __shared__ double tiles[];  // [4 waves][VS2_WIDE_ROWS][VS2_XPITCH] (VS2_WIDE_LDS doubles)
@@ -383,19 +406,33 @@ gram_diag_wide_kernel(vs_gram_args A) {
         c[4] = 0;
     }
     constexpr int NT = NB * (NB + 1) / 2;
-    constexpr int NJ = 4 * NB;          // loads per unit: 4 index rows each
+    constexpr int NJ = 4 * NB;          // loads per unit: 2 NB pairs (c row u, d row u), u = 4j + (lane >> 4)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int M = 2 * A.K;
+    const int K = A.K;
     const uint64_t rows = A.rows;
     double* tile = tiles + wave * (VS2_WIDE_ROWS(NB, FIRST) * VS2_XPITCH);
 
     const int mrow = lane >> 4, li = lane & 15;
-    // index row m = plane 2 + m (one output); rows past 2k read row 0 and are zeroed on the way into the tile
-    const double* p0 = A.f + (uint64_t)(2 + mrow) * rows + 2 * li;
-    const uint64_t jstride = 4 * rows;
-    double* wr = tile + mrow * VS2_XPITCH + 2 * li;                          // + 4j rows
+    // tile rows: s_u = c_u + d_u at row u, t_u = c_u - d_u at row K + u; rows from 2K on are padding, zeroed once.
+    // One output: c_u is plane 2 + u, d_u plane 2 + K + u of f; rows u >= K read u = 0 and are not stored.
+    const double* p0 = A.f + (uint64_t)(2 + mrow) * rows + 2 * li;           // c row mrow
+    const uint64_t jstride = 4 * rows, dstride = (uint64_t)K * rows;
+    for (int e = 2 * K * VS2_XPITCH + lane; e < 16 * NB * VS2_XPITCH; e += 64) tile[e] = 0.0;
+    double* wr = tile + mrow * VS2_XPITCH + 2 * li;                          // + 4j rows: s; + K rows more: t
+    double* wrt = wr + K * VS2_XPITCH;
+    bool need[NT];   // S block x T block tiles are never needed
+    {
+        int a = 0;
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+            for (int bj = bi; bj < NB; ++bj) {
+                need[a] = FULL ? (bi < NB / 2) == (bj < NB / 2) : !(16 * (bi + 1) <= K && 16 * bj >= K);
+                ++a;
+            }
+    }
     const double* rd = tile + (lane & 15) * VS2_XPITCH + 2 * (lane >> 4);    // + 16b rows, + 8 per quarter
     // FIRST: lanes 0..15 load a (plane 0), 16..31 b (plane 1), the rest load them again into two spare rows
     const double* pab = A.f + (uint64_t)(mrow & 1) * rows + 2 * li;
@@ -418,19 +455,21 @@ gram_diag_wide_kernel(vs_gram_args A) {
         const uint64_t s0 = u * VS2_XCHUNK;
         if (u < nfull) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const bool okj = j < 4 * (NB - 1) || 4 * j + mrow < M;   // only the last 16-row block can be ragged
-                raw[j] = __builtin_nontemporal_load((const vs_d2*)((okj ? p0 + j * jstride : p0) + s0));
+            for (int j = 0; j < NJ / 2; ++j) {
+                const double* q = (4 * j + mrow < K ? p0 + j * jstride : p0) + s0;
+                raw[2 * j] = __builtin_nontemporal_load((const vs_d2*)q);
+                raw[2 * j + 1] = __builtin_nontemporal_load((const vs_d2*)(q + dstride));
             }
             if (FIRST) rawab = __builtin_nontemporal_load((const vs_d2*)(pab + s0));
         } else {  // the ragged last unit
             const uint64_t s = s0 + 2 * li;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const bool okj = 4 * j + mrow < M;
-                const double* q = (okj ? p0 + j * jstride : p0) + s0;
-                raw[j].x = s < rows ? q[0] : 0.0;
-                raw[j].y = s + 1 < rows ? q[1] : 0.0;
+            for (int j = 0; j < NJ / 2; ++j) {
+                const double* q = (4 * j + mrow < K ? p0 + j * jstride : p0) + s0;
+                raw[2 * j].x = s < rows ? q[0] : 0.0;
+                raw[2 * j].y = s + 1 < rows ? q[1] : 0.0;
+                raw[2 * j + 1].x = s < rows ? q[dstride] : 0.0;
+                raw[2 * j + 1].y = s + 1 < rows ? q[dstride + 1] : 0.0;
             }
             if (FIRST) {
                 rawab.x = s < rows ? pab[s0] : 0.0;
@@ -440,10 +479,11 @@ gram_diag_wide_kernel(vs_gram_args A) {
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            vs_d2 v = raw[j];
-            if (j >= 4 * (NB - 1) && 4 * j + mrow >= M) v = (vs_d2){0.0, 0.0};
-            *(vs_d2*)(wr + 4 * j * VS2_XPITCH) = v;
+        for (int j = 0; j < NJ / 2; ++j) {
+            if (4 * j + mrow < K) {   // rows u >= K of the s part ARE rows of the t part
+                *(vs_d2*)(wr + 4 * j * VS2_XPITCH) = raw[2 * j] + raw[2 * j + 1];
+                *(vs_d2*)(wrt + 4 * j * VS2_XPITCH) = raw[2 * j] - raw[2 * j + 1];
+            }
         }
         if (FIRST) *(vs_d2*)wrab = rawab;
     };
@@ -468,7 +508,7 @@ gram_diag_wide_kernel(vs_gram_args A) {
                 for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
                     for (int bj = bi; bj < NB; ++bj) {
-                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[bi][t], fr[bj][t], acc[a], 0, 0, 0);
+                        if (need[a]) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[bi][t], fr[bj][t], acc[a], 0, 0, 0);
                         ++a;
                     }
             }
@@ -787,6 +827,182 @@ gram_macro_kernel(vs_gram_args A) {
     else gram_macro_body<MASKED, ALIGNED, FIRST, WIDE, false>(A, MI, MJ, tiles);
 }
 
+// 33 .. 128 index rows per half (32 < k*l <= 128): the S/T form of the macro kernel.  ONE 256-row tile holds
+// s_u = c_u + d_u (rows 0 .. 127, zero from K on) and t_u = c_u - d_u (rows 128 ..): a thread loads c and d of the same u
+// and sample rows, so both form in registers -- the same loads as an off-diagonal pair of gram_macro_kernel -- and the
+// workgroup computes the upper block triangles of S S^T and T T^T: 72 tiles of 16x16 instead of the 136 of the
+// [C; D] Gram matrix.  Wave w owns block row w of S S^T (8 - w tiles) and block row 7 - w of T T^T (w + 1 tiles):
+// nine accumulator tiles each, in slots whose meaning depends on w but whose register index does not
+// (slot s: S S^T tile (w, w + s) while s <= 7 - w, then T T^T tile (7 - w, s - 1)).  Tiles of all-zero blocks
+// (K < 128) are skipped.  Staging, double buffering and the WIDE fetch are gram_macro_kernel's.
+// Partials: [workgroup][S S^T, T T^T][128][128].
+template <bool MASKED, bool ALIGNED, bool WIDE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+gram_macro_st_kernel(vs_gram_args A) {
+    extern __shared__ double tiles[];  // [2 buffers][256][VS2_WPITCH]
+    if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = A.K;
+    const int nbl = (K + 15) / 16;     // live 16-row blocks per half
+    const uint64_t rows = A.rows;
+    constexpr int BUF = 2 * VS2_MACRO * VS2_WPITCH;  // doubles per buffer
+
+    // staging: loads j < NLD/2 are c rows u_j, loads j >= NLD/2 the d rows of the same u_j
+    constexpr int NLD = WIDE ? 8 : 4, NU = NLD / 2;
+    const int lrow = WIDE ? tid >> 4 : tid >> 3, piece = WIDE ? tid & 15 : tid & 7;
+    constexpr int USTEP = WIDE ? 32 : 64;   // u_j = lrow + USTEP j
+    const double* rp[WIDE ? 1 : NLD];
+    if (WIDE) {
+        rp[0] = A.f + 2 * piece;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int u = lrow + USTEP * j;
+            rp[j] = x_elem(A, u < K ? u : 0, 0) + 2 * piece;
+            rp[NU + j] = x_elem(A, K + (u < K ? u : 0), 0) + 2 * piece;
+        }
+    }
+    // WIDE (one output): c_u is plane 2 + u, d_u plane 2 + K + u; the address is rebuilt at every fetch
+    auto wide_ptr = [&](int j, int lr) {
+        const int u = lr + USTEP * (j % NU);
+        return rp[0] + (uint64_t)(2 + (j >= NU ? K : 0) + (u < K ? u : 0)) * rows;
+    };
+    double* wr = tiles + lrow * VS2_WPITCH + 2 * (piece & 7);   // + USTEP j rows: s; + 128 rows: t; + buffer
+    // fragments
+    const double* rdS = tiles + (lane & 15) * VS2_WPITCH + 2 * (lane >> 4);                 // + 16 blk rows
+    const double* rdT = rdS + VS2_MACRO * VS2_WPITCH;
+    const int nss = wave < nbl ? nbl - wave : 0;               // live S S^T tiles: (wave, wave .. nbl-1)
+    const int tr = 7 - wave;                                   // block row of T T^T
+
+    vs_d4 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
+
+    const uint64_t nfull = rows / VS2_WCHUNK;
+    const uint64_t nch = nfull + ((rows % VS2_WCHUNK) ? 1 : 0);
+    constexpr uint64_t GROUP = 4;
+    const uint64_t ngroups = (nch + GROUP - 1) / GROUP;
+    uint64_t mine = 0;   // chunks this workgroup walks (WIDE: whole pairs; a chunk past the end is zeros)
+    for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint64_t here = (g * GROUP + GROUP <= nch) ? GROUP : nch - g * GROUP;
+        mine += WIDE ? (here + 1) & ~(uint64_t)1 : here;
+    }
+    auto chunk_of = [&](uint64_t i) {
+        const uint64_t g = blockIdx.x + (i / GROUP) * gridDim.x;
+        return g * GROUP + (i % GROUP);
+    };
+    vs_d2 raw[NLD];
+    bool k0 = true, k1 = true;
+    auto fetch = [&](uint64_t c) {   // WIDE: c is the first chunk of a pair
+        const uint64_t s0 = c * VS2_WCHUNK;
+        const bool whole = WIDE ? s0 + 2 * VS2_WCHUNK <= rows : c < nfull;
+        int lr = lrow;
+        if (WIDE) asm volatile("" : "+v"(lr));   // not loop-invariant as far as the compiler can tell
+        if (whole) {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                if (lr + USTEP * (j % NU) >= K) continue;   // rows past K are zeros in the tile: nothing to load
+                const double* q = WIDE ? wide_ptr(j, lr) : rp[WIDE ? 0 : j];
+                if (ALIGNED) {
+                    raw[j] = __builtin_nontemporal_load((const vs_d2*)(q + s0));
+                } else {
+                    raw[j].x = __builtin_nontemporal_load(q + s0);
+                    raw[j].y = __builtin_nontemporal_load(q + s0 + 1);
+                }
+            }
+        } else {
+            const uint64_t sm = s0 + 2 * piece;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const bool in = lr + USTEP * (j % NU) < K;
+                const double* q = WIDE ? wide_ptr(j, lr) : rp[WIDE ? 0 : j];
+                raw[j].x = (in && sm < rows) ? q[s0] : 0.0;
+                raw[j].y = (in && sm + 1 < rows) ? q[s0 + 1] : 0.0;
+            }
+        }
+        if (MASKED) {
+            const uint64_t sm = s0 + 2 * piece;
+            k0 = sm < rows && A.keep[sm];
+            k1 = sm + 1 < rows && A.keep[sm + 1];
+        }
+    };
+    auto stash = [&](int b, int half) {   // WIDE: the threads holding sample rows 16 half .. of the pair write
+        if (WIDE && (piece >> 3) != half) return;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            vs_d2 c = raw[j], d = raw[NU + j];
+            if (MASKED) {
+                c.x = k0 ? c.x : 0.0;
+                c.y = k1 ? c.y : 0.0;
+                d.x = k0 ? d.x : 0.0;
+                d.y = k1 ? d.y : 0.0;
+            }
+            if (lrow + USTEP * j >= K) c = d = (vs_d2){0.0, 0.0};
+            *(vs_d2*)(wr + b * BUF + USTEP * j * VS2_WPITCH) = c + d;
+            *(vs_d2*)(wr + b * BUF + (VS2_MACRO + USTEP * j) * VS2_WPITCH) = c - d;
+        }
+    };
+
+    if (mine > 0) {
+        fetch(chunk_of(0));
+        stash(0, 0);
+        if (!WIDE && mine > 1) fetch(chunk_of(1));
+    }
+    __syncthreads();
+    for (uint64_t i = 0; i < mine; ++i) {
+        const int b = (int)(i & 1);
+        if (i + 1 < mine) stash(b ^ 1, (int)((i + 1) & 1));
+        if (WIDE) {
+            if (!(i & 1) && i + 2 < mine) fetch(chunk_of(i + 2));
+        } else {
+            if (i + 2 < mine) fetch(chunk_of(i + 2));
+        }
+        vs_d2 fa[2];
+        fa[0] = *(const vs_d2*)(rdS + b * BUF + 16 * wave * VS2_WPITCH);
+        fa[1] = *(const vs_d2*)(rdS + b * BUF + 16 * wave * VS2_WPITCH + 8);
+#pragma unroll
+        for (int sl = 0; sl < 9; ++sl) {
+            const bool ss = sl < 8 - wave;                 // wave-uniform
+            if (sl == 8 - wave) {                          // from here on: row block 7 - wave of T T^T
+                fa[0] = *(const vs_d2*)(rdT + b * BUF + 16 * tr * VS2_WPITCH);
+                fa[1] = *(const vs_d2*)(rdT + b * BUF + 16 * tr * VS2_WPITCH + 8);
+            }
+            const int blk = ss ? wave + sl : sl - 1;       // block of the other operand
+            const bool live = ss ? sl < nss : (tr < nbl && blk < nbl);
+            if (live) {
+                const double* rb = (ss ? rdS : rdT) + b * BUF + 16 * blk * VS2_WPITCH;
+                const vs_d2 f0 = *(const vs_d2*)rb;
+                const vs_d2 f1 = *(const vs_d2*)(rb + 8);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0][0], f0[0], acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0][1], f0[1], acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1][0], f1[0], acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1][1], f1[1], acc[sl], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // a tile belongs to one wave: straight to this workgroup's partial (all-zero and mirror tiles stay unwritten;
+    // the fold never reads them)
+    double* out = A.partials + (size_t)blockIdx.x * 2 * VS2_MTILE_OUT;
+#pragma unroll
+    for (int sl = 0; sl < 9; ++sl) {
+        const bool ss = sl < 8 - wave;
+        const int blk = ss ? wave + sl : sl - 1;
+        const int rowblk = ss ? wave : tr;
+        const bool live = ss ? sl < nss : (tr < nbl && blk < nbl);
+        if (live) {
+            double* o = out + (ss ? 0 : VS2_MTILE_OUT);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = (lane >> 4) + 4 * v, col = lane & 15;   // f64 C/D layout
+                o[(rowblk * 16 + row) * VS2_MACRO + (blk * 16 + col)] = acc[sl][v];
+            }
+        }
+    }
+}
+
 // The five scalar sums of the first-order record (sab, sa, sb, shifted s1, s2: varsens/saltelli.py:577,583) for
 // the one-pass route beyond 32 columns: a = fM_1, b = fM_2 only.  One full record per workgroup (zeros in the
 // dot-product part), appended to the macro kernel's records.
@@ -857,6 +1073,8 @@ struct vs_gram_fold_args {
     uint32_t P;
     int K, nsuper, npairs;
     int super;   // index rows per block of the partials: 64 (gram_diag_wave_kernel) or 128 (gram_macro_kernel)
+    int st;      // 1: the partials are sums over [S; T] (rows u and K + u): SS and TT go straight to `gram`;
+                 // 0: sums over [C; D]: DC, DD, CC for gram_convert_kernel
     double* gram;
     uint32_t* counters;
     int masked;
@@ -878,13 +1096,16 @@ gram_fold_kernel(vs_gram_fold_args A) {
     const size_t col = (size_t)blockIdx.x * 64 + lane;   // width is a multiple of 64
     const int pair = (int)(col / tile_out);
     const int e = (int)(col % tile_out);
-    int SI, SJ;
-    pair_from_index(pair, A.nsuper, SI, SJ);
+    int SI = 0, SJ = 0;
+    if (A.st != 2) pair_from_index(pair, A.nsuper, SI, SJ);
     const int li = e / SB, lj = e % SB;
     const int K = A.K;
-    const int gi = SI * SB + li, gj = SJ * SB + lj;
+    // st == 2 (gram_macro_st_kernel): tile 0 is S S^T, tile 1 T T^T, rows and columns u < K
+    const int gi = A.st == 2 ? li + pair * K : SI * SB + li, gj = A.st == 2 ? lj + pair * K : SJ * SB + lj;
     // entries of mirror blocks (never computed) and of padding rows are skipped
-    const bool live = !(SI == SJ && (lj / 16) < (li / 16)) && gi < 2 * K && gj < 2 * K;
+    const bool live = A.st == 2 ? (lj / 16) >= (li / 16) && li < K && lj < K
+                                : !(SI == SJ && (lj / 16) < (li / 16)) && gi < 2 * K && gj < 2 * K &&
+                                      !(A.st && (gi < K) != (gj < K));   // S.T products are by-products
     double s = 0.0, comp = 0.0;
     if (live) {
         constexpr uint32_t STEP = VS2_FOLD_THREADS / 64, BATCH = 8;
@@ -917,10 +1138,17 @@ gram_fold_kernel(vs_gram_fold_args A) {
     }
     const double total = S + Cc;   // = X_gi . X_gj
     if (!A.masked && total != total) atomicOr(&A.counters[CNT_NANFLAG], 1u);
+    const bool mirror = !(SI == SJ && (li / 16) == (lj / 16));  // diagonal 16-blocks hold both triangles
+    if (A.st) {
+        double* M = A.gram + (gi < K ? 0 : (size_t)K * K);   // SS, then TT
+        const int i = gi < K ? gi : gi - K, j = gj < K ? gj : gj - K;
+        M[(size_t)i * K + j] = total;
+        if (mirror) M[(size_t)j * K + i] = total;
+        return;
+    }
     double* DC = A.gram;
     double* DD = DC + (size_t)K * K;
     double* CC = DD + (size_t)K * K;
-    const bool mirror = !(SI == SJ && (li / 16) == (lj / 16));  // diagonal 16-blocks hold both triangles
     if (gi < K && gj < K) {
         CC[(size_t)gi * K + gj] = total;
         if (mirror) CC[(size_t)gj * K + gi] = total;
@@ -938,26 +1166,44 @@ __global__ void __launch_bounds__(256)
 finish_second_kernel(const double* __restrict__ gram, const double* __restrict__ first, uint64_t n, int k, int l,
                      double* __restrict__ s2, double* __restrict__ s2n) {
     const int K = k * l;
-    const double* DC = gram;
-    const double* DD = DC + (size_t)K * K;
-    const double* CC = DD + (size_t)K * K;
+    const double* SS = gram;                     // (C + D)(C + D)^T
+    const double* TT = SS + (size_t)K * K;       // (C - D)(C - D)^T
     const double* E_2 = first;
     const double* var_y = first + l;
     const double div = 2.0 * ((double)n - 1.0);
     const size_t total = (size_t)K * K;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t I = e / K, J = e % K;
+        const size_t J = e % K;
         const int p = (int)(J % l);  // output index of the LAST axis: E_2 / var_y broadcast over it
-        double a = DC[I * K + J] + DC[J * K + I];   // saltelli.py:612-613
+        double a = 0.5 * (SS[e] - TT[e]);            // D C^T + C D^T, saltelli.py:612-613
         a /= div;                                    // :614
         a -= E_2[p];                                 // :615
         a /= var_y[p];                               // :616
         s2[e] = a;
-        double b = DD[I * K + J] + CC[I * K + J];    // :618-619
+        double b = 0.5 * (SS[e] + TT[e]);            // D D^T + C C^T, :618-619
         b /= div;
         b -= E_2[p];
         b /= var_y[p];
         s2n[e] = b;
+    }
+}
+
+// Kernels that accumulate the Gram matrix of X = [C; D] (more than 128 index rows per half: see second_order_impl)
+// leave DC = D C^T, DD, CC in the workspace; this turns them into the interface's SS and TT.
+__global__ void __launch_bounds__(256)
+gram_convert_kernel(const double* __restrict__ cd, int K, double* __restrict__ gram, const uint32_t* __restrict__ counters,
+                    int masked) {
+    if (masked && counters[CNT_NANFLAG] == 0) return;
+    const double* DC = cd;
+    const double* DD = DC + (size_t)K * K;
+    const double* CC = DD + (size_t)K * K;
+    const size_t total = (size_t)K * K;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t I = e / K, J = e % K;
+        const double cross = DC[I * K + J] + DC[J * K + I];
+        const double same = DD[e] + CC[e];
+        gram[e] = same + cross;
+        gram[total + e] = same - cross;
     }
 }
 
@@ -973,9 +1219,15 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const int K = k * l;
     // up to 64 index rows: one 64-row block, wave-private kernel; beyond: 128-row macro blocks
     const bool macro = 2 * K > VS2_SUPER;
+    // 33 .. 128 index rows per half: the S/T macro kernel (one tile of 128 s rows + 128 t rows per workgroup, two
+    // 128 x 128 partials: "2 pairs" below, one grid row); beyond: the [C; D] macro kernel over pairs of 128-row blocks
+    // (49 .. 64 rows per half stay on the [C; D] kernel, measured: four live 16-row blocks leave half of the S/T
+    // kernel's waves one or two tiles per barrier -- 1.49 vs 1.62-1.67 ms at n = 2^22)
+    const bool macro_st = macro && K <= VS2_MACRO && !(K > 48 && K <= 64) && !with_first && ctx->tune.gram_st != 0;
     const int SB = macro ? VS2_MACRO : VS2_SUPER;
-    const int nsuper = (2 * K + SB - 1) / SB;
-    const int npairs = nsuper * (nsuper + 1) / 2;
+    const int nsuper = macro_st ? 1 : (2 * K + SB - 1) / SB;
+    const int npairs = macro_st ? 2 : nsuper * (nsuper + 1) / 2;
+    const int grid_rows = macro_st ? 1 : npairs;
     uint64_t nchunks = (rows + VS2_WCHUNK - 1) / VS2_WCHUNK;
     if (nchunks < 1) nchunks = 1;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
@@ -985,10 +1237,10 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     // 80 KiB each), 6 are launched -- the diagonal pairs finish early and the dispatcher evens it out (measured)
     const int nb_wave = (2 * K + 15) / 16;   // live 16-row blocks of the wave-private kernel (2K <= 64)
     const int per_cu = ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu
-                       : (macro ? 6 : (nb_wave <= 4 ? VS2_WAVES_PER_SIMD(nb_wave, false) : 3));
+                       : (macro_st ? 2 : macro ? 6 : (nb_wave <= 4 ? VS2_WAVES_PER_SIMD(nb_wave, false) : 3));
     // grid = want x npairs workgroups: never more than are resident at once (a single workgroup left over
     // would run a whole extra round on an empty chip)
-    uint64_t want = macro ? ((uint64_t)cus * per_cu) / npairs : ((uint64_t)cus * per_cu + npairs - 1) / npairs;
+    uint64_t want = macro ? ((uint64_t)cus * per_cu) / grid_rows : ((uint64_t)cus * per_cu + npairs - 1) / npairs;
     if (want < 1) want = 1;
     const uint64_t units = macro ? (nchunks + 3) / 4 : nchunks;   // the macro kernel walks groups of 4 chunks
     const uint32_t slab_wgs = (uint32_t)(units < want ? units : want);
@@ -1008,11 +1260,14 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     size_t first_doubles = with_first ? (size_t)P_first * plen + plen : 0;
     first_doubles = (first_doubles + 1) & ~(size_t)1;
     const uint32_t max_wgs = wide && wide_wgs > slab_wgs ? wide_wgs : slab_wgs;
-    int rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + (size_t)max_wgs * width));
+    // ... and DC, DD, CC (3 K^2) behind them, for gram_convert_kernel
+    const size_t cd_doubles = 3 * (size_t)K * K;
+    int rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + (size_t)max_wgs * width + cd_doubles));
     if (rc) return rc;
+    double* cd_dev = ctx->partials + first_doubles + (size_t)max_wgs * width;
 
     VS_HIP(hipMemsetAsync(ctx->counters + CNT_NANFLAG, 0, sizeof(uint32_t), ctx->stream));
-    VS_HIP(hipMemsetAsync(gram_dev, 0, sizeof(double) * 3 * (size_t)K * K, ctx->stream));
+    VS_HIP(hipMemsetAsync(cd_dev, 0, sizeof(double) * cd_doubles, ctx->stream));
 
     vs_gram_args A;
     A.f = f_dev;
@@ -1033,7 +1288,10 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     F.nsuper = nsuper;
     F.npairs = npairs;
     F.super = SB;
-    F.gram = gram_dev;
+    const bool st = !macro || macro_st;   // the kernels accumulate [S; T] sums (else [C; D] sums, converted at the end)
+    F.st = macro_st ? 2 : st ? 1 : 0;
+    F.gram = st ? gram_dev : cd_dev;
+    if (st) VS_HIP(hipMemsetAsync(gram_dev, 0, sizeof(double) * VS_GRAM_LEN(K), ctx->stream));
     F.counters = ctx->counters;
     const size_t lds_w = sizeof(double) * (nb_wave <= 4 ? (size_t)VS2_WAVE_LDS(nb_wave, false) : 0);   // wave-private tiles
     const size_t lds_m = sizeof(double) * 2 * 2 * VS2_MACRO * VS2_WPITCH;   // macro: two buffers of 256 rows
@@ -1043,7 +1301,14 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     X(false, false, false, false) X(false, true, false, false) X(true, false, false, false) X(true, true, false, false) \
     X(false, false, true, false) X(false, true, true, false) X(false, true, false, true) X(true, true, false, true) \
     X(false, true, true, true)
-    if (macro) {
+    if (macro_st) {
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+    } else if (macro) {
 #define VS2_SET_LDS(MK, AL, FI, WI) \
         VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<MK, AL, FI, WI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
         VS2_MACRO_INSTANCES(VS2_SET_LDS)
@@ -1070,7 +1335,15 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
         }
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
-            if (macro) {
+            if (macro_st) {
+                const dim3 grid(slab_wgs, 1);
+                if (masked && mwide) hipLaunchKernelGGL((gram_macro_st_kernel<true, true, true>), grid, dim3(512), lds_m, ctx->stream, A);
+                else if (masked && aligned) hipLaunchKernelGGL((gram_macro_st_kernel<true, true, false>), grid, dim3(512), lds_m, ctx->stream, A);
+                else if (masked) hipLaunchKernelGGL((gram_macro_st_kernel<true, false, false>), grid, dim3(512), lds_m, ctx->stream, A);
+                else if (mwide) hipLaunchKernelGGL((gram_macro_st_kernel<false, true, true>), grid, dim3(512), lds_m, ctx->stream, A);
+                else if (aligned) hipLaunchKernelGGL((gram_macro_st_kernel<false, true, false>), grid, dim3(512), lds_m, ctx->stream, A);
+                else hipLaunchKernelGGL((gram_macro_st_kernel<false, false, false>), grid, dim3(512), lds_m, ctx->stream, A);
+            } else if (macro) {
                 const dim3 grid(slab_wgs, npairs);
                 bool launched = false;
 #define VS2_LAUNCH_MACRO(MK, AL, FI, WI)                                                                        \
@@ -1084,31 +1357,34 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
             } else if (wide && !masked) {
                 const size_t lds_x = sizeof(double) * (size_t)(nb_wave == 3 ? VS2_WIDE_LDS(3, false) : VS2_WIDE_LDS(4, false));
                 A.slab_wgs = F.P = wide_wgs;
-                if (nb_wave == 3) {
-                    VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
-                    hipLaunchKernelGGL((gram_diag_wide_kernel<3, false>), dim3(wide_wgs), dim3(256), lds_x, ctx->stream, A);
-                } else {
-                    VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
-                    hipLaunchKernelGGL((gram_diag_wide_kernel<4, false>), dim3(wide_wgs), dim3(256), lds_x, ctx->stream, A);
-                }
+#define VS2_LAUNCH_WIDE(NBV, FU)                                                                                                  \
+    do {                                                                                                                          \
+        VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<NBV, false, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)lds_x));                                                                                  \
+        hipLaunchKernelGGL((gram_diag_wide_kernel<NBV, false, FU>), dim3(wide_wgs), dim3(256), lds_x, ctx->stream, A);           \
+    } while (0)
+                if (nb_wave == 3) VS2_LAUNCH_WIDE(3, false);
+                else if (K == 32) VS2_LAUNCH_WIDE(4, true);
+                else VS2_LAUNCH_WIDE(4, false);
+#undef VS2_LAUNCH_WIDE
             } else {
                 A.slab_wgs = F.P = slab_wgs;
                 const dim3 grid_diag(slab_wgs, 1);
                 const int nb = (2 * K + 15) / 16;
-#define VS2_LAUNCH_WAVE2(NBV, MK, AL) \
-    hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, MK, AL, false>), grid_diag, dim3(256), lds_w, ctx->stream, A)
-#define VS2_LAUNCH_WAVE(NBV)                                        \
-    do {                                                            \
-        if (masked && aligned) VS2_LAUNCH_WAVE2(NBV, true, true);   \
-        else if (masked) VS2_LAUNCH_WAVE2(NBV, true, false);        \
-        else if (aligned) VS2_LAUNCH_WAVE2(NBV, false, true);       \
-        else VS2_LAUNCH_WAVE2(NBV, false, false);                   \
+#define VS2_LAUNCH_WAVE2(NBV, MK, AL, FU) \
+    hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, MK, AL, false, FU>), grid_diag, dim3(256), lds_w, ctx->stream, A)
+#define VS2_LAUNCH_WAVE(NBV, FU)                                        \
+    do {                                                                \
+        if (masked && aligned) VS2_LAUNCH_WAVE2(NBV, true, true, FU);   \
+        else if (masked) VS2_LAUNCH_WAVE2(NBV, true, false, FU);        \
+        else if (aligned) VS2_LAUNCH_WAVE2(NBV, false, true, FU);       \
+        else VS2_LAUNCH_WAVE2(NBV, false, false, FU);                   \
     } while (0)
                 switch (nb) {
-                    case 1: VS2_LAUNCH_WAVE(1); break;
-                    case 2: VS2_LAUNCH_WAVE(2); break;
-                    case 3: VS2_LAUNCH_WAVE(3); break;
-                    default: VS2_LAUNCH_WAVE(4); break;
+                    case 1: VS2_LAUNCH_WAVE(1, false); break;
+                    case 2: if (K == 16) VS2_LAUNCH_WAVE(2, true); else VS2_LAUNCH_WAVE(2, false); break;
+                    case 3: VS2_LAUNCH_WAVE(3, false); break;
+                    default: if (K == 32) VS2_LAUNCH_WAVE(4, true); else VS2_LAUNCH_WAVE(4, false); break;
                 }
 #undef VS2_LAUNCH_WAVE
 #undef VS2_LAUNCH_WAVE2
@@ -1132,6 +1408,13 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
         }
         VS_HIP(hipGetLastError());
     }
+    if (!st) {
+        vs_launch_scope scope(ctx, VS_KERNEL_SECOND_FOLD);
+        const size_t total = (size_t)K * K;
+        hipLaunchKernelGGL(gram_convert_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)),
+                           dim3(256), 0, ctx->stream, cd_dev, K, gram_dev, ctx->counters, 0);
+    }
+    VS_HIP(hipGetLastError());
     return VS_OK;
 }
 
@@ -1150,7 +1433,10 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     VS_REQUIRE(rows <= 0xfffffff0ull, "rows per GPU must stay below 2^32");
     VS_REQUIRE(rows == 0 || f_dev, "f_dev is null");
     const bool one_pass = l == 1 && !(flags & VS_REDUCE_NAN_TRIM) && rows >= 1 && ctx->tune.reduce_both != 0;
-    if (one_pass && 2 * k > VS2_SUPER && (uint64_t)k <= 4096)   // first-order sums ride on the macro kernel's diagonal pairs
+    // beyond 128 columns the first-order sums ride on the [C; D] macro kernel's diagonal pairs; 33 .. 128 columns take the
+    // first-order kernel and the S/T macro kernel one after the other (4.8 + 12 ms at k = 128, n = 2^24: less than the
+    // one-pass form of the [C; D] kernel took)
+    if (one_pass && (k > VS2_MACRO || (k > 48 && k <= 64) || (2 * k > VS2_SUPER && ctx->tune.gram_st == 0)) && (uint64_t)k <= 4096)
         return second_order_impl(ctx, f_dev, rows, k, 1, 0, gram_dev, true, rank, max_ranks, acc_dev);
     const bool combined = one_pass && 2 * k <= VS2_SUPER;
     if (!combined) {
@@ -1178,7 +1464,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     first_doubles = (first_doubles + 1) & ~(size_t)1;
     int rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + (size_t)P * VS2_TILE_OUT));
     if (rc) return rc;
-    VS_HIP(hipMemsetAsync(gram_dev, 0, sizeof(double) * 3 * (size_t)K * K, ctx->stream));
+    VS_HIP(hipMemsetAsync(gram_dev, 0, sizeof(double) * VS_GRAM_LEN(K), ctx->stream));
     vs_gram_args A;
     A.f = f_dev;
     A.rows = rows;
@@ -1195,27 +1481,30 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     if (wide) {
         const size_t lds_x = sizeof(double) * (size_t)(nb == 3 ? VS2_WIDE_LDS(3, true) : VS2_WIDE_LDS(4, true));
         vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
-        if (nb == 3) {
-            VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
-            hipLaunchKernelGGL((gram_diag_wide_kernel<3, true>), dim3(P), dim3(256), lds_x, ctx->stream, A);
-        } else {
-            VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
-            hipLaunchKernelGGL((gram_diag_wide_kernel<4, true>), dim3(P), dim3(256), lds_x, ctx->stream, A);
-        }
+#define VS2_LAUNCH_WIDE(NBV, FU)                                                                                                 \
+    do {                                                                                                                         \
+        VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<NBV, true, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)lds_x));                                                                                 \
+        hipLaunchKernelGGL((gram_diag_wide_kernel<NBV, true, FU>), dim3(P), dim3(256), lds_x, ctx->stream, A);                   \
+    } while (0)
+        if (nb == 3) VS2_LAUNCH_WIDE(3, false);
+        else if (K == 32) VS2_LAUNCH_WIDE(4, true);
+        else VS2_LAUNCH_WIDE(4, false);
+#undef VS2_LAUNCH_WIDE
     } else {
         vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
-#define VS2_LAUNCH_BOTH(NBV)                                                                                           \
-    do {                                                                                                               \
-        if (aligned) hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, false, true, true>), dim3(P), dim3(256), lds_w,    \
-                                        ctx->stream, A);                                                               \
-        else hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, false, false, true>), dim3(P), dim3(256), lds_w,           \
-                                ctx->stream, A);                                                                       \
+#define VS2_LAUNCH_BOTH(NBV, FU)                                                                                          \
+    do {                                                                                                                  \
+        if (aligned) hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, false, true, true, FU>), dim3(P), dim3(256), lds_w,   \
+                                        ctx->stream, A);                                                                  \
+        else hipLaunchKernelGGL((gram_diag_wave_kernel<NBV, false, false, true, FU>), dim3(P), dim3(256), lds_w,          \
+                                ctx->stream, A);                                                                          \
     } while (0)
         switch (nb) {
-            case 1: VS2_LAUNCH_BOTH(1); break;
-            case 2: VS2_LAUNCH_BOTH(2); break;
-            case 3: VS2_LAUNCH_BOTH(3); break;
-            default: VS2_LAUNCH_BOTH(4); break;
+            case 1: VS2_LAUNCH_BOTH(1, false); break;
+            case 2: if (K == 16) VS2_LAUNCH_BOTH(2, true); else VS2_LAUNCH_BOTH(2, false); break;
+            case 3: VS2_LAUNCH_BOTH(3, false); break;
+            default: if (K == 32) VS2_LAUNCH_BOTH(4, true); else VS2_LAUNCH_BOTH(4, false); break;
         }
 #undef VS2_LAUNCH_BOTH
     }
@@ -1235,6 +1524,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     F.nsuper = 1;
     F.npairs = 1;
     F.super = VS2_SUPER;
+    F.st = 1;
     F.gram = gram_dev;
     F.counters = ctx->counters;
     F.masked = 0;

@@ -609,10 +609,10 @@ class Varsens(object):
     def _result_buffers(self, nacc, K):
         """The accumulator record and (second order) the 3 K^2 Gram sums as two windows of ONE device
         buffer: a rank's whole contribution crosses the GPUs in a single all-reduce."""
-        total = nacc + (3 * K * K if self._second_order else 0)
+        total = nacc + (_native.gram_len(K) if self._second_order else 0)
         whole = self._ctx.alloc(8 * total)
         acc = _native.DeviceView(whole, 0, 8 * nacc)
-        gram = _native.DeviceView(whole, 8 * nacc, 8 * 3 * K * K) if self._second_order else None
+        gram = _native.DeviceView(whole, 8 * nacc, 8 * _native.gram_len(K)) if self._second_order else None
         return acc, gram, whole
 
     def _finish(self, acc, nacc, gram, slots, whole):
