@@ -265,9 +265,20 @@ def main():
         t_eval = avg["eval"] * 1e-3
         eval_gbs = 8.0 * N_local / t_eval / 1e9
         eval_pmc = pmc_kernel("void scan_kernel<3, 8, 4, false", k, args.log2n) or {}   # linear objective, evaluation
-        # issued MFMA work of the Gram kernels: 16x16 tiles on and above the diagonal of the 2K x 2K Gram matrix
-        nb = (2 * k * l + 15) // 16
-        mfma_flops = nb * (nb + 1) / 2 * (rows / 4.0) * (2 * 16 * 16 * 4)
+        # issued MFMA work of the second-order kernels: 16x16 tiles of S S^T and T T^T (S = C + D, T = C - D: two
+        # symmetric K x K products); up to 32 index rows per half both live in one 2K-row tile whose
+        # S x T tiles are skipped
+        K2 = k * l
+        if K2 <= 32:
+            nb = (2 * K2 + 15) // 16
+            tiles = sum(1 for bi in range(nb) for bj in range(bi, nb) if not (16 * (bi + 1) <= K2 and 16 * bj >= K2))
+        elif K2 <= 128 and not 48 < K2 <= 64:
+            nbl = (K2 + 15) // 16
+            tiles = nbl * (nbl + 1)
+        else:   # [C; D] Gram matrix, 128-row macro blocks
+            nbm = (2 * K2 + 127) // 128
+            tiles = nbm * 36 + nbm * (nbm - 1) // 2 * 64
+        mfma_flops = tiles * (rows / 4.0) * (2 * 16 * 16 * 4)
         so_ms = avg_so.get("second_order")
         line = {
             # BASELINE.json's metric string; every sample is one model evaluation, generated, evaluated and
@@ -318,18 +329,20 @@ def main():
                               "valu_busy_frac": eval_pmc.get("valu_busy_frac"),
                               "note": "store-only kernel of the same shape sustains 5.6 TB/s (tools/write_bw.hip)"},
             "roofline_second_order": None if not so_ms else {
-                "kernel": "gram_diag_wide_kernel (sens_2 / sens_2n Gram sums, v_mfma_f64_16x16x4_f64)",
-                "bound": "mfma", "achieved": mfma_flops / (so_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": mfma_flops / (so_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                "kernel": "gram_diag_wide_kernel (sens_2 / sens_2n from S S^T and T T^T, S = C + D, T = C - D; "
+                          "v_mfma_f64_16x16x4_f64)",
+                "bound": "hbm", "achieved": 16.0 * k * l * rows / (so_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": 16.0 * k * l * rows / (so_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("void gram_diag_wide_kernel", k, args.log2n)
                            or pmc_traffic("void gram_diag_wave_kernel", k, args.log2n),
-                "avg_launch_ms": so_ms, "mfma_flops_per_launch": mfma_flops,
-                "algorithmic_hbm_gbs": 16.0 * k * l * rows / (so_ms * 1e-3) / 1e9,
-                "measured_fp64_mfma_rate_tflops": 77.6,
-                "note": "issued MFMA flops (upper-triangle 16x16 tiles); peak = data-sheet fp64 matrix rate; a bare "
-                        "issue loop with VGPR accumulators sustains 77.6 TFLOP/s at 2.4 GHz (tools/mfma_f64_peak.hip), "
-                        "and this kernel, streaming HBM beside the matrix pipe, runs at 2.0-2.1 GHz (~66 TFLOP/s "
-                        "at that clock); HBM side: the same launch reads algorithmic_hbm_gbs"},
+                "algorithmic_bytes_per_launch": 16 * k * l * rows,
+                "avg_launch_ms": so_ms, "mfma_tiles_16x16": tiles, "mfma_flops_per_launch": mfma_flops,
+                "mfma_tflops": mfma_flops / (so_ms * 1e-3) / 1e12, "mfma_peak_tflops": FP64_MFMA_PEAK_TFLOPS,
+                "mfma_frac": mfma_flops / (so_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                "note": "every fN_j / fN_nj value read once (8 B each); the reference's four tensordots need only "
+                        "D C^T + C D^T and D D^T + C C^T, i.e. (S S^T -+ T T^T) / 2: 6 tiles of 16x16 per 4 sample rows at "
+                        "k = 32 instead of the 10 of the [C; D] Gram matrix, which was matrix-pipe-bound at 0.44 ms "
+                        "(49 TFLOP/s of 78.6); the S/T form is bound by the HBM stream"},
         }
         if world == 1 and not args.no_cpu_baseline:
             n_small = min(rows, 1 << 22)   # the whole pass at the default size: 2.2 GB over PCIe, ~2 s of numpy

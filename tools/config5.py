@@ -26,9 +26,10 @@ last = {}
 for name, ms in rec:
     last[name] = ms
 print({a: round(b, 3) for a, b in last.items()}, flush=True)
-print("eval %.1f G evals/s ; reduce %.0f GB/s (%.1f%% of 8 TB/s) ; second order %.0f GB/s algorithmic, %.1f TFLOP/s (upper-triangle MFMA)" %
+nbl = (k + 15) // 16   # S S^T and T T^T, upper block triangles: nbl (nbl + 1) tiles of 16 x 16 per 4 sample rows
+print("eval %.1f G evals/s ; reduce %.0f GB/s (%.1f%% of 8 TB/s) ; second order %.0f GB/s algorithmic, %.1f TFLOP/s (%d MFMA tiles of S S^T, T T^T)" %
       (N / last["eval"] / 1e6, 8 * N / last["reduce_first"] / 1e6, 100 * 8 * N / last["reduce_first"] / 1e6 / 8000,
-       16.0 * k * n / last["second_order"] / 1e6, 2.0 * (2 * k) * (2 * k + 16) / 2 * n / last["second_order"] / 1e9))
+       16.0 * k * n / last["second_order"] / 1e6, nbl * (nbl + 1) * (n / 4.0) * 2048 / last["second_order"] / 1e9, nbl * (nbl + 1)))
 fin = ctx.download(out, (2 + 4 * k, 1))
 V = beta ** 2 / 12.0
 total = np.prod(1.0 + V) - 1.0           # closed form for a product of independent factors

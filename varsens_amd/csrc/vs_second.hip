@@ -1,28 +1,33 @@
-// Second-order Gram sums of Varsens.compute_varsens (varsens/saltelli.py:612-622).
+// Second-order sums of Varsens.compute_varsens (varsens/saltelli.py:612-622).
 //
-// With C = fN_j and D = fN_nj viewed as (K, rows) matrices, K = k*l, row index
-// j*l + o, the reference needs D C^T (+ its transpose), D D^T and C C^T: four
-// numpy.tensordot calls contracting the row axis.  Stack X = [C; D] (2K index
-// rows): all three are blocks of the Gram matrix G = X X^T.  This is the one
-// GEMM-shaped piece of the path, so it runs on the fp64 matrix cores:
-// v_mfma_f64_16x16x4_f64, D(16x16) += A(16x4) B(4x16), where A and B are both
-// "16 index rows x 4 sample rows" fragments of X (one double per lane).
+// With C = fN_j and D = fN_nj viewed as (K, rows) matrices, K = k*l, row index j*l + o, the reference
+// forms D C^T, C D^T, D D^T and C C^T (four numpy.tensordot calls contracting the row axis) and then
+// uses only D C^T + C D^T (:612-613) and D D^T + C C^T (:618-619).  With S = C + D and T = C - D:
+//     D C^T + C D^T = (S S^T - T T^T) / 2,      D D^T + C C^T = (S S^T + T T^T) / 2,
+// two symmetric K x K products instead of the upper triangle of the 2K x 2K Gram matrix of [C; D]: half the
+// matrix work.  This is the one GEMM-shaped piece of the path, so it runs on the fp64 matrix cores:
+// v_mfma_f64_16x16x4_f64, D(16x16) += A(16x4) B(4x16), where A and B are both "16 index rows x 4 sample
+// rows" fragments (one double per lane).  s and t form in registers on the way into LDS.  The interface
+// returns SS = S S^T and TT = T T^T (include/varsens_hip.h); vs_finish_second_order takes half-sum and
+// half-difference.
 //
-// Kernels by the number of index rows 2K:
-//   2K <= 64: one 64-row block, wave-private kernels -- every wave keeps the NB(NB+1)/2 accumulator tiles
-//     (16x16 each) of the block and walks its own sample rows through a private LDS tile, no workgroup barrier
+// Kernels by the number of index rows K per half:
+//   K <= 32: one tile of 2K rows (s rows, then t rows), wave-private kernels -- every wave keeps the accumulator
+//     tiles, skips the S x T ones and walks its own sample rows through a private LDS tile, no workgroup barrier
 //     in the loop: gram_diag_wave_kernel (16-sample-row chunks; any shape) and gram_diag_wide_kernel
-//     (32-sample-row units; one output, even row count, more than 32 index rows);
-//   2K > 64: gram_macro_kernel -- 128-row macro blocks, a workgroup of eight waves per pair (MI <= MJ) of them.
-// One dense partial per workgroup and pair goes to HBM; gram_fold_kernel sums the partials
-// (compensated) and scatters them into DC, DD, CC.
-// Roofline at k=32, rows=2^22: HBM 16*K*rows bytes = 2.15 GB => 0.31 ms at 7 TB/s; matrix pipe: 10 tiles x
-// rows/4 MFMAs of 64 clocks per SIMD => 0.275 ms at 2.4 GHz (77.6 TFLOP/s: tools/mfma_f64_peak.hip, VGPR
-// accumulators; the "47-49 TFLOP/s" quoted in earlier rounds was the AGPR form), 0.32 ms at the 2.05 GHz the
-// kernel actually runs at.  fp64 MFMA and v_fma_f64 share the pipe (tools/mfma_valu_overlap.hip).  What HBM
-// delivers depends on the shape of the wave-wide loads (tools/load_patterns.hip): 8 x 128-byte runs per
-// instruction cap it at 4.9 TB/s, 4 x 256-byte runs reach 6.7 -- hence the 32-sample-row staging.
-// Reported separately from the first-order pass.
+//     (32-sample-row units; one output, even row count, K > 16);
+//   32 < K <= 128: gram_macro_st_kernel -- a workgroup of eight waves, one 256-row tile (128 s rows, 128 t rows),
+//     72 tiles of S S^T and T T^T, nine per wave (49..64 stay on the kernel below: measured);
+//   K > 128: gram_macro_kernel over [C; D] -- 128-row macro blocks, a workgroup per pair (MI <= MJ) of them;
+//     gram_convert_kernel turns its D C^T, D D^T, C C^T into SS, TT.
+// One dense partial per workgroup goes to HBM; gram_fold_kernel sums the partials (compensated) and scatters.
+// Roofline at k=32, rows=2^22: HBM 16*K*rows bytes = 2.15 GB => 0.31 ms at 7 TB/s; matrix pipe: 6 tiles x
+// rows/4 MFMAs of 64 clocks per SIMD => 0.19 ms at 2.05 GHz (the [C; D] form: 10 tiles, 0.32 ms -- it was
+// pipe-bound at 0.44 ms).  The pipe sustains 77.6 TFLOP/s at 2.4 GHz with VGPR accumulators
+// (tools/mfma_f64_peak.hip; the "47-49 TFLOP/s" quoted in earlier rounds was the AGPR form); fp64 MFMA and
+// v_fma_f64 share it (tools/mfma_valu_overlap.hip).  What HBM delivers depends on the shape of the wave-wide
+// loads (tools/load_patterns.hip): 8 x 128-byte runs per instruction cap it at 4.9 TB/s, 4 x 256-byte runs
+// reach 6.7 -- hence the 32-sample-row staging.  Reported separately from the first-order pass.
 #include "vs_common.h"
 
 #define VS2_SUPER 64                 // index rows per super-block (4 MFMA blocks of 16)

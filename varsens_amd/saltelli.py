@@ -607,7 +607,7 @@ class Varsens(object):
         self._finish(acc, nacc, gram, world, whole)
 
     def _result_buffers(self, nacc, K):
-        """The accumulator record and (second order) the 3 K^2 Gram sums as two windows of ONE device
+        """The accumulator record and (second order) the 2 K^2 sums S S^T, T T^T as two windows of ONE device
         buffer: a rank's whole contribution crosses the GPUs in a single all-reduce."""
         total = nacc + (_native.gram_len(K) if self._second_order else 0)
         whole = self._ctx.alloc(8 * total)
