@@ -121,31 +121,28 @@ __device__ __forceinline__ void gram_first_record(const vs_gram_args& A, double*
     }
 }
 
-// Diagonal super-block pairs, wave-private form (the default when the row count is even): no
-// workgroup barrier in the loop.  A wave owns 16-sample-row chunks (the four waves of a
-// workgroup take adjacent chunks: 512 contiguous bytes per index row between them), keeps ALL
-// NB(NB+1)/2 accumulator tiles of the super-block in registers and stages its chunk through a
-// private LDS tile [64 index rows][16 sample rows], pitch 20 doubles:
-//   global: lane L loads 16 B = sample rows 2(L&7), 2(L&7)+1 of index row 8j + (L>>3): one
+// Up to 32 index rows per half (2K <= 64 tile rows), wave-private form: no workgroup barrier in the loop.  A wave
+// owns 16-sample-row chunks (the four waves of a workgroup take adjacent chunks: 512 contiguous bytes per index
+// row between them), keeps the accumulator tiles of the [s rows; t rows] tile in registers and stages its chunk
+// through a private LDS tile [16 NB tile rows][16 sample rows], pitch 20 doubles:
+//   global: lane L loads 16 B = sample rows 2(L&7), 2(L&7)+1 of c_u and of d_u, u = 8j + (L>>3): one
 //           instruction = 8 index rows x 128 contiguous bytes, non-temporal;
-//   LDS:    ds_write_b128 of the same, then per 16-row block two ds_read_b128 fragments
-//           (index row = lane&15, sample rows 2q, 2q+1 and 8+2q, 8+2q+1, q = lane>>4) -- pitch 20
-//           is conflict-free for the b128 lane groups of gfx950 (MI355X_MICROARCH.md, LDS);
-//   MFMA:   4 k-steps x NB(NB+1)/2 tiles; A and B fragments come from the same lane->sample map,
-//           and a Gram sum does not care in which order the sample rows are contracted.
-// The next chunk's global loads are in flight while the MFMAs of the current one run; with 3
-// waves per SIMD the matrix pipe always has a wave with operands ready.
+//   LDS:    ds_write_b128 of s = c + d to tile row u and of t = c - d to tile row K + u, then per 16-row block two
+//           ds_read_b128 fragments (tile row = lane&15, sample rows 2q, 2q+1 and 8+2q, 8+2q+1, q = lane>>4) --
+//           pitch 20 is conflict-free for the b128 lane groups of gfx950 (MI355X_MICROARCH.md, LDS);
+//   MFMA:   4 k-steps x the needed tiles (S x T tiles are skipped); A and B fragments come from the same
+//           lane->sample map, and a sum over sample rows does not care in which order they are contracted.
+// The next chunk's global loads are in flight while the MFMAs of the current one run.
 #define VS2_WCHUNK 16
 #define VS2_WPITCH 20
 typedef double vs_d2 __attribute__((ext_vector_type(2)));
 
 //
-// FIRST (vs_reduce_first_second_order; l == 1, one super-block, no mask): the first-order sums of
-// reduce_first_kernel ride along.  a = fM_1 and b = fM_2 are loaded in the fragment layout (the
-// sample rows a lane's fragments hold), so each fragment element meets its a and b in two fmas:
-// index row m < k is c_m (-> ac, bc), m >= k is d_{m-k} (-> ad, bd).  Sixteen lanes hold the same
-// a, b; lane&15 == 0 of each group carries the scalar sums (sab, sa, sb, shifted variance sums).
-// 58 more VGPRs: two waves per SIMD, which still saturates the matrix pipe.
+// FIRST (vs_reduce_first_second_order; l == 1, no mask): the first-order sums of reduce_first_kernel ride
+// along.  a = fM_1 and b = fM_2 are loaded in the fragment layout (the sample rows a lane's fragments hold),
+// so each fragment element meets its a and b in two fmas: tile row u < K is s_u (-> a.s, b.s), row K + u is
+// t_u (-> a.t, b.t); gram_first_record turns them into a.c, b.c, a.d, b.d.  Sixteen lanes hold the same a, b;
+// lane&15 == 0 of each group carries the scalar sums (sab, sa, sb, shifted variance sums).
 // Waves per SIMD (= resident workgroups per CU) by the number of live 16-row blocks: with few index rows a wave
 // has little in flight (16 sample rows x 16 NB index rows), so the small shapes -- BASELINE configs[1], [2] have
 // 12 and 6 index rows -- run more waves: they are bound by bytes in flight, not by the matrix pipe.
@@ -374,21 +371,21 @@ gram_diag_wave_kernel(vs_gram_args A) {
     if (FIRST) gram_first_record<NB>(A, tiles, pa, pb, t_sab, t_sa, t_sb, t_s1, t_s2);
 }
 
-// Wide form of the wave-private kernel (one output, even row count, no NaN mask, 2k > 32 index rows): the
-// same accumulators and fragments, but a wave stages 32 sample rows at a time and every load instruction reads
-// 4 index rows x 256 contiguous bytes.  Measured on MI355X (tools/load_patterns.hip): a wave-wide 16-byte load
+// Wide form of the wave-private kernel (one output, even row count, no NaN mask, 17 .. 32 index rows per half): the
+// same tile of s and t rows, accumulators and fragments, but a wave stages 32 sample rows at a time and every
+// load instruction reads 4 index rows x 256 contiguous bytes.  Measured on MI355X (tools/load_patterns.hip): a wave-wide 16-byte load
 // that gathers 8 x 128 B runs from 8 planes sustains 4.9 TB/s however many are in flight; 4 x 256 B runs
-// sustain 6.7 TB/s, 1 x 1 KB 7.0 TB/s.  With one output the index row m is plane 2 + m of f, so the lane's
-// pointer advances by a wave-uniform stride from one load to the next (no pointer per load in registers).
-//   global: load j, lane L: 16 B = sample rows 2(L&15), 2(L&15)+1 of index row 4j + (L>>4);
+// sustain 6.7 TB/s, 1 x 1 KB 7.0 TB/s.  With one output c_u is plane 2 + u and d_u plane 2 + K + u of f, so the
+// lane's pointer advances by wave-uniform strides from one load to the next (no pointer per load in registers).
+//   global: pair j, lane L: 16 B = sample rows 2(L&15), 2(L&15)+1 of c_u and of d_u, u = 4j + (L>>4);
 //   LDS:    tile [16 NB index rows (+ a, b rows)][32 sample rows], pitch 34 doubles: the 16 lanes of an index
 //           row write 256 contiguous bytes, and the b128 fragment reads (index row = lane&15, stride 272 B)
 //           fall into eight distinct 4-bank groups per 8 lanes;
-//   MFMA:   four 8-sample-row quarters x 2 k-steps x NB(NB+1)/2 tiles per staged unit.
+//   MFMA:   four 8-sample-row quarters x 2 k-steps x the needed tiles per staged unit.
 // 64 VGPRs of loads in flight per wave (16 KiB), two waves per SIMD: 128 KiB in flight per CU.
 // FIRST: a = fM_1, b = fM_2 of the unit are one more load (planes 0, 1) into two more tile rows; every lane
-// group reads them back in the fragment layout and meets each fragment element in two fmas (a.c, b.c, a.d, b.d
-// of the record).  The five scalar sums of the record come from first_head_kernel, as on the macro route: they
+// group reads them back in the fragment layout and meets each fragment element in two fmas (a.s, b.s, a.t, b.t;
+// gram_first_record turns them into the record's a.c, b.c, a.d, b.d).  The five scalar sums of the record come from first_head_kernel, as on the macro route: they
 // would cost 12 more VGPRs here, and the kernel sits at 256.
 #define VS2_XCHUNK 32
 #define VS2_XPITCH 34
@@ -1438,9 +1435,9 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     VS_REQUIRE(rows <= 0xfffffff0ull, "rows per GPU must stay below 2^32");
     VS_REQUIRE(rows == 0 || f_dev, "f_dev is null");
     const bool one_pass = l == 1 && !(flags & VS_REDUCE_NAN_TRIM) && rows >= 1 && ctx->tune.reduce_both != 0;
-    // beyond 128 columns the first-order sums ride on the [C; D] macro kernel's diagonal pairs; 33 .. 128 columns take the
-    // first-order kernel and the S/T macro kernel one after the other (4.8 + 12 ms at k = 128, n = 2^24: less than the
-    // one-pass form of the [C; D] kernel took)
+    // where the [C; D] macro kernel runs (beyond 128 columns, 49 .. 64) the first-order dot products ride on its diagonal
+    // pairs; 33 .. 48 and 65 .. 128 columns take the first-order kernel and the S/T macro kernel one after the other (4.8 +
+    // 13.9 ms at k = 128, n = 2^24: the one-pass [C; D] form took 22.4; riding on the S/T kernel spills in its loop)
     if (one_pass && (k > VS2_MACRO || (k > 48 && k <= 64) || (2 * k > VS2_SUPER && ctx->tune.gram_st == 0)) && (uint64_t)k <= 4096)
         return second_order_impl(ctx, f_dev, rows, k, 1, 0, gram_dev, true, rank, max_ranks, acc_dev);
     const bool combined = one_pass && 2 * k <= VS2_SUPER;
