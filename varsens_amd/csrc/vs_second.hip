@@ -17,7 +17,8 @@
 //     in the loop: gram_diag_wave_kernel (16-sample-row chunks; any shape) and gram_diag_wide_kernel
 //     (32-sample-row units; one output, even row count, K > 16);
 //   32 < K <= 128: gram_macro_st_kernel -- a workgroup of eight waves, one 256-row tile (128 s rows, 128 t rows),
-//     72 tiles of S S^T and T T^T, nine per wave (49..64 stay on the kernel below: measured);
+//     72 tiles of S S^T and T T^T, nine per wave; up to 64 rows (one output, even row count): gram_half_st_kernel --
+//     the tile holds two chunks, five tiles per wave, and carries the first-order dot products;
 //   K > 128: gram_macro_kernel over [C; D] -- 128-row macro blocks, a workgroup per pair (MI <= MJ) of them;
 //     gram_convert_kernel turns its D C^T, D D^T, C C^T into SS, TT.
 // One dense partial per workgroup goes to HBM; gram_fold_kernel sums the partials (compensated) and scatters.
@@ -1005,6 +1006,230 @@ gram_macro_st_kernel(vs_gram_args A) {
     }
 }
 
+// 33 .. 64 index rows per half, one output, even row count: the S/T macro kernel with TWO chunks per tile.  With at
+// most four live 16-row blocks per half the 256-row tile of gram_macro_st_kernel is half zeros and half of its waves
+// hold one or two tiles per barrier; here the tile holds [s (64 rows); t (64 rows)] of chunk 2i in rows 0..127 and of
+// chunk 2i+1 in rows 128..255 -- exactly what one WIDE fetch brings (32 sample rows: the threads with sample rows
+// 0..15 write the first half of the tile, the others the second) -- and waves 0..3 / 4..7 each take one chunk:
+// wave r of a group owns block row r of S S^T (4 - r tiles) and block row 3 - r of T T^T (r + 1 tiles), five
+// accumulator tiles in w-independent slots as in gram_macro_st_kernel.  One barrier per 32 sample rows, 20 MFMAs per
+// wave between barriers.  Two partials per workgroup (one per wave group): [S S^T, T T^T][64][64].
+// FIRST (no mask): a = fM_1, b = fM_2 of the pair of chunks sit in the padding of tile rows 0..7 and 128..135; every
+// wave meets them with its two A fragments (a.s, b.s of block row r; a.t, b.t of block row 3 - r) and the record
+// takes a.c = (a.s + a.t) / 2, a.d = (a.s - a.t) / 2, likewise for b.  One record per wave group; the five scalar sums
+// come from first_head_kernel.  (The 40 accumulator VGPRs leave room for this; at nine tiles per wave they do not.)
+#define VS2_HALF 64
+#define VS2_HTILE_OUT (VS2_HALF * VS2_HALF)
+template <bool MASKED, bool FIRST>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+gram_half_st_kernel(vs_gram_args A) {
+    extern __shared__ double tiles[];  // [2 buffers][2 chunks][128][VS2_WPITCH]
+    if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
+    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) {
+        // this kernel opens the call: reset the counters the two folds use (cf. reduce_first_kernel)
+        uint32_t* c = const_cast<uint32_t*>(A.counters);
+        c[0] = 0;
+        c[1] = 0xffffffffu;
+        c[2] = 0;
+        c[3] = 0;
+        c[4] = 0;
+    }
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, r = wave & 3;   // chunk of the pair this wave works on; its block row of S S^T
+    const int tr = 3 - r;                      // its block row of T T^T
+    const int K = A.K;
+    const int nbl = (K + 15) / 16;             // live 16-row blocks per half (3 or 4)
+    const uint64_t rows = A.rows;
+    constexpr int BUF = 2 * VS2_MACRO * VS2_WPITCH;  // doubles per buffer
+
+    // staging: thread t holds sample rows 2(t&15), 2(t&15)+1 of the 32 of c_u and d_u, u = (t>>4) + 32j, j < 2
+    const int lrow = tid >> 4, piece = tid & 15;
+    const double* base = A.f + 2 * piece;
+    auto ptr = [&](int j, int lr) {   // j < 2: c rows, else d rows; rebuilt at every fetch (one output: plane 2 [+ K] + u)
+        const int u = lr + 32 * (j & 1);
+        return base + (uint64_t)(2 + (j >= 2 ? K : 0) + (u < K ? u : 0)) * rows;
+    };
+    double* wr = tiles + ((piece >> 3) * VS2_MACRO + lrow) * VS2_WPITCH + 2 * (piece & 7);   // + 32j rows: s; + 64: t
+    const double* rdS = tiles + (grp * VS2_MACRO + (lane & 15)) * VS2_WPITCH + 2 * (lane >> 4);   // + 16 blk rows
+    const double* rdT = rdS + VS2_HALF * VS2_WPITCH;
+
+    vs_d4 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
+
+    // a workgroup takes two consecutive pairs of chunks per visit (512 contiguous bytes per index row)
+    const uint64_t npairs = (rows + 2 * VS2_WCHUNK - 1) / (2 * VS2_WCHUNK);
+    const uint64_t ngroups = (npairs + 1) / 2;
+    uint64_t mine = 0;   // pairs this workgroup walks
+    for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) mine += (2 * g + 2 <= npairs) ? 2 : npairs - 2 * g;
+    auto pair_of = [&](uint64_t i) { return 2 * (blockIdx.x + (i / 2) * gridDim.x) + (i & 1); };
+    vs_d2 raw[4];
+    bool k0 = true, k1 = true;
+    const bool abth = FIRST && tid < 32;   // threads 0..15 stage a (plane 0), 16..31 b (plane 1) of the pair
+    const double* abp = A.f + (tid >= 16 ? rows : 0) + 2 * (tid & 15);
+    vs_d2 rawab = (vs_d2){0.0, 0.0};
+    double pas = 0.0, pbs = 0.0, pat = 0.0, pbt = 0.0;
+    auto fetch = [&](uint64_t pr) {
+        const uint64_t s0 = pr * 2 * VS2_WCHUNK;
+        const bool whole = s0 + 2 * VS2_WCHUNK <= rows;
+        const uint64_t sm = s0 + 2 * piece;
+        int lr = lrow;
+        asm volatile("" : "+v"(lr));   // not loop-invariant as far as the compiler can tell
+        if (FIRST && abth) {
+            if (whole) {
+                rawab = __builtin_nontemporal_load((const vs_d2*)(abp + s0));
+            } else {
+                rawab.x = sm < rows ? abp[s0] : 0.0;
+                rawab.y = sm + 1 < rows ? abp[s0 + 1] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = lr + 32 * (j & 1) < K;   // rows past K are zeros in the tile: nothing to load
+            const double* q = ptr(j, lr) + s0;
+            if (whole) {
+                if (in) raw[j] = __builtin_nontemporal_load((const vs_d2*)q);
+            } else {
+                raw[j].x = (in && sm < rows) ? q[0] : 0.0;
+                raw[j].y = (in && sm + 1 < rows) ? q[1] : 0.0;
+            }
+        }
+        if (MASKED) {
+            k0 = sm < rows && A.keep[sm];
+            k1 = sm + 1 < rows && A.keep[sm + 1];
+        }
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            vs_d2 c = raw[j], d = raw[2 + j];
+            if (MASKED) {
+                c.x = k0 ? c.x : 0.0;
+                c.y = k1 ? c.y : 0.0;
+                d.x = k0 ? d.x : 0.0;
+                d.y = k1 ? d.y : 0.0;
+            }
+            if (lrow + 32 * j >= K) c = d = (vs_d2){0.0, 0.0};
+            *(vs_d2*)(wr + b * BUF + 32 * j * VS2_WPITCH) = c + d;
+            *(vs_d2*)(wr + b * BUF + (VS2_HALF + 32 * j) * VS2_WPITCH) = c - d;
+        }
+        // sample pair p of a chunk goes into the padding of that chunk's tile row p: a at [16,17], b at [18,19]
+        if (FIRST && abth)
+            *(vs_d2*)(tiles + b * BUF + (((tid & 15) >> 3) * VS2_MACRO + (tid & 7)) * VS2_WPITCH + 16 + 2 * (tid >> 4)) = rawab;
+    };
+
+    if (mine > 0) {
+        fetch(pair_of(0));
+        stash(0);
+        if (mine > 1) fetch(pair_of(1));
+    }
+    __syncthreads();
+    for (uint64_t i = 0; i < mine; ++i) {
+        const int b = (int)(i & 1);
+        // the next pair goes into the other buffer (everybody left it at the last barrier) ...
+        if (i + 1 < mine) stash(b ^ 1);
+        if (i + 2 < mine) fetch(pair_of(i + 2));
+        // ... while this one feeds the matrix pipe
+        vs_d2 fa[2];
+        fa[0] = *(const vs_d2*)(rdS + b * BUF + 16 * r * VS2_WPITCH);
+        fa[1] = *(const vs_d2*)(rdS + b * BUF + 16 * r * VS2_WPITCH + 8);
+        // FIRST: a, a, b, b of the sample rows 2q, 2q+1 (h = 0) and 8+2q, 8+2q+1 (h = 1) of the lane group q
+        const double* rdAB = tiles + b * BUF + (grp * VS2_MACRO + (lane >> 4)) * VS2_WPITCH + 16;
+        if (FIRST) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const vs_d4 ab = *(const vs_d4*)(rdAB + 4 * h * VS2_WPITCH);
+                pas = fma(ab[0], fa[h][0], pas);
+                pbs = fma(ab[2], fa[h][0], pbs);
+                pas = fma(ab[1], fa[h][1], pas);
+                pbs = fma(ab[3], fa[h][1], pbs);
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl) {
+            const bool ss = sl < 4 - r;                 // wave-uniform
+            if (sl == 4 - r) {                          // from here on: row block 3 - r of T T^T
+                fa[0] = *(const vs_d2*)(rdT + b * BUF + 16 * tr * VS2_WPITCH);
+                fa[1] = *(const vs_d2*)(rdT + b * BUF + 16 * tr * VS2_WPITCH + 8);
+                if (FIRST) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const vs_d4 ab = *(const vs_d4*)(rdAB + 4 * h * VS2_WPITCH);
+                        pat = fma(ab[0], fa[h][0], pat);
+                        pbt = fma(ab[2], fa[h][0], pbt);
+                        pat = fma(ab[1], fa[h][1], pat);
+                        pbt = fma(ab[3], fa[h][1], pbt);
+                    }
+                }
+            }
+            const int blk = ss ? r + sl : sl - 1;       // block of the other operand
+            const bool live = (ss ? r : tr) < nbl && blk < nbl;
+            if (live) {
+                const double* rb = (ss ? rdS : rdT) + b * BUF + 16 * blk * VS2_WPITCH;
+                const vs_d2 f0 = *(const vs_d2*)rb;
+                const vs_d2 f1 = *(const vs_d2*)(rb + 8);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0][0], f0[0], acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0][1], f0[1], acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1][0], f1[0], acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1][1], f1[1], acc[sl], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (FIRST) {
+        // the four lane groups of a wave hold the same index rows over different samples
+        pas += __shfl_xor(pas, 16, 64);
+        pas += __shfl_xor(pas, 32, 64);
+        pbs += __shfl_xor(pbs, 16, 64);
+        pbs += __shfl_xor(pbs, 32, 64);
+        pat += __shfl_xor(pat, 16, 64);
+        pat += __shfl_xor(pat, 32, 64);
+        pbt += __shfl_xor(pbt, 16, 64);
+        pbt += __shfl_xor(pbt, 32, 64);
+        double* red = tiles + grp * 2 * VS2_MACRO;   // the tiles are free: [wave group][s rows 0..63, t rows 64..127][2]
+        if (lane < 16) {
+            red[(16 * r + lane) * 2 + 0] = pas;
+            red[(16 * r + lane) * 2 + 1] = pbs;
+            red[(VS2_HALF + 16 * tr + lane) * 2 + 0] = pat;
+            red[(VS2_HALF + 16 * tr + lane) * 2 + 1] = pbt;
+        }
+        __syncthreads();
+        const int k = A.k;
+        const size_t plen = VS_PLEN(k);
+        double* rec = A.first_partials + ((size_t)blockIdx.x * 2 + grp) * plen;   // one record per wave group
+        for (size_t e = tid & 255; e < plen; e += 256) {
+            double v = 0.0;
+            if (e >= VS_P_HEAD) {   // the five scalar sums come from first_head_kernel's records
+                // record layout: head, ac[k], bd[k], ad[k], bc[k]
+                const int slot = (int)((e - VS_P_HEAD) / k), j = (int)((e - VS_P_HEAD) % k);
+                const int which = (slot == 0 || slot == 2) ? 0 : 1;
+                const double xs = red[j * 2 + which], xt = red[(VS2_HALF + j) * 2 + which];
+                v = (slot == 0 || slot == 3) ? 0.5 * (xs + xt) : 0.5 * (xs - xt);
+            }
+            rec[e] = v;
+        }
+    }
+    // a tile belongs to one wave: straight to the wave group's partial (all-zero and mirror tiles stay unwritten;
+    // the fold never reads them)
+    double* out = A.partials + ((size_t)blockIdx.x * 2 + grp) * 2 * VS2_HTILE_OUT;
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl) {
+        const bool ss = sl < 4 - r;
+        const int blk = ss ? r + sl : sl - 1;
+        const int rowblk = ss ? r : tr;
+        if (rowblk < nbl && blk < nbl) {
+            double* o = out + (ss ? 0 : VS2_HTILE_OUT);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = (lane >> 4) + 4 * v, col = lane & 15;   // f64 C/D layout
+                o[(rowblk * 16 + row) * VS2_HALF + (blk * 16 + col)] = acc[sl][v];
+            }
+        }
+    }
+}
+
 // The five scalar sums of the first-order record (sab, sa, sb, shifted s1, s2: varsens/saltelli.py:577,583) for
 // the one-pass route beyond 32 columns: a = fM_1, b = fM_2 only.  One full record per workgroup (zeros in the
 // dot-product part), appended to the macro kernel's records.
@@ -1225,11 +1450,15 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     // 128 x 128 partials: "2 pairs" below, one grid row); beyond: the [C; D] macro kernel over pairs of 128-row blocks
     // (49 .. 64 rows per half stay on the [C; D] kernel, measured: four live 16-row blocks leave half of the S/T
     // kernel's waves one or two tiles per barrier -- 1.49 vs 1.62-1.67 ms at n = 2^22)
-    const bool macro_st = macro && K <= VS2_MACRO && !(K > 48 && K <= 64) && !with_first && ctx->tune.gram_st != 0;
-    const int SB = macro ? VS2_MACRO : VS2_SUPER;
-    const int nsuper = macro_st ? 1 : (2 * K + SB - 1) / SB;
-    const int npairs = macro_st ? 2 : nsuper * (nsuper + 1) / 2;
-    const int grid_rows = macro_st ? 1 : npairs;
+    // 33 .. 64 rows per half, one output, even row count: two chunks per tile (gram_half_st_kernel; also carries the
+    // first-order dot products); other shapes of that range: 33 .. 48 the S/T kernel above, 49 .. 64 the [C; D] kernel
+    const bool half_st = macro && K <= VS2_HALF && l == 1 && rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0 &&
+                         ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
+    const bool macro_st = macro && !half_st && K <= VS2_MACRO && !(K > 48 && K <= 64) && !with_first && ctx->tune.gram_st != 0;
+    const int SB = half_st ? VS2_HALF : macro ? VS2_MACRO : VS2_SUPER;
+    const int nsuper = (macro_st || half_st) ? 1 : (2 * K + SB - 1) / SB;
+    const int npairs = (macro_st || half_st) ? 2 : nsuper * (nsuper + 1) / 2;
+    const int grid_rows = (macro_st || half_st) ? 1 : npairs;
     uint64_t nchunks = (rows + VS2_WCHUNK - 1) / VS2_WCHUNK;
     if (nchunks < 1) nchunks = 1;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
@@ -1239,7 +1468,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     // 80 KiB each), 6 are launched -- the diagonal pairs finish early and the dispatcher evens it out (measured)
     const int nb_wave = (2 * K + 15) / 16;   // live 16-row blocks of the wave-private kernel (2K <= 64)
     const int per_cu = ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu
-                       : (macro_st ? 2 : macro ? 6 : (nb_wave <= 4 ? VS2_WAVES_PER_SIMD(nb_wave, false) : 3));
+                       : ((macro_st || half_st) ? 2 : macro ? 6 : (nb_wave <= 4 ? VS2_WAVES_PER_SIMD(nb_wave, false) : 3));
     // grid = want x npairs workgroups: never more than are resident at once (a single workgroup left over
     // would run a whole extra round on an empty chip)
     uint64_t want = macro ? ((uint64_t)cus * per_cu) / grid_rows : ((uint64_t)cus * per_cu + npairs - 1) / npairs;
@@ -1256,12 +1485,13 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const size_t width = (size_t)npairs * tile_out;
     // workspace: [with_first: first-order records of the diagonal workgroups + folded record,] then the Gram partials
     const size_t plen = VS_PLEN(k);
-    const uint32_t P_diag = with_first ? slab_wgs * (uint32_t)nsuper : 0;                       // macro kernel's records
+    const uint32_t pslots = half_st ? 2 * slab_wgs : slab_wgs;   // partials (and first-order records) per pair
+    const uint32_t P_diag = with_first ? pslots * (uint32_t)nsuper : 0;                         // macro kernels' records
     const uint32_t P_head = with_first ? (uint32_t)((rows + 4095) / 4096 < (uint64_t)cus ? (rows + 4095) / 4096 : cus) : 0;
     const uint32_t P_first = P_diag + P_head;                                                   // + first_head_kernel's
     size_t first_doubles = with_first ? (size_t)P_first * plen + plen : 0;
     first_doubles = (first_doubles + 1) & ~(size_t)1;
-    const uint32_t max_wgs = wide && wide_wgs > slab_wgs ? wide_wgs : slab_wgs;
+    const uint32_t max_wgs = wide && wide_wgs > pslots ? wide_wgs : pslots;
     // ... and DC, DD, CC (3 K^2) behind them, for gram_convert_kernel
     const size_t cd_doubles = 3 * (size_t)K * K;
     int rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + (size_t)max_wgs * width + cd_doubles));
@@ -1290,8 +1520,8 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     F.nsuper = nsuper;
     F.npairs = npairs;
     F.super = SB;
-    const bool st = !macro || macro_st;   // the kernels accumulate [S; T] sums (else [C; D] sums, converted at the end)
-    F.st = macro_st ? 2 : st ? 1 : 0;
+    const bool st = !macro || macro_st || half_st;   // the kernels accumulate [S; T] sums (else [C; D] sums, converted at the end)
+    F.st = (macro_st || half_st) ? 2 : st ? 1 : 0;
     F.gram = st ? gram_dev : cd_dev;
     if (st) VS_HIP(hipMemsetAsync(gram_dev, 0, sizeof(double) * VS_GRAM_LEN(K), ctx->stream));
     F.counters = ctx->counters;
@@ -1303,7 +1533,11 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     X(false, false, false, false) X(false, true, false, false) X(true, false, false, false) X(true, true, false, false) \
     X(false, false, true, false) X(false, true, true, false) X(false, true, false, true) X(true, true, false, true) \
     X(false, true, true, true)
-    if (macro_st) {
+    if (half_st) {
+        VS_HIP(hipFuncSetAttribute((const void*)gram_half_st_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_half_st_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        VS_HIP(hipFuncSetAttribute((const void*)gram_half_st_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+    } else if (macro_st) {
         VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
         VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
         VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
@@ -1337,7 +1571,13 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
         }
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
-            if (macro_st) {
+            if (half_st) {
+                A.slab_wgs = slab_wgs;
+                F.P = pslots;
+                if (masked) hipLaunchKernelGGL((gram_half_st_kernel<true, false>), dim3(slab_wgs), dim3(512), lds_m, ctx->stream, A);
+                else if (with_first) hipLaunchKernelGGL((gram_half_st_kernel<false, true>), dim3(slab_wgs), dim3(512), lds_m, ctx->stream, A);
+                else hipLaunchKernelGGL((gram_half_st_kernel<false, false>), dim3(slab_wgs), dim3(512), lds_m, ctx->stream, A);
+            } else if (macro_st) {
                 const dim3 grid(slab_wgs, 1);
                 if (masked && mwide) hipLaunchKernelGGL((gram_macro_st_kernel<true, true, true>), grid, dim3(512), lds_m, ctx->stream, A);
                 else if (masked && aligned) hipLaunchKernelGGL((gram_macro_st_kernel<true, true, false>), grid, dim3(512), lds_m, ctx->stream, A);
@@ -1435,10 +1675,14 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     VS_REQUIRE(rows <= 0xfffffff0ull, "rows per GPU must stay below 2^32");
     VS_REQUIRE(rows == 0 || f_dev, "f_dev is null");
     const bool one_pass = l == 1 && !(flags & VS_REDUCE_NAN_TRIM) && rows >= 1 && ctx->tune.reduce_both != 0;
-    // where the [C; D] macro kernel runs (beyond 128 columns, 49 .. 64) the first-order dot products ride on its diagonal
-    // pairs; 33 .. 48 and 65 .. 128 columns take the first-order kernel and the S/T macro kernel one after the other (4.8 +
-    // 13.9 ms at k = 128, n = 2^24: the one-pass [C; D] form took 22.4; riding on the S/T kernel spills in its loop)
-    if (one_pass && (k > VS2_MACRO || (k > 48 && k <= 64) || (2 * k > VS2_SUPER && ctx->tune.gram_st == 0)) && (uint64_t)k <= 4096)
+    // the first-order dot products ride on gram_half_st_kernel (33 .. 64 columns, even row count) and, where the [C; D]
+    // macro kernel runs (beyond 128 columns; 49 .. 64 with an odd row count), on its diagonal pairs; the other shapes
+    // up to 128 columns take the first-order kernel and the S/T macro kernel one after the other (4.8 + 13.9 ms at
+    // k = 128, n = 2^24: the one-pass [C; D] form took 22.4; riding on the nine-tile S/T kernel spills in its loop)
+    const bool even = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
+    const bool half_route = 2 * k > VS2_SUPER && k <= VS2_HALF && even && ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
+    if (one_pass && (k > VS2_MACRO || half_route || (k > 48 && k <= 64) || (2 * k > VS2_SUPER && ctx->tune.gram_st == 0)) &&
+        (uint64_t)k <= 4096)
         return second_order_impl(ctx, f_dev, rows, k, 1, 0, gram_dev, true, rank, max_ranks, acc_dev);
     const bool combined = one_pass && 2 * k <= VS2_SUPER;
     if (!combined) {
