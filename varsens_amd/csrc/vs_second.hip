@@ -1418,9 +1418,7 @@ finish_second_kernel(const double* __restrict__ gram, const double* __restrict__
 // Kernels that accumulate the Gram matrix of X = [C; D] (more than 128 index rows per half: see second_order_impl)
 // leave DC = D C^T, DD, CC in the workspace; this turns them into the interface's SS and TT.
 __global__ void __launch_bounds__(256)
-gram_convert_kernel(const double* __restrict__ cd, int K, double* __restrict__ gram, const uint32_t* __restrict__ counters,
-                    int masked) {
-    if (masked && counters[CNT_NANFLAG] == 0) return;
+gram_convert_kernel(const double* __restrict__ cd, int K, double* __restrict__ gram) {
     const double* DC = cd;
     const double* DD = DC + (size_t)K * K;
     const double* CC = DD + (size_t)K * K;
@@ -1432,6 +1430,41 @@ gram_convert_kernel(const double* __restrict__ cd, int K, double* __restrict__ g
         gram[e] = same + cross;
         gram[total + e] = same - cross;
     }
+}
+
+// (MASKED, ALIGNED, FIRST, WIDE) instances of the [C; D] macro kernel the launches can pick
+#define VS2_MACRO_INSTANCES(X) \
+    X(false, false, false, false) X(false, true, false, false) X(true, false, false, false) X(true, true, false, false) \
+    X(false, false, true, false) X(false, true, true, false) X(false, true, false, true) X(true, true, false, true) \
+    X(false, true, true, true)
+// (MASKED, ALIGNED, WIDE) instances of the S/T macro kernel
+#define VS2_ST_INSTANCES(X) \
+    X(false, false, false) X(false, true, false) X(false, true, true) X(true, false, false) X(true, true, false) X(true, true, true)
+// (NB, FIRST, FULL) instances of the wide wave-private kernel
+#define VS2_WIDE_INSTANCES(X) X(3, false, false) X(4, false, false) X(4, false, true) X(3, true, false) X(4, true, false) X(4, true, true)
+
+// Kernels that ask for more than 64 KiB of dynamic LDS need the limit raised; once per context (= per device).
+static int gram_raise_lds_limits(vs_context* ctx) {
+    if (ctx->gram_lds_raised) return VS_OK;
+    const int lds_m = (int)(sizeof(double) * 2 * 2 * VS2_MACRO * VS2_WPITCH);   // macro kernels: two buffers of 256 tile rows
+#define VS2_SET(...) VS_HIP(hipFuncSetAttribute((const void*)__VA_ARGS__, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
+#define VS2_SET_MACRO(MK, AL, FI, WI) VS2_SET(gram_macro_kernel<MK, AL, FI, WI>)
+#define VS2_SET_ST(MK, AL, WI) VS2_SET(gram_macro_st_kernel<MK, AL, WI>)
+    VS2_MACRO_INSTANCES(VS2_SET_MACRO)
+    VS2_ST_INSTANCES(VS2_SET_ST)
+    VS2_SET(gram_half_st_kernel<false, false>)
+    VS2_SET(gram_half_st_kernel<true, false>)
+    VS2_SET(gram_half_st_kernel<false, true>)
+#undef VS2_SET_ST
+#undef VS2_SET_MACRO
+#undef VS2_SET
+#define VS2_SET_WIDE(NBV, FI, FU)                                                                                      \
+    VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<NBV, FI, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)(sizeof(double) * VS2_WIDE_LDS(NBV, FI))));
+    VS2_WIDE_INSTANCES(VS2_SET_WIDE)
+#undef VS2_SET_WIDE
+    ctx->gram_lds_raised = true;
+    return VS_OK;
 }
 
 // with_first (macro kernel, one output, no NaN trimming): also this rank's first-order record into acc_dev
@@ -1528,28 +1561,8 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const size_t lds_w = sizeof(double) * (nb_wave <= 4 ? (size_t)VS2_WAVE_LDS(nb_wave, false) : 0);   // wave-private tiles
     const size_t lds_m = sizeof(double) * 2 * 2 * VS2_MACRO * VS2_WPITCH;   // macro: two buffers of 256 rows
     const bool mwide = macro && l == 1 && aligned && ctx->tune.gram_wide != 0;   // two chunks per fetch, 256-byte runs
-    // (MASKED, ALIGNED, FIRST, WIDE) instances the launch below can pick
-#define VS2_MACRO_INSTANCES(X) \
-    X(false, false, false, false) X(false, true, false, false) X(true, false, false, false) X(true, true, false, false) \
-    X(false, false, true, false) X(false, true, true, false) X(false, true, false, true) X(true, true, false, true) \
-    X(false, true, true, true)
-    if (half_st) {
-        VS_HIP(hipFuncSetAttribute((const void*)gram_half_st_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_half_st_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_half_st_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-    } else if (macro_st) {
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_st_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-    } else if (macro) {
-#define VS2_SET_LDS(MK, AL, FI, WI) \
-        VS_HIP(hipFuncSetAttribute((const void*)gram_macro_kernel<MK, AL, FI, WI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-        VS2_MACRO_INSTANCES(VS2_SET_LDS)
-#undef VS2_SET_LDS
-    }
+    rc = gram_raise_lds_limits(ctx);
+    if (rc) return rc;
     if ((flags & VS_REDUCE_NAN_TRIM) && rows > 0) {
         const uint64_t count = 2 * rows;  // blocks 0 and 1 of output 0 are contiguous
         const uint64_t want_blocks = (count + 255) / 256;
@@ -1599,12 +1612,8 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
             } else if (wide && !masked) {
                 const size_t lds_x = sizeof(double) * (size_t)(nb_wave == 3 ? VS2_WIDE_LDS(3, false) : VS2_WIDE_LDS(4, false));
                 A.slab_wgs = F.P = wide_wgs;
-#define VS2_LAUNCH_WIDE(NBV, FU)                                                                                                  \
-    do {                                                                                                                          \
-        VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<NBV, false, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                   (int)lds_x));                                                                                  \
-        hipLaunchKernelGGL((gram_diag_wide_kernel<NBV, false, FU>), dim3(wide_wgs), dim3(256), lds_x, ctx->stream, A);           \
-    } while (0)
+#define VS2_LAUNCH_WIDE(NBV, FU) \
+    hipLaunchKernelGGL((gram_diag_wide_kernel<NBV, false, FU>), dim3(wide_wgs), dim3(256), lds_x, ctx->stream, A)
                 if (nb_wave == 3) VS2_LAUNCH_WIDE(3, false);
                 else if (K == 32) VS2_LAUNCH_WIDE(4, true);
                 else VS2_LAUNCH_WIDE(4, false);
@@ -1654,7 +1663,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
         vs_launch_scope scope(ctx, VS_KERNEL_SECOND_FOLD);
         const size_t total = (size_t)K * K;
         hipLaunchKernelGGL(gram_convert_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)),
-                           dim3(256), 0, ctx->stream, cd_dev, K, gram_dev, ctx->counters, 0);
+                           dim3(256), 0, ctx->stream, cd_dev, K, gram_dev);
     }
     VS_HIP(hipGetLastError());
     return VS_OK;
@@ -1710,6 +1719,8 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     first_doubles = (first_doubles + 1) & ~(size_t)1;
     int rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + (size_t)P * VS2_TILE_OUT));
     if (rc) return rc;
+    rc = gram_raise_lds_limits(ctx);
+    if (rc) return rc;
     VS_HIP(hipMemsetAsync(gram_dev, 0, sizeof(double) * VS_GRAM_LEN(K), ctx->stream));
     vs_gram_args A;
     A.f = f_dev;
@@ -1727,12 +1738,8 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     if (wide) {
         const size_t lds_x = sizeof(double) * (size_t)(nb == 3 ? VS2_WIDE_LDS(3, true) : VS2_WIDE_LDS(4, true));
         vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
-#define VS2_LAUNCH_WIDE(NBV, FU)                                                                                                 \
-    do {                                                                                                                         \
-        VS_HIP(hipFuncSetAttribute((const void*)gram_diag_wide_kernel<NBV, true, FU>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                   (int)lds_x));                                                                                 \
-        hipLaunchKernelGGL((gram_diag_wide_kernel<NBV, true, FU>), dim3(P), dim3(256), lds_x, ctx->stream, A);                   \
-    } while (0)
+#define VS2_LAUNCH_WIDE(NBV, FU) \
+    hipLaunchKernelGGL((gram_diag_wide_kernel<NBV, true, FU>), dim3(P), dim3(256), lds_x, ctx->stream, A)
         if (nb == 3) VS2_LAUNCH_WIDE(3, false);
         else if (K == 32) VS2_LAUNCH_WIDE(4, true);
         else VS2_LAUNCH_WIDE(4, false);
