@@ -376,7 +376,9 @@ def test_rccl_single_rank_allreduce(ctx):
                                       (64, 4099, 1), (65, 130, 1), (128, 2050, 1), (200, 97, 1), (50, 1000, 3), (129, 15, 1),
                                       # 32-sample-row staging (one output, even row count): ragged ends of every kind
                                       (17, 34, 1), (31, 30, 1), (28, 2, 1), (33, 46, 1), (64, 48, 1), (96, 62, 1),
-                                      (100, 4128, 1), (32, 65598, 1)])
+                                      (100, 4128, 1), (32, 65598, 1),
+                                      # several outputs on the two-chunk S/T kernel (33..64 index rows per half, even rows)
+                                      (20, 1000, 3), (11, 4096, 4), (16, 62, 4), (13, 3000, 3)])
 def test_second_order_gram(ctx, k, rows, l):
     rng = np.random.RandomState(k * 7 + rows + l)
     blocks = 1.0 + rng.randn(2 * k + 2, rows, l)

@@ -1006,7 +1006,7 @@ gram_macro_st_kernel(vs_gram_args A) {
     }
 }
 
-// 33 .. 64 index rows per half, one output, even row count: the S/T macro kernel with TWO chunks per tile.  With at
+// 33 .. 64 index rows per half, even row count: the S/T macro kernel with TWO chunks per tile.  With at
 // most four live 16-row blocks per half the 256-row tile of gram_macro_st_kernel is half zeros and half of its waves
 // hold one or two tiles per barrier; here the tile holds [s (64 rows); t (64 rows)] of chunk 2i in rows 0..127 and of
 // chunk 2i+1 in rows 128..255 -- exactly what one WIDE fetch brings (32 sample rows: the threads with sample rows
@@ -1020,9 +1020,11 @@ gram_macro_st_kernel(vs_gram_args A) {
 // come from first_head_kernel.  (The 40 accumulator VGPRs leave room for this; at nine tiles per wave they do not.)
 #define VS2_HALF 64
 #define VS2_HTILE_OUT (VS2_HALF * VS2_HALF)
-template <bool MASKED, bool FIRST>
+// ONE: one output -- c_u is plane 2 + u, d_u plane 2 + K + u, rebuilt at every fetch; several outputs keep a pointer per load.
+template <bool MASKED, bool FIRST, bool ONE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 gram_half_st_kernel(vs_gram_args A) {
+    static_assert(ONE || !FIRST, "the first-order sums ride along for one output only");
     extern __shared__ double tiles[];  // [2 buffers][2 chunks][128][VS2_WPITCH]
     if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
     if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1047,9 +1049,17 @@ gram_half_st_kernel(vs_gram_args A) {
     // staging: thread t holds sample rows 2(t&15), 2(t&15)+1 of the 32 of c_u and d_u, u = (t>>4) + 32j, j < 2
     const int lrow = tid >> 4, piece = tid & 15;
     const double* base = A.f + 2 * piece;
-    auto ptr = [&](int j, int lr) {   // j < 2: c rows, else d rows; rebuilt at every fetch (one output: plane 2 [+ K] + u)
+    const double* rp[ONE ? 1 : 4];
+    if (!ONE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = lrow + 32 * (j & 1);
+            rp[j] = x_elem(A, (j >= 2 ? K : 0) + (u < K ? u : 0), 0) + 2 * piece;
+        }
+    }
+    auto ptr = [&](int j, int lr) {   // j < 2: c rows, else d rows
         const int u = lr + 32 * (j & 1);
-        return base + (uint64_t)(2 + (j >= 2 ? K : 0) + (u < K ? u : 0)) * rows;
+        return ONE ? base + (uint64_t)(2 + (j >= 2 ? K : 0) + (u < K ? u : 0)) * rows : rp[ONE ? 0 : j];
     };
     double* wr = tiles + ((piece >> 3) * VS2_MACRO + lrow) * VS2_WPITCH + 2 * (piece & 7);   // + 32j rows: s; + 64: t
     const double* rdS = tiles + (grp * VS2_MACRO + (lane & 15)) * VS2_WPITCH + 2 * (lane >> 4);   // + 16 blk rows
@@ -1076,7 +1086,7 @@ gram_half_st_kernel(vs_gram_args A) {
         const bool whole = s0 + 2 * VS2_WCHUNK <= rows;
         const uint64_t sm = s0 + 2 * piece;
         int lr = lrow;
-        asm volatile("" : "+v"(lr));   // not loop-invariant as far as the compiler can tell
+        if (ONE) asm volatile("" : "+v"(lr));   // not loop-invariant as far as the compiler can tell
         if (FIRST && abth) {
             if (whole) {
                 rawab = __builtin_nontemporal_load((const vs_d2*)(abp + s0));
@@ -1452,9 +1462,11 @@ static int gram_raise_lds_limits(vs_context* ctx) {
 #define VS2_SET_ST(MK, AL, WI) VS2_SET(gram_macro_st_kernel<MK, AL, WI>)
     VS2_MACRO_INSTANCES(VS2_SET_MACRO)
     VS2_ST_INSTANCES(VS2_SET_ST)
-    VS2_SET(gram_half_st_kernel<false, false>)
-    VS2_SET(gram_half_st_kernel<true, false>)
-    VS2_SET(gram_half_st_kernel<false, true>)
+    VS2_SET(gram_half_st_kernel<false, false, true>)
+    VS2_SET(gram_half_st_kernel<true, false, true>)
+    VS2_SET(gram_half_st_kernel<false, true, true>)
+    VS2_SET(gram_half_st_kernel<false, false, false>)
+    VS2_SET(gram_half_st_kernel<true, false, false>)
 #undef VS2_SET_ST
 #undef VS2_SET_MACRO
 #undef VS2_SET
@@ -1483,9 +1495,9 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     // 128 x 128 partials: "2 pairs" below, one grid row); beyond: the [C; D] macro kernel over pairs of 128-row blocks
     // (49 .. 64 rows per half stay on the [C; D] kernel, measured: four live 16-row blocks leave half of the S/T
     // kernel's waves one or two tiles per barrier -- 1.49 vs 1.62-1.67 ms at n = 2^22)
-    // 33 .. 64 rows per half, one output, even row count: two chunks per tile (gram_half_st_kernel; also carries the
-    // first-order dot products); other shapes of that range: 33 .. 48 the S/T kernel above, 49 .. 64 the [C; D] kernel
-    const bool half_st = macro && K <= VS2_HALF && l == 1 && rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0 &&
+    // 33 .. 64 rows per half, even row count: two chunks per tile (gram_half_st_kernel; with one output it also carries
+    // the first-order dot products); odd row counts: 33 .. 48 the S/T kernel above, 49 .. 64 the [C; D] kernel
+    const bool half_st = macro && K <= VS2_HALF && rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0 &&
                          ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
     const bool macro_st = macro && !half_st && K <= VS2_MACRO && !(K > 48 && K <= 64) && !with_first && ctx->tune.gram_st != 0;
     const int SB = half_st ? VS2_HALF : macro ? VS2_MACRO : VS2_SUPER;
@@ -1587,9 +1599,12 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
             if (half_st) {
                 A.slab_wgs = slab_wgs;
                 F.P = pslots;
-                if (masked) hipLaunchKernelGGL((gram_half_st_kernel<true, false>), dim3(slab_wgs), dim3(512), lds_m, ctx->stream, A);
-                else if (with_first) hipLaunchKernelGGL((gram_half_st_kernel<false, true>), dim3(slab_wgs), dim3(512), lds_m, ctx->stream, A);
-                else hipLaunchKernelGGL((gram_half_st_kernel<false, false>), dim3(slab_wgs), dim3(512), lds_m, ctx->stream, A);
+                const dim3 g(slab_wgs), t(512);
+                if (masked && l == 1) hipLaunchKernelGGL((gram_half_st_kernel<true, false, true>), g, t, lds_m, ctx->stream, A);
+                else if (masked) hipLaunchKernelGGL((gram_half_st_kernel<true, false, false>), g, t, lds_m, ctx->stream, A);
+                else if (with_first) hipLaunchKernelGGL((gram_half_st_kernel<false, true, true>), g, t, lds_m, ctx->stream, A);
+                else if (l == 1) hipLaunchKernelGGL((gram_half_st_kernel<false, false, true>), g, t, lds_m, ctx->stream, A);
+                else hipLaunchKernelGGL((gram_half_st_kernel<false, false, false>), g, t, lds_m, ctx->stream, A);
             } else if (macro_st) {
                 const dim3 grid(slab_wgs, 1);
                 if (masked && mwide) hipLaunchKernelGGL((gram_macro_st_kernel<true, true, true>), grid, dim3(512), lds_m, ctx->stream, A);
