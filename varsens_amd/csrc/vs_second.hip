@@ -1243,14 +1243,13 @@ gram_half_st_kernel(vs_gram_args A) {
 // The five scalar sums of the first-order record (sab, sa, sb, shifted s1, s2: varsens/saltelli.py:577,583) for
 // the one-pass route beyond 32 columns: a = fM_1, b = fM_2 only.  One full record per workgroup (zeros in the
 // dot-product part), appended to the macro kernel's records.
-__global__ void __launch_bounds__(256)
+#define VS2_HEAD_THREADS 1024
+__global__ void __launch_bounds__(VS2_HEAD_THREADS)
 first_head_kernel(const double* __restrict__ f, uint64_t rows, int k, double* __restrict__ records) {
-    __shared__ double wsum[4][5];
+    __shared__ double wsum[VS2_HEAD_THREADS / 64][5];
     const double shift = vs_shift_estimate(f, rows);   // wave-wide call; every wave and the fold get the same bits
     double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
-        const double a = __builtin_nontemporal_load(f + r), b = __builtin_nontemporal_load(f + rows + r);
+    auto add = [&](double a, double b) {
         const double dx = a - shift, dy = b - shift;
         v[VS_P_SAB] = fma(a, b, v[VS_P_SAB]);
         v[VS_P_SA] += a;
@@ -1258,6 +1257,18 @@ first_head_kernel(const double* __restrict__ f, uint64_t rows, int k, double* __
         v[VS_P_S1] += dx + dy;
         v[VS_P_S2] = fma(dx, dx, v[VS_P_S2]);
         v[VS_P_S2] = fma(dy, dy, v[VS_P_S2]);
+    };
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rows % 2 == 0 && ((uintptr_t)f & 15) == 0) {   // 16-byte loads: two rows per thread and trip
+        for (uint64_t r = 2 * t0; r < rows; r += 2 * stride) {
+            const vs_d2 a = __builtin_nontemporal_load((const vs_d2*)(f + r));
+            const vs_d2 b = __builtin_nontemporal_load((const vs_d2*)(f + rows + r));
+            add(a.x, b.x);
+            add(a.y, b.y);
+        }
+    } else {
+        for (uint64_t r = t0; r < rows; r += stride) add(__builtin_nontemporal_load(f + r), __builtin_nontemporal_load(f + rows + r));
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1268,8 +1279,12 @@ first_head_kernel(const double* __restrict__ f, uint64_t rows, int k, double* __
     __syncthreads();
     const size_t plen = VS_PLEN(k);
     double* rec = records + (size_t)blockIdx.x * plen;
-    for (size_t e = threadIdx.x; e < plen; e += 256)
-        rec[e] = e < VS_P_HEAD ? ((wsum[0][e] + wsum[1][e]) + wsum[2][e]) + wsum[3][e] : 0.0;
+    for (size_t e = threadIdx.x; e < plen; e += VS2_HEAD_THREADS) {
+        double t = 0.0;
+        if (e < VS_P_HEAD)
+            for (int w = 0; w < VS2_HEAD_THREADS / 64; ++w) t += wsum[w][e];   // fixed order
+        rec[e] = t;
+    }
 }
 
 // NaN probe of the two blocks the Gram matrix never sees: fM_1 and fM_2 of output 0 (planes 0, 1).
@@ -1660,7 +1675,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
         if (with_first && !masked) {
             {
                 vs_launch_scope scope(ctx, VS_KERNEL_REDUCE_FIRST);
-                hipLaunchKernelGGL(first_head_kernel, dim3(P_head), dim3(256), 0, ctx->stream, f_dev, rows, k,
+                hipLaunchKernelGGL(first_head_kernel, dim3(P_head), dim3(VS2_HEAD_THREADS), 0, ctx->stream, f_dev, rows, k,
                                    ctx->partials + (size_t)P_diag * plen);
             }
             VS_HIP(hipGetLastError());
@@ -1779,7 +1794,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     VS_HIP(hipGetLastError());
     if (wide) {
         vs_launch_scope scope(ctx, VS_KERNEL_REDUCE_FIRST);
-        hipLaunchKernelGGL(first_head_kernel, dim3(P_head), dim3(256), 0, ctx->stream, f_dev, rows, k,
+        hipLaunchKernelGGL(first_head_kernel, dim3(P_head), dim3(VS2_HEAD_THREADS), 0, ctx->stream, f_dev, rows, k,
                            ctx->partials + (size_t)P * plen);
         VS_HIP(hipGetLastError());
     }
