@@ -249,6 +249,11 @@ def main():
     so_steps = max(3, min(args.steps, 20))
     t_so, recs_so, _ = timed(lambda: ctx.reduce_second_order(fbuf[0], rows, k, l, gram), so_steps, 2, profile=True)
     avg_so = averages(recs_so)
+    # both orders in one call (what Varsens(...) runs by default after the evaluation): one pass over the f-values
+    acc_bo = ctx.alloc(8 * nacc)
+    t_bo, recs_bo, _ = timed(lambda: ctx.reduce_first_second_order(fbuf[0], rows, k, l, acc_bo, gram, 0, rank, world),
+                             so_steps, 2, profile=True)
+    avg_bo = averages(recs_bo)
 
     # analytic check of the finished indices (linear objective: S_i = c_i^2 / sum c^2)
     c = np.arange(1, k + 1, dtype=float)
@@ -344,6 +349,10 @@ def main():
                         "k = 32 instead of the 10 of the [C; D] Gram matrix, which was matrix-pipe-bound at 0.44 ms "
                         "(49 TFLOP/s of 78.6); the S/T form is bound by the HBM stream"},
         }
+        line["both_orders_one_call"] = {
+            "ms_per_call": 1e3 * t_bo / so_steps, "kernels_ms": avg_bo,
+            "note": "vs_reduce_first_second_order on the same f-values: the first-order dot products ride on the "
+                    "second-order kernel's operand fragments (k <= 64); the separate passes take reduce_first + second_order"}
         if world == 1 and not args.no_cpu_baseline:
             n_small = min(rows, 1 << 22)   # the whole pass at the default size: 2.2 GB over PCIe, ~2 s of numpy
             blocks = np.empty((2 * k + 2, n_small, l))
