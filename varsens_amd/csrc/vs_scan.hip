@@ -6,45 +6,7 @@
 //   E_2, var_y, U_j, U_nj sums         varsens/saltelli.py:577,583,591-596 (fused kernel)
 //
 // Built with -ffp-contract=off (see vs_generate.hip).
-#include <cmath>
-
-#include "vs_common.h"
-
-#include "vs_device_scan.h"
-
-template <int KIND>
-struct builtin_term {
-    static __device__ __forceinline__ double pre(int c, const double* __restrict__ p) { return p[c]; }
-    static __device__ __forceinline__ double eval(double x, int, const double* __restrict__, double pc) {
-        return vs_term<KIND>(x, pc);
-    }
-};
-
-// Two shapes are held to 128 registers (a handful of spilled dwords) for four waves per SIMD instead of two or
-// three: 16 columns per wave without the fused sums (k <= 128: two workgroups of eight waves share a CU) and the
-// fused kernel at 8 columns per wave (k <= 32; measured 0.395 vs 0.407 ms at n = 2^22)
-#define VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI) \
-    (((L) == 16 && (W) == 8 && !(FUSED) && !(MULTI)) || ((L) == 8 && (W) == 4 && (FUSED)) ? 4 : 1)
-
-// GENV: 1 / 2 = Halton indices below 2^32 with identity / linear scaling (straight-line column code);
-//       0 = any generator and scaling
-template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
-__global__ void __launch_bounds__(VS_EVAL_ROWS* W)
-__attribute__((amdgpu_waves_per_eu(VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI))))
-scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
-    extern __shared__ double scan_lds[];  // totals slabs [2 families][W][64] (+ term slabs), vs_scan_lds
-    vs_scan_body<builtin_term<KIND>, KIND, L, W, FUSED, TLDS, MULTI, GENV>(A, scan_lds, shift_src, partials);
-    // counters of the fold that follows (see reduce_first_kernel).  At the END of the kernel: a global
-    // store in front of the row loop would make every load of design constants "possibly clobbered"
-    // and keep it out of the scalar cache.
-    if (FUSED && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        counters[0] = 0;
-        counters[1] = 0xffffffffu;
-        counters[2] = 0;
-        counters[3] = 0;
-        counters[4] = 0;
-    }
-}
+#include "vs_scan_impl.h"
 
 // Ishigami (k = 3, not separable): thread = design row.  The 8 values of a row -- f(M_1), f(M_2), N_j[0..2],
 // N_nj[0..2] -- from 6 sines; same operation order as eval_kernel<VS_OBJ_ISHIGAMI>, so the same bits.
@@ -140,10 +102,6 @@ fused_ishigami_kernel(vs_eval_args A, const double* shift_src, double* partials,
 //   k <=  8: 1 wave  x  8 columns     k <= 32: 4 waves x  8     k <=  96: 8 waves x 12
 //   k <= 16: 1 wave  x 16             k <= 48: 4 waves x 12     k <= 128: 8 waves x 16
 //   k <= 24: 2 waves x 12             k <= 64: 8 waves x  8     k <= 256: 8 waves x 32 (evaluation only)
-struct scan_shape {
-    int L, W;
-};
-
 // variant (VS_SCAN_SHAPE / VS_FUSED_VARIANT = L*100+W, measurements only): another instantiated shape
 static bool scan_shape_for(int k, bool fused, scan_shape* s, int variant = 0) {
     if (variant >= 100) {
@@ -198,73 +156,13 @@ unsigned vs_persistent_workgroups(vs_context* ctx, const void* kernel, int threa
     return (unsigned)(P < 1 ? 1 : P);
 }
 
-template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
-static int launch_scan_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
-    const size_t lds = sizeof(double) * vs_scan_lds<L, W, TLDS>::doubles;
-    const void* fn = (const void*)scan_kernel<KIND, L, W, FUSED, TLDS, MULTI, GENV>;
-    if (lds > 64 * 1024) VS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
-    if (plan_only) {
-        *P_io = FUSED ? vs_persistent_workgroups(ctx, fn, VS_EVAL_ROWS * W, lds, blocks, A.l) : (unsigned)blocks;
-        return VS_OK;
-    }
-    {
-        vs_launch_scope scope(ctx, FUSED ? VS_KERNEL_FUSED : VS_KERNEL_EVAL);
-        // outputs: grid.y (fused; evaluation without the in-kernel output loop) or inside the block walk (MULTI)
-        hipLaunchKernelGGL((scan_kernel<KIND, L, W, FUSED, TLDS, MULTI, GENV>), dim3(*P_io, MULTI ? 1u : (unsigned)A.l),
-                           dim3(VS_EVAL_ROWS * W), lds, ctx->stream, A, shift_dev, ctx->partials, ctx->counters);
-    }
-    VS_HIP(hipGetLastError());
-    return VS_OK;
-}
-
-// the specialised column code for the common designs: Halton (indices below 2^32: every design the scan
-// kernels accept) with identity or linear scaling; Sobol, raw points and power scaling take the general one
-template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
-static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
-    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0;
-    if (halton && A.D.scale_mode == VS_SCALE_IDENTITY)
-        return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 1>(ctx, A, P_io, shift_dev, plan_only);
-    if (halton && A.D.scale_mode == VS_SCALE_LINEAR)
-        return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 2>(ctx, A, P_io, shift_dev, plan_only);
-    return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 0>(ctx, A, P_io, shift_dev, plan_only);
-}
-
-template <int KIND, bool FUSED>
-static int launch_scan_kind(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned* P_io, const double* shift_dev,
-                            bool plan_only) {
-    // l > 1: the outputs share one generated row inside the kernel (MULTI), except at 32 columns per wave,
-    // where the coordinates no longer fit the registers beside the terms (then: one grid.y plane per output)
-    const bool multi = !FUSED && A.l > 1 && s.L < 32;
-#define VS_SCAN_CASE(LL, WW, TL)                                                                                       \
-    if (s.L == LL && s.W == WW) {                                                                                      \
-        if constexpr (!FUSED && LL < 32) {                                                                             \
-            if (multi) return launch_scan_lw<KIND, LL, WW, false, false, true>(ctx, A, P_io, shift_dev, plan_only);    \
-        }                                                                                                              \
-        return launch_scan_lw<KIND, LL, WW, FUSED, FUSED && TL, false>(ctx, A, P_io, shift_dev, plan_only);            \
-    }
-    VS_SCAN_CASE(8, 1, false)
-    VS_SCAN_CASE(16, 1, false)
-    VS_SCAN_CASE(12, 2, false)
-    VS_SCAN_CASE(8, 4, false)
-    VS_SCAN_CASE(12, 4, false)
-    VS_SCAN_CASE(8, 8, false)
-    VS_SCAN_CASE(12, 8, false)
-    VS_SCAN_CASE(16, 8, true)
-    if constexpr (!FUSED) {
-        VS_SCAN_CASE(32, 8, false)
-    }
-#undef VS_SCAN_CASE
-    return vs_fail(VS_ERR_ARG, "no scan kernel for L=%d W=%d", s.L, s.W);
-}
-
 template <bool FUSED>
 static int launch_scan(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned* P_io, const double* shift_dev,
                        bool plan_only) {
     switch (A.kind) {
-        case VS_OBJ_G_FUNCTION: return launch_scan_kind<VS_OBJ_G_FUNCTION, FUSED>(ctx, A, s, P_io, shift_dev, plan_only);
-        case VS_OBJ_POLYNOMIAL: return launch_scan_kind<VS_OBJ_POLYNOMIAL, FUSED>(ctx, A, s, P_io, shift_dev, plan_only);
-        case VS_OBJ_LINEAR: return launch_scan_kind<VS_OBJ_LINEAR, FUSED>(ctx, A, s, P_io, shift_dev, plan_only);
+        case VS_OBJ_G_FUNCTION: return vs_scan_launch_g(ctx, A, s, P_io, shift_dev, plan_only, FUSED);
+        case VS_OBJ_POLYNOMIAL: return vs_scan_launch_poly(ctx, A, s, P_io, shift_dev, plan_only, FUSED);
+        case VS_OBJ_LINEAR: return vs_scan_launch_lin(ctx, A, s, P_io, shift_dev, plan_only, FUSED);
     }
     return vs_fail(VS_ERR_ARG, "objective kind %d is not separable", A.kind);
 }

@@ -1,0 +1,120 @@
+// The scan kernels and their launch templates, per objective kind (vs_device_scan.h holds the device code).  Included
+// by vs_scan_g.hip, vs_scan_poly.hip and vs_scan_lin.hip -- one translation unit per built-in separable objective, so
+// that the ~100 kernel instances compile side by side -- and by vs_scan.hip for the shape type.
+#pragma once
+#include <cmath>
+
+#include "vs_common.h"
+
+#include "vs_device_scan.h"
+
+struct scan_shape {
+    int L, W;
+};
+
+unsigned vs_persistent_workgroups(vs_context* ctx, const void* kernel, int threads, size_t lds, uint64_t blocks, int l);
+
+// one entry per objective kind: launch (or plan) the evaluation (fused = false) or the fused evaluate+reduce kernel
+int vs_scan_launch_g(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned* P_io, const double* shift_dev,
+                     bool plan_only, bool fused);
+int vs_scan_launch_poly(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned* P_io, const double* shift_dev,
+                        bool plan_only, bool fused);
+int vs_scan_launch_lin(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned* P_io, const double* shift_dev,
+                       bool plan_only, bool fused);
+
+#ifdef VS_SCAN_KIND
+template <int KIND>
+struct builtin_term {
+    static __device__ __forceinline__ double pre(int c, const double* __restrict__ p) { return p[c]; }
+    static __device__ __forceinline__ double eval(double x, int, const double* __restrict__, double pc) {
+        return vs_term<KIND>(x, pc);
+    }
+};
+
+// Two shapes are held to 128 registers (a handful of spilled dwords) for four waves per SIMD instead of two or
+// three: 16 columns per wave without the fused sums (k <= 128: two workgroups of eight waves share a CU) and the
+// fused kernel at 8 columns per wave (k <= 32; measured 0.395 vs 0.407 ms at n = 2^22)
+#define VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI) \
+    (((L) == 16 && (W) == 8 && !(FUSED) && !(MULTI)) || ((L) == 8 && (W) == 4 && (FUSED)) ? 4 : 1)
+
+// GENV: 1 / 2 = Halton indices below 2^32 with identity / linear scaling (straight-line column code);
+//       0 = any generator and scaling
+template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
+__global__ void __launch_bounds__(VS_EVAL_ROWS* W)
+__attribute__((amdgpu_waves_per_eu(VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI))))
+scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
+    extern __shared__ double scan_lds[];  // totals slabs [2 families][W][64] (+ term slabs), vs_scan_lds
+    vs_scan_body<builtin_term<KIND>, KIND, L, W, FUSED, TLDS, MULTI, GENV>(A, scan_lds, shift_src, partials);
+    // counters of the fold that follows (see reduce_first_kernel).  At the END of the kernel: a global
+    // store in front of the row loop would make every load of design constants "possibly clobbered"
+    // and keep it out of the scalar cache.
+    if (FUSED && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        counters[0] = 0;
+        counters[1] = 0xffffffffu;
+        counters[2] = 0;
+        counters[3] = 0;
+        counters[4] = 0;
+    }
+}
+
+template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
+static int launch_scan_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
+    const size_t lds = sizeof(double) * vs_scan_lds<L, W, TLDS>::doubles;
+    const void* fn = (const void*)scan_kernel<KIND, L, W, FUSED, TLDS, MULTI, GENV>;
+    if (lds > 64 * 1024) VS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
+    if (plan_only) {
+        *P_io = FUSED ? vs_persistent_workgroups(ctx, fn, VS_EVAL_ROWS * W, lds, blocks, A.l) : (unsigned)blocks;
+        return VS_OK;
+    }
+    {
+        vs_launch_scope scope(ctx, FUSED ? VS_KERNEL_FUSED : VS_KERNEL_EVAL);
+        // outputs: grid.y (fused; evaluation without the in-kernel output loop) or inside the block walk (MULTI)
+        hipLaunchKernelGGL((scan_kernel<KIND, L, W, FUSED, TLDS, MULTI, GENV>), dim3(*P_io, MULTI ? 1u : (unsigned)A.l),
+                           dim3(VS_EVAL_ROWS * W), lds, ctx->stream, A, shift_dev, ctx->partials, ctx->counters);
+    }
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+// the specialised column code for the common designs: Halton (indices below 2^32: every design the scan
+// kernels accept) with identity or linear scaling; Sobol, raw points and power scaling take the general one
+template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
+static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
+    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0;
+    if (halton && A.D.scale_mode == VS_SCALE_IDENTITY)
+        return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 1>(ctx, A, P_io, shift_dev, plan_only);
+    if (halton && A.D.scale_mode == VS_SCALE_LINEAR)
+        return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 2>(ctx, A, P_io, shift_dev, plan_only);
+    return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 0>(ctx, A, P_io, shift_dev, plan_only);
+}
+
+template <int KIND, bool FUSED>
+static int launch_scan_kind(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned* P_io, const double* shift_dev,
+                            bool plan_only) {
+    // l > 1: the outputs share one generated row inside the kernel (MULTI), except at 32 columns per wave,
+    // where the coordinates no longer fit the registers beside the terms (then: one grid.y plane per output)
+    const bool multi = !FUSED && A.l > 1 && s.L < 32;
+#define VS_SCAN_CASE(LL, WW, TL)                                                                                       \
+    if (s.L == LL && s.W == WW) {                                                                                      \
+        if constexpr (!FUSED && LL < 32) {                                                                             \
+            if (multi) return launch_scan_lw<KIND, LL, WW, false, false, true>(ctx, A, P_io, shift_dev, plan_only);    \
+        }                                                                                                              \
+        return launch_scan_lw<KIND, LL, WW, FUSED, FUSED && TL, false>(ctx, A, P_io, shift_dev, plan_only);            \
+    }
+    VS_SCAN_CASE(8, 1, false)
+    VS_SCAN_CASE(16, 1, false)
+    VS_SCAN_CASE(12, 2, false)
+    VS_SCAN_CASE(8, 4, false)
+    VS_SCAN_CASE(12, 4, false)
+    VS_SCAN_CASE(8, 8, false)
+    VS_SCAN_CASE(12, 8, false)
+    VS_SCAN_CASE(16, 8, true)
+    if constexpr (!FUSED) {
+        VS_SCAN_CASE(32, 8, false)
+    }
+#undef VS_SCAN_CASE
+    return vs_fail(VS_ERR_ARG, "no scan kernel for L=%d W=%d", s.L, s.W);
+}
+
+#endif  // VS_SCAN_KIND
