@@ -449,10 +449,16 @@ gram_diag_wide_kernel(vs_gram_args A) {
     const uint64_t nfull = rows / VS2_XCHUNK;
     const uint64_t nun = nfull + ((rows % VS2_XCHUNK) ? 1 : 0);
     const uint64_t W = (uint64_t)gridDim.x * 4;
-    double pa[NB], pb[NB];   // FIRST: a.x and b.x of index row lane&15 of every block (the five scalar sums of the
-                             // record come from first_head_kernel, as on the macro route)
+    double pa[NB], pb[NB];   // FIRST: a.x and b.x of tile row lane&15 of every block
 #pragma unroll
     for (int b = 0; b < NB; ++b) pa[b] = pb[b] = 0.0;
+    // The five scalar sums of the record (sab, sa, sb, shifted variance sums): with the compile-time tile set (FULL:
+    // six accumulator tiles instead of ten) they fit beside everything else; otherwise first_head_kernel adds them.
+    constexpr bool HEAD = FIRST && FULL;
+    const int fq = lane >> 4;
+    double shift = 0.0;
+    if (HEAD) shift = vs_shift_estimate(A.f, rows);  // wave-wide call, same bits in every wave and in the fold
+    double t_sab = 0.0, t_sa = 0.0, t_sb = 0.0, t_s1 = 0.0, t_s2 = 0.0;
     vs_d2 raw[NJ], rawab = (vs_d2){0.0, 0.0};
     auto fetch = [&](uint64_t u) {
         const uint64_t s0 = u * VS2_XCHUNK;
@@ -526,6 +532,17 @@ gram_diag_wide_kernel(vs_gram_args A) {
                         pa[blk] = fma(a, fr[blk][t], pa[blk]);
                         pb[blk] = fma(b, fr[blk][t], pb[blk]);
                     }
+                    if (HEAD) {   // sixteen lanes hold the same a, b: gram_first_record takes lane&15 == 0 of each group
+                        const bool live = u < nfull || u * VS2_XCHUNK + 8 * hh + 2 * fq + t < rows;
+                        const double dx = live ? a - shift : 0.0;
+                        const double dy = live ? b - shift : 0.0;
+                        t_sab = fma(a, b, t_sab);
+                        t_sa += a;
+                        t_sb += b;
+                        t_s1 += dx + dy;
+                        t_s2 = fma(dx, dx, t_s2);
+                        t_s2 = fma(dy, dy, t_s2);
+                    }
                 }
             }
         }
@@ -555,7 +572,7 @@ gram_diag_wide_kernel(vs_gram_args A) {
             __syncthreads();
             ++a;
         }
-    if (FIRST) gram_first_record<NB>(A, tiles, pa, pb, 0.0, 0.0, 0.0, 0.0, 0.0);
+    if (FIRST) gram_first_record<NB>(A, tiles, pa, pb, t_sab, t_sa, t_sb, t_s1, t_s2);
 }
 
 // More than 64 index rows (k*l > 32): 128-row macro blocks.  One workgroup of eight waves owns a pair
@@ -1466,7 +1483,7 @@ gram_convert_kernel(const double* __restrict__ cd, int K, double* __restrict__ g
 #define VS2_ST_INSTANCES(X) \
     X(false, false, false) X(false, true, false) X(false, true, true) X(true, false, false) X(true, true, false) X(true, true, true)
 // (NB, FIRST, FULL) instances of the wide wave-private kernel
-#define VS2_WIDE_INSTANCES(X) X(3, false, false) X(4, false, false) X(4, false, true) X(3, true, false) X(4, true, false) X(4, true, true)
+#define VS2_WIDE_INSTANCES(X) X(3, false, false) X(4, false, false) X(4, false, true) X(3, true, false) X(4, true, true)
 
 // Kernels that ask for more than 64 KiB of dynamic LDS need the limit raised; once per context (= per device).
 static int gram_raise_lds_limits(vs_context* ctx) {
@@ -1736,14 +1753,17 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     const uint64_t want = (uint64_t)cus * (ctx->tune.gram_wgs_per_cu > 0 ? ctx->tune.gram_wgs_per_cu
                                                                           : VS2_WAVES_PER_SIMD(nb, true));
     const bool aligned = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
-    const bool wide = aligned && nb >= 3 && ctx->tune.gram_wide != 0;   // gram_diag_wide_kernel, two workgroups per CU
+    // gram_diag_wide_kernel, two workgroups per CU; 25 .. 31 columns stay on the 16-row kernel: with four blocks and a
+    // tile set known only at run time the wide form spills beside the first-order sums (0.84 vs 0.40 ms at k = 28)
+    const bool wide = aligned && nb >= 3 && !(nb == 4 && K != 32) && ctx->tune.gram_wide != 0;
     const uint64_t wide_units = (rows + VS2_XCHUNK - 1) / VS2_XCHUNK;
     const uint64_t wide_want = (uint64_t)cus * 2;   // all that are resident (LDS)
     const uint32_t P = wide ? (uint32_t)(wide_units < wide_want ? wide_units : wide_want)
                             : (uint32_t)(nchunks < want ? nchunks : want);
     const size_t plen = VS_PLEN(k);
-    // the wide kernel leaves the five scalar sums of the record to first_head_kernel (P_head more records)
-    const uint32_t P_head = wide ? (uint32_t)((rows + 4095) / 4096 < (uint64_t)cus ? (rows + 4095) / 4096 : cus) : 0;
+    // the wide kernel with three blocks leaves the five scalar sums of the record to first_head_kernel (P_head more records)
+    const bool head_in_kernel = wide && nb == 4 && K == 32;   // gram_diag_wide_kernel<4, true, FULL>
+    const uint32_t P_head = wide && !head_in_kernel ? (uint32_t)((rows + 4095) / 4096 < (uint64_t)cus ? (rows + 4095) / 4096 : cus) : 0;
     // workspace: first-order records [P + P_head][plen] + folded [plen] (vs_fold_partials' layout), then Gram partials
     size_t first_doubles = (size_t)(P + P_head) * plen + plen;
     first_doubles = (first_doubles + 1) & ~(size_t)1;
@@ -1771,8 +1791,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
 #define VS2_LAUNCH_WIDE(NBV, FU) \
     hipLaunchKernelGGL((gram_diag_wide_kernel<NBV, true, FU>), dim3(P), dim3(256), lds_x, ctx->stream, A)
         if (nb == 3) VS2_LAUNCH_WIDE(3, false);
-        else if (K == 32) VS2_LAUNCH_WIDE(4, true);
-        else VS2_LAUNCH_WIDE(4, false);
+        else VS2_LAUNCH_WIDE(4, true);
 #undef VS2_LAUNCH_WIDE
     } else {
         vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
@@ -1792,7 +1811,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
 #undef VS2_LAUNCH_BOTH
     }
     VS_HIP(hipGetLastError());
-    if (wide) {
+    if (P_head) {
         vs_launch_scope scope(ctx, VS_KERNEL_REDUCE_FIRST);
         hipLaunchKernelGGL(first_head_kernel, dim3(P_head), dim3(VS2_HEAD_THREADS), 0, ctx->stream, f_dev, rows, k,
                            ctx->partials + (size_t)P * plen);
