@@ -31,6 +31,8 @@
 extern "C" {
 #endif
 
+/* 2: perm slices per rank, vs_accumulate, vs_context_set_eval_order, vs_eval_reduce_supported.
+ * 3: the second-order sums are S S^T and T T^T (VS_GRAM_LEN doubles) instead of D C^T, D D^T, C C^T. */
 #define VS_ABI_VERSION 3
 
 typedef enum vs_status {
