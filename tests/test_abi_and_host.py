@@ -58,6 +58,10 @@ def test_acc_layout_helpers(native):
     assert native.acc_len(32, 1, 1) == 4 + 131 + 3
     assert native.acc_len(6, 2, 8) == 4 + 2 * 27 + 8 * 5
     assert native.first_order_len(6, 2) == 52
+    assert native.gram_len(12) == 2 * 12 * 12     # S S^T and T T^T (include/varsens_hip.h: VS_GRAM_LEN)
+    header = open(os.path.join(ROOT, "include", "varsens_hip.h")).read()
+    assert "#define VS_GRAM_LEN(K) (2 * (size_t)(K) * (size_t)(K))" in header
+    assert "#define VS_ABI_VERSION %d" % native.ABI_VERSION in header
 
 
 # ---- scale.py (varsens/tests/test_scaling.py restated) --------------------------------
