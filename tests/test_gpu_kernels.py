@@ -645,6 +645,31 @@ def test_reduce_very_wide_k(ctx):
     np.testing.assert_allclose(G[1], (C - D) @ (C - D).T, rtol=1e-11, atol=1e-11)
 
 
+@pytest.mark.parametrize("k,l", [(5, 1), (7, 3), (40, 1)])
+def test_finish_second_order_formulas(ctx, k, l):
+    """vs_finish_second_order alone: from uploaded S S^T, T T^T and a first-order block to the reference's
+    sens_2 / sens_2n (varsens/saltelli.py:612-622, E_2 and var_y broadcast over the LAST output axis)."""
+    from varsens_amd import _native
+    rng = np.random.RandomState(k * 10 + l)
+    K, n = k * l, 777
+    C = 2.0 + rng.rand(K, n)
+    D = 2.0 + rng.rand(K, n)
+    S, T = C + D, C - D
+    gram = ctx.upload(np.concatenate([(S @ S.T).ravel(), (T @ T.T).ravel()]))
+    first = np.zeros((2 + 4 * k, l))
+    first[0] = 4.0 + rng.rand(l)          # E_2
+    first[1] = 0.5 + rng.rand(l)          # var_y
+    s2, s2n = ctx.alloc(8 * K * K), ctx.alloc(8 * K * K)
+    ctx.finish_second_order(gram, ctx.upload(first), n, k, l, s2, s2n)
+    div = 2.0 * (n - 1)
+    want2 = ((D @ C.T + C @ D.T) / div).reshape(k, l, k, l)
+    want2 = (want2 - first[0]) / first[1]
+    want2n = ((D @ D.T + C @ C.T) / div).reshape(k, l, k, l)
+    want2n = (want2n - first[0]) / first[1]
+    np.testing.assert_allclose(ctx.download(s2, (k, l, k, l)), want2, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ctx.download(s2n, (k, l, k, l)), want2n, rtol=1e-12, atol=1e-12)
+
+
 def test_abi_argument_errors(ctx):
     """Bad arguments come back as VS_ERR_ARG with a message, never as a crash."""
     from varsens_amd import _native
