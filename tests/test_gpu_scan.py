@@ -99,6 +99,31 @@ def test_scan_eval_default_route(ctx, kind, k, n, l):
     assert np.max(np.abs(got - strict) / np.maximum(np.abs(strict), 1e-300)) <= 6e-15
 
 
+def test_g_function_quotient_is_the_correctly_rounded_one(ctx):
+    """The scan kernels take (|4x-2| + a) / (1 + a) from a host-rounded reciprocal by Markstein's fma sequence: the
+    bits must be those of the division (numpy's, the reference's) for every parameter the host admits -- tiny, huge,
+    many-ones significands -- and a parameter it does not admit (1 + a with an all-ones significand, a = -1) must
+    route the objective to the kernels that divide."""
+    from varsens_amd import _native
+    k, n = 24, 20000
+    a = np.array([0.0, 0.5, 3.0, 9.0, 99.0, 99.0, 1e-12, 1e-300, 1e6, 2.0 ** 52, 1.0 / 3.0, 2.0 / 3.0, 0.1, 0.7,
+                  1.0 - 2.0 ** -51, 2.0 ** -53, 7.0 - 2.0 ** -49, 1e15 / 3.0, np.pi, np.e, 0.999999999999, 123456.789,
+                  2.0 ** 40 - 0.25, 5e-324])
+    assert len(a) == k
+    S = orc.build_sample(k, n)
+    d = design(ctx, k, n)
+    _, obj, got = device_blocks(ctx, d, "g_function", k, 1, a[None, :], n)
+    assert ctx.eval_reduce_supported(d, obj)
+    same(got, blocks_of(orc.evaluate_scan("g_function", a[None, :], S[0], S[1])))
+    for bad in (1.0 - 2.0 ** -52, 7.0 - 2.0 ** -50, -1.0, np.inf):        # 1 + a = 1.11...1b (twice), 0, inf
+        b = a.copy()
+        b[5] = bad
+        _, obj, got = device_blocks(ctx, d, "g_function", k, 1, b[None, :], n)
+        assert not ctx.eval_reduce_supported(d, obj)
+        with np.errstate(all="ignore"):
+            same(got, strict_blocks("g_function", b[None, :], S))
+
+
 @pytest.mark.parametrize("kind,k,n,l", [("g_function", 6, 1024, 1), ("g_function", 6, 1000, 2), ("linear", 1, 7, 1),
                                         ("polynomial", 2, 64, 1), ("g_function", 9, 65, 1), ("linear", 16, 1, 1),
                                         ("polynomial", 17, 4097, 1), ("linear", 32, 500, 1), ("g_function", 31, 200, 3)])

@@ -64,24 +64,30 @@ struct vs_scan_col {
     vs_base B;      // Halton constants of the column
     double w, lo;   // linear scaling: x * w + lo
     double pre;     // the term's parameter (Term::pre), when it has one per column
+    double pre2;    // a second per-column value (Term::pre2; the g-function's rounded reciprocal), 0 if none
 };
 
-// Term concept: pre(c, params) -> the value eval() needs from memory for column c (0 if none);
-//               eval(x, c, params, pre) -> t_c(x)
+// Term concept: pre(c, params), pre2(c, params, lk) -> the values eval() needs from memory for column c (0 if none;
+//               lk = l*k: arrays that follow the l*k parameters of all outputs are reached through it);
+//               eval(x, c, params, pre, pre2) -> t_c(x)
 template <class Term, int GENV, bool MULTI>
 __device__ __forceinline__ void vs_scan_col_load(vs_scan_col& C, const vs_design_dev& D, const double* __restrict__ params,
-                                                 int c, int k) {
+                                                 int c, int k, int lk) {
     C.B = {2u, 1u, 2.0, 0.5, 0.5};
     C.w = 1.0;
     C.lo = 0.0;
     C.pre = 0.0;
+    C.pre2 = 0.0;
     if (c < k) {
         if (GENV != 0 || D.generator == VS_GEN_HALTON) C.B = D.bases[c];
         if (GENV == 2) {
             C.w = D.width[c];
             C.lo = D.lower[c];
         }
-        if (!MULTI) C.pre = Term::pre(c, params);
+        if (!MULTI) {
+            C.pre = Term::pre(c, params);
+            C.pre2 = Term::pre2(c, params, lk);
+        }
     }
 }
 
@@ -261,12 +267,13 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     // GENV 1 / 2: Halton below 2^32 with identity / linear scaling -- straight-line code per column;
     // GENV 0: any generator and scaling, decided by (wave-uniform) branches per column.
     vs_scan_col Cnext;
-    vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, VS_SCAN_COLUMN(q, 0, W), k);
+    const int lk = A.l * k;
+    vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, VS_SCAN_COLUMN(q, 0, W), k, lk);
 #pragma unroll
     for (int j = 0; j < L; ++j) {
         const int c = VS_SCAN_COLUMN(q, j, W);  // wave-uniform
         const vs_scan_col C = Cnext;
-        if (j + 1 < L) vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, VS_SCAN_COLUMN(q, j + 1, W), k);
+        if (j + 1 < L) vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, VS_SCAN_COLUMN(q, j + 1, W), k, lk);
         double t1 = ident, t2 = ident;
         if (c < k) {
             double x1, x2;
@@ -280,8 +287,8 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
                 t2 = vs_apply_scale_compact<!FUSED>(A.D, x2, c);
             }
             if (!MULTI) {
-                t1 = Term::eval(t1, c, params, C.pre);
-                t2 = Term::eval(t2, c, params, C.pre);
+                t1 = Term::eval(t1, c, params, C.pre, C.pre2);
+                t2 = Term::eval(t2, c, params, C.pre, C.pre2);
             }
         }
         if (TLDS) {
@@ -320,9 +327,9 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
                 const int c = VS_SCAN_COLUMN(qo, j, W);
                 ua[j] = ub[j] = ident;
                 if (c < k) {
-                    const double pre = Term::pre(c, po);
-                    ua[j] = Term::eval(ta[TLDS ? 0 : j], c, po, pre);
-                    ub[j] = Term::eval(tb[TLDS ? 0 : j], c, po, pre);
+                    const double pre = Term::pre(c, po), pre2 = Term::pre2(c, po, lk);
+                    ua[j] = Term::eval(ta[TLDS ? 0 : j], c, po, pre, pre2);
+                    ub[j] = Term::eval(tb[TLDS ? 0 : j], c, po, pre, pre2);
                 }
                 Ta = vs_fold<FOLD>(Ta, ua[j]);
                 Tb = vs_fold<FOLD>(Tb, ub[j]);

@@ -14,6 +14,8 @@
 // operation.
 #include <cmath>
 
+#include <vector>
+
 #include "vs_common.h"
 
 #include "vs_device_gen.h"
@@ -394,8 +396,28 @@ extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, cons
     o->l = l;
     o->nparams = nparams;
     if (nparams) {
-        if (hipMalloc(&o->params, sizeof(double) * nparams) != hipSuccess ||
-            hipMemcpyAsync(o->params, params, sizeof(double) * nparams, hipMemcpyHostToDevice, ctx->stream) !=
+        // G_FUNCTION: t = (|4x - 2| + a) / (1 + a) (varsens/tests/test_g_function.py:9-14).  The scan kernels take the
+        // quotient from the correctly rounded reciprocal r = RN(1 / (1 + a)), computed here in IEEE double, by
+        // Markstein's fma sequence -- two steps of q += fma(-q, d, n) * r give RN(n / d) exactly when r is the correctly
+        // rounded reciprocal of a normal d whose significand is not all ones and nothing leaves the normal range
+        // (checked below; otherwise the objective keeps to the kernels that divide).  The reciprocals follow the
+        // l*k parameters in the same device buffer.
+        std::vector<double> host(params, params + nparams);
+        if (kind == VS_OBJ_G_FUNCTION) {
+            bool ok = true;
+            for (size_t i = 0; i < nparams; ++i) {
+                const double d = 1.0 + params[i];
+                uint64_t bits;
+                memcpy(&bits, &d, sizeof(bits));
+                const bool plain = std::isfinite(params[i]) && std::isfinite(d) && fabs(d) > 0x1p-200 && fabs(d) < 0x1p200 &&
+                                   fabs(params[i]) < 0x1p200 && (bits & 0x000fffffffffffffull) != 0x000fffffffffffffull;
+                ok = ok && plain;
+                host.push_back(plain ? 1.0 / d : 0.0);
+            }
+            o->recip_ok = ok;
+        }
+        if (hipMalloc(&o->params, sizeof(double) * host.size()) != hipSuccess ||
+            hipMemcpyAsync(o->params, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, ctx->stream) !=
                 hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
             vs_objective_destroy(ctx, o);
@@ -757,7 +779,8 @@ enum fused_route { FUSED_NONE = 0, FUSED_SCAN, FUSED_ISHIGAMI, FUSED_USER };
 // kernels fold in scan order.
 static fused_route fused_route_for(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
     const bool separable = obj->kind == VS_OBJ_G_FUNCTION || obj->kind == VS_OBJ_POLYNOMIAL || obj->kind == VS_OBJ_LINEAR;
-    const bool scan_ok = design_compact(design) && design->d.scale_mode != VS_SCALE_POWER && ctx->tune.eval_mode != 1;
+    const bool scan_ok = design_compact(design) && design->d.scale_mode != VS_SCALE_POWER && ctx->tune.eval_mode != 1 &&
+                         (obj->kind != VS_OBJ_G_FUNCTION || obj->recip_ok);
     if (separable && scan_ok && vs_scan_covers(obj->kind, obj->k, true)) return FUSED_SCAN;
     if (obj->kind == VS_OBJ_ISHIGAMI) return FUSED_ISHIGAMI;
     if (obj->kind == VS_OBJ_SOURCE && obj->fused_function && scan_ok) return FUSED_USER;
@@ -848,7 +871,8 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
     // separable built-ins: the segmented scan (O(k) folds per row, association order of
     // vs_device_scan.h) wherever it applies; the chain scheme (strict left-to-right folds, O(k^2)) beyond
     // 256 columns, for Halton indices beyond 2^32, and when the context asks for the strict order
-    if (vs_scan_covers(obj->kind, obj->k, false) && design_compact(design) && ctx->tune.eval_scratch != 1 &&
+    if (vs_scan_covers(obj->kind, obj->k, false) && (obj->kind != VS_OBJ_G_FUNCTION || obj->recip_ok) &&
+        design_compact(design) && ctx->tune.eval_scratch != 1 &&
         ctx->tune.eval_mode != 1)
         return vs_scan_eval(ctx, A);
     switch (obj->kind) {

@@ -13,7 +13,8 @@
 // below serves contexts in strict evaluation order.
 struct vs_user_term_t {
     static __device__ __forceinline__ double pre(int, const double* __restrict__) { return 0.0; }
-    static __device__ __forceinline__ double eval(double x, int c, const double* __restrict__ p, double) {
+    static __device__ __forceinline__ double pre2(int, const double* __restrict__, int) { return 0.0; }
+    static __device__ __forceinline__ double eval(double x, int c, const double* __restrict__ p, double, double) {
         return vs_user_term(x, c, p);
     }
 };

@@ -26,7 +26,20 @@ int vs_scan_launch_lin(vs_context* ctx, const vs_eval_args& A, scan_shape s, uns
 template <int KIND>
 struct builtin_term {
     static __device__ __forceinline__ double pre(int c, const double* __restrict__ p) { return p[c]; }
-    static __device__ __forceinline__ double eval(double x, int, const double* __restrict__, double pc) {
+    // G_FUNCTION: r = RN(1 / (1 + a)), stored behind the l*k parameters by vs_objective_create
+    static __device__ __forceinline__ double pre2(int c, const double* __restrict__ p, int lk) {
+        return KIND == VS_OBJ_G_FUNCTION ? p[c + lk] : 0.0;
+    }
+    static __device__ __forceinline__ double eval(double x, int, const double* __restrict__, double pc, double r) {
+        if (KIND == VS_OBJ_G_FUNCTION) {
+            // (|4x - 2| + a) / (1 + a) as the correctly rounded quotient, without the division: Markstein's sequence on
+            // the correctly rounded reciprocal (two steps; the second is exact for every normal n / d -- the host
+            // admits only such d).  Same bits as vs_term<G>'s division; 5 fp64 instructions instead of ~13.
+            const double n = fabs(4.0 * x - 2.0) + pc, d = 1.0 + pc;
+            double q = n * r;
+            q = fma(fma(-q, d, n), r, q);
+            return fma(fma(-q, d, n), r, q);
+        }
         return vs_term<KIND>(x, pc);
     }
 };
