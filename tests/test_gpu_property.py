@@ -1,5 +1,7 @@
 """Randomised shapes (hypothesis): the kernels against the oracle over many small (k, rows, l) combinations,
 including the edges of tiles, passes and blocks (k around 32/64, rows around 64/512/2048, odd rows)."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -21,7 +23,10 @@ def ctx():
 EDGE_ROWS = st.one_of(st.integers(1, 70), st.sampled_from([63, 64, 65, 127, 128, 129, 511, 512, 513, 2047, 2048, 2049, 4097]),
                       st.integers(71, 6000))
 EDGE_K = st.one_of(st.integers(1, 12), st.sampled_from([15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 70]))
-COMMON = dict(deadline=None, max_examples=150, suppress_health_check=list(HealthCheck), derandomize=True)
+# VS_PROPERTY_EXAMPLES=N: a soak run with N random examples per test instead of the fixed 150 / 100
+_SOAK = int(os.environ.get("VS_PROPERTY_EXAMPLES", "0"))
+COMMON = dict(deadline=None, max_examples=_SOAK or 150, suppress_health_check=list(HealthCheck), derandomize=not _SOAK,
+              database=None)
 
 
 @settings(**COMMON)
@@ -64,7 +69,7 @@ def test_reduction_any_shape(k, rows, l, seed, offset):
 GRAM_K = st.one_of(st.integers(13, 34), st.sampled_from([40, 48, 63, 64, 65, 100, 127, 128, 129, 130]))
 
 
-@settings(**dict(COMMON, max_examples=100))
+@settings(**dict(COMMON, max_examples=_SOAK or 100))
 @given(k=GRAM_K, rows=EDGE_ROWS, seed=st.integers(0, 2 ** 20), trim=st.booleans())
 def test_both_orders_any_shape(k, rows, seed, trim):
     """vs_reduce_first_second_order (one output) against the two separate passes and against numpy, over the
