@@ -2,6 +2,7 @@
 """bench.py -- the Saltelli hot path on MI355X, one process per GPU.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N --steps K --warmup W         (no launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -89,6 +90,53 @@ def cpu_baseline(k, f_small, n_small, cores):
     }, R
 
 
+def spawn_ranks(world, argv=None, script=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process (the
+    reference's fan-out is a PBS array job, varsens/cluster/accre-submit.sh:27).  The parent never imports the
+    engine and never touches a GPU; it relays rank 0's result line only when every rank ended with status 0
+    and returns the worst status otherwise (3 = a rank ended on the host fallback exchange)."""
+    import socket
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    probe = socket.socket()
+    probe.bind(("127.0.0.1", 0))
+    port = probe.getsockname()[1]
+    probe.close()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only does dmabuf IPC (RCCL needs it)
+        env.pop("TORCHELASTIC_RUN_ID", None)                 # the children rendezvous over dist.TcpRendezvous
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr.fileno()))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # a rank that fails leaves its peers inside a collective that never completes: once one has ended badly
+    # (or rank 0 is through), the rest get a grace period and are then killed -- each by its own handle
+    grace, deadline = 60.0, None
+    while any(p.poll() is None for p in procs):
+        if deadline is None and (procs[0].poll() is not None or any(p.poll() not in (None, 0) for p in procs)):
+            deadline = time.time() + grace
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10.0)
+    out0 = b"".join(chunks)
+    worst = max(codes, key=lambda c: (c != 0, abs(c)))
+    if worst == 0:
+        sys.stdout.write(out0.decode())
+        sys.stdout.flush()
+    else:
+        sys.stderr.write("bench.py: rank exit codes %s; no result line\n%s" % (codes, out0.decode()))
+    return worst if worst >= 0 else 128 - worst
+
+
 def averages(recs):
     per = {}
     for name, ms in recs:
@@ -112,14 +160,29 @@ def main():
                     help="host = rehearsal of the multi-rank flow without RCCL (records cross the host over gloo)")
     ap.add_argument("--shared-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses GPU 0")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch rehearsal without a GPU: start the ranks, run the host collectives, print who came")
     args = ap.parse_args()
 
-    from varsens_amd import _native, dist
-    from varsens_amd.saltelli import seed1_permutation
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))    # before anything that could initialise a GPU in this process
 
+    from varsens_amd import dist
     group = dist.HostGroup()
     if group.world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, group.world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d in the environment" % (args.gpus, group.world))
+    if args.rendezvous_only:
+        group.barrier()
+        who = group.gather_objects({"rank": group.rank, "local_rank": group.local_rank, "pid": os.getpid()})
+        slowest = group.max(float(group.rank))
+        if group.rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": group.world, "backend": group.backend,
+                              "ranks": who, "max_rank": slowest}), flush=True)
+        group.close()
+        return
+
+    from varsens_amd import _native
+    from varsens_amd.saltelli import seed1_permutation
     ctx = _native.Context(0 if args.shared_device else group.local_rank)
     world, rank = group.world, group.rank
     exchange = "none (single GPU)" if world == 1 else "rccl all-reduce (xGMI)"
@@ -137,8 +200,9 @@ def main():
             comm.close()
         comm = dist.HostExchange(ctx, group)
         host_fallback = args.exchange != "host"
-        exchange = ("host exchange over gloo (requested: rehearsal)" if args.exchange == "host" else
-                    "HOST FALLBACK over gloo (RCCL init failed on at least one rank)")
+        exchange = ("host exchange over the %s rendezvous (requested: rehearsal)" % group.backend
+                    if args.exchange == "host" else
+                    "HOST FALLBACK over the %s rendezvous (RCCL init failed on at least one rank)" % group.backend)
 
     k = args.k
     if args.strong:
@@ -361,13 +425,14 @@ def main():
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
             cpu, _ = cpu_baseline(k, blocks, n_small, cores)
             line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
+        # a run that ended on the host fallback is not a scaling number: its line goes to stderr only
+        print(json.dumps(line), flush=True, file=sys.stderr if host_fallback else sys.stdout)
     comm.close()
     ctx.close()
     group.close()
     if host_fallback:
         sys.stderr.write("bench.py: --gpus %d ended on the HOST FALLBACK exchange (RCCL did not initialise); the "
-                         "line above is not a scaling number\n" % world)
+                         "line above (stderr only) is not a scaling number\n" % world)
         sys.exit(3)
 
 

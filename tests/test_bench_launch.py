@@ -1,0 +1,71 @@
+"""`python bench.py --gpus N` without a launcher starts its own ranks (the reference's fan-out
+is the PBS array job of varsens/cluster/accre-submit.sh:27).  CPU side: the spawn / relay / exit-code logic and
+the torch-free rendezvous; the GPU side (two ranks sharing the one card) is in test_gpu_api.py."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def clean_env():
+    env = dict(os.environ)
+    for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+                 "VARSENS_RENDEZVOUS"):
+        env.pop(name, None)
+    return env
+
+
+def test_bench_spawns_its_own_ranks_and_relays_one_line():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--rendezvous-only"], env=clean_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr
+    lines = [x for x in p.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 3 and line["backend"] == "tcp"
+    assert [r["rank"] for r in line["ranks"]] == [0, 1, 2]
+    assert len({r["pid"] for r in line["ranks"]}) == 3 and os.getpid() not in {r["pid"] for r in line["ranks"]}
+
+
+def test_parent_never_loads_the_engine():
+    """The spawning parent must not initialise a GPU: it may not even import the binding."""
+    code = textwrap.dedent("""
+        import sys
+        sys.argv = ["bench.py", "--gpus", "2", "--rendezvous-only"]
+        sys.path.insert(0, %r)
+        import bench
+        try:
+            bench.main()
+        except SystemExit as e:
+            assert e.code == 0, e.code
+        bad = [m for m in sys.modules if m.startswith("varsens_amd") or m == "torch"]
+        assert not bad, bad
+    """) % ROOT
+    p = subprocess.run([sys.executable, "-c", code], env=clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=240)
+    assert p.returncode == 0, p.stderr
+    assert json.loads(p.stdout.strip())["n_gpus"] == 2
+
+
+def test_failed_rank_gives_no_result_line_and_the_worst_status(tmp_path):
+    child = tmp_path / "child.py"
+    child.write_text(textwrap.dedent("""
+        import os, sys
+        rank = int(os.environ["RANK"])
+        assert os.environ["WORLD_SIZE"] == "3" and os.environ["MASTER_ADDR"] == "127.0.0.1"
+        assert os.environ["LOCAL_RANK"] == str(rank) and "TORCHELASTIC_RUN_ID" not in os.environ
+        if rank == 0:
+            print('{"value": 1}', flush=True)
+        sys.exit(3 if rank == 2 else 0)
+    """))
+    code = "import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.spawn_ranks(3, [], script=%r))" \
+        % (ROOT, str(child))
+    p = subprocess.run([sys.executable, "-c", code], env=clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=240)
+    assert p.returncode == 3
+    assert p.stdout.strip() == "", "a failed run must not put a result line on stdout"
+    assert "[0, 0, 3]" in p.stderr

@@ -1,4 +1,5 @@
-"""N>1 host path on CPU: two processes, torch.distributed gloo, world_size 2.
+"""N>1 host path on CPU: two processes, world_size 2, over both rendezvous back ends
+(the torch-free TCP store and torch.distributed gloo).
 
 Covers what runs on the host in a multi-GPU job: the launcher environment -> HostGroup,
 shipping the 128-byte communicator id, barrier / max-over-ranks timing, the row split, and
@@ -13,6 +14,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -24,7 +26,10 @@ WORKER = textwrap.dedent("""
     from oracle import saltelli_oracle as orc
 
     g = dist.HostGroup()
-    assert g.world == 2
+    assert g.world == 2 and g.backend == os.environ["VARSENS_RENDEZVOUS"]
+    if g.backend == "tcp":
+        assert "torch" not in sys.modules, "the tcp rendezvous must not import torch"
+    assert [o["r"] for o in g.gather_objects({"r": g.rank})] == [0, 1]
     uid = bytes(range(128)) if g.rank == 0 else None
     uid = g.broadcast_bytes(uid, src=0)
     assert uid == bytes(range(128))
@@ -84,14 +89,16 @@ def free_port():
     return port
 
 
-def test_two_rank_host_path(tmp_path):
+@pytest.mark.parametrize("backend", ["tcp", "gloo"])
+def test_two_rank_host_path(tmp_path, backend):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VARSENS_RENDEZVOUS=backend)
+        env.pop("TORCHELASTIC_RUN_ID", None)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []

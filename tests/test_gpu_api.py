@@ -486,6 +486,32 @@ def test_two_process_sharded_run_equals_single_process(vs, tmp_path, rows_per_pa
         numpy.testing.assert_allclose(two[f], getattr(one, f), rtol=1e-9, atol=1e-12)
 
 
+def test_bench_launches_its_own_ranks(vs):
+    """`python3 bench.py --gpus 2` with NO launcher (the shape of the driver's N=1 command): the parent starts the
+    two ranks itself over the torch-free rendezvous and relays exactly one result line.  Both ranks share GPU 0
+    and the records cross the host -- RCCL refuses two ranks on one device; the RCCL leg needs >= 2 GPUs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--exchange", "host",
+                        "--shared-device", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [x for x in p.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert len(line["stages_ms_per_rank"]) == 2
+    assert [r["rank"] for r in line["stages_ms_per_rank"]] == [0, 1]
+    assert line["config"]["n_global"] == 2 * line["config"]["n_per_gpu"]
+    assert line["max_abs_err_sens_vs_analytic"] < 1e-4
+    assert "rehearsal" in line["exchange"]
+
+
 def test_sobol_with_opaque_scaling_and_discard(vs):
     from scipy.stats import qmc
     k, n, discard = 5, 32, 7

@@ -6,15 +6,25 @@ contiguous row ranges, one per rank (one process per GPU).  Each rank
 generates, evaluates and reduces its own rows; the only exchange is ONE sum
 all-reduce of the accumulator record over RCCL (vs_comm_allreduce).  The
 reference has no counterpart: its scale-out is PBS array jobs over exported
-text files (varsens/cluster/accre-job.sh:13).
+text files (varsens/cluster/accre-job.sh:13, accre-submit.sh:27).
 
 Process-group plumbing (who am I, shipping the 128-byte RCCL id, barriers and
-max-over-ranks timing) rides on torch.distributed's CPU ``gloo`` group when
-the job was started by ``torch.distributed.run``; nothing on the data path
-touches torch.
+max-over-ranks timing) needs no torch: ``TcpRendezvous`` is a small store on
+MASTER_ADDR:MASTER_PORT kept by rank 0 (every collective is one all-gather of
+pickled values through it).  A job started by ``torch.distributed.run`` finds
+that port taken by the launcher's own store, so there the same plumbing rides
+on torch.distributed's CPU ``gloo`` group.  ``VARSENS_RENDEZVOUS=tcp|gloo``
+overrides the choice (tcp under torchrun listens on MASTER_PORT+1 unless
+``VARSENS_RENDEZVOUS_PORT`` names the port).  Nothing on the data path touches
+either.
 """
 import os
+import pickle
+import socket
+import struct
 import sys
+import threading
+import time
 
 import numpy
 
@@ -34,38 +44,155 @@ def shard_rows(n, world, rank):
     return begin, count
 
 
+def _send_msg(sock, obj):
+    data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    sock.sendall(struct.pack("<Q", len(data)) + data)
+
+
+def _recv_exact(sock, count):
+    chunks = []
+    while count:
+        piece = sock.recv(min(count, 1 << 20))
+        if not piece:
+            raise EOFError("rendezvous peer closed the connection")
+        chunks.append(piece)
+        count -= len(piece)
+    return b"".join(chunks)
+
+
+def _recv_msg(sock):
+    (size,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return pickle.loads(_recv_exact(sock, size))
+
+
+class TcpRendezvous(object):
+    """All-gather of small picklable values over one TCP connection per rank to a store thread on
+    rank 0.  Every rank must take part in every round, in the same order (as with any collective)."""
+
+    def __init__(self, rank, world, addr, port, timeout=300.0):
+        self.rank, self.world = rank, world
+        self._server = None
+        if rank == 0:
+            listener = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            listener.bind((addr, port))
+            listener.listen(world)
+            listener.settimeout(timeout)
+            self._server = threading.Thread(target=self._serve, args=(listener, timeout), daemon=True)
+            self._server.start()
+        deadline = time.time() + timeout
+        while True:
+            try:
+                self._sock = socket.create_connection((addr, port), timeout=5.0)
+                break
+            except OSError:
+                if time.time() > deadline:
+                    raise Exception("rank %d: no rendezvous store at %s:%d after %.0f s" % (rank, addr, port, timeout))
+                time.sleep(0.05)
+        self._sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        self._sock.settimeout(timeout)
+        _send_msg(self._sock, rank)
+
+    def _serve(self, listener, timeout):
+        peers = [None] * self.world
+        try:
+            for _ in range(self.world):
+                conn, _ = listener.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(None)
+                r = _recv_msg(conn)
+                if not (isinstance(r, int) and 0 <= r < self.world and peers[r] is None):
+                    raise Exception("rendezvous: unexpected rank announcement %r" % (r,))
+                peers[r] = conn
+            while True:
+                # a rank that leaves sends no further round: EOFError ends the store
+                values = [_recv_msg(c) for c in peers]
+                for c in peers:
+                    _send_msg(c, values)
+        except (EOFError, OSError):
+            pass
+        finally:
+            listener.close()
+            for c in peers:
+                if c is not None:
+                    c.close()
+
+    def all_gather(self, value):
+        _send_msg(self._sock, value)
+        return _recv_msg(self._sock)
+
+    def close(self):
+        try:
+            self.all_gather(None)       # nobody leaves while a peer still waits for a round
+        except Exception:
+            pass
+        self._sock.close()
+        if self._server is not None:
+            self._server.join(timeout=5.0)
+
+
+def _rendezvous_backend():
+    """'tcp' (no torch) unless torch.distributed.run started the job, whose own store sits on MASTER_PORT."""
+    choice = os.environ.get("VARSENS_RENDEZVOUS", "").strip().lower()
+    if choice in ("tcp", "gloo"):
+        return choice
+    if choice:
+        raise Exception("VARSENS_RENDEZVOUS=%r: expected 'tcp' or 'gloo'" % choice)
+    return "gloo" if "TORCHELASTIC_RUN_ID" in os.environ else "tcp"
+
+
 class HostGroup(object):
     """The CPU side of a multi-process job (rank/world from the launcher's environment)."""
 
-    def __init__(self, backend="gloo"):
+    def __init__(self, backend=None):
         self.rank = int(os.environ.get("RANK", 0))
         self.world = int(os.environ.get("WORLD_SIZE", 1))
         self.local_rank = int(os.environ.get("LOCAL_RANK", self.rank))
+        self.backend = None
         self._dist = None
+        self._tcp = None
         if self.world > 1:
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29500")
-            if not dist.is_initialized():
-                # gloo announces its connections on the C-level stdout; a bench line must stay alone there
+            self.backend = backend or _rendezvous_backend()
+            addr = os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            port = int(os.environ.setdefault("MASTER_PORT", "29500"))
+            if self.backend == "tcp":
+                if "VARSENS_RENDEZVOUS_PORT" in os.environ:
+                    port = int(os.environ["VARSENS_RENDEZVOUS_PORT"])
+                elif "TORCHELASTIC_RUN_ID" in os.environ:
+                    port += 1
+                self._tcp = TcpRendezvous(self.rank, self.world, addr, port)
+                self._tcp.all_gather(None)
+            elif self.backend == "gloo":
+                self._init_gloo()
+            else:
+                raise Exception("unknown rendezvous back end %r" % (self.backend,))
+
+    def _init_gloo(self):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            # gloo announces its connections on the C-level stdout; a bench line must stay alone there
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+                dist.barrier()
+            finally:
                 sys.stdout.flush()
-                saved = os.dup(1)
-                os.dup2(2, 1)
-                try:
-                    dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
-                    dist.barrier()
-                finally:
-                    sys.stdout.flush()
-                    os.dup2(saved, 1)
-                    os.close(saved)
-            self._dist = dist
+                os.dup2(saved, 1)
+                os.close(saved)
+        self._dist = dist
 
     def barrier(self):
-        if self._dist is not None:
+        if self._tcp is not None:
+            self._tcp.all_gather(None)
+        elif self._dist is not None:
             self._dist.barrier()
 
     def broadcast_bytes(self, payload, src=0):
         """Rank `src` passes `payload` (bytes); every rank returns the same bytes."""
+        if self._tcp is not None:
+            return self._tcp.all_gather(payload if self.rank == src else None)[src]
         if self._dist is None:
             return payload
         box = [payload if self.rank == src else None]
@@ -73,6 +200,8 @@ class HostGroup(object):
         return box[0]
 
     def max(self, value):
+        if self._tcp is not None:
+            return max(self._tcp.all_gather(float(value)))
         if self._dist is None:
             return float(value)
         import torch
@@ -82,6 +211,8 @@ class HostGroup(object):
 
     def gather_objects(self, obj):
         """Every rank's `obj` (picklable), in rank order, on every rank."""
+        if self._tcp is not None:
+            return self._tcp.all_gather(obj)
         if self._dist is None:
             return [obj]
         box = [None] * self.world
@@ -92,6 +223,11 @@ class HostGroup(object):
         """Sum a host float64 array over ranks (host-side checks and CPU tests; the GPU data
         path uses RcclComm.allreduce on device memory instead)."""
         a = numpy.ascontiguousarray(array, dtype=numpy.float64)
+        if self._tcp is not None:
+            total = numpy.zeros_like(a)
+            for part in self._tcp.all_gather(a):     # rank order on every rank: the same bits everywhere
+                total += part
+            return total
         if self._dist is None:
             return a.copy()
         import torch
@@ -100,6 +236,9 @@ class HostGroup(object):
         return t.numpy()
 
     def close(self):
+        if self._tcp is not None:
+            self._tcp.close()
+            self._tcp = None
         if self._dist is not None and self._dist.is_initialized():
             self._dist.destroy_process_group()
         self._dist = None
