@@ -160,15 +160,18 @@ typedef struct vs_design_desc {
     const double* upper;   /* host, k entries (LINEAR/POWER) */
     const uint32_t* perm;  /* host: M_2[r] = second_half[perm[r - perm_begin]] for the rows
                               [perm_begin, perm_begin + perm_count) (the seed-1 shuffle, saltelli.py:100-101);
-                              NULL = identity.  perm_count = 0 means all n rows from row 0.  A rank of a
-                              multi-GPU job passes its own shard's slice only; vs_eval then accepts rows of
-                              that slice, and vs_sample_flat needs the whole shuffle. */
+                              NULL = identity.  perm_count = 0 means all n rows from row 0 (n entries are
+                              read); perm_count = VS_PERM_EMPTY means an EMPTY slice (a rank with no rows:
+                              `perm` must be non-NULL and is not read).  A rank of a multi-GPU job passes its
+                              own shard's slice only; vs_eval then accepts rows of that slice, and
+                              vs_sample_flat needs the whole shuffle. */
     const double* raw;     /* host (2n,k) unit-cube points for VS_GEN_RAW
                               (Sample(raw=...), saltelli.py:69-73), uploaded */
     const uint32_t* sobol_directions; /* host (k,32) for VS_GEN_SOBOL, uploaded */
     uint64_t perm_begin;   /* first design row `perm` covers */
-    uint64_t perm_count;   /* entries in `perm` (0: n) */
+    uint64_t perm_count;   /* entries in `perm` (0: n; VS_PERM_EMPTY: none) */
 } vs_design_desc;
+#define VS_PERM_EMPTY UINT64_MAX
 
 /* Host helper (no GPU involved): out[r] = index of the row that numpy.random.seed(1);
  * numpy.random.shuffle(M_2) (saltelli.py:100-101) moves to position r -- MT19937 init_genrand(1),

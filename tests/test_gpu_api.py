@@ -352,6 +352,70 @@ def test_empty_shard(vs):
     ctx.reduce_first_order(o._f, 0, 4, 1, acc, 0, 1, 2)
     rec = ctx.download(acc, (_native.acc_len(4, 1, 2),))
     assert rec[0] == 0 and rec[2] == 1 and not numpy.isnan(rec).any() and numpy.all(rec[4:] == 0)
+    # the same through a sharded Sample: an empty slice of the shuffle crosses the C ABI as VS_PERM_EMPTY
+    # (perm_count = 0 would mean "all n rows" there)
+    s0 = vs.Sample(4, 8, vs.scale.Identity(), verbose=False, shard=(8, 0))
+    o0 = vs.Objective(4, 8, s0, vs.objectives.GFunction([1, 2, 3, 4]), verbose=False, shard=(8, 0))
+    assert o0._rows == 0
+    with pytest.raises(Exception):
+        ctx.eval(s0._design, o._device_objective(), 0, 8, ctx.alloc(8 * 80))   # rows outside the (empty) slice
+
+
+class _OneOfTwo(object):
+    """A communicator stand-in: this process plays rank `rank` of 2 and nothing is exchanged, so the result
+    attributes are partial; the accumulator records of the two ranks are added on the host by the test."""
+    world = 2
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def allreduce(self, buf, count):
+        pass
+
+    def max(self, value):
+        return 10
+
+
+def test_sharded_run_with_a_host_callable(vs):
+    """Varsens(python_callable, scaling, k, n, shard=..., comm=...): a host callable is fed through
+    vs_sample_flat, whose N_j / N_nj rows need M_2 rows from anywhere in the shuffle, so the Sample of such a run
+    keeps the whole shuffle; only the Objective is sharded.  The two ranks' records add up to the whole run's."""
+    from varsens_amd import _native
+    k, n = 5, 20
+    a = numpy.array([0.0, 0.5, 3.0, 9.0, 99.0])
+    f = lambda x: numpy.prod((numpy.abs(4 * x - 2) + a) / (1 + a))
+    whole = vs.Varsens(f, vs.scale.Identity(), k, n, verbose=False, second_order=False)
+    per = _native.acc_per_output(k)
+    total = numpy.zeros(per)
+    for rank, shard in enumerate([(0, 10), (10, 10)]):
+        part = vs.Varsens(f, vs.scale.Identity(), k, n, verbose=False, second_order=False, shard=shard,
+                          comm=_OneOfTwo(rank))
+        assert part.sample._shard is None and part.objective._rows == 10
+        numpy.testing.assert_array_equal(part.objective.fN_j, whole.objective.fN_j[:, shard[0]:shard[0] + 10])
+        numpy.testing.assert_array_equal(part.objective.fM_2, whole.objective.fM_2[shard[0]:shard[0] + 10])
+        total += part.accumulators[4:4 + per]
+    numpy.testing.assert_allclose(total, whole.accumulators[4:4 + per], rtol=1e-13)
+    # a device objective with the same shard does slice the shuffle
+    part = vs.Varsens(vs.objectives.GFunction(a), vs.scale.Identity(), k, n, verbose=False, second_order=False,
+                      shard=(10, 10), comm=_OneOfTwo(1))
+    assert part.sample._shard == (10, 10)
+
+
+def test_sample_attributes_are_materialised_once(vs, monkeypatch):
+    """The reference's idiom is `sample.M_1[i]` inside a loop (varsens/saltelli.py:335-355,
+    tests/test_sample.py:44-54): every attribute costs one launch and one download, however often it is read."""
+    s = vs.Sample(5, 13, vs.scale.Identity(), verbose=False)
+    calls = []
+    real = s._ctx.sample_flat
+    monkeypatch.setattr(s._ctx, "sample_flat", lambda *a: (calls.append(a[1:3]), real(*a))[1])
+    want = orc.build_sample(5, 13)
+    for i in range(13):
+        numpy.testing.assert_array_equal(s.M_1[i], want[0][i])
+        numpy.testing.assert_array_equal(s.M_2[i], want[1][i])
+        for j in range(5):
+            assert s.N_j[j][i][j] == s.M_1[i][j] and s.N_nj[j][i][j] == s.M_2[i][j]
+    assert sorted(calls) == sorted([(0, 13), (13, 13), (26, 65), (91, 65)])
+    assert s.M_1 is s.M_1 and not s.M_1.flags.writeable
 
 
 # ---------------------------------------------------------------- file formats (saltelli.py:173-250, 393-472)
@@ -508,7 +572,7 @@ def test_bench_launches_its_own_ranks(vs):
     assert len(line["stages_ms_per_rank"]) == 2
     assert [r["rank"] for r in line["stages_ms_per_rank"]] == [0, 1]
     assert line["config"]["n_global"] == 2 * line["config"]["n_per_gpu"]
-    assert line["max_abs_err_sens_vs_analytic"] < 1e-4
+    assert line["max_abs_err_sens_vs_analytic"] < 1e-3      # quasi-Monte Carlo error of 2^23 draws in 32 dimensions
     assert "rehearsal" in line["exchange"]
 
 

@@ -116,6 +116,90 @@ def test_eval_gfunction_bit_exact(ctx, k, n, l):
     assert np.max(np.abs(got - strict) / np.abs(strict)) <= 6e-15      # reassociation of <= 256 factors
 
 
+# Halton designs around index 2^32.  The scan kernels keep 32-bit indices and per-column
+# constant digit counts; vs_eval / vs_eval_reduce_first_order must leave them exactly when the LAST index of the
+# design, first_index + 2n - 1, reaches 2^32 (vs_generate.hip design_compact) -- an off-by-one is a silent
+# wrong answer.  discard moves the design (saltelli.py:28-33,83): first_index = 1 + 20k + discard.
+_K32, _N32 = 5, 64
+_EDGE = 2 ** 32 - 2 * _N32 - (1 + 20 * _K32)      # discard with first_index + 2n - 1 == 2^32 - 1
+_DISCARDS_32 = [("last index 2^32-1: the scan kernels' last design", _EDGE, True),
+                ("last index 2^32: first design beyond them", _EDGE + 1, False),
+                ("2^32 inside M_2", _EDGE + 40, False),
+                ("2^32 inside M_1", _EDGE + 100, False),
+                ("all indices above 2^32", _EDGE + 300, False)]
+
+
+@pytest.mark.parametrize("label,discard,compact", _DISCARDS_32, ids=[c[0] for c in _DISCARDS_32])
+@pytest.mark.parametrize("scaled", [False, True], ids=["identity", "linear"])
+def test_designs_around_index_2_pow_32(ctx, label, discard, compact, scaled):
+    from varsens_amd import _native
+    k, n = _K32, _N32
+    first = orc.halton_skip(k, discard)
+    assert (first + 2 * n - 1 < 2 ** 32) == compact
+    lo, hi = np.linspace(-2.0, 1.0, k), np.linspace(3.0, 9.0, k)
+    if scaled:
+        d = make_design(ctx, k, n, _native.SCALE_LINEAR, lo, hi, discard=discard)
+        S = orc.build_sample(k, n, lambda x: orc.scale_linear(x, lo, hi), discard=discard)
+    else:
+        d = make_design(ctx, k, n, discard=discard)
+        S = orc.build_sample(k, n, discard=discard)
+    # vs_sample_flat
+    rows = 2 * n * (k + 1)
+    buf = ctx.alloc(8 * rows * k)
+    ctx.sample_flat(d, 0, rows, buf)
+    same(ctx.download(buf, (rows, k)), orc.flat_sample(*S))
+    # vs_eval: scan order while the design is compact, the strict chain kernels beyond
+    a = np.array([0.0, 0.5, 3.0, 9.0, 99.0])
+    for kind, name, params in ((_native.OBJ_G_FUNCTION, "g_function", a),
+                               (_native.OBJ_LINEAR, "linear", np.arange(1.0, k + 1)),
+                               (_native.OBJ_POLYNOMIAL, "polynomial", 1.0 / (1.0 + np.arange(k) / 8.0))):
+        f, got = eval_dev(ctx, d, kind, k, 1, params, n)
+        same(got, oracle_blocks(orc.evaluate_engine_order(name, params, S[0], S[1], strict=not compact)))
+        # a window of rows (row_begin > 0) takes the same route
+        _, part = eval_dev(ctx, d, kind, k, 1, params, n, begin=7, count=50)
+        same(part, got[:, 7:57])
+        # vs_eval_reduce_first_order: offered exactly while the scan kernels apply, and then equal to the
+        # two-kernel path on the same design
+        obj = ctx.objective_create(kind, k, 1, params)
+        assert ctx.eval_reduce_supported(d, obj) == compact
+        nacc = _native.acc_len(k, 1, 1)
+        acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
+        ctx.reduce_first_order(f, n, k, 1, acc1)
+        r1 = ctx.download(acc1, (nacc,))
+        ex = orc.exact_accumulators(*orc.evaluate_engine_order(name, params, S[0], S[1], strict=not compact))
+        np.testing.assert_allclose(r1[4 + 3:4 + 3 + k], ex["ac"][:, 0], rtol=1e-13)
+        if compact:
+            ctx.eval_reduce_first_order(d, obj, 0, n, acc2)
+            r2 = ctx.download(acc2, (nacc,))
+            np.testing.assert_allclose(r2[4:4 + 3 + 4 * k], r1[4:4 + 3 + 4 * k], rtol=1e-13)
+        else:
+            with pytest.raises(_native.VarsensHipError):
+                ctx.eval_reduce_first_order(d, obj, 0, n, acc2)
+
+
+@pytest.mark.parametrize("label,discard,compact", _DISCARDS_32, ids=[c[0] for c in _DISCARDS_32])
+def test_ishigami_around_index_2_pow_32(ctx, label, discard, compact):
+    """Ishigami has its own thread-per-row kernels (evaluation and fused), offered for every design: they must
+    carry 64-bit Halton indices themselves."""
+    from varsens_amd import _native
+    k, n = 3, _N32
+    discard += 20 * (_K32 - k)                     # same first index as the k = 5 designs above
+    lo, hi = np.full(k, -np.pi), np.full(k, np.pi)
+    d = make_design(ctx, k, n, _native.SCALE_LINEAR, lo, hi, discard=discard)
+    S = orc.build_sample(k, n, lambda x: orc.scale_linear(x, lo, hi), discard=discard)
+    f, got = eval_dev(ctx, d, _native.OBJ_ISHIGAMI, k, 1, [7.0, 0.1], n)
+    want = oracle_blocks(orc.evaluate_rows(lambda X: orc.ishigami_rows(X, 7.0, 0.1), *S))
+    np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-14)          # device sin: a few ulp
+    obj = ctx.objective_create(_native.OBJ_ISHIGAMI, k, 1, [7.0, 0.1])
+    assert ctx.eval_reduce_supported(d, obj)
+    nacc = _native.acc_len(k, 1, 1)
+    acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
+    ctx.reduce_first_order(f, n, k, 1, acc1)
+    ctx.eval_reduce_first_order(d, obj, 0, n, acc2)
+    r1, r2 = ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,))
+    np.testing.assert_allclose(r2[4:4 + 3 + 4 * k], r1[4:4 + 3 + 4 * k], rtol=1e-12, atol=1e-12)
+
+
 @pytest.fixture(scope="module")
 def strict_ctx():
     """A context in strict evaluation order: separable objectives fold left to right (chain kernels), the
@@ -146,12 +230,37 @@ def tuned_context(monkeypatch, **env):
     """A second context on GPU 0 created under measurement knobs (the engine reads them once, at
     vs_context_create)."""
     from varsens_amd import _native
+    monkeypatch.setenv("VS_TUNING", "1")   # the knobs count only under this switch
     for name, value in env.items():
         monkeypatch.setenv(name, str(value))
     c = _native.Context(0)
-    for name in env:
+    for name in list(env) + ["VS_TUNING"]:
         monkeypatch.delenv(name)
     return c
+
+
+def test_tuning_knobs_need_the_switch_and_a_valid_value(ctx, monkeypatch, capfd):
+    """A stray VS_* variable in a user's shell must not change kernels: without VS_TUNING=1 the knobs
+    are ignored, with it a value outside the knob's range keeps the default; both are said on stderr."""
+    from varsens_amd import _native
+    k, n = 12, 4096
+    a = np.linspace(0.1, 9.0, k)
+    _, want = eval_dev(ctx, make_design(ctx, k, n), _native.OBJ_G_FUNCTION, k, 1, a, n)
+    monkeypatch.setenv("VS_EVAL_MODE", "1")          # would select the strict-order kernels
+    monkeypatch.setenv("VS_SCAN_SHAPE", "777")       # not an instantiated shape: would make vs_eval fail
+    c2 = _native.Context(0)
+    _, got = eval_dev(c2, make_design(c2, k, n), _native.OBJ_G_FUNCTION, k, 1, a, n)
+    same(got, want)
+    c2.close()
+    monkeypatch.setenv("VS_TUNING", "1")
+    monkeypatch.setenv("VS_EVAL_MODE", "9")
+    monkeypatch.delenv("VS_SCAN_SHAPE")
+    c3 = _native.Context(0)
+    _, got = eval_dev(c3, make_design(c3, k, n), _native.OBJ_G_FUNCTION, k, 1, a, n)
+    same(got, want)
+    c3.close()
+    err = capfd.readouterr().err
+    assert "VS_EVAL_MODE=9 is outside" in err
 
 
 def test_eval_scratch_tile_path_forced(strict_ctx, monkeypatch):
@@ -445,9 +554,7 @@ def test_wide_staging_agrees_with_the_chunk_kernels(ctx, k, rows, monkeypatch):
     blocks = 2.0 + rng.randn(2 * k + 2, rows, 1)
     host = _native.to_planar(blocks)
     nacc = _native.acc_len(k, 1, 1)
-    monkeypatch.setenv("VS_GRAM_WIDE", "0")
-    narrow = _native.Context(0)
-    monkeypatch.delenv("VS_GRAM_WIDE")
+    narrow = tuned_context(monkeypatch, VS_GRAM_WIDE=0)
     out = []
     for c in (ctx, narrow):
         f = c.upload(host)

@@ -34,10 +34,12 @@ def scan_ctx():
     import os
     from varsens_amd import _native
     os.environ["VS_EVAL_MODE"] = "2"
+    os.environ["VS_TUNING"] = "1"
     try:
         c = _native.Context(0)
     finally:
         del os.environ["VS_EVAL_MODE"]
+        del os.environ["VS_TUNING"]
     yield c
     c.close()
 

@@ -4,6 +4,7 @@ fused evaluate+reduce kernels, for several k.  One context per mode (the knobs a
     python tools/eval_modes.py [log2 of total f-values, default 28]
 """
 import os, sys, time
+os.environ["VS_TUNING"] = "1"   # the engine honours its VS_* measurement knobs only under this switch
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from varsens_amd import _native

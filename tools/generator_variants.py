@@ -1,6 +1,7 @@
 """Evaluation / fused kernels by generator and scaling (the scan kernels' specialised vs general column code):
     python tools/generator_variants.py [K] [LOG2N]"""
 import os, sys
+os.environ["VS_TUNING"] = "1"   # the engine honours its VS_* measurement knobs only under this switch
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from varsens_amd import _native

@@ -1,5 +1,6 @@
 """BASELINE configs[2]: Ishigami, k=3, n=2^22, linear scaling to [-pi, pi]: kernel times."""
 import os, sys
+os.environ["VS_TUNING"] = "1"   # the engine honours its VS_* measurement knobs only under this switch
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from varsens_amd import _native

@@ -3,6 +3,7 @@
     python tools/scan_sweep.py
 """
 import os, sys
+os.environ["VS_TUNING"] = "1"   # the engine honours its VS_* measurement knobs only under this switch
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from varsens_amd import _native

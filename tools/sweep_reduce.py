@@ -1,6 +1,7 @@
 """Sweep the reduction kernel's launch shape (16-byte loads per thread x workgroups per CU).
 The knobs are read when a context is created, so every setting gets its own context."""
 import os, sys
+os.environ["VS_TUNING"] = "1"   # the engine honours its VS_* measurement knobs only under this switch
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from varsens_amd import _native

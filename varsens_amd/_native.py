@@ -16,6 +16,7 @@ ABI_VERSION = 3
 COMM_ID_BYTES = 128
 
 GEN_HALTON, GEN_SOBOL, GEN_RAW = 0, 1, 2
+PERM_EMPTY = (1 << 64) - 1   # VS_PERM_EMPTY: vs_design_desc.perm_count of a rank without rows
 SCALE_IDENTITY, SCALE_LINEAR, SCALE_POWER = 0, 1, 2
 OBJ_G_FUNCTION, OBJ_ISHIGAMI, OBJ_LINEAR, OBJ_POLYNOMIAL, OBJ_INVERT, OBJ_SOURCE = 1, 2, 3, 4, 5, 6
 REDUCE_NAN_TRIM = 1
@@ -371,8 +372,10 @@ class Context(object):
         desc.perm = ptr(perm, np.uint32)
         if perm is not None:
             count = keep[-1].size
-            if keep[-1].ndim != 1 or perm_begin < 0 or perm_begin + count > n or (perm_begin == 0 and count == 0):
+            if keep[-1].ndim != 1 or perm_begin < 0 or perm_begin + count > n:
                 raise VarsensHipError("perm must hold the shuffle entries of rows [perm_begin, perm_begin+len) of n")
+            if count == 0:      # an empty shard: 0 would mean "all n rows" to the C ABI
+                desc.perm, count = ptr(np.zeros(1, np.uint32), np.uint32), PERM_EMPTY
             desc.perm_begin, desc.perm_count = int(perm_begin), int(count)
         desc.raw = ptr(raw, np.float64, (2 * n, k))
         desc.sobol_directions = ptr(sobol_directions, np.uint32, (k, 32))

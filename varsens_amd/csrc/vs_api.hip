@@ -57,26 +57,50 @@ extern "C" int vs_context_create(int device, vs_context** out) {
         return vs_fail(VS_ERR_HIP, "hipStreamCreate failed");
     }
     ctx->stream = ctx->streams[0];
-    {   // the only place the environment is read
-        auto env_long = [](const char* name, long dflt) {
+    {   // the only place the environment is read.  The knobs are measurement tooling (tools/, a few tests): they
+        // count only under VS_TUNING=1, so that a stray VS_* variable in a user's shell cannot change kernels, and
+        // a value outside a knob's range keeps the default (both said once on stderr)
+        const char* gate = getenv("VS_TUNING");
+        const bool tuning = gate && strtol(gate, nullptr, 0) == 1;
+        bool ignored = false;
+        auto knob = [&](const char* name, long dflt, long lo, long hi) {
             const char* v = getenv(name);
-            return v && *v ? strtol(v, nullptr, 0) : dflt;
+            if (!v || !*v) return dflt;
+            if (!tuning) {
+                ignored = true;
+                return dflt;
+            }
+            char* end = nullptr;
+            const long x = strtol(v, &end, 0);
+            if (end == v || *end || x < lo || x > hi) {
+                fprintf(stderr, "libvarsens_hip: %s=%s is outside [%ld, %ld]; keeping %ld\n", name, v, lo, hi, dflt);
+                return dflt;
+            }
+            return x;
         };
         vs_tuning& t = ctx->tune;
-        t.reduce_nv = (int)env_long("VS_REDUCE_NV", t.reduce_nv);
-        t.reduce_wgs_per_cu = (int)env_long("VS_REDUCE_WGS_PER_CU", t.reduce_wgs_per_cu);
-        t.eval_scratch = (int)env_long("VS_EVAL_SCRATCH", t.eval_scratch);
-        t.eval_waves = (int)env_long("VS_EVAL_WAVES_PER_WG", t.eval_waves);
-        t.eval_mode = (int)env_long("VS_EVAL_MODE", t.eval_mode);
-        t.fused_wgs_per_cu = (int)env_long("VS_FUSED_WGS_PER_CU", t.fused_wgs_per_cu);
-        t.fused_variant = (int)env_long("VS_FUSED_VARIANT", t.fused_variant);
-        t.scan_shape = (int)env_long("VS_SCAN_SHAPE", t.scan_shape);
-        t.scan_general = (int)env_long("VS_SCAN_GENERAL", t.scan_general);
-        t.gram_wgs_per_cu = (int)env_long("VS_GRAM_WGS_PER_CU", t.gram_wgs_per_cu);
-        t.gram_wide = (int)env_long("VS_GRAM_WIDE", t.gram_wide);
-        t.gram_st = (int)env_long("VS_GRAM_ST", t.gram_st);
-        t.reduce_both = (int)env_long("VS_REDUCE_BOTH", t.reduce_both);
-        t.profile_mask = env_long("VS_PROFILE_MASK", t.profile_mask);
+        t.reduce_nv = (int)knob("VS_REDUCE_NV", t.reduce_nv, 2, 8);
+        if (t.reduce_nv != 2 && t.reduce_nv != 4 && t.reduce_nv != 8) t.reduce_nv = 4;
+        t.reduce_wgs_per_cu = (int)knob("VS_REDUCE_WGS_PER_CU", t.reduce_wgs_per_cu, 1, 8);
+        t.eval_scratch = (int)knob("VS_EVAL_SCRATCH", t.eval_scratch, 0, 1);
+        t.eval_waves = (int)knob("VS_EVAL_WAVES_PER_WG", t.eval_waves, 0, 8);
+        if (t.eval_waves != 0 && t.eval_waves != 4 && t.eval_waves != 8) t.eval_waves = 0;
+        t.eval_mode = (int)knob("VS_EVAL_MODE", t.eval_mode, 0, 2);
+        t.fused_wgs_per_cu = (int)knob("VS_FUSED_WGS_PER_CU", t.fused_wgs_per_cu, 0, 8);
+        // shapes are L*100+W; one that is not instantiated makes the launch fail with VS_ERR_ARG naming the knob
+        t.fused_variant = (int)knob("VS_FUSED_VARIANT", t.fused_variant, 0, 3216);
+        t.scan_shape = (int)knob("VS_SCAN_SHAPE", t.scan_shape, 0, 3216);
+        t.scan_general = (int)knob("VS_SCAN_GENERAL", t.scan_general, 0, 1);
+        t.gram_wgs_per_cu = (int)knob("VS_GRAM_WGS_PER_CU", t.gram_wgs_per_cu, 0, 8);
+        t.gram_wide = (int)knob("VS_GRAM_WIDE", t.gram_wide, 0, 1);
+        t.gram_st = (int)knob("VS_GRAM_ST", t.gram_st, 0, 1);
+        t.reduce_both = (int)knob("VS_REDUCE_BOTH", t.reduce_both, 0, 1);
+        t.profile_mask = knob("VS_PROFILE_MASK", t.profile_mask, -1, 0x7fffffffL);
+        static bool told = false;
+        if (ignored && !told) {
+            told = true;
+            fprintf(stderr, "libvarsens_hip: VS_* tuning variables are set but VS_TUNING=1 is not: ignored\n");
+        }
     }
     for (int i = 0; i < 8; ++i)
         if (hipEventCreateWithFlags(&ctx->events[i], hipEventDisableTiming) != hipSuccess) {
@@ -213,7 +237,9 @@ __global__ void __launch_bounds__(256) accumulate_kernel(double* __restrict__ ds
 extern "C" int vs_accumulate(vs_context* ctx, double* dst_dev, const double* src_dev, size_t count) {
     VS_REQUIRE(ctx && (count == 0 || (dst_dev && src_dev)), "null argument");
     if (!count) return VS_OK;
+    VS_HIP(hipSetDevice(ctx->device));
     const size_t blocks = (count + 255) / 256;
+    vs_launch_scope scope(ctx, VS_KERNEL_FOLD);
     hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, ctx->stream,
                        dst_dev, src_dev, count);
     VS_HIP(hipGetLastError());

@@ -220,7 +220,9 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
         VS_REQUIRE(desc->first_index + 2 * n <= (1ull << 32), "Sobol indices must stay below 2^32");
     }
     // the shuffle may be given for a slice of rows only (a rank's shard): perm_count entries from row perm_begin
-    const uint64_t perm_count = desc->perm ? (desc->perm_count ? desc->perm_count : n) : 0;
+    const uint64_t perm_count = !desc->perm ? 0
+                                : desc->perm_count == VS_PERM_EMPTY ? 0   // a rank without rows: nothing is read
+                                : desc->perm_count ? desc->perm_count : n;
     if (desc->perm) {
         VS_REQUIRE(desc->perm_begin <= n && perm_count <= n - desc->perm_begin,
                    "perm slice [%llu,+%llu) exceeds n=%llu", (unsigned long long)desc->perm_begin,

@@ -110,6 +110,7 @@ class Sample(object):
         self.scaling = scaling
         self.verbose = verbose
         self._host = {}       # name -> host array, for samples loaded from a flat file
+        self._cache = {}      # attribute name -> materialised (read-only) host array; a design never changes
         self._design = None
         k, n = self.k, self.n
 
@@ -140,7 +141,7 @@ class Sample(object):
         perm_begin = 0
         if self._shard is not None:
             perm_begin, count = _shard_rows(n, self._shard)
-            perm = perm[perm_begin:perm_begin + count] if count else None
+            perm = perm[perm_begin:perm_begin + count]
 
         if generator == 'halton':
             gen, first = _native.GEN_HALTON, 1 + 20 * k + int(discard)   # saltelli.py:83: skip 20k + discard
@@ -189,21 +190,32 @@ class Sample(object):
         buf.free()
         return out
 
+    def _attribute(self, name, begin, count, shape):
+        """One launch and one download per attribute, however often it is read: the reference's own idiom is
+        ``sample.M_1[i]`` inside a loop (varsens/saltelli.py:335-355, tests/test_sample.py:44-54).  The array is
+        handed out read-only -- the design lives on the GPU, writing into a host copy could not change it."""
+        out = self._cache.get(name)
+        if out is None:
+            out = self._rows(begin, count).reshape(shape)
+            out.setflags(write=False)
+            self._cache[name] = out
+        return out
+
     @property
     def M_1(self):
-        return self._rows(0, self.n)
+        return self._attribute('M_1', 0, self.n, (self.n, self.k))
 
     @property
     def M_2(self):
-        return self._rows(self.n, self.n)
+        return self._attribute('M_2', self.n, self.n, (self.n, self.k))
 
     @property
     def N_j(self):
-        return self._rows(2 * self.n, self.k * self.n).reshape(self.k, self.n, self.k)
+        return self._attribute('N_j', 2 * self.n, self.k * self.n, (self.k, self.n, self.k))
 
     @property
     def N_nj(self):
-        return self._rows((2 + self.k) * self.n, self.k * self.n).reshape(self.k, self.n, self.k)
+        return self._attribute('N_nj', (2 + self.k) * self.n, self.k * self.n, (self.k, self.n, self.k))
 
     def generate_N_j(self, M_1, M_2):
         """k copies of M_2, copy i carrying column i of M_1 (varsens/saltelli.py:112-125).
@@ -518,7 +530,9 @@ class Varsens(object):
             self.k = k
             self.n = n
             kw = dict(context=ctx) if ctx is not None else {}
-            if shard is not None:
+            if shard is not None and isinstance(objective, _objectives.DeviceObjective):
+                # the rank's kernels need only its own entries of the shuffle; a host callable is fed through
+                # vs_sample_flat, whose N_j / N_nj rows read M_2 rows anywhere in the shuffle: whole design
                 kw['shard'] = shard
             self.sample = Sample(k, n, scaling_func, verbose=verbose, **kw)
         elif not isinstance(objective, Objective):
@@ -532,6 +546,7 @@ class Varsens(object):
             kw = dict(shard=shard) if shard is not None else {}
             if vectorized:
                 kw['vectorized'] = True
+            self._max_rows = _shard_rows(int(self.n), shard)[1]
             self._stream_rows = self._streaming_rows(objective, shard, ctx)
             if self._fused_candidate(objective) or self._stream_rows:
                 kw['lazy'] = True   # the values are only produced if somebody asks for them
@@ -542,6 +557,7 @@ class Varsens(object):
         self.compute_varsens()
 
     _stream_rows = 0
+    _max_rows = 0
 
     def _max_rows_over_ranks(self, rows):
         """The largest shard of the job: every streaming decision is taken from it, so that all ranks
@@ -557,13 +573,21 @@ class Varsens(object):
     def _streaming_rows(self, objective, shard, ctx):
         """Draws per pass when the f-values are to be streamed through HBM in row ranges, else 0.
         Rank-invariant: computed from the largest shard over the ranks."""
-        if not isinstance(objective, _objectives.DeviceObjective) or self._rows_per_pass in (None, 0, False):
+        if not isinstance(objective, _objectives.DeviceObjective):
             return 0
         k = int(self.k)
         rows = self._max_rows_over_ranks(_shard_rows(int(self.n), shard)[1])
         self._max_rows = rows
-        hbm = None if self._rows_per_pass != 'auto' else (ctx or self.sample._ctx).info()['hbm_bytes']
-        return stream_rows_per_pass(self._rows_per_pass, rows, 8 * 2 * (k + 1) * int(objective.outputs(k)), hbm)
+        hbm = (ctx or self.sample._ctx).info()['hbm_bytes']
+        per_row = 8 * 2 * (k + 1) * int(objective.outputs(k))
+        stream = stream_rows_per_pass(self._rows_per_pass, rows, per_row, hbm)
+        if not stream and per_row * rows > 0.9 * hbm and not self._fused_candidate(objective):
+            # rows_per_pass = 0 / None, or a count >= the largest shard, mean "resident": say so before a
+            # hipMalloc of 2n(k+1) values fails
+            raise Exception("rows_per_pass=%r keeps all %d draws of the largest shard resident: %.1f GB of objective "
+                            "values do not fit the %.1f GB of this GPU; pass rows_per_pass='auto' or a smaller count"
+                            % (self._rows_per_pass, rows, per_row * rows / 1e9, hbm / 1e9))
+        return stream
 
     def _fused_candidate(self, objective):
         """First order only and a device objective: the engine is asked whether its fused
@@ -654,7 +678,7 @@ class Varsens(object):
         world = self._comm.world if self._comm is not None else 1
         rank = self._comm.rank if self._comm is not None else 0
         R = int(rows_per_pass)
-        passes = stream_passes(getattr(self, '_max_rows', obj._rows), R)   # the same on every rank
+        passes = stream_passes(self._max_rows, R)   # from the largest shard: the same on every rank
         if passes * R < obj._rows:
             raise Exception("streamed passes (%d x %d rows) do not cover this rank's %d rows" % (passes, R, obj._rows))
         slots = passes * world
