@@ -1,0 +1,33 @@
+// Shared by the translation units of the second-order pass (vs_second.hip, vs_gram_st.hip).
+#pragma once
+
+#include "vs_common.h"
+
+#define VS2_SUPER 64                 // index rows per super-block (4 MFMA blocks of 16)
+#define VS2_CHUNK 64                 // sample rows a workgroup of four waves takes per visit (4 x VS2_WCHUNK)
+#define VS2_TILE_OUT (VS2_SUPER * VS2_SUPER)
+#define VS2_WCHUNK 16                // sample rows of one LDS sub-tile
+#define VS2_WPITCH 20                // doubles per tile row: 16 sample rows + 4 of padding (conflict-free b128 fragments)
+#define VS2_MACRO 128                // index rows per macro block
+#define VS2_MTILE_OUT (VS2_MACRO * VS2_MACRO)
+
+typedef double vs_d2 __attribute__((ext_vector_type(2)));
+typedef double vs_d4 __attribute__((ext_vector_type(4)));
+
+enum { CNT_NANFLAG = 0 };
+
+struct vs_gram_args {
+    const double* f;
+    uint64_t rows;
+    int k, l, K;
+    int nsuper;          // ceil(2K / 64)
+    uint32_t slab_wgs;   // grid.x
+    double* partials;    // [slab_wgs][npairs][64][64]
+    double* first_partials;  // combined pass only: [slab_wgs][VS_PLEN(k)] first-order records
+    const uint8_t* keep;
+    const uint32_t* counters;
+};
+
+// vs_gram_st.hip: the S/T kernel for 65 .. 128 index rows per half (one output, even row count, no mask)
+int vs_gram_st128_prepare(vs_context* ctx);
+int vs_gram_st128_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, unsigned workgroups);

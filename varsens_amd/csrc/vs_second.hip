@@ -29,27 +29,7 @@
 // v_fma_f64 share it (tools/mfma_valu_overlap.hip).  What HBM delivers depends on the shape of the wave-wide
 // loads (tools/load_patterns.hip): 8 x 128-byte runs per instruction cap it at 4.9 TB/s, 4 x 256-byte runs
 // reach 6.7 -- hence the 32-sample-row staging.  Reported separately from the first-order pass.
-#include "vs_common.h"
-
-#define VS2_SUPER 64                 // index rows per super-block (4 MFMA blocks of 16)
-#define VS2_CHUNK 64                 // sample rows a workgroup of four waves takes per visit (4 x VS2_WCHUNK)
-#define VS2_TILE_OUT (VS2_SUPER * VS2_SUPER)
-
-typedef double vs_d4 __attribute__((ext_vector_type(4)));
-
-enum { CNT_NANFLAG = 0 };
-
-struct vs_gram_args {
-    const double* f;
-    uint64_t rows;
-    int k, l, K;
-    int nsuper;          // ceil(2K / 64)
-    uint32_t slab_wgs;   // grid.x
-    double* partials;    // [slab_wgs][npairs][64][64]
-    double* first_partials;  // combined pass only: [slab_wgs][VS_PLEN(k)] first-order records
-    const uint8_t* keep;
-    const uint32_t* counters;
-};
+#include "vs_second.h"
 
 __device__ __forceinline__ void pair_from_index(int p, int ntile, int& I, int& J) {
     // pairs 0..ntile-1 are the diagonal (I,I); then I < J row by row
@@ -134,9 +114,6 @@ __device__ __forceinline__ void gram_first_record(const vs_gram_args& A, double*
 //   MFMA:   4 k-steps x the needed tiles (S x T tiles are skipped); A and B fragments come from the same
 //           lane->sample map, and a sum over sample rows does not care in which order they are contracted.
 // The next chunk's global loads are in flight while the MFMAs of the current one run.
-#define VS2_WCHUNK 16
-#define VS2_WPITCH 20
-typedef double vs_d2 __attribute__((ext_vector_type(2)));
 
 //
 // FIRST (vs_reduce_first_second_order; l == 1, no mask): the first-order sums of reduce_first_kernel ride
@@ -585,8 +562,6 @@ gram_diag_wide_kernel(vs_gram_args A) {
 // are needed (wave-uniform skip; two workgroups share a CU, so the shorter waves leave the pipe to others).
 // LDS tile [256 index rows][16 sample rows], pitch 20 doubles, lane -> sample map and ds_read_b128 fragments
 // exactly as in gram_diag_wave_kernel.
-#define VS2_MACRO 128
-#define VS2_MTILE_OUT (VS2_MACRO * VS2_MACRO)
 
 //
 // FIRST (vs_reduce_first_second_order; one output, no mask): the first-order sums of reduce_first_kernel ride
@@ -1507,6 +1482,8 @@ static int gram_raise_lds_limits(vs_context* ctx) {
                                (int)(sizeof(double) * VS2_WIDE_LDS(NBV, FI))));
     VS2_WIDE_INSTANCES(VS2_SET_WIDE)
 #undef VS2_SET_WIDE
+    int rc_st = vs_gram_st128_prepare(ctx);
+    if (rc_st) return rc_st;
     ctx->gram_lds_raised = true;
     return VS_OK;
 }
@@ -1531,7 +1508,13 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     // the first-order dot products); odd row counts: 33 .. 48 the S/T kernel above, 49 .. 64 the [C; D] kernel
     const bool half_st = macro && K <= VS2_HALF && rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0 &&
                          ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
-    const bool macro_st = macro && !half_st && K <= VS2_MACRO && !(K > 48 && K <= 64) && !with_first && ctx->tune.gram_st != 0;
+    // 65 .. 128 rows per half, one output, even row count: gram_st128_kernel (vs_gram_st.hip) takes the unmasked pass
+    // (one workgroup per CU; with_first: it carries the first-order dot products); the masked pass and the other
+    // shapes of this range stay on gram_macro_st_kernel
+    const bool st128 = macro && K > VS2_HALF && K <= VS2_MACRO && l == 1 && rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0 &&
+                       ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
+    const bool macro_st = macro && !half_st && K <= VS2_MACRO && !(K > 48 && K <= 64) && (!with_first || st128) &&
+                          ctx->tune.gram_st != 0;
     const int SB = half_st ? VS2_HALF : macro ? VS2_MACRO : VS2_SUPER;
     const int nsuper = (macro_st || half_st) ? 1 : (2 * K + SB - 1) / SB;
     const int npairs = (macro_st || half_st) ? 2 : nsuper * (nsuper + 1) / 2;
@@ -1552,6 +1535,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     if (want < 1) want = 1;
     const uint64_t units = macro ? (nchunks + 3) / 4 : nchunks;   // the macro kernel walks groups of 4 chunks
     const uint32_t slab_wgs = (uint32_t)(units < want ? units : want);
+    const uint32_t st128_wgs = (uint32_t)(units < (uint64_t)cus ? units : (uint64_t)cus);   // one per CU (160 KiB of LDS)
     // the wide wave-private kernel (32 sample rows per unit, two workgroups per CU) takes the unmasked pass of
     // one-output problems with 33..64 index rows
     const bool wide = !macro && l == 1 && aligned && nb_wave >= 3 && ctx->tune.gram_wide != 0;
@@ -1562,7 +1546,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const size_t width = (size_t)npairs * tile_out;
     // workspace: [with_first: first-order records of the diagonal workgroups + folded record,] then the Gram partials
     const size_t plen = VS_PLEN(k);
-    const uint32_t pslots = half_st ? 2 * slab_wgs : slab_wgs;   // partials (and first-order records) per pair
+    const uint32_t pslots = half_st ? 2 * slab_wgs : (st128 && with_first) ? st128_wgs : slab_wgs;   // partials (and first-order records) per pair
     const uint32_t P_diag = with_first ? pslots * (uint32_t)nsuper : 0;                         // macro kernels' records
     const uint32_t P_head = with_first ? (uint32_t)((rows + 4095) / 4096 < (uint64_t)cus ? (rows + 4095) / 4096 : cus) : 0;
     const uint32_t P_first = P_diag + P_head;                                                   // + first_head_kernel's
@@ -1607,6 +1591,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const bool mwide = macro && l == 1 && aligned && ctx->tune.gram_wide != 0;   // two chunks per fetch, 256-byte runs
     rc = gram_raise_lds_limits(ctx);
     if (rc) return rc;
+    VS_REQUIRE(!(with_first && macro_st) || st128, "no one-pass kernel for this shape");
     if ((flags & VS_REDUCE_NAN_TRIM) && rows > 0) {
         const uint64_t count = 2 * rows;  // blocks 0 and 1 of output 0 are contiguous
         const uint64_t want_blocks = (count + 255) / 256;
@@ -1637,7 +1622,12 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
                 else if (with_first) hipLaunchKernelGGL((gram_half_st_kernel<false, true, true>), g, t, lds_m, ctx->stream, A);
                 else if (l == 1) hipLaunchKernelGGL((gram_half_st_kernel<false, false, true>), g, t, lds_m, ctx->stream, A);
                 else hipLaunchKernelGGL((gram_half_st_kernel<false, false, false>), g, t, lds_m, ctx->stream, A);
+            } else if (macro_st && st128 && !masked) {
+                A.slab_wgs = F.P = st128_wgs;
+                rc = vs_gram_st128_launch(ctx, A, with_first, st128_wgs);
+                if (rc) return rc;
             } else if (macro_st) {
+                A.slab_wgs = F.P = slab_wgs;
                 const dim3 grid(slab_wgs, 1);
                 if (masked && mwide) hipLaunchKernelGGL((gram_macro_st_kernel<true, true, true>), grid, dim3(512), lds_m, ctx->stream, A);
                 else if (masked && aligned) hipLaunchKernelGGL((gram_macro_st_kernel<true, true, false>), grid, dim3(512), lds_m, ctx->stream, A);
@@ -1737,7 +1727,10 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     // k = 128, n = 2^24: the one-pass [C; D] form took 22.4; riding on the nine-tile S/T kernel spills in its loop)
     const bool even = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
     const bool half_route = 2 * k > VS2_SUPER && k <= VS2_HALF && even && ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
-    if (one_pass && (k > VS2_MACRO || half_route || (k > 48 && k <= 64) || (2 * k > VS2_SUPER && ctx->tune.gram_st == 0)) &&
+    // 65 .. 128 columns, even row count: gram_st128_kernel carries them too (two waves per SIMD, 256 VGPRs)
+    const bool st128_route = k > VS2_HALF && k <= VS2_MACRO && even && ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
+    if (one_pass && (k > VS2_MACRO || half_route || st128_route || (k > 48 && k <= 64) ||
+                     (2 * k > VS2_SUPER && ctx->tune.gram_st == 0)) &&
         (uint64_t)k <= 4096)
         return second_order_impl(ctx, f_dev, rows, k, 1, 0, gram_dev, true, rank, max_ranks, acc_dev);
     const bool combined = one_pass && 2 * k <= VS2_SUPER;
