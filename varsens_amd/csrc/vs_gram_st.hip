@@ -32,18 +32,18 @@ constexpr int STAGE = 2 * SUB;                    // doubles per stage: 32 sampl
 constexpr int ST_ROWS = 2 * VS2_WCHUNK;           // sample rows per stage
 constexpr size_t ST_LDS_BYTES = sizeof(double) * 2 * STAGE;   // two stages: 163 840 B
 
-template <int W, bool FULLK, bool FIRST>
+template <int W, int NBL, bool FULLK, bool FIRST>
 __device__ __forceinline__ void st128_body(const vs_gram_args& A, double* tiles) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int K = A.K;
-    const int nbl = FULLK ? 8 : (K + 15) / 16;   // live 16-row blocks per half
+    static_assert(!FULLK || NBL == 8, "FULLK means K == 128");
+    constexpr int nbl = NBL;                     // live 16-row blocks per half = (K + 15) / 16: a compile-time fact
     const uint64_t rows = A.rows;
     constexpr int TR = 7 - W;                    // block row of T T^T
 
     // staging: thread t holds sample rows 2p, 2p+1 (p = t & 15) of the stage for c_u and d_u, u = (t >> 4) + 32 j
     const int lrow = tid >> 4, piece = tid & 15;
-    const double* gc = A.f + (uint64_t)(2 + lrow) * rows + 2 * piece;   // c_u, j = 0; plane of c_u is 2 + u, of d_u 2 + K + u
     const uint64_t jstep = 32 * rows, dstep = (uint64_t)K * rows;
     double* wr = tiles + (piece >> 3) * SUB + lrow * VS2_WPITCH + 2 * (piece & 7);   // + 32 j rows: s; + 128 rows: t
     const double* rd = tiles + (lane & 15) * VS2_WPITCH + 2 * (lane >> 4);           // + 16 blk rows (+ 128: t)
@@ -57,12 +57,9 @@ __device__ __forceinline__ void st128_body(const vs_gram_args& A, double* tiles)
     const uint64_t ngroups = (nst + 1) / 2;
     uint64_t mine = 0;
     for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) mine += (2 * g + 2 <= nst) ? 2 : nst - 2 * g;
-    auto stage_of = [&](uint64_t i) { return 2 * (blockIdx.x + (i / 2) * gridDim.x) + (i & 1); };
-
     vs_d2 raw[8];
     // FIRST: threads 0..15 stage a (plane 0), 16..31 b (plane 1)
     const bool abth = FIRST && tid < 32;
-    const double* abp = A.f + (tid >= 16 ? rows : 0) + 2 * (tid & 15);
     vs_d2 rawab = (vs_d2){0.0, 0.0};
     double pas = 0.0, pbs = 0.0, pat = 0.0, pbt = 0.0;
 
@@ -70,11 +67,19 @@ __device__ __forceinline__ void st128_body(const vs_gram_args& A, double* tiles)
         const uint64_t s0 = st * ST_ROWS;
         // rows is even and a thread's two sample rows start at an even index: both are inside or both outside
         const bool in_rows = s0 + 2 * piece < rows;
-        if (FIRST && abth) rawab = in_rows ? __builtin_nontemporal_load((const vs_d2*)(abp + s0)) : (vs_d2){0.0, 0.0};
+        // the eight addresses are rebuilt from the thread's row at every fetch (a handful of integer instructions)
+        // instead of living in sixteen registers between fetches
+        int lr = lrow;
+        asm volatile("" : "+v"(lr));   // not loop-invariant as far as the compiler can tell
+        if (FIRST && abth) {
+            const double* qab = A.f + (lr >= 1 ? rows : 0) + 2 * piece + s0;   // tid < 32: lr = tid >> 4 is 0 (a) or 1 (b)
+            rawab = in_rows ? __builtin_nontemporal_load((const vs_d2*)qab) : (vs_d2){0.0, 0.0};
+        }
+        const double* q0 = A.f + (uint64_t)(2 + lr) * rows + 2 * piece + s0;   // c_u, u = lr; plane of c_u is 2 + u, of d_u 2 + K + u
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const bool in = (FULLK || lrow + 32 * (j & 3) < K) && in_rows;   // rows past K are zeros in the tile
-            const double* q = gc + (j & 3) * jstep + (j >= 4 ? dstep : 0) + s0;
+            const bool in = (FULLK || lr + 32 * (j & 3) < K) && in_rows;   // rows past K are zeros in the tile
+            const double* q = q0 + (j & 3) * jstep + (j >= 4 ? dstep : 0);
             raw[j] = in ? __builtin_nontemporal_load((const vs_d2*)q) : (vs_d2){0.0, 0.0};
         }
     };
@@ -89,48 +94,68 @@ __device__ __forceinline__ void st128_body(const vs_gram_args& A, double* tiles)
         if (FIRST && abth)
             *(vs_d2*)(tiles + b * STAGE + ((tid & 15) >> 3) * SUB + (tid & 7) * VS2_WPITCH + 16 + 2 * (tid >> 4)) = rawab;
     };
-    // the 36 MFMAs of one sub-tile; every address is a compile-time offset from `base`
-    auto subtile = [&](int off) {   // off: the sub-tile's first double in `tiles`
+    // A sub-tile's nine tiles go in three groups of three slots; the fragments of a group are read into
+    // registers one group ahead of its MFMAs (explicit software pipeline, pinned with sched_barrier: the
+    // compiler cannot move LDS reads across the LDS writes of `stash`, so left alone the reads of the second
+    // sub-tile queue behind the eight ds_write_b128 of every wave -- measured: 0.2 ms of 2.6 at n = 2^22).
+    // Every address is a compile-time offset from `rd + off`.
+    struct frags {
+        vs_d2 as0, as1, at0, at1;
+        vs_d2 b0[3], b1[3];
+    };
+    auto slot_live = [&](int sl) {
+        const bool ss = sl < 8 - W;
+        const int blk = ss ? W + sl : sl - 1;
+        return FULLK || ((ss ? W : TR) < nbl && blk < nbl);
+    };
+    auto load_group = [&](int off, int lo, int hi, frags& F) {
         const double* base = rd + off;
-        const vs_d2 as0 = *(const vs_d2*)(base + 16 * W * VS2_WPITCH);
-        const vs_d2 as1 = *(const vs_d2*)(base + 16 * W * VS2_WPITCH + 8);
-        const vs_d2 at0 = *(const vs_d2*)(base + (VS2_MACRO + 16 * TR) * VS2_WPITCH);
-        const vs_d2 at1 = *(const vs_d2*)(base + (VS2_MACRO + 16 * TR) * VS2_WPITCH + 8);
-        if (FIRST) {
-            // a, a, b, b of the sample rows 2q, 2q+1 (row q) and 8+2q, 8+2q+1 (row 4+q) of the lane group q = lane >> 4
-            const double* rdab = tiles + off + (lane >> 4) * VS2_WPITCH + 16;
-            const vs_d4 ab0 = *(const vs_d4*)rdab;
-            const vs_d4 ab1 = *(const vs_d4*)(rdab + 4 * VS2_WPITCH);
-            pas = fma(ab0[0], as0[0], pas);
-            pbs = fma(ab0[2], as0[0], pbs);
-            pas = fma(ab0[1], as0[1], pas);
-            pbs = fma(ab0[3], as0[1], pbs);
-            pas = fma(ab1[0], as1[0], pas);
-            pbs = fma(ab1[2], as1[0], pbs);
-            pas = fma(ab1[1], as1[1], pas);
-            pbs = fma(ab1[3], as1[1], pbs);
-            pat = fma(ab0[0], at0[0], pat);
-            pbt = fma(ab0[2], at0[0], pbt);
-            pat = fma(ab0[1], at0[1], pat);
-            pbt = fma(ab0[3], at0[1], pbt);
-            pat = fma(ab1[0], at1[0], pat);
-            pbt = fma(ab1[2], at1[0], pbt);
-            pat = fma(ab1[1], at1[1], pat);
-            pbt = fma(ab1[3], at1[1], pbt);
+        bool need_s = false, need_t = false;   // slots below 8 - W are S S^T tiles (folds at compile time)
+#pragma unroll
+        for (int sl = lo; sl < hi; ++sl) {
+            need_s |= slot_live(sl) && sl < 8 - W;
+            need_t |= slot_live(sl) && sl >= 8 - W;
+        }
+        if (FIRST) {   // the first-order sums take the S fragments with slot 0's group, the T fragments with slot 8's
+            need_s |= lo == 0 && W < nbl;
+            need_t |= hi == 9 && TR < nbl;
+        }
+        if (need_s) {
+            F.as0 = *(const vs_d2*)(base + 16 * W * VS2_WPITCH);
+            F.as1 = *(const vs_d2*)(base + 16 * W * VS2_WPITCH + 8);
+        }
+        if (need_t) {
+            F.at0 = *(const vs_d2*)(base + (VS2_MACRO + 16 * TR) * VS2_WPITCH);
+            F.at1 = *(const vs_d2*)(base + (VS2_MACRO + 16 * TR) * VS2_WPITCH + 8);
         }
 #pragma unroll
-        for (int sl = 0; sl < 9; ++sl) {
-            const bool ss = sl < 8 - W;                  // S S^T tile (W, W + sl), else T T^T tile (TR, sl - 1)
+        for (int sl = lo; sl < hi; ++sl) {
+            const bool ss = sl < 8 - W;
             const int blk = ss ? W + sl : sl - 1;        // block of the other operand
-            const bool live = FULLK || ((ss ? W : TR) < nbl && blk < nbl);
-            if (live) {
-                const vs_d2 a0 = ss ? as0 : at0, a1 = ss ? as1 : at1;
-                vs_d2 f0 = a0, f1 = a1;                  // diagonal tile: both operands are the A fragments
-                if (blk != (ss ? W : TR)) {
-                    const double* rb = base + ((ss ? 0 : VS2_MACRO) + 16 * blk) * VS2_WPITCH;
-                    f0 = *(const vs_d2*)rb;
-                    f1 = *(const vs_d2*)(rb + 8);
-                }
+            if (slot_live(sl) && blk != (ss ? W : TR)) {  // the diagonal tiles take the A fragments twice
+                const double* rb = base + ((ss ? 0 : VS2_MACRO) + 16 * blk) * VS2_WPITCH;
+                F.b0[sl - lo] = *(const vs_d2*)rb;
+                F.b1[sl - lo] = *(const vs_d2*)(rb + 8);
+            }
+        }
+    };
+    // FIRST: a, a, b, b of the sample rows 2q, 2q+1 (tile row q) and 8+2q, 8+2q+1 (row 4+q) of the lane group
+    // q = lane >> 4, read with the fragments of the group before
+    vs_d4 ab0 = (vs_d4){0.0, 0.0, 0.0, 0.0}, ab1 = ab0;
+    auto load_ab = [&](int off) {
+        const double* rdab = tiles + off + (lane >> 4) * VS2_WPITCH + 16;
+        ab0 = *(const vs_d4*)rdab;
+        ab1 = *(const vs_d4*)(rdab + 4 * VS2_WPITCH);
+    };
+    auto mfma_group = [&](int lo, int hi, const frags& F) {
+#pragma unroll
+        for (int sl = lo; sl < hi; ++sl) {
+            const bool ss = sl < 8 - W;                  // S S^T tile (W, W + sl), else T T^T tile (TR, sl - 1)
+            const int blk = ss ? W + sl : sl - 1;
+            if (slot_live(sl)) {
+                const vs_d2 a0 = ss ? F.as0 : F.at0, a1 = ss ? F.as1 : F.at1;
+                const bool diag = blk == (ss ? W : TR);
+                const vs_d2 f0 = diag ? a0 : F.b0[sl - lo], f1 = diag ? a1 : F.b1[sl - lo];
                 acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], f0[0], acc[sl], 0, 0, 0);
                 acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], f0[1], acc[sl], 0, 0, 0);
                 acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], f1[0], acc[sl], 0, 0, 0);
@@ -138,6 +163,36 @@ __device__ __forceinline__ void st128_body(const vs_gram_args& A, double* tiles)
             }
         }
     };
+    // FIRST: the sub-tile's a, b against the wave's two A fragments (one group of every sub-tile holds each)
+    auto first_sums = [&](int lo, int hi, const frags& F) {
+        if (lo == 0 && W < nbl) {        // the group with slot 0 holds the S fragments; block rows past nbl are zeros
+            pas = fma(ab0[0], F.as0[0], pas);
+            pbs = fma(ab0[2], F.as0[0], pbs);
+            pas = fma(ab0[1], F.as0[1], pas);
+            pbs = fma(ab0[3], F.as0[1], pbs);
+            pas = fma(ab1[0], F.as1[0], pas);
+            pbs = fma(ab1[2], F.as1[0], pbs);
+            pas = fma(ab1[1], F.as1[1], pas);
+            pbs = fma(ab1[3], F.as1[1], pbs);
+        }
+        if (hi == 9 && TR < nbl) {       // the group with slot 8 holds the T fragments
+            pat = fma(ab0[0], F.at0[0], pat);
+            pbt = fma(ab0[2], F.at0[0], pbt);
+            pat = fma(ab0[1], F.at0[1], pat);
+            pbt = fma(ab0[3], F.at0[1], pbt);
+            pat = fma(ab1[0], F.at1[0], pat);
+            pbt = fma(ab1[2], F.at1[0], pbt);
+            pat = fma(ab1[1], F.at1[1], pat);
+            pbt = fma(ab1[3], F.at1[1], pbt);
+        }
+    };
+#define ST_PIN() __builtin_amdgcn_sched_barrier(0)
+
+    // gridDim.x as an opaque scalar: left to itself the compiler re-reads it from the dispatch packet inside the loop
+    // (s_load + s_waitcnt lgkmcnt(0), which also waits for every LDS write of the stash in front of it)
+    uint32_t G = A.slab_wgs;
+    asm volatile("" : "+s"(G));
+    auto stage_of = [&](uint64_t i) { return 2 * (blockIdx.x + (i / 2) * (uint64_t)G) + (i & 1); };
 
     if (mine > 0) {
         fetch(stage_of(0));
@@ -145,16 +200,36 @@ __device__ __forceinline__ void st128_body(const vs_gram_args& A, double* tiles)
         if (mine > 1) fetch(stage_of(1));
     }
     __syncthreads();
+    // groups 0..5 of a stage: sub-tile g / 3, slots 3 (g % 3) .. 3 (g % 3) + 2; group g lives in F[g & 1]
+    frags F[2];
+    if (mine > 0) load_group(0, 0, 3, F[0]);
     for (uint64_t i = 0; i < mine; ++i) {
         const int b = (int)(i & 1);
-        subtile(b * STAGE);
-        // the next stage goes into the other buffer (everybody left it at the last barrier); its registers are
-        // then free for the fetch after it, which has the rest of this iteration and half of the next to land
-        if (i + 1 < mine) stash(b ^ 1);
-        if (i + 2 < mine) fetch(stage_of(i + 2));
-        subtile(b * STAGE + SUB);
-        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const int lo = 3 * (g % 3), off = b * STAGE + (g / 3) * SUB;
+            if (g + 1 < 6) {
+                load_group(b * STAGE + ((g + 1) / 3) * SUB, 3 * ((g + 1) % 3), 3 * ((g + 1) % 3) + 3, F[(g + 1) & 1]);
+            } else {
+                // every LDS read of this stage has been issued (group 5 sits in F[1]); the barrier -- it waits for
+                // them -- frees the buffer for the stash of the next iteration and publishes the other one, whose
+                // first group is read here: barrier and read latency hide behind the twelve MFMAs of group 5
+                __syncthreads();
+                if (i + 1 < mine) load_group((b ^ 1) * STAGE, 0, 3, F[0]);
+            }
+            if (FIRST && g % 3 == 0) load_ab(off);      // used with this group (S fragments) and the third (T)
+            ST_PIN();
+            mfma_group(lo, lo + 3, F[g & 1]);
+            if (FIRST) first_sums(lo, lo + 3, F[g & 1]);
+            ST_PIN();
+            // the next stage goes into the other buffer (everybody left it at the last barrier) while both waves
+            // of the SIMD have MFMAs queued; its registers are then free for the fetch after it, which has the
+            // rest of this iteration and a third of the next to land
+            if (g == 1 && i + 1 < mine) stash(b ^ 1);
+            if (g == 3 && i + 2 < mine) fetch(stage_of(i + 2));
+        }
     }
+#undef ST_PIN
 
     if (FIRST) {
         // the four lane groups of a wave hold the same index rows over different samples
@@ -209,7 +284,7 @@ __device__ __forceinline__ void st128_body(const vs_gram_args& A, double* tiles)
     }
 }
 
-template <bool FULLK, bool FIRST>
+template <int NBL, bool FULLK, bool FIRST>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gram_st128_kernel(vs_gram_args A) {
     extern __shared__ double tiles[];   // [2 stages][2 sub-tiles][256 tile rows][VS2_WPITCH]
@@ -224,28 +299,30 @@ gram_st128_kernel(vs_gram_args A) {
     }
     // one body per wave index: the s_barrier count is the same in all of them
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-        case 0: st128_body<0, FULLK, FIRST>(A, tiles); break;
-        case 1: st128_body<1, FULLK, FIRST>(A, tiles); break;
-        case 2: st128_body<2, FULLK, FIRST>(A, tiles); break;
-        case 3: st128_body<3, FULLK, FIRST>(A, tiles); break;
-        case 4: st128_body<4, FULLK, FIRST>(A, tiles); break;
-        case 5: st128_body<5, FULLK, FIRST>(A, tiles); break;
-        case 6: st128_body<6, FULLK, FIRST>(A, tiles); break;
-        default: st128_body<7, FULLK, FIRST>(A, tiles); break;
+        case 0: st128_body<0, NBL, FULLK, FIRST>(A, tiles); break;
+        case 1: st128_body<1, NBL, FULLK, FIRST>(A, tiles); break;
+        case 2: st128_body<2, NBL, FULLK, FIRST>(A, tiles); break;
+        case 3: st128_body<3, NBL, FULLK, FIRST>(A, tiles); break;
+        case 4: st128_body<4, NBL, FULLK, FIRST>(A, tiles); break;
+        case 5: st128_body<5, NBL, FULLK, FIRST>(A, tiles); break;
+        case 6: st128_body<6, NBL, FULLK, FIRST>(A, tiles); break;
+        default: st128_body<7, NBL, FULLK, FIRST>(A, tiles); break;
     }
 }
 
 }  // namespace
 
+// (NBL, FULLK) instances: 5 .. 8 live blocks per half; K == 128 also drops the row-below-K tests
+#define VS_ST_INSTANCES(X) X(5, false) X(6, false) X(7, false) X(8, false) X(8, true)
+
 int vs_gram_st128_prepare(vs_context* ctx) {
     (void)ctx;
-#define VS_ST_SET(FK, FI)                                                                        \
-    VS_HIP(hipFuncSetAttribute((const void*)gram_st128_kernel<FK, FI>,                           \
+#define VS_ST_SET(NB, FK)                                                                                      \
+    VS_HIP(hipFuncSetAttribute((const void*)gram_st128_kernel<NB, FK, false>,                                  \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_LDS_BYTES));                \
+    VS_HIP(hipFuncSetAttribute((const void*)gram_st128_kernel<NB, FK, true>,                                   \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_LDS_BYTES));
-    VS_ST_SET(false, false)
-    VS_ST_SET(false, true)
-    VS_ST_SET(true, false)
-    VS_ST_SET(true, true)
+    VS_ST_INSTANCES(VS_ST_SET)
 #undef VS_ST_SET
     return VS_OK;
 }
@@ -253,11 +330,18 @@ int vs_gram_st128_prepare(vs_context* ctx) {
 // A.K in 65..128, A.l == 1, A.rows even, A.f 16-byte aligned (the caller checks); `workgroups` <= CUs
 int vs_gram_st128_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, unsigned workgroups) {
     const dim3 grid(workgroups), block(512);
+    const int nbl = (A.K + 15) / 16;
     const bool full = A.K == VS2_MACRO;
-    if (full && with_first) hipLaunchKernelGGL((gram_st128_kernel<true, true>), grid, block, ST_LDS_BYTES, ctx->stream, A);
-    else if (full) hipLaunchKernelGGL((gram_st128_kernel<true, false>), grid, block, ST_LDS_BYTES, ctx->stream, A);
-    else if (with_first) hipLaunchKernelGGL((gram_st128_kernel<false, true>), grid, block, ST_LDS_BYTES, ctx->stream, A);
-    else hipLaunchKernelGGL((gram_st128_kernel<false, false>), grid, block, ST_LDS_BYTES, ctx->stream, A);
+    VS_REQUIRE(nbl >= 5 && nbl <= 8 && A.l == 1, "gram_st128_kernel takes 65 .. 128 index rows of one output");
+    bool launched = false;
+#define VS_ST_LAUNCH(NB, FK)                                                                                   \
+    if (!launched && nbl == NB && full == FK) {                                                                \
+        if (with_first) hipLaunchKernelGGL((gram_st128_kernel<NB, FK, true>), grid, block, ST_LDS_BYTES, ctx->stream, A);  \
+        else hipLaunchKernelGGL((gram_st128_kernel<NB, FK, false>), grid, block, ST_LDS_BYTES, ctx->stream, A);           \
+        launched = true;                                                                                       \
+    }
+    VS_ST_INSTANCES(VS_ST_LAUNCH)
+#undef VS_ST_LAUNCH
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
