@@ -28,6 +28,6 @@ struct vs_gram_args {
     const uint32_t* counters;
 };
 
-// vs_gram_st.hip: the S/T kernel for 65 .. 128 index rows per half (one output, even row count, no mask)
-int vs_gram_st128_prepare(vs_context* ctx);
-int vs_gram_st128_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, unsigned workgroups);
+// vs_gram_st.hip: the S/T kernel for 33 .. 128 index rows per half (one output, even row count, no mask)
+int vs_gram_st_prepare(vs_context* ctx);
+int vs_gram_st_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, unsigned workgroups);

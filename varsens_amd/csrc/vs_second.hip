@@ -1482,7 +1482,7 @@ static int gram_raise_lds_limits(vs_context* ctx) {
                                (int)(sizeof(double) * VS2_WIDE_LDS(NBV, FI))));
     VS2_WIDE_INSTANCES(VS2_SET_WIDE)
 #undef VS2_SET_WIDE
-    int rc_st = vs_gram_st128_prepare(ctx);
+    int rc_st = vs_gram_st_prepare(ctx);
     if (rc_st) return rc_st;
     ctx->gram_lds_raised = true;
     return VS_OK;
@@ -1508,9 +1508,9 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     // the first-order dot products); odd row counts: 33 .. 48 the S/T kernel above, 49 .. 64 the [C; D] kernel
     const bool half_st = macro && K <= VS2_HALF && rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0 &&
                          ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
-    // 65 .. 128 rows per half, one output, even row count: gram_st128_kernel (vs_gram_st.hip) takes the unmasked pass
+    // 33 .. 128 rows per half, one output, even row count: gram_st_kernel (vs_gram_st.hip) takes the unmasked pass
     // (one workgroup per CU; with_first: it carries the first-order dot products); the masked pass and the other
-    // shapes of this range stay on gram_macro_st_kernel
+    // shapes of this range stay on gram_macro_st_kernel / gram_half_st_kernel
     const bool st128 = macro && K > VS2_HALF && K <= VS2_MACRO && l == 1 && rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0 &&
                        ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
     const bool macro_st = macro && !half_st && K <= VS2_MACRO && !(K > 48 && K <= 64) && (!with_first || st128) &&
@@ -1535,7 +1535,8 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     if (want < 1) want = 1;
     const uint64_t units = macro ? (nchunks + 3) / 4 : nchunks;   // the macro kernel walks groups of 4 chunks
     const uint32_t slab_wgs = (uint32_t)(units < want ? units : want);
-    const uint32_t st128_wgs = (uint32_t)(units < (uint64_t)cus ? units : (uint64_t)cus);   // one per CU (160 KiB of LDS)
+    const bool st_new = st128 || (half_st && l == 1);   // the unmasked pass runs on gram_st_kernel
+    const uint32_t st_wgs = (uint32_t)(units < (uint64_t)cus ? units : (uint64_t)cus);   // one per CU (160 KiB of LDS)
     // the wide wave-private kernel (32 sample rows per unit, two workgroups per CU) takes the unmasked pass of
     // one-output problems with 33..64 index rows
     const bool wide = !macro && l == 1 && aligned && nb_wave >= 3 && ctx->tune.gram_wide != 0;
@@ -1546,13 +1547,15 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const size_t width = (size_t)npairs * tile_out;
     // workspace: [with_first: first-order records of the diagonal workgroups + folded record,] then the Gram partials
     const size_t plen = VS_PLEN(k);
-    const uint32_t pslots = half_st ? 2 * slab_wgs : (st128 && with_first) ? st128_wgs : slab_wgs;   // partials (and first-order records) per pair
+    const uint32_t pslots_old = half_st ? 2 * slab_wgs : slab_wgs;   // partials per pair: the older kernels (masked pass)
+    const uint32_t pslots_new = half_st ? 2 * st_wgs : st_wgs;        //   gram_st_kernel
+    const uint32_t pslots = (st_new && with_first) ? pslots_new : pslots_old;   // first-order records per pair
     const uint32_t P_diag = with_first ? pslots * (uint32_t)nsuper : 0;                         // macro kernels' records
     const uint32_t P_head = with_first ? (uint32_t)((rows + 4095) / 4096 < (uint64_t)cus ? (rows + 4095) / 4096 : cus) : 0;
     const uint32_t P_first = P_diag + P_head;                                                   // + first_head_kernel's
     size_t first_doubles = with_first ? (size_t)P_first * plen + plen : 0;
     first_doubles = (first_doubles + 1) & ~(size_t)1;
-    const uint32_t max_wgs = wide && wide_wgs > pslots ? wide_wgs : pslots;
+    const uint32_t max_wgs = wide && wide_wgs > pslots_old ? wide_wgs : pslots_old;
     // ... and DC, DD, CC (3 K^2) behind them, for gram_convert_kernel
     const size_t cd_doubles = 3 * (size_t)K * K;
     int rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + (size_t)max_wgs * width + cd_doubles));
@@ -1613,9 +1616,14 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
         }
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
-            if (half_st) {
+            if (half_st && st_new && !masked) {
+                A.slab_wgs = st_wgs;
+                F.P = pslots_new;
+                rc = vs_gram_st_launch(ctx, A, with_first, st_wgs);
+                if (rc) return rc;
+            } else if (half_st) {
                 A.slab_wgs = slab_wgs;
-                F.P = pslots;
+                F.P = pslots_old;
                 const dim3 g(slab_wgs), t(512);
                 if (masked && l == 1) hipLaunchKernelGGL((gram_half_st_kernel<true, false, true>), g, t, lds_m, ctx->stream, A);
                 else if (masked) hipLaunchKernelGGL((gram_half_st_kernel<true, false, false>), g, t, lds_m, ctx->stream, A);
@@ -1623,8 +1631,8 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
                 else if (l == 1) hipLaunchKernelGGL((gram_half_st_kernel<false, false, true>), g, t, lds_m, ctx->stream, A);
                 else hipLaunchKernelGGL((gram_half_st_kernel<false, false, false>), g, t, lds_m, ctx->stream, A);
             } else if (macro_st && st128 && !masked) {
-                A.slab_wgs = F.P = st128_wgs;
-                rc = vs_gram_st128_launch(ctx, A, with_first, st128_wgs);
+                A.slab_wgs = F.P = st_wgs;
+                rc = vs_gram_st_launch(ctx, A, with_first, st_wgs);
                 if (rc) return rc;
             } else if (macro_st) {
                 A.slab_wgs = F.P = slab_wgs;
@@ -1727,7 +1735,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     // k = 128, n = 2^24: the one-pass [C; D] form took 22.4; riding on the nine-tile S/T kernel spills in its loop)
     const bool even = rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0;
     const bool half_route = 2 * k > VS2_SUPER && k <= VS2_HALF && even && ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
-    // 65 .. 128 columns, even row count: gram_st128_kernel carries them too (two waves per SIMD, 256 VGPRs)
+    // 65 .. 128 columns, even row count: gram_st_kernel carries them too (two waves per SIMD, 256 VGPRs)
     const bool st128_route = k > VS2_HALF && k <= VS2_MACRO && even && ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
     if (one_pass && (k > VS2_MACRO || half_route || st128_route || (k > 48 && k <= 64) ||
                      (2 * k > VS2_SUPER && ctx->tune.gram_st == 0)) &&
