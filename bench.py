@@ -61,10 +61,23 @@ def pmc_traffic(prefix, k, log2n):
     return (2.0 * c["FETCH_SIZE_avg_per_launch"] + c.get("WRITE_SIZE_avg_per_launch", 0.0)) * 1024.0
 
 
+def blas_threads():
+    """Threads numpy's BLAS will use for the tensordot leg (threadpoolctl if importable, else the affinity mask)."""
+    try:
+        from threadpoolctl import threadpool_info
+        n = [p.get("num_threads") for p in threadpool_info() if p.get("user_api") == "blas"]
+        if n:
+            return int(max(n))
+    except Exception:
+        pass
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
 def cpu_baseline(k, f_small, n_small, cores):
     """Reference CPU path, restated (oracle = numpy port), timed on this host.
     (a) reference-style evaluation: one Python call per sample row (saltelli.py:329-355);
-    (b) compute_varsens with the reference's numpy formulas (saltelli.py:572-622)."""
+    (b) compute_varsens with the reference's numpy formulas (saltelli.py:572-609), single-threaded by construction;
+    (c) the second-order leg, four numpy.tensordot calls (saltelli.py:612-619), on numpy's default BLAS threads."""
     from oracle import saltelli_oracle as orc
     c = np.arange(1, k + 1, dtype=float)
     n_eval = 32768 if n_small > (1 << 16) else 4096   # ~2 M reference-style calls: a second or two
@@ -77,6 +90,12 @@ def cpu_baseline(k, f_small, n_small, cores):
     t0 = time.perf_counter()
     R = orc.compute_varsens(blocks[0], blocks[1], blocks[2:2 + k], blocks[2 + k:], n_small, second_order=False)
     t_red = time.perf_counter() - t0
+    # (c) the whole of compute_varsens with second order, as Varsens(...) runs it by default; the tensordot part is the
+    # difference to (b)
+    t0 = time.perf_counter()
+    R2 = orc.compute_varsens(blocks[0], blocks[1], blocks[2:2 + k], blocks[2 + k:], n_small, second_order=True)
+    t_both = time.perf_counter() - t0
+    threads = blas_threads()
     samples = 2 * n_small * (k + 1)
     per_sample = t_eval / evals + t_red / samples
     return {
@@ -87,7 +106,12 @@ def cpu_baseline(k, f_small, n_small, cores):
                   "single-threaded as in the reference" % (evals, k, n_eval, k, n_small),
         "eval_loop_evals_per_s": evals / t_eval, "eval_loop_threads": 1,
         "reduce_only_gsamples_per_s": samples / t_red / 1e9,
-    }, R
+        "second_order": {
+            "compute_varsens_with_second_order_s": t_both, "tensordot_leg_s": max(t_both - t_red, 0.0),
+            "gsamples_per_s": samples / t_both / 1e9, "blas_threads": threads, "cores": threads,
+            "sample": "oracle compute_varsens(second_order=True) on the same k=%d n=%d f-values: first order as above "
+                      "plus four numpy.tensordot calls on %d BLAS thread(s)" % (k, n_small, threads)},
+    }, R2
 
 
 def spawn_ranks(world, argv=None, script=None):
@@ -319,6 +343,34 @@ def main():
                              so_steps, 2, profile=True)
     avg_bo = averages(recs_bo)
 
+    # what Varsens(objective, scaling, k, n) runs by DEFAULT (second_order=True): evaluation + both reductions in one
+    # call + both finishing kernels, f-values rotating as in the headline leg; beside `value`, never instead of it
+    s2, s2n = ctx.alloc(8 * k * l * k * l), ctx.alloc(8 * k * l * k * l)
+    first_bo = ctx.alloc(8 * _native.first_order_len(k, l))
+
+    def api_default_step():
+        i = counter[0]
+        counter[0] += 1
+        ctx.stream_select(0)
+        ctx.eval(design, objective, begin, rows, fbuf[i % F_BUFFERS])
+        ctx.reduce_first_second_order(fbuf[(i - 1) % F_BUFFERS], rows, k, l, acc_bo, gram, 0, rank, world)
+        ctx.finish_first_order(acc_bo, n, k, l, first_bo, world)
+        ctx.finish_second_order(gram, first_bo, n, k, l, s2, s2n)
+        return first_bo
+
+    t_api = recs_api = None
+    if world == 1:   # the N > 1 form of this call adds the one all-reduce of record + Gram sums (saltelli.py: _finish)
+        t_api, recs_api, _ = timed(api_default_step, so_steps, 2, profile=True)
+    # a linear fill of one f-value buffer, timed in this run: what the chip's store path takes for the same bytes
+    # without any arithmetic (hipMemsetAsync)
+    ctx.memset(fbuf[0], 0)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.memset(fbuf[0], 0)
+    ctx.sync()
+    fill_gbs = 5 * 8.0 * N_local / (time.perf_counter() - t0) / 1e9
+
     # analytic check of the finished indices (linear objective: S_i = c_i^2 / sum c^2)
     c = np.arange(1, k + 1, dtype=float)
     truth = c * c / np.sum(c * c)
@@ -341,7 +393,7 @@ def main():
         if K2 <= 32:
             nb = (2 * K2 + 15) // 16
             tiles = sum(1 for bi in range(nb) for bj in range(bi, nb) if not (16 * (bi + 1) <= K2 and 16 * bj >= K2))
-        elif K2 <= 128 and not 48 < K2 <= 64:
+        elif K2 <= 128:   # gram_st_kernel (even row count: every bench shape)
             nbl = (K2 + 15) // 16
             tiles = nbl * (nbl + 1)
         else:   # [C; D] Gram matrix, 128-row macro blocks
@@ -389,14 +441,17 @@ def main():
                          "avg_launch_ms": avg["reduce_first"],
                          "input_last_written": "one step earlier (3 rotating buffers): not an Infinity-Cache number"},
             "roofline_eval": {"kernel": "scan_kernel (Halton -> scale -> column swap -> evaluate, 8 B written per evaluation)",
-                              "bound": "hbm", "achieved": eval_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              # co-limited: the vector pipe is busy 0.87 of the launch (Halton digit loops) while the
+                              # stores run at 0.75 of the HBM peak; neither alone is the roof
+                              "bound": "valu+store", "achieved": eval_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": eval_gbs / HBM_PEAK_GBS,
                               "traffic": (eval_pmc.get("WRITE_SIZE_avg_per_launch") or 0) * 1024.0 or None,
                               "algorithmic_bytes_per_launch": 8 * N_local, "avg_launch_ms": avg["eval"],
-                              "write_stream_ceiling_gbs": 5600.0,
-                              "frac_of_write_ceiling": eval_gbs / 5600.0,
+                              "linear_fill_gbs_this_run": fill_gbs,
                               "valu_busy_frac": eval_pmc.get("valu_busy_frac"),
-                              "note": "store-only kernel of the same shape sustains 5.6 TB/s (tools/write_bw.hip)"},
+                              "note": "linear_fill = hipMemsetAsync over one f-value buffer, timed in this run (host "
+                                      "clock around 5 fills): the store path without arithmetic; valu_busy_frac from "
+                                      "the committed counter passes"},
             "roofline_second_order": None if not so_ms else {
                 "kernel": "gram_diag_wide_kernel (sens_2 / sens_2n from S S^T and T T^T, S = C + D, T = C - D; "
                           "v_mfma_f64_16x16x4_f64)",
@@ -413,6 +468,14 @@ def main():
                         "k = 32 instead of the 10 of the [C; D] Gram matrix, which was matrix-pipe-bound at 0.44 ms "
                         "(49 TFLOP/s of 78.6); the S/T form is bound by the HBM stream"},
         }
+        if t_api is not None:
+            line["api_default"] = {
+                "value": N_total / (t_api / so_steps) / 1e9, "unit": "GSamples/s", "ms_per_pass": 1e3 * t_api / so_steps,
+                "kernels_ms": averages(recs_api),
+                "note": "Varsens(objective, scaling, k, n) with its default second_order=True: vs_eval + "
+                        "vs_reduce_first_second_order + vs_finish_first_order + vs_finish_second_order per pass "
+                        "(sens, sens_t, sens_2, sens_2n), f-values rotating; the headline `value` is the first-order "
+                        "pass north_star names"}
         line["both_orders_one_call"] = {
             "ms_per_call": 1e3 * t_bo / so_steps, "kernels_ms": avg_bo,
             "note": "vs_reduce_first_second_order on the same f-values: the first-order dot products ride on the "

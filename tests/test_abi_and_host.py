@@ -165,6 +165,11 @@ def test_bench_cpu_baseline_leg():
         assert key in cpu
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["unit"] == "GSamples/s" and cpu["value"] > 0
     assert R["sens"].shape == (k, 1)
+    # the second-order leg (four tensordots, saltelli.py:612-619) on numpy's default BLAS threads, count stated
+    so = cpu["second_order"]
+    assert so["blas_threads"] >= 1 and so["cores"] == so["blas_threads"] and so["gsamples_per_s"] > 0
+    assert so["compute_varsens_with_second_order_s"] >= so["tensordot_leg_s"] >= 0
+    assert R["sens_2"].shape == (k, 1, k, 1) and cpu["host_cores_available"] == 8
     assert bench.pmc_traffic("void reduce_first_kernel", 32, 22) is None or bench.pmc_traffic("void reduce_first_kernel", 32, 22) > 2.2e9
 
 
