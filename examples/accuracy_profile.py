@@ -18,22 +18,36 @@ with some a_i < 1, whose true Monte Carlo error dominates.)
 
     python examples/accuracy_profile.py --k 6 --b 30
     python examples/accuracy_profile.py --k 24 --b 30 --nmax 1310720     # far beyond the reference's 20480
+    python examples/accuracy_profile.py --all --b 30 --out profiles/r03  # dims 6, 24, 48, 96, 192 beside the published CSVs
 
 Every model is evaluated and reduced on the device (fused evaluate+reduce kernel); the design is built
-once per n, as in the reference.
+once per n, as in the reference.  Per model the device's numbers equal the reference arithmetic's on the
+same model to 1e-10 (tests/test_gpu_api.py::test_accuracy_profile_errors_equal_the_oracles); what differs
+from the published files is WHICH models were drawn (the reference used Python's global `random`, unseeded).
 """
 import argparse
+import json
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import varsens_amd as vs  # noqa: E402
 
 # mean column of varsens/profile/error-profile-dim6.csv (n -> published mean), for side-by-side reading
 PUBLISHED_DIM6 = {5: 5.982e-2, 10: 1.538e-2, 20: 3.314e-3, 40: 6.941e-4, 80: 1.580e-4, 160: 3.999e-5, 320: 1.230e-5,
                   640: 2.431e-6, 1280: 7.431e-7, 2560: 1.517e-7, 5120: 3.862e-8, 10240: 9.736e-9, 20480: 2.410e-9}
+
+
+def published(k):
+    """{n: (mean, sd, lci, uci, max)} of varsens/profile/error-profile-dim<k>.csv (fixture: numbers only), or {}."""
+    path = os.path.join(ROOT, "tests", "golden", "published_error_profiles.json")
+    if not os.path.isfile(path):
+        return {}
+    rows = json.load(open(path))["dims"].get(str(k), [])
+    return {int(r[0]): tuple(r[1:]) for r in rows}
 
 
 def g_truth(a):
@@ -57,24 +71,47 @@ def profile_row(k, n, b, rng):
     return n, mu, sd, mu - half, mu + half, errs.max(), float(np.median(errs)), float(np.median(errs)) / k
 
 
+def model_error(k, a, sample):
+    """sum_i (V_i - S_i var_y)^2 of one model on the device (varsens/profile/parameters.py:51-76)."""
+    v = vs.Varsens(vs.objectives.GFunction(a), sample=sample, verbose=False, second_order=False)
+    estimate = v.sens[:, 0] * v.var_y[0]
+    return float(np.sum((g_truth(a) - estimate) ** 2)), estimate
+
+
+def run_dim(k, b, nmax, seed, out=None):
+    rng = np.random.RandomState(seed)
+    pub = published(k)
+    lines = ["# k=%d b=%d seed=%d; device: n, mean, sd, lci, uci, max, median, median/k | published "
+             "(varsens/profile/error-profile-dim%d.csv): mean, sd, max | 1/n^2" % (k, b, seed, k)]
+    n = 5
+    while n <= nmax:
+        row = profile_row(k, n, b, rng)
+        line = "%d,%.6e,%.6e,%.6e,%.6e,%.6e,%.6e,%.6e" % row
+        if n in pub:
+            line += " | %.6e,%.6e,%.6e" % (pub[n][0], pub[n][1], pub[n][4])
+        line += " | %.6e" % (1.0 / n ** 2)
+        lines.append(line)
+        print(line, flush=True)
+        n *= 2
+    if out:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "accuracy_profile_k%d_b%d.csv" % (k, b)), "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--k", type=int, default=6)
     ap.add_argument("--b", type=int, default=30)
     ap.add_argument("--nmax", type=int, default=20480)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--all", action="store_true", help="the five published dimensionalities 6, 24, 48, 96, 192")
+    ap.add_argument("--out", default=None, help="directory for accuracy_profile_k<k>_b<b>.csv")
     args = ap.parse_args()
-    rng = np.random.RandomState(args.seed)
-    n = 5
-    print("# k=%d b=%d  columns: n, mean, sd, lci, uci, max, median, median/k%s" %
-          (args.k, args.b, "   [published dim6 mean; 1/n^2]" if args.k == 6 else ""))
-    while n <= args.nmax:
-        row = profile_row(args.k, n, args.b, rng)
-        extra = ""
-        if args.k == 6 and n in PUBLISHED_DIM6:
-            extra = "   [%.3e; %.3e]" % (PUBLISHED_DIM6[n], 1.0 / n ** 2)
-        print("%d,%.6e,%.6e,%.6e,%.6e,%.6e,%.6e,%.6e%s" % (row + (extra,)), flush=True)
-        n *= 2
+    for k in ((6, 24, 48, 96, 192) if args.all else (args.k,)):
+        print("# k=%d b=%d  columns: n, mean, sd, lci, uci, max, median, median/k | published mean, sd, max | 1/n^2" %
+              (k, args.b))
+        run_dim(k, args.b, args.nmax, args.seed, args.out)
 
 
 if __name__ == "__main__":

@@ -342,6 +342,35 @@ def test_accuracy_profile_reproduces_the_published_curve(vs):
         assert abs(row[6] * (n - 1.0) ** 2 / 6.0 - 1.0) < 0.10           # median = k/(n-1)^2
 
 
+def test_accuracy_profile_errors_equal_the_oracles(vs):
+    """f4 as a parity row: for the SAME random models the device's per-model numbers -- S_i var_y and the error
+    sum_i (V_i - S_i var_y)^2 of varsens/profile/parameters.py:51-76 -- equal the reference arithmetic's (oracle:
+    row-by-row g-function, numpy compute_varsens) to 1e-10.  Dims 6 and 24 at three of the published n."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "accuracy_profile", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "accuracy_profile.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = numpy.random.RandomState(4)
+    for k, n in ((6, 80), (6, 1280), (6, 20480), (24, 80), (24, 1280), (24, 5120)):
+        s = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
+        S = orc.build_sample(k, n)
+        for _ in range(3):
+            a = rng.uniform(0.0, 99.0, size=k)
+            err, estimate = mod.model_error(k, a, s)
+            F = orc.evaluate_rows(lambda X: orc.g_function_rows(X, a), *S)
+            ref = orc.compute_varsens(*F, n, second_order=False)
+            want = ref["sens"][:, 0] * ref["var_y"][0]
+            numpy.testing.assert_allclose(estimate, want, rtol=1e-10, atol=1e-15)
+            want_err = float(numpy.sum((mod.g_truth(a) - want) ** 2))
+            assert abs(err - want_err) <= 1e-9 * want_err, (k, n, err, want_err)
+    # the fixture of published rows is data only and complete
+    pub = mod.published(6)
+    assert len(pub) == 13 and abs(pub[20480][0] - 2.410422773150111570e-09) < 1e-24
+    assert mod.published(12) == pub and len(mod.published(192)) == 13   # (the dim-192 file lists n = 2480 and 5240)
+
+
 def test_empty_shard(vs):
     """A rank may own no rows (n < ranks): evaluation and reduction accept a zero-row shard."""
     from varsens_amd import _native
