@@ -270,8 +270,10 @@ int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint64_t rows, i
  * no f-values are written or read (the record equals vs_eval + vs_reduce_first_order's up to
  * summation order and, for separable objectives, the association order of the k-term folds:
  * rounding-level differences, <= ~2e-13 relative on the record).  Covers G_FUNCTION / POLYNOMIAL /
- * LINEAR objectives (any number of outputs) and separable source objectives with k <= 128 on
- * designs with identity or linear scaling, and ISHIGAMI; returns VS_ERR_ARG otherwise (callers then
+ * LINEAR objectives (any number of outputs, k <= 128, identity, linear or power scaling), separable
+ * source objectives with k <= 128 on designs with identity or linear scaling, and ISHIGAMI; returns
+ * VS_ERR_ARG otherwise (k > 128, INVERT, general source objectives, Halton indices beyond 2^32,
+ * a context in strict evaluation order; callers then
  * use the two-kernel path; vs_eval_reduce_supported tells in advance: *supported = 1 or 0).  NaN
  * values propagate (as on the reference's live-evaluation route, saltelli.py:329-355).
  * Replaces saltelli.py:329-355 + :577,583,591-596 in one kernel. */

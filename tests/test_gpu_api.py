@@ -539,10 +539,18 @@ def test_fused_through_api_wider_shapes(vs):
             numpy.testing.assert_allclose(getattr(a, f), getattr(b, f), rtol=1e-12, err_msg=f)
         for f in ("sens", "sens_t"):
             numpy.testing.assert_allclose(getattr(a, f), getattr(b, f), rtol=1e-9, atol=1e-11, err_msg=f)
-    # power scaling is left to the two-kernel route
+    # power scaling: fused for the built-in objectives (round 3), two-kernel route for a run-time compiled one
     p = vs.Varsens(vs.objectives.Linear(numpy.ones(5)), vs.scale.Power(1.0, 10.0), 5, 1000, verbose=False,
                    second_order=False)
-    assert p.objective._f is not None
+    assert p.objective._f is None
+    q = vs.Varsens(vs.objectives.Linear(numpy.ones(5)), vs.scale.Power(1.0, 10.0), 5, 1000, verbose=False,
+                   second_order=False, fused=False)
+    numpy.testing.assert_allclose(p.sens, q.sens, rtol=1e-9, atol=1e-11)
+    numpy.testing.assert_allclose(p.var_y, q.var_y, rtol=1e-12)
+    u = vs.Varsens(vs.objectives.SeparableExpression("return p[c] * x;", params=numpy.ones(5), fold="sum"),
+                   vs.scale.Power(1.0, 10.0), 5, 1000, verbose=False, second_order=False)
+    assert u.objective._f is not None
+    numpy.testing.assert_allclose(u.sens, q.sens, rtol=1e-9, atol=1e-11)
 
 
 # ---------------------------------------------------------------- multi-process flow (rehearsal on one GPU)

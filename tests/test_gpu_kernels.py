@@ -712,9 +712,39 @@ def test_fused_refuses_what_it_does_not_cover(ctx):
     inv = ctx.objective_create(_native.OBJ_INVERT, 8, 8, None)                 # not separable
     assert not ctx.eval_reduce_supported(d8, inv)
     lo, hi = np.full(8, 1.0), np.full(8, 10.0)
-    dp = make_design(ctx, 8, 100, _native.SCALE_POWER, lo, hi)                 # power scaling: two-kernel path
+    dp = make_design(ctx, 8, 100, _native.SCALE_POWER, lo, hi)                 # power scaling: built-ins have fused instances
     lin = ctx.objective_create(_native.OBJ_LINEAR, 8, 1, np.ones(8))
-    assert not ctx.eval_reduce_supported(dp, lin) and ctx.eval_reduce_supported(d8, lin)
+    assert ctx.eval_reduce_supported(dp, lin) and ctx.eval_reduce_supported(d8, lin)
+
+
+@pytest.mark.parametrize("kind,k,n,l", [("g", 6, 5000, 1), ("lin", 32, 3001, 1), ("poly", 70, 1000, 2), ("g", 128, 700, 1)])
+def test_fused_power_scaling_matches_two_kernel_path(ctx, kind, k, n, l):
+    """scale.Power designs through the fused evaluate+reduce kernels (round 3: own instances, GENV 3): the scaled
+    coordinates come from the same out-of-line pow() as vs_eval's, so the record differs from the two-kernel
+    path's by summation order only."""
+    from varsens_amd import _native
+    rng = np.random.RandomState(k + n)
+    one = {"g": rng.rand(k) * 5, "lin": np.arange(1, k + 1, dtype=float), "poly": 1.0 / (1.0 + np.arange(k) / 8.0)}[kind]
+    params = np.stack([one, one[::-1]])[:l]
+    code = {"g": _native.OBJ_G_FUNCTION, "lin": _native.OBJ_LINEAR, "poly": _native.OBJ_POLYNOMIAL}[kind]
+    lo, hi = np.full(k, 1e-2), np.linspace(0.5, 1.0, k)       # scale.py:62: lower * (upper / lower) ** x
+    d = make_design(ctx, k, n, _native.SCALE_POWER, lo, hi)
+    obj = ctx.objective_create(code, k, l, params)
+    assert ctx.eval_reduce_supported(d, obj)
+    nacc = _native.acc_len(k, l, 1)
+    f = ctx.alloc(8 * 2 * (k + 1) * n * l)
+    ctx.eval(d, obj, 0, n, f)
+    acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
+    ctx.reduce_first_order(f, n, k, l, acc1)
+    ctx.eval_reduce_first_order(d, obj, 0, n, acc2)
+    r1, r2 = ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,))
+    per = _native.acc_per_output(k)
+    np.testing.assert_allclose(r2[4:4 + l * per], r1[4:4 + l * per], rtol=2e-13)
+    # and against the oracle's power scaling (numpy pow vs device pow: a few ulp per coordinate)
+    S = orc.build_sample(k, n, lambda x: orc.scale_power(x, lo, hi))
+    name = {"g": "g_function", "lin": "linear", "poly": "polynomial"}[kind]
+    ex = orc.exact_accumulators(*orc.evaluate_engine_order(name, params, S[0], S[1]))
+    np.testing.assert_allclose(r2[4 + 3:4 + 3 + k], ex["ac"][:, 0], rtol=1e-12)
 
 
 def test_variance_with_outlier_in_first_value(ctx):

@@ -49,9 +49,10 @@ __device__ __attribute__((noinline, const)) double vs_scale_power(double lower, 
     return lower * pow(ratio, p);  // scale.py:62
 }
 
-// POWER = false (the fused kernels): no power scaling in the kernel at all -- a call in a kernel that
-// carries 4L sums in registers costs spills around every call site; the host sends power-scaled
-// designs through vs_eval + vs_reduce_first_order instead.
+// POWER = false (the fused kernels' general variant, GENV 0): no power scaling in the kernel at all -- a call
+// in a kernel that carries 4L sums in registers costs spills around every call site.  Power-scaled designs get
+// their own fused instances (GENV 3, built-in objectives), so that Sobol / raw designs and the run-time compiled
+// kernels do not pay for it.
 template <bool POWER>
 __device__ __forceinline__ double vs_apply_scale_compact(const vs_design_dev& D, double p, int c) {
     if (D.scale_mode == VS_SCALE_LINEAR) return p * D.width[c] + D.lower[c];   // scale.py:33
@@ -79,7 +80,7 @@ __device__ __forceinline__ void vs_scan_col_load(vs_scan_col& C, const vs_design
     C.pre = 0.0;
     C.pre2 = 0.0;
     if (c < k) {
-        if (GENV != 0 || D.generator == VS_GEN_HALTON) C.B = D.bases[c];
+        if (GENV == 1 || GENV == 2 || D.generator == VS_GEN_HALTON) C.B = D.bases[c];
         if (GENV == 2) {
             C.w = D.width[c];
             C.lo = D.lower[c];
@@ -265,7 +266,8 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     // parameter: 14 scalar registers -- is fetched while the column BEFORE it is computed: a scalar load
     // takes hundreds of cycles, and each column's digit loop starts on these values.
     // GENV 1 / 2: Halton below 2^32 with identity / linear scaling -- straight-line code per column;
-    // GENV 0: any generator and scaling, decided by (wave-uniform) branches per column.
+    // GENV 0: any generator and scaling, decided by (wave-uniform) branches per column (fused: no power scaling);
+    // GENV 3: as 0, power scaling included also when fused.
     vs_scan_col Cnext;
     const int lk = A.l * k;
     vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, VS_SCAN_COLUMN(q, 0, W), k, lk);
@@ -277,14 +279,14 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
         double t1 = ident, t2 = ident;
         if (c < k) {
             double x1, x2;
-            if (GENV != 0) {
+            if (GENV == 1 || GENV == 2) {
                 vs_radical_inverse_pair((vs_u32)(A.D.first_index + r), (vs_u32)(A.D.first_index + A.D.n + src2), C.B, x1, x2);
                 t1 = GENV == 2 ? x1 * C.w + C.lo : x1;   // scale.py:33
                 t2 = GENV == 2 ? x2 * C.w + C.lo : x2;
             } else {
                 vs_unit_pair(A.D, C.B, r, A.D.n + src2, c, x1, x2);
-                t1 = vs_apply_scale_compact<!FUSED>(A.D, x1, c);
-                t2 = vs_apply_scale_compact<!FUSED>(A.D, x2, c);
+                t1 = vs_apply_scale_compact<!FUSED || GENV == 3>(A.D, x1, c);
+                t2 = vs_apply_scale_compact<!FUSED || GENV == 3>(A.D, x2, c);
             }
             if (!MULTI) {
                 t1 = Term::eval(t1, c, params, C.pre, C.pre2);

@@ -776,16 +776,17 @@ static bool design_compact(const vs_design* g) {
 enum fused_route { FUSED_NONE = 0, FUSED_SCAN, FUSED_ISHIGAMI, FUSED_USER };
 
 // which fused kernel serves (design, objective): the scan kernels, Ishigami's own, or a run-time
-// compiled one.  The scan kernels leave power scaling to the two-kernel path; a context in strict
+// compiled one.  A context in strict
 // evaluation order (vs_context_set_eval_order) has no fused path for separable objectives -- the fused
 // kernels fold in scan order.
 static fused_route fused_route_for(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
     const bool separable = obj->kind == VS_OBJ_G_FUNCTION || obj->kind == VS_OBJ_POLYNOMIAL || obj->kind == VS_OBJ_LINEAR;
-    const bool scan_ok = design_compact(design) && design->d.scale_mode != VS_SCALE_POWER && ctx->tune.eval_mode != 1 &&
-                         (obj->kind != VS_OBJ_G_FUNCTION || obj->recip_ok);
+    // power scaling: the built-in objectives have fused instances for it (GENV 3); a run-time compiled one does not
+    const bool scan_ok = design_compact(design) && ctx->tune.eval_mode != 1 && (obj->kind != VS_OBJ_G_FUNCTION || obj->recip_ok);
     if (separable && scan_ok && vs_scan_covers(obj->kind, obj->k, true)) return FUSED_SCAN;
     if (obj->kind == VS_OBJ_ISHIGAMI) return FUSED_ISHIGAMI;
-    if (obj->kind == VS_OBJ_SOURCE && obj->fused_function && scan_ok) return FUSED_USER;
+    if (obj->kind == VS_OBJ_SOURCE && obj->fused_function && scan_ok && design->d.scale_mode != VS_SCALE_POWER)
+        return FUSED_USER;
     return FUSED_NONE;
 }
 

@@ -51,7 +51,7 @@ struct builtin_term {
     (((L) == 16 && (W) == 8 && !(FUSED) && !(MULTI)) || ((L) == 8 && (W) == 4 && (FUSED)) ? 4 : 1)
 
 // GENV: 1 / 2 = Halton indices below 2^32 with identity / linear scaling (straight-line column code);
-//       0 = any generator and scaling
+//       0 = any generator and scaling (fused: except power scaling); 3 = fused, power scaling
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
 __global__ void __launch_bounds__(VS_EVAL_ROWS* W)
 __attribute__((amdgpu_waves_per_eu(VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI))))
@@ -99,6 +99,10 @@ static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io
         return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 1>(ctx, A, P_io, shift_dev, plan_only);
     if (halton && A.D.scale_mode == VS_SCALE_LINEAR)
         return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 2>(ctx, A, P_io, shift_dev, plan_only);
+    if constexpr (FUSED) {   // the fused kernels' general variant carries no pow(): power scaling has its own instance
+        if (A.D.scale_mode == VS_SCALE_POWER)
+            return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 3>(ctx, A, P_io, shift_dev, plan_only);
+    }
     return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 0>(ctx, A, P_io, shift_dev, plan_only);
 }
 
