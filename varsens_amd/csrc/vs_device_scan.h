@@ -174,6 +174,15 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
             }
         }
     }
+    // evaluation: f(M_1[r]) and f(M_2[r]) leave now.  Stored at the end (rounds 1-2) they stayed live through the
+    // whole output walk; at 16 columns per wave, held to 128 registers, that made the compiler spill three terms and
+    // reload them between the stores -- each reload behind `s_waitcnt vmcnt(0)`, a wait for every store issued so
+    // far to reach memory (stores and loads share the counter): six per wave (profiles/r03/eval_k128_n24_before.json:
+    // scratch 28 B, SQ_INSTS_VMEM_RD 10 per wave).  Now 118 registers, nothing spilled.
+    if (!FUSED && q == 0 && valid) {
+        VS_STORE(f + lane, a);
+        VS_STORE(f + rows + lane, b);
+    }
     // ---- outputs, sub-block by sub-block
     double pa = Pa, pb = Pb;
 #pragma unroll
@@ -216,19 +225,14 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
     }
 #undef VS_TA
 #undef VS_TB
-    if (q == 0 && valid) {
-        if (FUSED) {
-            const double dx = a - shift, dy = b - shift;
-            acc.sab = fma(a, b, acc.sab);
-            acc.sa += a;
-            acc.sb += b;
-            acc.s1 += dx + dy;
-            acc.s2 = fma(dx, dx, acc.s2);
-            acc.s2 = fma(dy, dy, acc.s2);
-        } else {
-            VS_STORE(f + lane, a);
-            VS_STORE(f + rows + lane, b);
-        }
+    if (FUSED && q == 0 && valid) {
+        const double dx = a - shift, dy = b - shift;
+        acc.sab = fma(a, b, acc.sab);
+        acc.sa += a;
+        acc.sb += b;
+        acc.s1 += dx + dy;
+        acc.s2 = fma(dx, dx, acc.s2);
+        acc.s2 = fma(dy, dy, acc.s2);
     }
 }
 
