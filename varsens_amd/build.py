@@ -73,7 +73,8 @@ def build(force=False, verbose=True):
             return OUT
         embed_sources()
         hipcc = _hipcc()
-        cflags = [f for f in FLAGS if f != "-shared"]
+        # VS_EXTRA_CFLAGS: diagnostic builds of the tools/ scripts (e.g. -DVS_SCAN_STAMPS); never set by the product
+        cflags = [f for f in FLAGS if f != "-shared"] + os.environ.get("VS_EXTRA_CFLAGS", "").split()
 
         def compile_one(src):
             obj = os.path.join(objdir, src.replace(".hip", ".o"))

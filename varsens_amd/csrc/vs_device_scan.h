@@ -216,7 +216,9 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
                     acc.v[jj][3] = fma(b, cj, acc.v[jj][3]);
                 }
             } else if (i < k && valid) {
-                // wave-uniform plane address + lane: scalar base and one vector offset per store
+                // wave-uniform plane address + lane: scalar base and one vector offset per store.  (The scalar-base
+                // form of the store instruction, through inline asm, was measured in round 3: k = 64 3 % faster,
+                // k = 32 7 % slower, k = 128 the same.)
                 VS_STORE(f + (vs_u64)(2 + i) * rows + lane, cj);
                 VS_STORE(f + (vs_u64)(2 + k + i) * rows + lane, dj);
             }
@@ -262,6 +264,14 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     const double ident = FOLD == VS_OBJ_LINEAR ? 0.0 : 1.0;
     const vs_u64 src2 = vs_perm_at(A.D, r);  // row of the un-shuffled second half behind M_2[r]
     double* f = FUSED ? nullptr : fplane + rb * T;   // wave-uniform: the block's first row in plane 0
+#ifdef VS_SCAN_STAMPS   // diagnostic build (tools/scan_stamps.py): shader-clock stamps of every 512th block, behind the f-values
+    // (all stores at the end: a global store in front of the column loop would keep the design constants out of the
+    // scalar cache)
+    // s_memtime through a plain (non-volatile) asm tied to a value of the place it stamps: the builtin counts as a
+    // memory clobber and would do the same to the scalar loads
+    long long stamp0, stamp1 = 0;
+    asm("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(stamp0) : "v"(lane));
+#endif
 
     // ---- this wave's segment: coordinates -> terms (registers, or the wave's LDS slab) and their totals
     double ta[TLDS ? 1 : L], tb[TLDS ? 1 : L];
@@ -319,7 +329,22 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (!MULTI) {
+#ifdef VS_SCAN_STAMPS
+        asm("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(stamp1) : "v"(Ta), "v"(Tb));
+#endif
         vs_scan_finish<FOLD, L, W, FUSED, TLDS>(ta, tb, tl, Ta, Tb, tot, q, lane, f, rows, k, valid, shift, acc);
+#ifdef VS_SCAN_STAMPS
+        if constexpr (!FUSED) {
+            if ((blockIdx.x & 511) == 0 && lane == 0) {
+                long long* stamps = (long long*)(A.f + (2 * (vs_u64)k + 2) * rows) + ((vs_u64)(blockIdx.x >> 9) * W + (threadIdx.x >> 6)) * 4;
+                stamps[0] = stamp0;
+                stamps[1] = stamp1;
+                long long stamp3;
+                asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(stamp3));
+                stamps[3] = stamp3;
+            }
+        }
+#endif
     } else {
         const vs_u64 plane = (2 * (vs_u64)k + 2) * rows;
         for (int o = 0; o < A.l; ++o) {
