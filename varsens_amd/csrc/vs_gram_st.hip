@@ -20,8 +20,9 @@
 //  * a stage is 80 KiB of tile: 32 sample rows at NB = 8 (two 16-row sub-tiles of 256 tile rows, every wave
 //    works on both), 64 at NB = 4 (four sub-tiles of 128 tile rows; waves 0..3 take the first two, 4..7 the
 //    others); two stages = all 160 KiB of LDS; one barrier per 72 (NB = 8) or 40 (NB = 4) MFMAs per wave;
-//  * a fetch is 4 index rows x 256 contiguous bytes per wave-wide load (the shape that streams at 6.7 TB/s,
-//    tools/load_patterns.hip), eight 16-byte loads per thread and stage, addresses rebuilt per fetch;
+//  * a fetch is eight 16-byte loads per thread and stage, addresses rebuilt per fetch; a wave-wide load covers
+//    4 index rows x 256 contiguous bytes at NB = 8 and 2 x 512 at NB = 4 (tools/load_patterns.hip: 4 x 256 streams
+//    at 6.7 TB/s, 1 x 1024 at 7.0, 8 x 128 at 4.9);
 //  * explicit software pipeline, pinned with sched_barrier: the fragments of a group of tiles are read one group
 //    ahead of its MFMAs; the next stage's LDS writes and the fetch after it go between groups, where both waves
 //    of a SIMD have MFMAs queued (the compiler cannot move LDS reads across those writes; left alone the reads
@@ -78,11 +79,14 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
     const int K = A.K;
     const uint64_t rows = A.rows;
 
-    // staging: thread t holds sample rows 2p, 2p+1 (p = t & 15) of a 32-sample unit for c_u and d_u;
-    // NB = 8: one unit per stage, u = (t >> 4) + 32 j, j < 4; NB = 4: two units, u = (t >> 4) + 32 j, j < 2
-    const int lrow = tid >> 4, piece = tid & 15;
-    const uint64_t jstep = 32 * rows, dstep = (uint64_t)K * rows;
-    double* wr = tiles + (piece >> 3) * SUB + lrow * VS2_WPITCH + 2 * (piece & 7);   // + 32 j rows: s; + NROWS rows: t; + 2 SUB: unit 1
+    // staging: a stage is ST_ROWS sample rows = PIECES pairs per index row; thread t holds pair p = t % PIECES of the
+    // index rows u = t / PIECES + RSTEP j, j < 4, for c_u and for d_u: eight 16-byte loads.  A wave-wide load is
+    // 4 index rows x 256 B at NB = 8 (32-sample stages) and 2 x 512 B at NB = 4 (64-sample stages)
+    constexpr int PIECES = ST_ROWS / 2, RSTEP = 512 / PIECES;
+    static_assert(4 * RSTEP == NROWS, "four row blocks per half");
+    const int lrow = tid / PIECES, piece = tid % PIECES;
+    const uint64_t jstep = (uint64_t)RSTEP * rows, dstep = (uint64_t)K * rows;
+    double* wr = tiles + (piece >> 3) * SUB + lrow * VS2_WPITCH + 2 * (piece & 7);   // + RSTEP j rows: s; + NROWS rows: t
     const double* rd = tiles + 2 * grp * SUB + (lane & 15) * VS2_WPITCH + 2 * (lane >> 4);   // + 16 blk rows (+ NROWS: t)
 
     vs_d4 acc[NSLOT];
@@ -102,52 +106,45 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
     auto stage_of = [&](uint64_t i) { return VISIT * (blockIdx.x + (i / VISIT) * (uint64_t)G) + (i % VISIT); };
 
     vs_d2 raw[DEPTH][8];
-    // FIRST: a (plane 0) and b (plane 1) of the stage: 32 threads per unit
-    const bool abth = FIRST && tid < 16 * NSUB;
+    // FIRST: a (plane 0) and b (plane 1) of the stage: threads 0 .. PIECES-1 and PIECES .. 2 PIECES-1 (lrow 0 and 1)
+    const bool abth = FIRST && tid < 2 * PIECES;
     vs_d2 rawab[DEPTH];
 #pragma unroll
     for (int z = 0; z < DEPTH; ++z) rawab[z] = (vs_d2){0.0, 0.0};
     double pas = 0.0, pbs = 0.0, pat = 0.0, pbt = 0.0;
 
-    // load j of a thread: NB = 8: row block j & 3, d for j >= 4; NB = 4: row block j & 1, d for j & 2, unit j >> 2
+    // load j of a thread: row block j & 3, d for j >= 4
     auto fetch = [&](uint64_t st, int set) {
         const uint64_t s0 = st * ST_ROWS;
         // the eight addresses are rebuilt from the thread's row at every fetch (a handful of integer instructions)
         // instead of living in sixteen registers between fetches
         int lr = lrow;
         asm volatile("" : "+v"(lr));   // not loop-invariant as far as the compiler can tell
+        // rows is even and a thread's two sample rows start at an even index: both are inside or both outside
+        const bool in_rows = s0 + 2 * piece < rows;
         if (FIRST && abth) {
-            // tid < 32 (NB = 8) / < 64 (NB = 4): lr = tid >> 4; bit 0: a or b, bit 1: unit
-            const uint64_t sab = s0 + 32 * (lr >> 1) + 2 * piece;
-            const double* qab = A.f + ((lr & 1) ? rows : 0) + sab;
-            rawab[set] = sab < rows ? __builtin_nontemporal_load((const vs_d2*)qab) : (vs_d2){0.0, 0.0};
+            const double* qab = A.f + (lr ? rows : 0) + s0 + 2 * piece;
+            rawab[set] = in_rows ? __builtin_nontemporal_load((const vs_d2*)qab) : (vs_d2){0.0, 0.0};
         }
         const double* q0 = A.f + (uint64_t)(2 + lr) * rows + 2 * piece + s0;   // c_u, u = lr; plane of c_u is 2 + u, of d_u 2 + K + u
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int jb = NB == 8 ? (j & 3) : (j & 1);
-            const bool isd = NB == 8 ? j >= 4 : (j & 2) != 0;
-            const int un = NB == 8 ? 0 : (j >> 2);
-            // rows is even and a thread's two sample rows start at an even index: both are inside or both outside
-            const bool in = (FULLK || lr + 32 * jb < K) && s0 + 32 * un + 2 * piece < rows;   // rows past K are zeros in the tile
-            const double* q = q0 + jb * jstep + (isd ? dstep : 0) + 32 * un;
+            const int jb = j & 3;
+            const bool in = (FULLK || lr + RSTEP * jb < K) && in_rows;   // rows past K are zeros in the tile
+            const double* q = q0 + jb * jstep + (j >= 4 ? dstep : 0);
             raw[set][j] = in ? __builtin_nontemporal_load((const vs_d2*)q) : (vs_d2){0.0, 0.0};
         }
     };
     auto stash = [&](int b, int set) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            // the c and d loads of the same rows and samples
-            const int jc = NB == 8 ? j : ((j & 1) | ((j >> 1) << 2)), jd = NB == 8 ? j + 4 : jc + 2;
-            const int jb = NB == 8 ? j : (j & 1), un = NB == 8 ? 0 : (j >> 1);
-            const vs_d2 c = raw[set][jc], d = raw[set][jd];
-            *(vs_d2*)(wr + b * STAGE + 2 * un * SUB + 32 * jb * VS2_WPITCH) = c + d;
-            *(vs_d2*)(wr + b * STAGE + 2 * un * SUB + (NROWS + 32 * jb) * VS2_WPITCH) = c - d;
+            const vs_d2 c = raw[set][j], d = raw[set][4 + j];   // the c and d loads of the same rows and samples
+            *(vs_d2*)(wr + b * STAGE + RSTEP * j * VS2_WPITCH) = c + d;
+            *(vs_d2*)(wr + b * STAGE + (NROWS + RSTEP * j) * VS2_WPITCH) = c - d;
         }
         // sample pair p of a sub-tile goes into the padding of that sub-tile's row p: a at [16,17], b at [18,19]
         if (FIRST && abth)
-            *(vs_d2*)(tiles + b * STAGE + (2 * (tid >> 5) + ((tid & 15) >> 3)) * SUB + (tid & 7) * VS2_WPITCH + 16 +
-                      2 * ((tid >> 4) & 1)) = rawab[set];
+            *(vs_d2*)(tiles + b * STAGE + (piece >> 3) * SUB + (piece & 7) * VS2_WPITCH + 16 + 2 * lrow) = rawab[set];
     };
 
     // fragments of one group of GS tiles; every address is a compile-time offset from `rd + off`
