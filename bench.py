@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # data-sheet fp64 matrix rate (the guide lists no fp64 figure); tools/mfma_f64_peak.hip measures 77.6
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "bench_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "bench_pmc.json")
 F_BUFFERS = 3
 
 
@@ -54,11 +54,12 @@ def pmc_kernel(prefix, k, log2n):
 
 
 def pmc_traffic(prefix, k, log2n):
-    """HBM bytes per launch: FETCH_SIZE doubled per the gfx950 wide-load correction, plus WRITE_SIZE (both KB)."""
+    """HBM bytes per launch: FETCH_SIZE doubled per the gfx950 wide-load correction, plus WRITE_SIZE (both KB)
+    (tools/pmc_run.py writes per-launch averages under the counters' own names)."""
     c = pmc_kernel(prefix, k, log2n)
-    if not c or "FETCH_SIZE_avg_per_launch" not in c:
+    if not c or "FETCH_SIZE" not in c:
         return None
-    return (2.0 * c["FETCH_SIZE_avg_per_launch"] + c.get("WRITE_SIZE_avg_per_launch", 0.0)) * 1024.0
+    return (2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
 
 
 def blas_threads():
@@ -436,7 +437,7 @@ def main():
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic("void reduce_first_kernel", k, args.log2n),
-                         "traffic_source": "profiles/r02/bench_pmc.json (separate rocprofv3 --pmc passes)",
+                         "traffic_source": "profiles/r03/bench_pmc.json (separate rocprofv3 --pmc passes, tools/pmc_run.py)",
                          "algorithmic_bytes_per_launch": 8 * N_local,
                          "avg_launch_ms": avg["reduce_first"],
                          "input_last_written": "one step earlier (3 rotating buffers): not an Infinity-Cache number"},
@@ -445,7 +446,7 @@ def main():
                               # stores run at 0.75 of the HBM peak; neither alone is the roof
                               "bound": "valu+store", "achieved": eval_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": eval_gbs / HBM_PEAK_GBS,
-                              "traffic": (eval_pmc.get("WRITE_SIZE_avg_per_launch") or 0) * 1024.0 or None,
+                              "traffic": (eval_pmc.get("WRITE_SIZE") or 0) * 1024.0 or None,
                               "algorithmic_bytes_per_launch": 8 * N_local, "avg_launch_ms": avg["eval"],
                               "linear_fill_gbs_this_run": fill_gbs,
                               "valu_busy_frac": eval_pmc.get("valu_busy_frac"),

@@ -1,67 +1,32 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): bench line + rocprofv3 kernel stats + PMC passes of `bench.py`, and the
-# kernel stats of BASELINE configs[4] (k=128, n=2^24) incl. the second-order Gram kernels.
+# Run on the GPU box (via gpurun): the committed profiles/rNN set.
+#   bench line; rocprofv3 --kernel-trace --stats of bench.py; counter passes (tools/pmc_run.py: one group per pass,
+#   never together with sys/hip/hsa traces) over bench.py, over the Gram kernels at k = 32 / 64 / 128 and over the
+#   config-5 evaluation; BASELINE configs[4] on one GPU (tools/config5.py) with its kernel stats.
 # Summaries land in gpurun_out/profiles/ ; copy the ones to be judged into profiles/rNN/.
-# The program itself follows `--` (no env/bash hop: the profiler's preload initialises the GPU).
+# Every profiled program follows `--` itself (no env/bash hop: the profiler's preload initialises the GPU).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles
-rm -rf $OUT; mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
-echo "bench done" 
+echo "bench done"
+python3 $R/tools/pmc_run.py bench_pmc -- python3 $R/bench.py --steps 5 --warmup 1 --prewarm-steps 20 --no-cpu-baseline
+cp $R/gpurun_out/pmc/bench_pmc.json $OUT/bench_pmc.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
-echo "stats done"
-S="--steps 5 --warmup 1 --prewarm-steps 20 --no-cpu-baseline"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/p_fetch -- python3 $R/bench.py $S > $OUT/p_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/p_write -- python3 $R/bench.py $S > $OUT/p_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/p_sq1 -- python3 $R/bench.py $S > $OUT/p_sq1.log 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/p_sq2 -- python3 $R/bench.py $S > $OUT/p_sq2.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/p_grbm -- python3 $R/bench.py $S > $OUT/p_grbm.log 2>&1
-echo "pmc done"
+cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/bench_kernel_stats.csv
+echo "bench stats + pmc done"
+K=128 LOG2N=24 python3 $R/tools/pmc_run.py gram_k128_n24 --kernels gram_,first_head,reduce_first -- python3 $R/tools/gram_only.py
+K=64 LOG2N=22 python3 $R/tools/pmc_run.py gram_k64_n22 --kernels gram_,first_head,reduce_first -- python3 $R/tools/gram_only.py
+K=32 LOG2N=22 python3 $R/tools/pmc_run.py gram_k32_n22 --kernels gram_,first_head,reduce_first -- python3 $R/tools/gram_only.py
+python3 $R/tools/pmc_run.py eval_k128_n24 --kernels scan_kernel -- python3 $R/tools/eval_one.py 128 24 eval poly
+for n in gram_k128_n24 gram_k64_n22 gram_k32_n22 eval_k128_n24; do cp $R/gpurun_out/pmc/$n.json $R/gpurun_out/pmc/${n}_kernel_stats.csv $OUT/; done
+echo "kernel pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python3 $R/tools/config5.py > $OUT/config5.log 2>&1
+cp $(find $OUT/stats5 -name '*kernel_stats.csv' | head -1) $OUT/config5_kernel_stats.csv
+rm -rf $OUT/stats $OUT/stats5
 echo "config5 done"
-python3 - <<'PY'
-import csv, glob, collections, json, os, shutil
-out = os.environ.get("GRAFT_REPO_ROOT", os.getcwd()) + "/gpurun_out/profiles"
-for sub, name in (("stats", "bench_kernel_stats.csv"), ("stats5", "config5_kernel_stats.csv")):
-    found = glob.glob(out + "/%s/**/*kernel_stats.csv" % sub, recursive=True)
-    if found:
-        shutil.copy(found[0], out + "/" + name)
-pmc = {}
-for which in ("p_fetch", "p_write", "p_sq1", "p_sq2", "p_grbm"):
-    for f in glob.glob(out + "/%s/**/*counter_collection.csv" % which, recursive=True):
-        rows = list(csv.DictReader(open(f)))
-        # full-size launches only: the fused path's one-row evaluation (variance shift) shares a kernel name with
-        # the full evaluation -- keep the launches with the kernel's largest grid
-        biggest = collections.defaultdict(int)
-        for row in rows:
-            biggest[row["Kernel_Name"]] = max(biggest[row["Kernel_Name"]], int(row["Grid_Size"]))
-        agg = collections.defaultdict(list)
-        for row in rows:
-            if int(row["Grid_Size"]) == biggest[row["Kernel_Name"]]:
-                agg[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
-        for (kname, c), v in agg.items():
-            if kname.startswith("__amd_rocclr"):
-                continue
-            pmc.setdefault(kname, {})[c + "_avg_per_launch"] = sum(v) / len(v)
-            pmc[kname]["launches"] = len(v)
-            pmc[kname]["grid_size"] = biggest[kname]
-for kname, c in pmc.items():
-    # share of SIMD cycles with a vector instruction in flight: SQ_ACTIVE_INST_VALU counts quad-cycles summed over
-    # the SIMDs, SQ_BUSY_CYCLES sums the busy cycles of the shader engines' SQs (both per launch)
-    if "SQ_ACTIVE_INST_VALU_avg_per_launch" in c and "GRBM_GUI_ACTIVE_avg_per_launch" in c and c["GRBM_GUI_ACTIVE_avg_per_launch"] > 0:
-        cycles = c["GRBM_GUI_ACTIVE_avg_per_launch"] / 8.0          # sum over the 8 XCDs -> cycles of the launch
-        c["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU_avg_per_launch"] / (cycles * 1024.0)   # 256 CUs x 4 SIMDs
-json.dump({"note": "rocprofv3 --pmc passes (one counter group per pass) over `bench.py --steps 5 --warmup 1 --prewarm-steps 20`; "
-                   "per-launch averages. FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts half the bytes of "
-                   "16-B-per-lane coalesced loads (MI355X_MICROARCH.md, HBM) -- doubled by the reader, not here. "
-                   "valu_busy_frac = 4 * SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs): the counter books 4 "
-                   "cycles per vector instruction.",
-           "kernels": pmc}, open(out + "/bench_pmc.json", "w"), indent=1)
-for d in ("stats", "stats5", "p_fetch", "p_write", "p_sq1", "p_sq2", "p_grbm"):
-    shutil.rmtree(out + "/" + d, ignore_errors=True)
-PY
 cat $OUT/bench_n1.json
 cat $OUT/bench_kernel_stats.csv
 cat $OUT/config5.log

@@ -15,16 +15,24 @@ N = 2 * (k + 1) * n
 f = ctx.alloc(8 * N)
 acc = ctx.alloc(8 * _native.acc_len(k, 1, 1)); out = ctx.alloc(8 * _native.first_order_len(k, 1))
 gram = ctx.alloc(8 * _native.gram_len(k))
-ctx.profile_begin(64)
-for _ in range(2):
+ctx.profile_begin(256)
+for _ in range(5):
     ctx.eval(design, obj, 0, n, f)
     ctx.reduce_first_order(f, n, k, 1, acc)
     ctx.finish_first_order(acc, n, k, 1, out)
     ctx.reduce_second_order(f, n, k, 1, gram)
+    ctx.reduce_first_second_order(f, n, k, 1, acc, gram)
 rec = ctx.profile_end()
-last = {}
+# medians over five rounds (the first is cold: clocks, page tables); "both_orders" = every kernel of the one-call form
+per = {}
 for name, ms in rec:
-    last[name] = ms
+    per.setdefault(name, []).append(ms)
+calls = 5
+last = {"eval": float(np.median(per["eval"])), "reduce_first": float(np.median(per["reduce_first"][0::2])),
+        "second_order": float(np.median(per["second_order"][0::2])),
+        "both_orders_one_call_gram_kernel": float(np.median(per["second_order"][1::2])),
+        "fold": float(np.median(per["fold"])), "finish": float(np.median(per["finish"])),
+        "second_fold": float(np.median(per["second_fold"]))}
 print({a: round(b, 3) for a, b in last.items()}, flush=True)
 nbl = (k + 15) // 16   # S S^T and T T^T, upper block triangles: nbl (nbl + 1) tiles of 16 x 16 per 4 sample rows
 print("eval %.1f G evals/s ; reduce %.0f GB/s (%.1f%% of 8 TB/s) ; second order %.0f GB/s algorithmic, %.1f TFLOP/s (%d MFMA tiles of S S^T, T T^T)" %
