@@ -40,10 +40,11 @@
 // and barrier 0.66 = the MFMA + fragment-read loop alone.  The 0.24 ms of the loads are NOT: the address
 // arithmetic (wave-uniform offsets, one vector add per load: same time), the wait for the data (never stashing
 // what was loaded: same time), prefetch distance (two stages in flight: same), code size (waves r and r + 4 share a
-// body: same), one burst per stage (spread over the stage: same) or the workgroup-to-sample-range map (runs of
-// 1 .. 256 visits per workgroup: same).  What remains is the memory pipeline taking 128 rows x 512 B from 128
-// planes 32 MB apart per stage and CU (translations per byte, not bytes) and the clock the chip gives a kernel
-// that streams HBM beside the fp64 matrix pipe.
+// body: same), one burst per stage (spread over the stage: same), the shape of a wave-wide load (2 x 512 B instead
+// of 4 x 256 B: same), the workgroup-to-sample-range map (runs of 1 .. 256 visits per workgroup: same) -- or who
+// issues them: with four extra waves issuing the loads and the compute waves touching neither vector memory nor
+// LDS writes, the time is the same 1.0 ms.  The HBM stream itself takes the matrix pipe's throughput (clock 2.11
+// instead of 2.28 GHz, and a lower busy fraction at that clock).
 #include "vs_second.h"
 
 namespace {
