@@ -16,9 +16,10 @@
 //     tiles, skips the S x T ones and walks its own sample rows through a private LDS tile, no workgroup barrier
 //     in the loop: gram_diag_wave_kernel (16-sample-row chunks; any shape) and gram_diag_wide_kernel
 //     (32-sample-row units; one output, even row count, K > 16);
-//   32 < K <= 128: gram_macro_st_kernel -- a workgroup of eight waves, one 256-row tile (128 s rows, 128 t rows),
-//     72 tiles of S S^T and T T^T, nine per wave; up to 64 rows (one output, even row count): gram_half_st_kernel --
-//     the tile holds two chunks, five tiles per wave, and carries the first-order dot products;
+//   32 < K <= 128, one output, even row count, no mask: gram_st_kernel (vs_gram_st.hip; carries the first-order dot
+//     products); the other shapes of that range: gram_macro_st_kernel -- a workgroup of eight waves, one 256-row tile
+//     (128 s rows, 128 t rows), 72 tiles of S S^T and T T^T, nine per wave -- and, up to 64 rows with an even row
+//     count, gram_half_st_kernel -- the tile holds two chunks, five tiles per wave;
 //   K > 128: gram_macro_kernel over [C; D] -- 128-row macro blocks, a workgroup per pair (MI <= MJ) of them;
 //     gram_convert_kernel turns its D C^T, D D^T, C C^T into SS, TT.
 // One dense partial per workgroup goes to HBM; gram_fold_kernel sums the partials (compensated) and scatters.
@@ -1010,28 +1011,16 @@ gram_macro_st_kernel(vs_gram_args A) {
 // wave r of a group owns block row r of S S^T (4 - r tiles) and block row 3 - r of T T^T (r + 1 tiles), five
 // accumulator tiles in w-independent slots as in gram_macro_st_kernel.  One barrier per 32 sample rows, 20 MFMAs per
 // wave between barriers.  Two partials per workgroup (one per wave group): [S S^T, T T^T][64][64].
-// FIRST (no mask): a = fM_1, b = fM_2 of the pair of chunks sit in the padding of tile rows 0..7 and 128..135; every
-// wave meets them with its two A fragments (a.s, b.s of block row r; a.t, b.t of block row 3 - r) and the record
-// takes a.c = (a.s + a.t) / 2, a.d = (a.s - a.t) / 2, likewise for b.  One record per wave group; the five scalar sums
-// come from first_head_kernel.  (The 40 accumulator VGPRs leave room for this; at nine tiles per wave they do not.)
+// Since round 3 this kernel serves the NaN-masked pass and several outputs only: the unmasked pass of one output --
+// with or without the first-order dot products -- runs on gram_st_kernel (vs_gram_st.hip).
 #define VS2_HALF 64
 #define VS2_HTILE_OUT (VS2_HALF * VS2_HALF)
 // ONE: one output -- c_u is plane 2 + u, d_u plane 2 + K + u, rebuilt at every fetch; several outputs keep a pointer per load.
-template <bool MASKED, bool FIRST, bool ONE>
+template <bool MASKED, bool ONE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 gram_half_st_kernel(vs_gram_args A) {
-    static_assert(ONE || !FIRST, "the first-order sums ride along for one output only");
     extern __shared__ double tiles[];  // [2 buffers][2 chunks][128][VS2_WPITCH]
     if (MASKED && A.counters[CNT_NANFLAG] == 0) return;
-    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) {
-        // this kernel opens the call: reset the counters the two folds use (cf. reduce_first_kernel)
-        uint32_t* c = const_cast<uint32_t*>(A.counters);
-        c[0] = 0;
-        c[1] = 0xffffffffu;
-        c[2] = 0;
-        c[3] = 0;
-        c[4] = 0;
-    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1073,24 +1062,12 @@ gram_half_st_kernel(vs_gram_args A) {
     auto pair_of = [&](uint64_t i) { return 2 * (blockIdx.x + (i / 2) * gridDim.x) + (i & 1); };
     vs_d2 raw[4];
     bool k0 = true, k1 = true;
-    const bool abth = FIRST && tid < 32;   // threads 0..15 stage a (plane 0), 16..31 b (plane 1) of the pair
-    const double* abp = A.f + (tid >= 16 ? rows : 0) + 2 * (tid & 15);
-    vs_d2 rawab = (vs_d2){0.0, 0.0};
-    double pas = 0.0, pbs = 0.0, pat = 0.0, pbt = 0.0;
     auto fetch = [&](uint64_t pr) {
         const uint64_t s0 = pr * 2 * VS2_WCHUNK;
         const bool whole = s0 + 2 * VS2_WCHUNK <= rows;
         const uint64_t sm = s0 + 2 * piece;
         int lr = lrow;
         if (ONE) asm volatile("" : "+v"(lr));   // not loop-invariant as far as the compiler can tell
-        if (FIRST && abth) {
-            if (whole) {
-                rawab = __builtin_nontemporal_load((const vs_d2*)(abp + s0));
-            } else {
-                rawab.x = sm < rows ? abp[s0] : 0.0;
-                rawab.y = sm + 1 < rows ? abp[s0 + 1] : 0.0;
-            }
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool in = lr + 32 * (j & 1) < K;   // rows past K are zeros in the tile: nothing to load
@@ -1121,9 +1098,6 @@ gram_half_st_kernel(vs_gram_args A) {
             *(vs_d2*)(wr + b * BUF + 32 * j * VS2_WPITCH) = c + d;
             *(vs_d2*)(wr + b * BUF + (VS2_HALF + 32 * j) * VS2_WPITCH) = c - d;
         }
-        // sample pair p of a chunk goes into the padding of that chunk's tile row p: a at [16,17], b at [18,19]
-        if (FIRST && abth)
-            *(vs_d2*)(tiles + b * BUF + (((tid & 15) >> 3) * VS2_MACRO + (tid & 7)) * VS2_WPITCH + 16 + 2 * (tid >> 4)) = rawab;
     };
 
     if (mine > 0) {
@@ -1141,34 +1115,12 @@ gram_half_st_kernel(vs_gram_args A) {
         vs_d2 fa[2];
         fa[0] = *(const vs_d2*)(rdS + b * BUF + 16 * r * VS2_WPITCH);
         fa[1] = *(const vs_d2*)(rdS + b * BUF + 16 * r * VS2_WPITCH + 8);
-        // FIRST: a, a, b, b of the sample rows 2q, 2q+1 (h = 0) and 8+2q, 8+2q+1 (h = 1) of the lane group q
-        const double* rdAB = tiles + b * BUF + (grp * VS2_MACRO + (lane >> 4)) * VS2_WPITCH + 16;
-        if (FIRST) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const vs_d4 ab = *(const vs_d4*)(rdAB + 4 * h * VS2_WPITCH);
-                pas = fma(ab[0], fa[h][0], pas);
-                pbs = fma(ab[2], fa[h][0], pbs);
-                pas = fma(ab[1], fa[h][1], pas);
-                pbs = fma(ab[3], fa[h][1], pbs);
-            }
-        }
 #pragma unroll
         for (int sl = 0; sl < 5; ++sl) {
             const bool ss = sl < 4 - r;                 // wave-uniform
             if (sl == 4 - r) {                          // from here on: row block 3 - r of T T^T
                 fa[0] = *(const vs_d2*)(rdT + b * BUF + 16 * tr * VS2_WPITCH);
                 fa[1] = *(const vs_d2*)(rdT + b * BUF + 16 * tr * VS2_WPITCH + 8);
-                if (FIRST) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const vs_d4 ab = *(const vs_d4*)(rdAB + 4 * h * VS2_WPITCH);
-                        pat = fma(ab[0], fa[h][0], pat);
-                        pbt = fma(ab[2], fa[h][0], pbt);
-                        pat = fma(ab[1], fa[h][1], pat);
-                        pbt = fma(ab[3], fa[h][1], pbt);
-                    }
-                }
             }
             const int blk = ss ? r + sl : sl - 1;       // block of the other operand
             const bool live = (ss ? r : tr) < nbl && blk < nbl;
@@ -1183,39 +1135,6 @@ gram_half_st_kernel(vs_gram_args A) {
             }
         }
         __syncthreads();
-    }
-    if (FIRST) {
-        // the four lane groups of a wave hold the same index rows over different samples
-        pas += __shfl_xor(pas, 16, 64);
-        pas += __shfl_xor(pas, 32, 64);
-        pbs += __shfl_xor(pbs, 16, 64);
-        pbs += __shfl_xor(pbs, 32, 64);
-        pat += __shfl_xor(pat, 16, 64);
-        pat += __shfl_xor(pat, 32, 64);
-        pbt += __shfl_xor(pbt, 16, 64);
-        pbt += __shfl_xor(pbt, 32, 64);
-        double* red = tiles + grp * 2 * VS2_MACRO;   // the tiles are free: [wave group][s rows 0..63, t rows 64..127][2]
-        if (lane < 16) {
-            red[(16 * r + lane) * 2 + 0] = pas;
-            red[(16 * r + lane) * 2 + 1] = pbs;
-            red[(VS2_HALF + 16 * tr + lane) * 2 + 0] = pat;
-            red[(VS2_HALF + 16 * tr + lane) * 2 + 1] = pbt;
-        }
-        __syncthreads();
-        const int k = A.k;
-        const size_t plen = VS_PLEN(k);
-        double* rec = A.first_partials + ((size_t)blockIdx.x * 2 + grp) * plen;   // one record per wave group
-        for (size_t e = tid & 255; e < plen; e += 256) {
-            double v = 0.0;
-            if (e >= VS_P_HEAD) {   // the five scalar sums come from first_head_kernel's records
-                // record layout: head, ac[k], bd[k], ad[k], bc[k]
-                const int slot = (int)((e - VS_P_HEAD) / k), j = (int)((e - VS_P_HEAD) % k);
-                const int which = (slot == 0 || slot == 2) ? 0 : 1;
-                const double xs = red[j * 2 + which], xt = red[(VS2_HALF + j) * 2 + which];
-                v = (slot == 0 || slot == 3) ? 0.5 * (xs + xt) : 0.5 * (xs - xt);
-            }
-            rec[e] = v;
-        }
     }
     // a tile belongs to one wave: straight to the wave group's partial (all-zero and mirror tiles stay unwritten;
     // the fold never reads them)
@@ -1473,11 +1392,9 @@ static int gram_raise_lds_limits(vs_context* ctx) {
 #define VS2_SET_ST(MK, AL, WI) VS2_SET(gram_macro_st_kernel<MK, AL, WI>)
     VS2_MACRO_INSTANCES(VS2_SET_MACRO)
     VS2_ST_INSTANCES(VS2_SET_ST)
-    VS2_SET(gram_half_st_kernel<false, false, true>)
-    VS2_SET(gram_half_st_kernel<true, false, true>)
-    VS2_SET(gram_half_st_kernel<false, true, true>)
-    VS2_SET(gram_half_st_kernel<false, false, false>)
-    VS2_SET(gram_half_st_kernel<true, false, false>)
+    VS2_SET(gram_half_st_kernel<true, true>)
+    VS2_SET(gram_half_st_kernel<false, false>)
+    VS2_SET(gram_half_st_kernel<true, false>)
 #undef VS2_SET_ST
 #undef VS2_SET_MACRO
 #undef VS2_SET
@@ -1629,11 +1546,10 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
                 A.slab_wgs = slab_wgs;
                 F.P = pslots_old;
                 const dim3 g(slab_wgs), t(512);
-                if (masked && l == 1) hipLaunchKernelGGL((gram_half_st_kernel<true, false, true>), g, t, lds_m, ctx->stream, A);
-                else if (masked) hipLaunchKernelGGL((gram_half_st_kernel<true, false, false>), g, t, lds_m, ctx->stream, A);
-                else if (with_first) hipLaunchKernelGGL((gram_half_st_kernel<false, true, true>), g, t, lds_m, ctx->stream, A);
-                else if (l == 1) hipLaunchKernelGGL((gram_half_st_kernel<false, false, true>), g, t, lds_m, ctx->stream, A);
-                else hipLaunchKernelGGL((gram_half_st_kernel<false, false, false>), g, t, lds_m, ctx->stream, A);
+                // (the unmasked pass of one output runs on gram_st_kernel, above)
+                if (masked && l == 1) hipLaunchKernelGGL((gram_half_st_kernel<true, true>), g, t, lds_m, ctx->stream, A);
+                else if (masked) hipLaunchKernelGGL((gram_half_st_kernel<true, false>), g, t, lds_m, ctx->stream, A);
+                else hipLaunchKernelGGL((gram_half_st_kernel<false, false>), g, t, lds_m, ctx->stream, A);
             } else if (macro_st && st128 && !masked) {
                 A.slab_wgs = F.P = st_wgs;
                 rc = vs_gram_st_launch(ctx, A, with_first, st_wgs);
