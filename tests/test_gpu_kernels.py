@@ -487,7 +487,11 @@ def test_rccl_single_rank_allreduce(ctx):
                                       (17, 34, 1), (31, 30, 1), (28, 2, 1), (33, 46, 1), (64, 48, 1), (96, 62, 1),
                                       (100, 4128, 1), (32, 65598, 1),
                                       # several outputs on the two-chunk S/T kernel (33..64 index rows per half, even rows)
-                                      (20, 1000, 3), (11, 4096, 4), (16, 62, 4), (13, 3000, 3)])
+                                      (20, 1000, 3), (11, 4096, 4), (16, 62, 4), (13, 3000, 3),
+                                      # gram_st_kernel (round 3): every count of live 16-row blocks, partly filled last
+                                      # blocks, one and many stages per workgroup, ragged last stage
+                                      (50, 200, 1), (56, 1000, 1), (63, 70, 1), (72, 2048, 1), (90, 330, 1), (112, 64, 1),
+                                      (120, 500, 1), (127, 34, 1), (64, 100002, 1), (128, 70000, 1), (80, 40000, 1)])
 def test_second_order_gram(ctx, k, rows, l):
     rng = np.random.RandomState(k * 7 + rows + l)
     blocks = 1.0 + rng.randn(2 * k + 2, rows, l)
@@ -517,7 +521,10 @@ def test_second_order_gram(ctx, k, rows, l):
 @pytest.mark.parametrize("k,rows,l", [(6, 1000, 1), (32, 5000, 1), (16, 200000, 1), (3, 5, 1), (12, 100003, 1),
                                       (1, 17, 1), (25, 4096, 1), (40, 3000, 1), (5, 700, 2), (33, 2, 1), (64, 4099, 1),
                                       (65, 777, 1), (128, 10000, 1), (129, 2050, 1), (200, 333, 1), (48, 65536, 1),
-                                      (17, 34, 1), (31, 30, 1), (32, 65598, 1), (33, 46, 1), (64, 48, 1), (96, 62, 1)])
+                                      (17, 34, 1), (31, 30, 1), (32, 65598, 1), (33, 46, 1), (64, 48, 1), (96, 62, 1),
+                                      # gram_st_kernel carrying the first-order dot products (round 3)
+                                      (50, 200, 1), (56, 1000, 1), (63, 70, 1), (72, 2048, 1), (90, 330, 1), (112, 64, 1),
+                                      (120, 500, 1), (127, 34, 1), (64, 100002, 1), (128, 70000, 1), (80, 40000, 1)])
 def test_first_and_second_order_in_one_pass(ctx, k, rows, l):
     """vs_reduce_first_second_order fills the record and the Gram matrices of the two separate passes
     (l == 1: k <= 32 the wave-private kernel, beyond that the macro kernel's diagonal pairs carry the dot
