@@ -22,7 +22,7 @@ def ctx():
 
 EDGE_ROWS = st.one_of(st.integers(1, 70), st.sampled_from([63, 64, 65, 127, 128, 129, 511, 512, 513, 2047, 2048, 2049, 4097]),
                       st.integers(71, 6000))
-EDGE_K = st.one_of(st.integers(1, 12), st.sampled_from([15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 70]))
+EDGE_K = st.one_of(st.integers(1, 12), st.sampled_from([15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 70, 80, 81, 96, 97, 112, 113, 127, 128]))
 # VS_PROPERTY_EXAMPLES=N: a soak run with N random examples per test instead of the fixed 150 / 100
 _SOAK = int(os.environ.get("VS_PROPERTY_EXAMPLES", "0"))
 COMMON = dict(deadline=None, max_examples=_SOAK or 150, suppress_health_check=list(HealthCheck), derandomize=not _SOAK,
