@@ -33,7 +33,7 @@ extern "C" {
 
 /* 2: perm slices per rank, vs_accumulate, vs_context_set_eval_order, vs_eval_reduce_supported.
  * 3: the second-order sums are S S^T and T T^T (VS_GRAM_LEN doubles) instead of D C^T, D D^T, C C^T. */
-#define VS_ABI_VERSION 3
+#define VS_ABI_VERSION 4
 
 typedef enum vs_status {
     VS_OK = 0,
@@ -127,6 +127,11 @@ enum {
 
 int vs_profile_begin(vs_context* ctx, int capacity);
 int vs_profile_end(vs_context* ctx, vs_profile_record* out, int capacity, int* count);
+/* Which launches the next vs_profile_begin brackets: bit VS_KERNEL_x of kernel_mask (0 = all, the default).  Each
+ * bracketed launch costs two event packets on its stream -- 0.7276 ms per k = 32, n = 2^22 pass with every kernel
+ * bracketed, 0.7052 with the reduction only, 0.6979 with none (tools/step_overhead.py) -- so a timed loop brackets the
+ * kernel it wants to price and nothing else. */
+int vs_profile_select(vs_context* ctx, uint32_t kernel_mask);
 
 /* ------------------------------------------------ a1: low-discrepancy points
  * Replaces ghalton.Halton(k).get(m) (varsens/saltelli.py:82-84): rows are the

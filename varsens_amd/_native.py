@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARSENS_HIP_LIB") or os.path.join(_HERE, "libvarsens_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128
 
 GEN_HALTON, GEN_SOBOL, GEN_RAW = 0, 1, 2
@@ -102,6 +102,7 @@ SIGNATURES = {
     "vs_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     "vs_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vs_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "vs_profile_select": (C.c_int, [C.c_void_p, C.c_uint32]),
     "vs_profile_end": (C.c_int, [C.c_void_p, C.POINTER(ProfileRecord), C.c_int, C.POINTER(C.c_int)]),
     "vs_halton_fill": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "vs_sobol_fill": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
@@ -321,7 +322,17 @@ class Context(object):
             raise VarsensHipError("accumulate exceeds a device buffer")
         _check(self.lib.vs_accumulate(self.handle, C.c_void_p(dst_buf.ptr), C.c_void_p(src_buf.ptr), int(count)))
 
-    def profile_begin(self, capacity=4096):
+    def profile_begin(self, capacity=4096, only=None):
+        """Bracket the launches that follow with HIP events; `only`: names (KERNEL_NAMES) of the kernels to bracket,
+        default all.  Every bracketed launch costs two event packets on its stream (vs_profile_select)."""
+        mask = 0
+        if only is not None:
+            ids = {name: kid for kid, name in KERNEL_NAMES.items()}
+            for name in only:
+                if name not in ids:
+                    raise VarsensHipError("unknown kernel name %r (known: %s)" % (name, sorted(ids)))
+                mask |= 1 << ids[name]
+        _check(self.lib.vs_profile_select(self.handle, mask))
         self._prof_capacity = int(capacity)
         _check(self.lib.vs_profile_begin(self.handle, self._prof_capacity))
 

@@ -369,6 +369,13 @@ extern "C" int vs_profile_begin(vs_context* ctx, int capacity) {
     return VS_OK;
 }
 
+extern "C" int vs_profile_select(vs_context* ctx, uint32_t kernel_mask) {
+    VS_REQUIRE(ctx, "ctx is null");
+    VS_REQUIRE(!ctx->profiling, "vs_profile_select between vs_profile_begin and vs_profile_end");
+    ctx->profile_select = kernel_mask;
+    return VS_OK;
+}
+
 extern "C" int vs_profile_end(vs_context* ctx, vs_profile_record* out, int capacity, int* count) {
     VS_REQUIRE(ctx && count, "null argument");
     ctx->profiling = false;
@@ -391,6 +398,7 @@ extern "C" int vs_profile_end(vs_context* ctx, vs_profile_record* out, int capac
 vs_launch_scope::vs_launch_scope(vs_context* c, int kernel_id) : ctx(c) {
     if (!ctx->profiling || ctx->prof.size() >= ctx->prof_capacity) return;
     if (!((ctx->tune.profile_mask >> kernel_id) & 1)) return;  // tuning aid: bracket only some kernel ids
+    if (ctx->profile_select && !((ctx->profile_select >> kernel_id) & 1u)) return;   // vs_profile_select
     slot = (int)ctx->prof.size();
     vs_prof_slot s = ctx->prof_pool[slot];
     s.kernel_id = kernel_id;

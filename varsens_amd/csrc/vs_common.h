@@ -56,6 +56,7 @@ struct vs_context {
     uint32_t* counters_host = nullptr;  // pinned mirror
     // profiling
     bool profiling = false;
+    uint32_t profile_select = 0;    // vs_profile_select: kernel ids to bracket (0 = all)
     bool gram_lds_raised = false;   // second-order kernels with more than 64 KiB of dynamic LDS: limit raised once
     std::vector<vs_prof_slot> prof;
     std::vector<vs_prof_slot> prof_pool;
