@@ -371,12 +371,12 @@ def main():
     if world == 1:   # the N > 1 form of this call adds the one all-reduce of record + Gram sums (saltelli.py: _finish)
         t_api, recs_api, _ = timed(api_default_step, so_steps, 2, profile=True)
     # a linear fill of one f-value buffer, timed in this run: what the chip's store path takes for the same bytes
-    # without any arithmetic (hipMemsetAsync)
-    ctx.memset(fbuf[0], 0)
+    # without any arithmetic (hipMemsetAsync); on the spare buffer: fbuf[0] still feeds the CPU baseline below
+    ctx.memset(fbuf[1], 0)
     ctx.sync()
     t0 = time.perf_counter()
     for _ in range(5):
-        ctx.memset(fbuf[0], 0)
+        ctx.memset(fbuf[1], 0)
     ctx.sync()
     fill_gbs = 5 * 8.0 * N_local / (time.perf_counter() - t0) / 1e9
 
