@@ -112,3 +112,41 @@ def test_two_rank_host_path(tmp_path, backend):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out)
         assert "rank %d ok" % rank in out
+
+
+FAILING = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, %r)
+    from varsens_amd import dist
+    g = dist.HostGroup()
+    g.barrier()
+    if g.rank == 1:
+        os._exit(7)                      # dies without a word, in the middle of the job
+    t0 = time.time()
+    try:
+        g.max(1.0)                       # a collective the dead rank never joins
+    except Exception as exc:
+        print("rank 0 noticed after %%.1f s: %%s" %% (time.time() - t0, type(exc).__name__))
+        sys.exit(5)
+    print("rank 0 went on alone")
+""") % ROOT
+
+
+def test_a_dead_rank_is_noticed_not_waited_for(tmp_path):
+    """Failure detection on the torch-free rendezvous: when a rank dies, the store on rank 0 sees its connection
+    close and ends the job for everybody -- the survivors get an exception at their next collective instead of
+    hanging in it (bench.py's parent then kills what is left, tests/test_bench_launch.py)."""
+    script = tmp_path / "failing.py"
+    script.write_text(FAILING)
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VARSENS_RENDEZVOUS="tcp")
+        env.pop("TORCHELASTIC_RUN_ID", None)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    out0, _ = procs[0].communicate(timeout=60)
+    procs[1].communicate(timeout=60)
+    assert procs[1].returncode == 7
+    assert procs[0].returncode == 5 and "noticed" in out0, out0
