@@ -29,6 +29,25 @@ import time
 import numpy
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """Libraries that announce themselves on the C-level stdout (gloo's connection notes, RCCL's version banner at
+    communicator creation) must not reach a stdout that carries one JSON line: file descriptor 1 points at stderr
+    for the duration."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def shard_rows(n, world, rank):
     """Contiguous rows [begin, begin+count) of rank `rank`; counts differ by at most 2 and all
     but the last are even (the streaming reduction reads double2 pairs)."""
@@ -170,17 +189,9 @@ class HostGroup(object):
     def _init_gloo(self):
         import torch.distributed as dist
         if not dist.is_initialized():
-            # gloo announces its connections on the C-level stdout; a bench line must stay alone there
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
+            with stdout_to_stderr():   # gloo announces its connections on the C-level stdout
                 dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
                 dist.barrier()
-            finally:
-                sys.stdout.flush()
-                os.dup2(saved, 1)
-                os.close(saved)
         self._dist = dist
 
     def barrier(self):
@@ -253,14 +264,17 @@ class RcclComm(object):
         self.world = group.world
         self.rank = group.rank
         if self.world > 1:
-            uid = ctx.comm_unique_id() if group.rank == 0 else None
-            uid = group.broadcast_bytes(uid, src=0)
-            ctx.comm_init(uid, self.world, self.rank)
-            # RCCL builds its rings/connections on the first collective: pay that here, not in a timed pass
-            warm = ctx.upload(numpy.zeros(8))
-            ctx.comm_allreduce(warm, 8)
-            ctx.sync()
-            warm.free()
+            # RCCL prints a version banner on the C-level stdout when the library or a communicator comes up
+            # (seen on the GPU boxes: "RCCL version : ..." five lines): keep it off a stdout that carries one JSON line
+            with stdout_to_stderr():
+                uid = ctx.comm_unique_id() if group.rank == 0 else None
+                uid = group.broadcast_bytes(uid, src=0)
+                ctx.comm_init(uid, self.world, self.rank)
+                # RCCL builds its rings/connections on the first collective: pay that here, not in a timed pass
+                warm = ctx.upload(numpy.zeros(8))
+                ctx.comm_allreduce(warm, 8)
+                ctx.sync()
+                warm.free()
 
     def allreduce(self, buf, count):
         if self.world > 1:
