@@ -1,6 +1,6 @@
 // sens_2 / sens_2n sums for 33 .. 128 index rows per half (varsens/saltelli.py:612-619): S S^T and T T^T of
-// S = C + D, T = C - D on the fp64 matrix cores, one output, even row count, no NaN mask -- BASELINE configs[4]
-// (k = 128, n = 2^24) and every k in 33 .. 128.  Replaces gram_macro_st_kernel (65 .. 128 rows: NB = 8 blocks of
+// S = C + D, T = C - D on the fp64 matrix cores, any number of outputs (index rows = k l), even row count, no NaN
+// mask -- BASELINE configs[4] (k = 128, n = 2^24) and every k l in 33 .. 128.  Replaces gram_macro_st_kernel (65 .. 128 rows: NB = 8 blocks of
 // 16 per half) and gram_half_st_kernel (33 .. 64: NB = 4) for those shapes; tile ownership and partials are theirs
 // (vs_second.hip): a wave with block row R owns row R of S S^T (NB - R tiles) and row NB-1-R of T T^T (R + 1).
 //
@@ -56,8 +56,12 @@ constexpr size_t ST_LDS_BYTES = sizeof(double) * 2 * STAGE;   // two stages: 163
 // FULLK: K == 16 NB (no row-below-K tests)
 // R: the wave's block row of S S^T (compile-time); grp: its wave group (NB = 4: which two sub-tiles of the stage it works
 // on -- waves r and r + 4 share one body: half the code, which has to stay inside the instruction cache)
-template <int R, int NB, int NBL, bool FULLK, bool FIRST>
+// ONE: one output (index row u is plane 2 + u for c_u, 2 + K + u for d_u: wave-uniform strides between a thread's loads);
+// otherwise row m = j l + o lives in plane o (2k + 2) + 2 + j (+ k for d): the eight plane offsets of a thread are
+// worked out once
+template <int R, int NB, int NBL, bool FULLK, bool FIRST, bool ONE>
 __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, const int grp) {
+    static_assert(ONE || !FIRST, "the first-order sums ride along for one output only");
     static_assert(NB == 8 || NB == 4, "128 or 64 index rows per half");
     static_assert(!FULLK || NBL == NB, "FULLK means K == 16 NB");
     constexpr int NROWS = 16 * NB;                   // index rows per half in the tile
@@ -67,7 +71,9 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
     static_assert(R < NB, "block row");
     constexpr int TR = NB - 1 - R;                   // block row of T T^T
     constexpr int NSLOT = NB + 1;                    // accumulator tiles per wave
-    constexpr int GS = 3;                            // tiles per pipeline group
+    // tiles per pipeline group: three; two where the nine-tile kernel also carries the first-order sums (at three its
+    // 256 registers ran out and a thread-constant was reloaded from scratch once per stage, behind a vmcnt(0))
+    constexpr int GS = 3;
     constexpr int NGS = (NSLOT + GS - 1) / GS;       // groups per sub-tile: 3 (slots 0-2, 3-5, 6-8) or 2 (0-2, 3-4)
     constexpr int NG = 2 * NGS;                      // groups per stage and wave
     // One fetch in flight.  Two (a second register set, the stage loop unrolled by two so that the set is a
@@ -87,6 +93,16 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
     static_assert(4 * RSTEP == NROWS, "four row blocks per half");
     const int lrow = tid / PIECES, piece = tid % PIECES;
     const uint64_t jstep = (uint64_t)RSTEP * rows, dstep = (uint64_t)K * rows;
+    uint64_t poff[ONE ? 1 : 8];   // several outputs: first double of the plane of load j (dead rows: row 0, never loaded)
+    if (!ONE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int u = lrow + RSTEP * (j & 3);
+            const int mm = u < K ? u : 0;
+            const int jj = mm / A.l, o = mm - jj * A.l;
+            poff[ONE ? 0 : j] = ((uint64_t)o * (2 * (uint64_t)A.k + 2) + (j >= 4 ? 2 + A.k : 2) + (uint64_t)jj) * rows;
+        }
+    }
     double* wr = tiles + (piece >> 3) * SUB + lrow * VS2_WPITCH + 2 * (piece & 7);   // + RSTEP j rows: s; + NROWS rows: t
     const double* rd = tiles + 2 * grp * SUB + (lane & 15) * VS2_WPITCH + 2 * (lane >> 4);   // + 16 blk rows (+ NROWS: t)
 
@@ -132,7 +148,7 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
         for (int j = 0; j < 8; ++j) {
             const int jb = j & 3;
             const bool in = (FULLK || lr + RSTEP * jb < K) && in_rows;   // rows past K are zeros in the tile
-            const double* q = q0 + jb * jstep + (j >= 4 ? dstep : 0);
+            const double* q = ONE ? q0 + jb * jstep + (j >= 4 ? dstep : 0) : A.f + poff[ONE ? 0 : j] + 2 * piece + s0;
             raw[set][j] = in ? __builtin_nontemporal_load((const vs_d2*)q) : (vs_d2){0.0, 0.0};
         }
     };
@@ -329,7 +345,7 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
     }
 }
 
-template <int NB, int NBL, bool FULLK, bool FIRST>
+template <int NB, int NBL, bool FULLK, bool FIRST, bool ONE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gram_st_kernel(vs_gram_args A) {
     extern __shared__ double tiles[];   // [2 stages][sub-tiles][tile rows][VS2_WPITCH]
@@ -346,21 +362,21 @@ gram_st_kernel(vs_gram_args A) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if constexpr (NB == 8) {
         switch (wave) {
-            case 0: st_body<0, NB, NBL, FULLK, FIRST>(A, tiles, 0); break;
-            case 1: st_body<1, NB, NBL, FULLK, FIRST>(A, tiles, 0); break;
-            case 2: st_body<2, NB, NBL, FULLK, FIRST>(A, tiles, 0); break;
-            case 3: st_body<3, NB, NBL, FULLK, FIRST>(A, tiles, 0); break;
-            case 4: st_body<4, NB, NBL, FULLK, FIRST>(A, tiles, 0); break;
-            case 5: st_body<5, NB, NBL, FULLK, FIRST>(A, tiles, 0); break;
-            case 6: st_body<6, NB, NBL, FULLK, FIRST>(A, tiles, 0); break;
-            default: st_body<7, NB, NBL, FULLK, FIRST>(A, tiles, 0); break;
+            case 0: st_body<0, NB, NBL, FULLK, FIRST, ONE>(A, tiles, 0); break;
+            case 1: st_body<1, NB, NBL, FULLK, FIRST, ONE>(A, tiles, 0); break;
+            case 2: st_body<2, NB, NBL, FULLK, FIRST, ONE>(A, tiles, 0); break;
+            case 3: st_body<3, NB, NBL, FULLK, FIRST, ONE>(A, tiles, 0); break;
+            case 4: st_body<4, NB, NBL, FULLK, FIRST, ONE>(A, tiles, 0); break;
+            case 5: st_body<5, NB, NBL, FULLK, FIRST, ONE>(A, tiles, 0); break;
+            case 6: st_body<6, NB, NBL, FULLK, FIRST, ONE>(A, tiles, 0); break;
+            default: st_body<7, NB, NBL, FULLK, FIRST, ONE>(A, tiles, 0); break;
         }
     } else {
         switch (wave & 3) {
-            case 0: st_body<0, NB, NBL, FULLK, FIRST>(A, tiles, wave >> 2); break;
-            case 1: st_body<1, NB, NBL, FULLK, FIRST>(A, tiles, wave >> 2); break;
-            case 2: st_body<2, NB, NBL, FULLK, FIRST>(A, tiles, wave >> 2); break;
-            default: st_body<3, NB, NBL, FULLK, FIRST>(A, tiles, wave >> 2); break;
+            case 0: st_body<0, NB, NBL, FULLK, FIRST, ONE>(A, tiles, wave >> 2); break;
+            case 1: st_body<1, NB, NBL, FULLK, FIRST, ONE>(A, tiles, wave >> 2); break;
+            case 2: st_body<2, NB, NBL, FULLK, FIRST, ONE>(A, tiles, wave >> 2); break;
+            default: st_body<3, NB, NBL, FULLK, FIRST, ONE>(A, tiles, wave >> 2); break;
         }
     }
 }
@@ -375,29 +391,34 @@ gram_st_kernel(vs_gram_args A) {
 int vs_gram_st_prepare(vs_context* ctx) {
     (void)ctx;
 #define VS_ST_SET(NB, NL, FK)                                                                                  \
-    VS_HIP(hipFuncSetAttribute((const void*)gram_st_kernel<NB, NL, FK, false>,                                 \
+    VS_HIP(hipFuncSetAttribute((const void*)gram_st_kernel<NB, NL, FK, false, true>,                           \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_LDS_BYTES));                \
-    VS_HIP(hipFuncSetAttribute((const void*)gram_st_kernel<NB, NL, FK, true>,                                  \
+    VS_HIP(hipFuncSetAttribute((const void*)gram_st_kernel<NB, NL, FK, true, true>,                            \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_LDS_BYTES));                \
+    VS_HIP(hipFuncSetAttribute((const void*)gram_st_kernel<NB, NL, FK, false, false>,                          \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_LDS_BYTES));
     VS_ST_INSTANCES(VS_ST_SET)
 #undef VS_ST_SET
     return VS_OK;
 }
 
-// A.K in 33..128, A.l == 1, A.rows even, A.f 16-byte aligned (the caller checks); `workgroups` <= CUs.
+// A.K = k l in 33..128, A.rows even, A.f 16-byte aligned (the caller checks); `workgroups` <= CUs; with_first: one output.
 // Partials: K > 64: one per workgroup, [S S^T, T T^T][128][128]; else two (one per wave group), [..][64][64].
 int vs_gram_st_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, unsigned workgroups) {
     const dim3 grid(workgroups), block(512);
     const int nb = A.K > 64 ? 8 : 4;
     const int nbl = (A.K + 15) / 16;
     const bool full = A.K == 16 * nb;
-    VS_REQUIRE(A.K > 32 && A.K <= 128 && A.l == 1, "gram_st_kernel takes 33 .. 128 index rows of one output");
+    const bool one = A.l == 1;
+    VS_REQUIRE(A.K > 32 && A.K <= 128 && A.K == A.k * A.l, "gram_st_kernel takes 33 .. 128 index rows per half");
+    VS_REQUIRE(one || !with_first, "the first-order sums ride along for one output only");
     VS_REQUIRE(A.slab_wgs == workgroups, "slab_wgs must be the grid size");
     bool launched = false;
 #define VS_ST_LAUNCH(NB, NL, FK)                                                                               \
     if (!launched && nb == NB && nbl == NL && full == FK) {                                                    \
-        if (with_first) hipLaunchKernelGGL((gram_st_kernel<NB, NL, FK, true>), grid, block, ST_LDS_BYTES, ctx->stream, A);  \
-        else hipLaunchKernelGGL((gram_st_kernel<NB, NL, FK, false>), grid, block, ST_LDS_BYTES, ctx->stream, A);           \
+        if (with_first) hipLaunchKernelGGL((gram_st_kernel<NB, NL, FK, true, true>), grid, block, ST_LDS_BYTES, ctx->stream, A);  \
+        else if (one) hipLaunchKernelGGL((gram_st_kernel<NB, NL, FK, false, true>), grid, block, ST_LDS_BYTES, ctx->stream, A);   \
+        else hipLaunchKernelGGL((gram_st_kernel<NB, NL, FK, false, false>), grid, block, ST_LDS_BYTES, ctx->stream, A);          \
         launched = true;                                                                                       \
     }
     VS_ST_INSTANCES(VS_ST_LAUNCH)

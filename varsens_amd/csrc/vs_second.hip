@@ -1393,7 +1393,6 @@ static int gram_raise_lds_limits(vs_context* ctx) {
     VS2_MACRO_INSTANCES(VS2_SET_MACRO)
     VS2_ST_INSTANCES(VS2_SET_ST)
     VS2_SET(gram_half_st_kernel<true, true>)
-    VS2_SET(gram_half_st_kernel<false, false>)
     VS2_SET(gram_half_st_kernel<true, false>)
 #undef VS2_SET_ST
 #undef VS2_SET_MACRO
@@ -1432,7 +1431,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     // 33 .. 128 rows per half, one output, even row count: gram_st_kernel (vs_gram_st.hip) takes the unmasked pass
     // (one workgroup per CU; with_first: it carries the first-order dot products); the masked pass and the other
     // shapes of this range stay on gram_macro_st_kernel / gram_half_st_kernel
-    const bool st128 = macro && K > VS2_HALF && K <= VS2_MACRO && l == 1 && rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0 &&
+    const bool st128 = macro && K > VS2_HALF && K <= VS2_MACRO && rows % 2 == 0 && ((uintptr_t)f_dev & 15) == 0 &&
                        ctx->tune.gram_wide != 0 && ctx->tune.gram_st != 0;
     const bool macro_st = macro && !half_st && K <= VS2_MACRO && !(K > 48 && K <= 64) && (!with_first || st128) &&
                           ctx->tune.gram_st != 0;
@@ -1456,7 +1455,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     if (want < 1) want = 1;
     const uint64_t units = macro ? (nchunks + 3) / 4 : nchunks;   // the macro kernel walks groups of 4 chunks
     const uint32_t slab_wgs = (uint32_t)(units < want ? units : want);
-    const bool st_new = st128 || (half_st && l == 1);   // the unmasked pass runs on gram_st_kernel
+    const bool st_new = st128 || half_st;   // the unmasked pass runs on gram_st_kernel (any number of outputs)
     const uint32_t st_wgs = (uint32_t)(units < (uint64_t)cus ? units : (uint64_t)cus);   // one per CU (160 KiB of LDS)
     // the wide wave-private kernel (32 sample rows per unit, two workgroups per CU) takes the unmasked pass of
     // one-output problems with 33..64 index rows
@@ -1546,10 +1545,9 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
                 A.slab_wgs = slab_wgs;
                 F.P = pslots_old;
                 const dim3 g(slab_wgs), t(512);
-                // (the unmasked pass of one output runs on gram_st_kernel, above)
-                if (masked && l == 1) hipLaunchKernelGGL((gram_half_st_kernel<true, true>), g, t, lds_m, ctx->stream, A);
-                else if (masked) hipLaunchKernelGGL((gram_half_st_kernel<true, false>), g, t, lds_m, ctx->stream, A);
-                else hipLaunchKernelGGL((gram_half_st_kernel<false, false>), g, t, lds_m, ctx->stream, A);
+                // (the unmasked pass runs on gram_st_kernel, above: only the masked one comes here)
+                if (l == 1) hipLaunchKernelGGL((gram_half_st_kernel<true, true>), g, t, lds_m, ctx->stream, A);
+                else hipLaunchKernelGGL((gram_half_st_kernel<true, false>), g, t, lds_m, ctx->stream, A);
             } else if (macro_st && st128 && !masked) {
                 A.slab_wgs = F.P = st_wgs;
                 rc = vs_gram_st_launch(ctx, A, with_first, st_wgs);
