@@ -333,21 +333,39 @@ struct mt19937 {
 extern "C" int vs_seed1_permutation(uint32_t* out, uint64_t n) {
     VS_REQUIRE(out || n == 0, "out is null");
     VS_REQUIRE(n <= 0xffffffffull, "n=%llu out of range", (unsigned long long)n);
+    if (n < 2) {
+        if (n) out[0] = 0;
+        return VS_OK;
+    }
     for (uint64_t i = 0; i < n; ++i) out[i] = (uint32_t)i;
+    // Two stages per batch: (1) draw the next BATCH swap partners -- the generator does not depend on the array, so
+    // the masked rejection runs branch-free (a rejected draw is overwritten by the next one) and every partner's
+    // cache line is requested as soon as it is known; (2) do the swaps, whose random reads then hit the cache.
+    // Same draws in the same order as the one-loop form (i = n-1 .. 1, j = first masked draw <= i): twice as fast
+    // at n = 2^20 .. 2^22 (1.3 x at 2^24, where the partners also miss the TLB; a huge-page buffer was slower:
+    // its page faults cost more than the misses).
+    constexpr uint32_t BATCH = 2048;
+    uint32_t partner[BATCH + 1];
     mt19937 rng(1u);
-    for (uint64_t i = n; i-- > 1;) {  // i = n-1 .. 1
-        uint32_t mask = (uint32_t)i;
-        mask |= mask >> 1;
-        mask |= mask >> 2;
-        mask |= mask >> 4;
-        mask |= mask >> 8;
-        mask |= mask >> 16;
-        uint32_t j;
-        while ((j = rng.next() & mask) > (uint32_t)i) {
+    uint32_t i = (uint32_t)(n - 1);
+    while (i >= 1) {
+        const uint32_t want = i < BATCH ? i : BATCH;   // swaps of this batch: i, i-1, .., i-want+1
+        uint32_t got = 0, ii = i;
+        while (got < want) {
+            const uint32_t mask = 0xffffffffu >> __builtin_clz(ii);   // ii >= 1
+            const uint32_t j = rng.next() & mask;
+            partner[got] = j;
+            __builtin_prefetch(out + j, 1);
+            const uint32_t ok = j <= ii ? 1u : 0u;
+            got += ok;
+            ii -= ok;
         }
-        const uint32_t t = out[i];
-        out[i] = out[j];
-        out[j] = t;
+        for (uint32_t t = 0; t < want; ++t, --i) {
+            const uint32_t j = partner[t];
+            const uint32_t v = out[i];
+            out[i] = out[j];
+            out[j] = v;
+        }
     }
     return VS_OK;
 }
