@@ -118,9 +118,10 @@ def test_seed1_permutation_matches_reference(golden):
 
 
 def test_native_permutation_is_numpys_legacy_shuffle(native):
-    for n in (0, 1, 2, 3, 5, 13, 624, 625, 1024, 2047, 2048, 2049, 2050, 4096, 4097, 6145, 100003, 1 << 20):   # 2048 = the batch of the swap loop
+    """vs_seed1_permutation (C restatement of MT19937 + legacy shuffle) == numpy RandomState(1).shuffle."""
     import time
-    for n in (0, 1, 2, 3, 5, 13, 624, 625, 1024, 4097, 100003, 1 << 20):
+    # 2048 = the batch of the swap loop
+    for n in (0, 1, 2, 3, 5, 13, 624, 625, 1024, 2047, 2048, 2049, 2050, 4096, 4097, 6145, 100003, 1 << 20):
         want = np.arange(n, dtype=np.uint32)
         np.random.RandomState(1).shuffle(want)
         assert np.array_equal(native.seed1_permutation(n), want), n
