@@ -32,8 +32,10 @@ extern "C" {
 #endif
 
 /* 2: perm slices per rank, vs_accumulate, vs_context_set_eval_order, vs_eval_reduce_supported.
- * 3: the second-order sums are S S^T and T T^T (VS_GRAM_LEN doubles) instead of D C^T, D D^T, C C^T. */
-#define VS_ABI_VERSION 4
+ * 3: the second-order sums are S S^T and T T^T (VS_GRAM_LEN doubles) instead of D C^T, D D^T, C C^T.
+ * 4: VS_PERM_EMPTY, vs_profile_select.
+ * 5: vs_eval_reduce_first_second_order, vs_eval_reduce_both_supported. */
+#define VS_ABI_VERSION 5
 
 typedef enum vs_status {
     VS_OK = 0,
@@ -286,6 +288,20 @@ int vs_eval_reduce_supported(vs_context* ctx, const vs_design* design, const vs_
 int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                                uint64_t row_begin, uint64_t row_count, int rank, int max_ranks,
                                double* acc_dev);
+
+/* Fused path for BOTH orders: the same evaluation walk writes s = c + d, t = c - d of every 64-row block into an
+ * LDS tile, and the workgroup multiplies it on the fp64 matrix cores (S S^T, T T^T) and takes the first-order dot
+ * products off the same fragments: this rank's record (acc_dev, as vs_reduce_first_order) and Gram sums (gram_dev,
+ * VS_GRAM_LEN(k) doubles, as vs_reduce_second_order) without any f-value in HBM.  Covers G_FUNCTION / POLYNOMIAL /
+ * LINEAR objectives with ONE output and k <= 32 (every generator and scaling of the design; Halton indices below
+ * 2^32; not a context in strict evaluation order); VS_ERR_ARG otherwise -- vs_eval_reduce_both_supported tells in
+ * advance, callers then use vs_eval + vs_reduce_first_second_order.  NaN values propagate.  Results equal the
+ * two-kernel path's up to summation order (<= ~2e-13 relative on the sums).
+ * Replaces saltelli.py:329-355 + :577,583,591-596 + :612-619 in one kernel. */
+int vs_eval_reduce_both_supported(vs_context* ctx, const vs_design* design, const vs_objective* obj, int* supported);
+int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_design* design, const vs_objective* obj,
+                                      uint64_t row_begin, uint64_t row_count, int rank, int max_ranks,
+                                      double* acc_dev, double* gram_dev);
 
 /* Finished indices from a (summed) record; divisors use the REQUESTED global n
  * even when rows were trimmed (saltelli.py:576-577,591).  out_dev layout

@@ -514,10 +514,40 @@ def test_fused_first_order_through_api(vs, golden):
     # what the fused kernels do not cover takes the two-kernel path by itself, or says so when fused=True was asked
     with pytest.raises(Exception, match="fused=True"):
         vs.Varsens(vs.objectives.Invert(), vs.scale.Identity(), 3, 64, verbose=False, second_order=False, fused=True)
-    with pytest.raises(Exception, match="fused=True needs"):
-        vs.Varsens(vs.objectives.GFunction(model), vs.scale.Identity(), 6, 64, verbose=False, fused=True)  # second order
+    with pytest.raises(Exception, match="fused=True needs"):   # second order with two outputs: no fused kernel
+        vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 64, verbose=False, fused=True)
     vi = vs.Varsens(vs.objectives.Invert(), vs.scale.Identity(), 3, 64, verbose=False, second_order=False)
     assert vi.sens.shape == (3, 3)
+
+
+def test_fused_both_orders_through_api(vs, golden):
+    """The default call -- Varsens(objective, scaling, k, n) with its second-order indices -- on a built-in separable
+    objective with one output and k <= 32 runs in ONE kernel (vs_eval_reduce_first_second_order): nothing is written
+    to HBM, and the results are the reference's (golden G2) and the two-kernel route's."""
+    g = golden("g2_gfunc_k6_n51200")
+    v = vs.Varsens(vs.objectives.GFunction(model), vs.scale.Identity(), 6, 51200, verbose=False)
+    assert v.objective._f is None
+    for f in ("E_2", "var_y", "U_j", "U_nj"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-13)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-10, atol=1e-13, err_msg=f)
+    cases = [(vs.objectives.Linear(numpy.arange(1.0, 33.0)), vs.scale.Linear(-1.0, 2.0), 32, 30001),
+             (vs.objectives.Polynomial(1.0 / (1.0 + numpy.arange(17) / 8.0)), vs.scale.Power(1.0, 10.0), 17, 4096),
+             (vs.objectives.GFunction(numpy.linspace(0, 9, 16)), vs.scale.Identity(), 16, 1000)]
+    for obj, sc, k, n in cases:
+        a = vs.Varsens(obj, sc, k, n, verbose=False, fused=True)
+        assert a.objective._f is None, type(obj).__name__
+        b = vs.Varsens(obj, sc, k, n, verbose=False, fused=False)
+        assert b.objective._f is not None
+        for f in ("E_2", "var_y", "U_j", "U_nj"):
+            numpy.testing.assert_allclose(getattr(a, f), getattr(b, f), rtol=1e-12, err_msg=f)
+        for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+            numpy.testing.assert_allclose(getattr(a, f), getattr(b, f), rtol=1e-9, atol=1e-11, err_msg=f)
+    # beyond 32 columns, several outputs, Ishigami: the two-kernel route by itself
+    w = vs.Varsens(vs.objectives.Linear(numpy.ones(40)), vs.scale.Identity(), 40, 500, verbose=False)
+    assert w.objective._f is not None and w.sens_2.shape == (40, 1, 40, 1)
+    i3 = vs.Varsens(vs.objectives.Ishigami(), vs.scale.Linear(-numpy.pi, numpy.pi), 3, 2000, verbose=False)
+    assert i3.objective._f is not None
 
 
 def test_fused_through_api_wider_shapes(vs):

@@ -491,7 +491,10 @@ def test_rccl_single_rank_allreduce(ctx):
                                       # gram_st_kernel (round 3): every count of live 16-row blocks, partly filled last
                                       # blocks, one and many stages per workgroup, ragged last stage
                                       (50, 200, 1), (56, 1000, 1), (63, 70, 1), (72, 2048, 1), (90, 330, 1), (112, 64, 1),
-                                      (120, 500, 1), (127, 34, 1), (64, 100002, 1), (128, 70000, 1), (80, 40000, 1)])
+                                      (120, 500, 1), (127, 34, 1), (64, 100002, 1), (128, 70000, 1), (80, 40000, 1),
+                                      # ... with several outputs (index row = output * k + column; 65..128 rows per half)
+                                      (32, 2048, 4), (24, 1000, 5), (22, 70, 3), (43, 500, 2), (9, 40000, 9), (16, 62, 8),
+                                      (37, 100002, 3), (1, 3000, 128), (2, 64, 33)])
 def test_second_order_gram(ctx, k, rows, l):
     rng = np.random.RandomState(k * 7 + rows + l)
     blocks = 1.0 + rng.randn(2 * k + 2, rows, l)
@@ -752,6 +755,75 @@ def test_fused_power_scaling_matches_two_kernel_path(ctx, kind, k, n, l):
     name = {"g": "g_function", "lin": "linear", "poly": "polynomial"}[kind]
     ex = orc.exact_accumulators(*orc.evaluate_engine_order(name, params, S[0], S[1]))
     np.testing.assert_allclose(r2[4 + 3:4 + 3 + k], ex["ac"][:, 0], rtol=1e-12)
+
+
+@pytest.mark.parametrize("kind,k,n,mode", [
+    ("g", 6, 1024, 0), ("lin", 32, 4096, 0), ("poly", 32, 70001, 1), ("g", 17, 333, 0), ("lin", 16, 5000, 1),
+    ("poly", 1, 64, 0), ("g", 3, 1, 0), ("lin", 9, 63, 0), ("g", 24, 65, 2), ("poly", 31, 20000, 0), ("lin", 12, 129, 2),
+    ("g", 32, 1 << 18, 0), ("lin", 2, 100003, 0), ("g", 8, 300000, 1), ("poly", 20, 640, 0)])
+def test_fused_both_orders_matches_two_kernel_path(ctx, kind, k, n, mode):
+    """vs_eval_reduce_first_second_order (round 3: s/t rows of every 64-row block into an LDS tile, MFMA Gram and the
+    first-order dot products in the evaluating workgroup) == vs_eval + vs_reduce_first_second_order up to summation
+    order, for every scaling mode, ragged last blocks, one workgroup and many, k on both sides of 16."""
+    from varsens_amd import _native
+    rng = np.random.RandomState(k * 31 + n)
+    params = {"g": rng.rand(k) * 5, "lin": np.arange(1, k + 1, dtype=float), "poly": 1.0 / (1.0 + np.arange(k) / 8.0)}[kind]
+    code = {"g": _native.OBJ_G_FUNCTION, "lin": _native.OBJ_LINEAR, "poly": _native.OBJ_POLYNOMIAL}[kind]
+    lo = hi = None
+    if mode == 1:
+        lo, hi = np.linspace(-1, 0.5, k), np.linspace(1, 3, k)
+    elif mode == 2:
+        lo, hi = np.full(k, 1e-2), np.linspace(0.5, 1.0, k)
+    d = make_design(ctx, k, n, mode, lo, hi)
+    obj = ctx.objective_create(code, k, 1, params)
+    assert ctx.eval_reduce_both_supported(d, obj)
+    nacc, ng = _native.acc_len(k, 1, 1), _native.gram_len(k)
+    f = ctx.alloc(8 * 2 * (k + 1) * n)
+    ctx.eval(d, obj, 0, n, f)
+    acc1, acc2, g1, g2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc), ctx.alloc(8 * ng), ctx.alloc(8 * ng)
+    ctx.reduce_first_second_order(f, n, k, 1, acc1, g1)
+    ctx.eval_reduce_first_second_order(d, obj, 0, n, acc2, g2)
+    r1, r2 = ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,))
+    G1, G2 = ctx.download(g1, (2, k, k)), ctx.download(g2, (2, k, k))
+    assert r2[0] == r1[0] == n and r2[1] == 0
+    per = _native.acc_per_output(k)
+    np.testing.assert_allclose(r2[4:4 + per], r1[4:4 + per], rtol=1e-12)
+    np.testing.assert_allclose(r2[4 + per:], r1[4 + per:], rtol=1e-9, atol=1e-9 * abs(r1[4 + per + 1]))   # count, mean, m2
+    scale = np.abs(G1).max()
+    np.testing.assert_allclose(G2, G1, rtol=1e-12, atol=1e-13 * scale)
+    assert np.array_equal(G2[0], G2[0].T) and np.array_equal(G2[1], G2[1].T)
+    # and straight against the f-values: S S^T, T T^T in numpy
+    F = ctx.download(f, (2 * k + 2, n))
+    S, T = F[2:2 + k] + F[2 + k:], F[2:2 + k] - F[2 + k:]
+    np.testing.assert_allclose(G2[0], S @ S.T, rtol=1e-12, atol=1e-12 * scale)
+    np.testing.assert_allclose(G2[1], T @ T.T, rtol=1e-12, atol=1e-12 * scale)
+    np.testing.assert_allclose(r2[4 + 3:4 + 3 + k], F[2:2 + k] @ F[0], rtol=1e-12)            # a . c_i
+
+
+def test_fused_both_orders_coverage(ctx):
+    from varsens_amd import _native
+    d = make_design(ctx, 40, 100)
+    assert not ctx.eval_reduce_both_supported(d, ctx.objective_create(_native.OBJ_LINEAR, 40, 1, np.ones(40)))   # k > 32
+    d8 = make_design(ctx, 8, 100)
+    assert not ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 2, np.ones(16)))   # two outputs
+    assert not ctx.eval_reduce_both_supported(make_design(ctx, 3, 100), ctx.objective_create(_native.OBJ_ISHIGAMI, 3, 1, np.array([7.0, 0.1])))
+    lin = ctx.objective_create(_native.OBJ_LINEAR, 8, 1, np.ones(8))
+    assert ctx.eval_reduce_both_supported(d8, lin)
+    acc, g = ctx.alloc(8 * _native.acc_len(8, 1, 1)), ctx.alloc(8 * _native.gram_len(8))
+    with pytest.raises(_native.VarsensHipError):
+        ctx.eval_reduce_first_second_order(make_design(ctx, 40, 100), ctx.objective_create(_native.OBJ_LINEAR, 40, 1, np.ones(40)), 0, 100, acc, g)
+    # a Sobol design and raw points go through the general column code
+    from varsens_amd.saltelli import sobol_directions
+    n = 3000
+    ds = ctx.design_create(_native.GEN_SOBOL, 8, n, 4096, 0, None, None, orc.seed1_permutation(n).astype(np.uint32), None, sobol_directions(8))
+    f = ctx.alloc(8 * 18 * n)
+    ctx.eval(ds, lin, 0, n, f)
+    acc1, g1 = ctx.alloc(8 * _native.acc_len(8, 1, 1)), ctx.alloc(8 * _native.gram_len(8))
+    ctx.reduce_first_second_order(f, n, 8, 1, acc1, g1)
+    ctx.eval_reduce_first_second_order(ds, lin, 0, n, acc, g)
+    np.testing.assert_allclose(ctx.download(g, (2, 8, 8)), ctx.download(g1, (2, 8, 8)), rtol=1e-12)
+    n8 = _native.acc_len(8, 1, 1)
+    np.testing.assert_allclose(ctx.download(acc, (n8,))[4:4 + 35], ctx.download(acc1, (n8,))[4:4 + 35], rtol=1e-12)
 
 
 def test_variance_with_outlier_in_first_value(ctx):

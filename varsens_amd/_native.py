@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARSENS_HIP_LIB") or os.path.join(_HERE, "libvarsens_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128
 
 GEN_HALTON, GEN_SOBOL, GEN_RAW = 0, 1, 2
@@ -121,6 +121,9 @@ SIGNATURES = {
     "vs_reduce_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_void_p]),
     "vs_eval_reduce_supported": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "vs_eval_reduce_both_supported": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "vs_eval_reduce_first_second_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int,
+                                                    C.c_int, C.c_void_p, C.c_void_p]),
     "vs_eval_reduce_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int,
                                              C.c_int, C.c_void_p]),
     "vs_finish_first_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
@@ -448,6 +451,18 @@ class Context(object):
     def eval_reduce_first_order(self, design, objective, row_begin, row_count, acc_buf, rank=0, max_ranks=1):
         _check(self.lib.vs_eval_reduce_first_order(self.handle, design.h, objective.h, int(row_begin), int(row_count),
                                                    int(rank), int(max_ranks), C.c_void_p(acc_buf.ptr)))
+
+    def eval_reduce_both_supported(self, design, objective):
+        """True when the fused evaluate + first/second-order kernels cover this (design, objective)."""
+        flag = C.c_int(0)
+        _check(self.lib.vs_eval_reduce_both_supported(self.handle, design.h, objective.h, C.byref(flag)))
+        return bool(flag.value)
+
+    def eval_reduce_first_second_order(self, design, objective, row_begin, row_count, acc_buf, gram_buf, rank=0,
+                                       max_ranks=1):
+        _check(self.lib.vs_eval_reduce_first_second_order(self.handle, design.h, objective.h, int(row_begin),
+                                                          int(row_count), int(rank), int(max_ranks),
+                                                          C.c_void_p(acc_buf.ptr), C.c_void_p(gram_buf.ptr)))
 
     def finish_first_order(self, acc_buf, n, k, l, out_buf, max_ranks=1):
         _check(self.lib.vs_finish_first_order(self.handle, C.c_void_p(acc_buf.ptr), int(n), int(k), int(l),

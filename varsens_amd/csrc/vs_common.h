@@ -138,6 +138,9 @@ int vs_workspace_scratch(vs_context* ctx, size_t bytes);
 int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, const double* shift_dev,
                      int shift_stride, const double* f_dev, int rank, int max_ranks, double* acc_dev);
 
+// vs_second.hip: fold of P partials [S S^T, T T^T][SB][SB] into the interface's Gram sums
+int vs_gram_fold_st(vs_context* ctx, const double* partials, uint32_t P, int K, int SB, double* gram_dev);
+
 // partial record of one workgroup for one output: 5 head values + 4 per block j
 #define VS_P_SAB 0
 #define VS_P_SA 1

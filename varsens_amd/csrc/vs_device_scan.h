@@ -118,13 +118,138 @@ struct vs_scan_acc {
 // wait.  Interleaved, every wave gets one column of each run of W primes.  The folds run in scan-position order.
 #define VS_SCAN_COLUMN(q, j, W) ((j) * (W) + (q))
 
+// ---- fused evaluate + BOTH orders (NBH > 0; k <= 16 NBH <= 32 columns, one output, four waves) -----------------
+// Instead of storing c_i, d_i the output walk writes s_i = c_i + d_i and t_i = c_i - d_i of the block's 64 rows
+// into an LDS tile [index row][sample row = lane]: s_i at tile row i, t_i at 16 NBH + i (rows i >= k stay zero),
+// a and b behind them; after a second barrier the four waves multiply the tile on the fp64 matrix cores (S S^T and
+// T T^T, varsens/saltelli.py:612-619) and take the first-order dot products off the same fragments -- no f-values
+// in HBM for the whole of compute_varsens.  Pitch 68 doubles: a wave writes 512 contiguous bytes per tile row, and
+// the b128 fragment reads (index row lane & 15, sample pair lane >> 4) fall on the banks of the pitch-36 tile of
+// gram_diag_wide_kernel (136 r mod 64 = 72 r mod 64 = 8 r): conflict-free.
+#define VS_GT_PITCH 68
+#define VS_GT_ROWS(NBH) (32 * (NBH) + 2)
+#define VS_GT_DOUBLES(NBH) (VS_GT_ROWS(NBH) * VS_GT_PITCH)
+typedef double vs_d2 __attribute__((ext_vector_type(2)));
+typedef double vs_d4 __attribute__((ext_vector_type(4)));
+
+// Wave q of four owns block X = {S0, S1, T0, T1}[q] (NBH = 2) and accumulates
+//   d: X X^T over all 64 samples (16 MFMAs), o: its half of the samples of S0 S1^T (q < 2) or T0 T1^T (8 MFMAs),
+//   pa, pb: a . x and b . x of its 16 index rows;
+// NBH = 1: X = S0 (q < 2) or T0, each wave over its half of the samples (d: 8 MFMAs; no o).
+struct vs_gram_regs {
+    vs_d4 d, o;
+    double pa, pb;
+};
+
+template <int NBH>
+__device__ __forceinline__ void vs_gram_consume(const double* __restrict__ tile, int q, int lane, vs_gram_regs& G) {
+    constexpr int P = VS_GT_PITCH, HALF = 16 * NBH;
+    const int part = q >> 1, odd = q & 1;
+    const double* base = tile + (size_t)(part * HALF + (lane & 15)) * P + 2 * (lane >> 4);   // block 0 of S or of T
+    const double* rx = base + (NBH == 2 ? 16 * odd * P : 0);                                  // the wave's own block
+    const double* rab = tile + (size_t)(2 * HALF) * P + 2 * (lane >> 4);                      // a; b one row further
+    // eight quarters of 8 samples: lane group g = lane >> 4 holds samples 8 h + 2 g, + 1 of its index row
+    auto diag = [&](int h) {
+        const vs_d2 x = *(const vs_d2*)(rx + 8 * h);
+        const vs_d2 av = *(const vs_d2*)(rab + 8 * h), bv = *(const vs_d2*)(rab + P + 8 * h);
+        G.d = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0], x[0], G.d, 0, 0, 0);
+        G.d = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1], x[1], G.d, 0, 0, 0);
+        G.pa = fma(av[0], x[0], G.pa);
+        G.pb = fma(bv[0], x[0], G.pb);
+        G.pa = fma(av[1], x[1], G.pa);
+        G.pb = fma(bv[1], x[1], G.pb);
+    };
+    if (NBH == 2) {
+#pragma unroll
+        for (int h = 0; h < 8; ++h) diag(h);
+#pragma unroll
+        for (int h2 = 0; h2 < 4; ++h2) {   // rows of block 0 x columns of block 1, this wave's half of the samples
+            const int h = 4 * odd + h2;
+            const vs_d2 x0 = *(const vs_d2*)(base + 8 * h), x1 = *(const vs_d2*)(base + 16 * P + 8 * h);
+            G.o = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[0], x1[0], G.o, 0, 0, 0);
+            G.o = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[1], x1[1], G.o, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int h2 = 0; h2 < 4; ++h2) diag(4 * odd + h2);
+    }
+}
+
+// End of the kernel: the workgroup's Gram partial [S S^T, T T^T][16 NBH][16 NBH] (upper 16-blocks; the layout
+// gram_fold_kernel reads with st = 2) and its first-order record (layout of reduce_first_kernel's partials).
+// `lds`: at least 2 * 256 + 128 + 8 doubles, free by now; head[5]: sab, sa, sb, s1, s2 (meaningful in wave 0).
+template <int NBH>
+__device__ __forceinline__ void vs_gram_epilogue(double* __restrict__ lds, int q, int lane, vs_gram_regs& G,
+                                                 const double (&head)[5], int k, double* __restrict__ gout,
+                                                 double* __restrict__ rec) {
+    constexpr int SB = 16 * NBH;
+    const int part = q >> 1, odd = q & 1;
+    double* red2 = lds;               // [part][16][16]: the odd waves' share of a tile the even waves store
+    double* dots = lds + 512;         // [wave][16 rows][a, b]
+    double* hd = lds + 512 + 128;     // the five head sums
+    G.pa += __shfl_xor(G.pa, 16, 64);
+    G.pa += __shfl_xor(G.pa, 32, 64);
+    G.pb += __shfl_xor(G.pb, 16, 64);
+    G.pb += __shfl_xor(G.pb, 32, 64);
+    __syncthreads();   // every wave is done with the tile
+    if (lane < 16) {
+        dots[(q * 16 + lane) * 2 + 0] = G.pa;
+        dots[(q * 16 + lane) * 2 + 1] = G.pb;
+    }
+    if (odd) {
+        const vs_d4 share = NBH == 2 ? G.o : G.d;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red2[part * 256 + ((lane >> 4) + 4 * v) * 16 + (lane & 15)] = share[v];
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int z = 0; z < 5; ++z) {
+            const double t = vs_wave_sum_dpp(head[z]);
+            if (lane == 63) hd[z] = t;
+        }
+    }
+    __syncthreads();
+    double* o = gout + (size_t)part * SB * SB;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int row = (lane >> 4) + 4 * v, col = lane & 15;   // f64 C/D layout
+        if (NBH == 2) {
+            o[(16 * odd + row) * SB + 16 * odd + col] = G.d[v];
+            if (!odd) o[row * SB + 16 + col] = G.o[v] + red2[part * 256 + row * 16 + col];
+        } else if (!odd) {
+            o[row * SB + col] = G.d[v] + red2[part * 256 + row * 16 + col];
+        }
+    }
+    // record: head, ac[k], bd[k], ad[k], bc[k] with a.c = (a.s + a.t) / 2, a.d = (a.s - a.t) / 2
+    const size_t plen = 5 + 4 * (size_t)k;
+    for (size_t e = threadIdx.x; e < plen; e += 256) {
+        double v = hd[e < 5 ? e : 0];
+        if (e >= 5) {
+            const int slot = (int)((e - 5) / k), j = (int)((e - 5) % k);
+            const int which = (slot == 0 || slot == 2) ? 0 : 1;
+            double xs, xt;
+            if (NBH == 2) {   // s row j: wave j >> 4, t row j: wave 2 + (j >> 4)
+                xs = dots[j * 2 + which];
+                xt = dots[(32 + j) * 2 + which];
+            } else {          // two waves per block, half of the samples each
+                xs = dots[j * 2 + which] + dots[(16 + j) * 2 + which];
+                xt = dots[(32 + j) * 2 + which] + dots[(48 + j) * 2 + which];
+            }
+            v = (slot == 0 || slot == 3) ? 0.5 * (xs + xt) : 0.5 * (xs - xt);
+        }
+        rec[e] = v;
+    }
+}
+
 // Everything behind the terms of one output: totals exchange, prefixes, suffix checkpoints, outputs.
 // ta/tb: the wave's 2L terms in registers (TLDS: in its LDS slab `tl` instead); Ta/Tb their totals.
-template <int FOLD, int L, int W, bool FUSED, bool TLDS>
+// NBH > 0 (FUSED): the outputs go into the Gram tile `gt` (tile + lane) instead of the 4L register sums.
+template <int FOLD, int L, int W, bool FUSED, bool TLDS, int NBH = 0>
 __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L], const double (&tb)[TLDS ? 1 : L],
                                                const double* __restrict__ tl, double Ta, double Tb,
                                                double* __restrict__ tot, int q, int lane, double* __restrict__ f,
-                                               vs_u64 rows, int k, bool valid, double shift, vs_scan_acc<L>& acc) {
+                                               vs_u64 rows, int k, bool valid, double shift, vs_scan_acc<L>& acc,
+                                               double* __restrict__ gt = nullptr) {
     constexpr int T = VS_EVAL_ROWS;
     constexpr int SUB = L < VS_SCAN_SUB ? L : VS_SCAN_SUB;
     constexpr int NSUB = L / SUB;
@@ -208,7 +333,12 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
             const double dj = vs_fold<FOLD>(vs_fold<FOLD>(pa, ub[j]), sa[j]);  // N_nj[i]: M_1 with column i from M_2
             pa = vs_fold<FOLD>(pa, ua[j]);
             pb = vs_fold<FOLD>(pb, ub[j]);
-            if (FUSED) {
+            if (NBH > 0) {
+                if (i < k) {  // rows past the block's last design row are zeros in the tile
+                    gt[(size_t)i * VS_GT_PITCH] = valid ? cj + dj : 0.0;
+                    gt[(size_t)(16 * NBH + i) * VS_GT_PITCH] = valid ? cj - dj : 0.0;
+                }
+            } else if (FUSED) {
                 if (valid) {  // columns beyond k hold the identity; their sums are dropped at the end
                     acc.v[jj][0] = fma(a, cj, acc.v[jj][0]);
                     acc.v[jj][1] = fma(b, dj, acc.v[jj][1]);
@@ -227,6 +357,10 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
     }
 #undef VS_TA
 #undef VS_TB
+    if (NBH > 0 && q == 0) {
+        gt[(size_t)(32 * NBH) * VS_GT_PITCH] = valid ? a : 0.0;
+        gt[(size_t)(32 * NBH + 1) * VS_GT_PITCH] = valid ? b : 0.0;
+    }
     if (FUSED && q == 0 && valid) {
         const double dx = a - shift, dy = b - shift;
         acc.sab = fma(a, b, acc.sab);
@@ -242,11 +376,11 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
 // registers and every output o builds its own terms from them (parameters params + o*k, plane o of
 // the f-values; the two totals slabs alternate per output, one barrier each) -- the generator runs
 // once per row whatever l is.  Otherwise one output (`params`, `fplane` are that output's).
-template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
+template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV, int NBH = 0>
 __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const double* __restrict__ params,
                                               int q, int lane, vs_u64 rb, double* __restrict__ tot,
                                               double* __restrict__ tl, double* __restrict__ fplane, double shift,
-                                              vs_scan_acc<L>& acc) {
+                                              vs_scan_acc<L>& acc, double* __restrict__ gt = nullptr) {
     constexpr int T = VS_EVAL_ROWS;
     // q is loop-invariant in the persistent walk; tied to the block index here, or the optimiser hoists
     // every column's addresses and masks (all derived from q) out of that loop and spills scalars for
@@ -332,7 +466,7 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
 #ifdef VS_SCAN_STAMPS
         asm("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(stamp1) : "v"(Ta), "v"(Tb));
 #endif
-        vs_scan_finish<FOLD, L, W, FUSED, TLDS>(ta, tb, tl, Ta, Tb, tot, q, lane, f, rows, k, valid, shift, acc);
+        vs_scan_finish<FOLD, L, W, FUSED, TLDS, NBH>(ta, tb, tl, Ta, Tb, tot, q, lane, f, rows, k, valid, shift, acc, gt);
 #ifdef VS_SCAN_STAMPS
         if constexpr (!FUSED) {
             if ((blockIdx.x & 511) == 0 && lane == 0) {
@@ -447,6 +581,44 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
             }
         }
     }
+}
+
+// The whole kernel body of the fused evaluate + both-orders pass (see vs_gram_consume): four waves, L columns each,
+// k <= 16 NBH; persistent workgroups walk the 64-row blocks with TWO barriers per block -- totals published (inside
+// vs_scan_finish), tile written -- and multiply block n while the faster waves generate block n + 1 (a wave writes
+// the tile of block n + 1 only behind that block's first barrier, which every wave reaches after its MFMAs of block n;
+// one totals slab for the same reason).  LDS: [2][4][64] totals, then the tile.
+// Partials: first_partials[blockIdx.x][5 + 4k], gram_partials[blockIdx.x][2][16 NBH][16 NBH].
+template <class Term, int FOLD, int L, int NBH, int GENV>
+__device__ __forceinline__ void vs_scan_gram_body(const vs_eval_args& A, double* __restrict__ lds,
+                                                  const double* __restrict__ shift_src,
+                                                  double* __restrict__ first_partials,
+                                                  double* __restrict__ gram_partials) {
+    constexpr int T = VS_EVAL_ROWS, W = 4;
+    static_assert(NBH == 1 || NBH == 2, "16 or 32 index rows per half");
+    static_assert(L * W >= 16 * NBH || L * W >= 8, "columns");
+    const int k = A.D.k;
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* tile = lds + 2 * W * T;
+    for (int e = threadIdx.x; e < VS_GT_DOUBLES(NBH); e += W * T) tile[e] = 0.0;   // rows k .. 16 NBH - 1 stay zero
+    const double shift = shift_src[0];
+    vs_scan_acc<L> acc;
+    acc.sab = acc.sa = acc.sb = acc.s1 = acc.s2 = 0.0;
+    vs_gram_regs G;
+    G.d = G.o = (vs_d4){0.0, 0.0, 0.0, 0.0};
+    G.pa = G.pb = 0.0;
+    __syncthreads();
+    const vs_u64 nblocks = (A.rows + T - 1) / T;
+    for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+        vs_scan_block<Term, FOLD, L, W, true, false, false, GENV, NBH>(A, A.params, q, lane, rb, lds, nullptr, nullptr,
+                                                                       shift, acc, tile + lane);
+        __syncthreads();
+        vs_gram_consume<NBH>(tile, q, lane, G);
+    }
+    const double head[5] = {acc.sab, acc.sa, acc.sb, acc.s1, acc.s2};
+    vs_gram_epilogue<NBH>(tile, q, lane, G, head, k, gram_partials + (size_t)blockIdx.x * 2 * (16 * NBH) * (16 * NBH),
+                          first_partials + (size_t)blockIdx.x * (5 + 4 * (size_t)k));
 }
 
 #endif  // VS_DEVICE_SCAN_H

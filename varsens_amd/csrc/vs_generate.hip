@@ -847,6 +847,68 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
     return vs_fold_partials(ctx, P, k, l, row_count, shift_buf, (int)shift_stride, nullptr, rank, max_ranks, acc_dev);
 }
 
+// vs_scan_gram.hip
+int vs_scan_gram_launch(vs_context* ctx, const vs_eval_args& A, int nbh, unsigned* P_io, const double* shift_dev,
+                        double* first_partials, double* gram_partials, bool plan_only);
+
+// the fused both-orders kernels: built-in separable objectives in scan form, one output, k <= 32
+static bool fused_both_route(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
+    return obj->l == 1 && obj->k <= 32 && obj->k == design->d.k && fused_route_for(ctx, design, obj) == FUSED_SCAN;
+}
+
+extern "C" int vs_eval_reduce_both_supported(vs_context* ctx, const vs_design* design, const vs_objective* obj,
+                                             int* supported) {
+    VS_REQUIRE(ctx && design && obj && supported, "null argument");
+    *supported = fused_both_route(ctx, design, obj) ? 1 : 0;
+    return VS_OK;
+}
+
+extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_design* design, const vs_objective* obj,
+                                                 uint64_t row_begin, uint64_t row_count, int rank, int max_ranks,
+                                                 double* acc_dev, double* gram_dev) {
+    VS_REQUIRE(ctx && design && obj && acc_dev && gram_dev, "null argument");
+    VS_REQUIRE(obj->k == design->d.k, "objective has k=%d, design has k=%d", obj->k, design->d.k);
+    VS_REQUIRE(row_begin <= design->d.n && row_count <= design->d.n - row_begin, "rows exceed n");
+    VS_REQUIRE(max_ranks >= 1 && rank >= 0 && rank < max_ranks, "rank %d not in [0,%d)", rank, max_ranks);
+    VS_REQUIRE(row_count >= 1, "the fused path needs at least one row");
+    VS_REQUIRE(rows_in_perm_slice(design, row_begin, row_count), "rows lie outside the design's shuffle slice");
+    VS_HIP(hipSetDevice(ctx->device));
+    if (!fused_both_route(ctx, design, obj))
+        return vs_fail(VS_ERR_ARG, "the fused both-orders path covers G_FUNCTION / POLYNOMIAL / LINEAR objectives with one "
+                                   "output and k <= 32 (Halton indices below 2^32, scan evaluation order); use vs_eval + "
+                                   "vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
+    const int k = obj->k;
+    const int nbh = k <= 16 ? 1 : 2, SB = 16 * nbh;
+    vs_eval_args A;
+    A.D = to_dev(design);
+    A.kind = obj->kind;
+    A.l = 1;
+    A.params = obj->params;
+    A.row_begin = row_begin;
+    A.rows = row_count;
+    A.f = nullptr;
+    unsigned P = 1;
+    int rc = vs_scan_gram_launch(ctx, A, nbh, &P, nullptr, nullptr, nullptr, true);
+    if (rc) return rc;
+    // workspace: [P][plen] first-order records + [plen] folded (vs_fold_partials' layout) + the f-values of one design
+    // row (the variance shift), then [P][2][SB][SB] Gram partials
+    const size_t plen = VS_PLEN(k), shift_stride = 2 * (size_t)k + 2;
+    size_t first_doubles = (size_t)P * plen + plen + shift_stride;
+    first_doubles = (first_doubles + 1) & ~(size_t)1;
+    const size_t gram_doubles = (size_t)P * 2 * SB * SB;
+    rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + gram_doubles));
+    if (rc) return rc;
+    double* shift_buf = ctx->partials + (size_t)P * plen + plen;
+    double* gram_partials = ctx->partials + first_doubles;
+    rc = vs_eval(ctx, design, obj, row_begin, 1, shift_buf);   // f(M_1[row_begin]): a one-row evaluation
+    if (rc) return rc;
+    rc = vs_scan_gram_launch(ctx, A, nbh, &P, shift_buf, ctx->partials, gram_partials, false);
+    if (rc) return rc;
+    rc = vs_fold_partials(ctx, P, k, 1, row_count, shift_buf, (int)shift_stride, nullptr, rank, max_ranks, acc_dev);
+    if (rc) return rc;
+    return vs_gram_fold_st(ctx, gram_partials, P, k, SB, gram_dev);
+}
+
 extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                        uint64_t row_begin, uint64_t row_count, double* f_dev) {
     VS_REQUIRE(ctx && design && obj, "null argument");

@@ -22,6 +22,11 @@ int vs_scan_launch_poly(vs_context* ctx, const vs_eval_args& A, scan_shape s, un
 int vs_scan_launch_lin(vs_context* ctx, const vs_eval_args& A, scan_shape s, unsigned* P_io, const double* shift_dev,
                        bool plan_only, bool fused);
 
+// fused evaluate + both orders (k <= 32, one output; vs_scan_gram.hip): plan or launch; nbh = 16-row blocks per half
+// (1: k <= 16, 2: k <= 32)
+int vs_scan_gram_launch(vs_context* ctx, const vs_eval_args& A, int nbh, unsigned* P_io, const double* shift_dev,
+                        double* first_partials, double* gram_partials, bool plan_only);
+
 #ifdef VS_SCAN_KIND
 template <int KIND>
 struct builtin_term {
@@ -132,6 +137,66 @@ static int launch_scan_kind(vs_context* ctx, const vs_eval_args& A, scan_shape s
     }
 #undef VS_SCAN_CASE
     return vs_fail(VS_ERR_ARG, "no scan kernel for L=%d W=%d", s.L, s.W);
+}
+
+// ---- fused evaluate + both orders: four waves x L columns, tile of 16 NBH index rows per half (vs_device_scan.h)
+template <int KIND, int L, int NBH, int GENV>
+__global__ void __launch_bounds__(VS_EVAL_ROWS * 4) __attribute__((amdgpu_waves_per_eu(4)))
+scan_gram_kernel(vs_eval_args A, const double* shift_src, double* first_partials, double* gram_partials,
+                 uint32_t* counters) {
+    extern __shared__ double scan_lds[];   // [2][4][64] totals, then the tile [32 NBH + 2][68]
+    vs_scan_gram_body<builtin_term<KIND>, KIND, L, NBH, GENV>(A, scan_lds, shift_src, first_partials, gram_partials);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // counters of the folds that follow, at the END (see scan_kernel)
+        counters[0] = 0;
+        counters[1] = 0xffffffffu;
+        counters[2] = 0;
+        counters[3] = 0;
+        counters[4] = 0;
+    }
+}
+
+template <int KIND, int L, int NBH, int GENV>
+static int launch_scan_gram_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
+                              double* first_partials, double* gram_partials, bool plan_only) {
+    const size_t lds = sizeof(double) * (2 * 4 * VS_EVAL_ROWS + VS_GT_DOUBLES(NBH));
+    const void* fn = (const void*)scan_gram_kernel<KIND, L, NBH, GENV>;
+    const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
+    if (plan_only) {
+        // twice the resident set (as the first-order fused kernels; 0.61 vs 0.65 ms at k = 32, n = 2^22) -- but every
+        // workgroup leaves a Gram partial for the folds: with fewer than 32 blocks each, the resident set alone
+        unsigned P = vs_persistent_workgroups(ctx, fn, VS_EVAL_ROWS * 4, lds, blocks, 1);
+        if (ctx->tune.fused_wgs_per_cu == 0 && blocks < 32ull * P) P = (P + 1) / 2;
+        *P_io = P;
+        return VS_OK;
+    }
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_FUSED);
+        hipLaunchKernelGGL((scan_gram_kernel<KIND, L, NBH, GENV>), dim3(*P_io), dim3(VS_EVAL_ROWS * 4), lds, ctx->stream, A,
+                           shift_dev, first_partials, gram_partials, ctx->counters);
+    }
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+template <int KIND, int L, int NBH>
+static int launch_scan_gram_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
+                               double* first_partials, double* gram_partials, bool plan_only) {
+    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0;
+#define VS_GRAM_GENV(G) \
+    return launch_scan_gram_g<KIND, L, NBH, G>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
+    if (halton && A.D.scale_mode == VS_SCALE_IDENTITY) VS_GRAM_GENV(1);
+    if (halton && A.D.scale_mode == VS_SCALE_LINEAR) VS_GRAM_GENV(2);
+    if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAM_GENV(3);
+    VS_GRAM_GENV(0);
+#undef VS_GRAM_GENV
+}
+
+template <int KIND>
+static int launch_scan_gram_kind(vs_context* ctx, const vs_eval_args& A, int nbh, unsigned* P_io, const double* shift_dev,
+                                 double* first_partials, double* gram_partials, bool plan_only) {
+    if (nbh == 1) return launch_scan_gram_lw<KIND, 4, 1>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only);
+    if (nbh == 2) return launch_scan_gram_lw<KIND, 8, 2>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only);
+    return vs_fail(VS_ERR_ARG, "the fused both-orders kernels take k <= 32");
 }
 
 #endif  // VS_SCAN_KIND

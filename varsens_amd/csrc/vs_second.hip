@@ -1632,6 +1632,30 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     return VS_OK;
 }
 
+// Fold of P partials [S S^T, T T^T][SB][SB] (upper 16-blocks; rows and columns below K) into gram_dev: the layout of
+// gram_st_kernel and of the fused evaluate + both-orders kernels (vs_scan_gram.hip), whose caller this is.
+int vs_gram_fold_st(vs_context* ctx, const double* partials, uint32_t P, int K, int SB, double* gram_dev) {
+    VS_REQUIRE(K >= 1 && K <= SB && (2 * SB * SB) % 64 == 0, "bad fold shape K=%d SB=%d", K, SB);
+    VS_HIP(hipMemsetAsync(gram_dev, 0, sizeof(double) * VS_GRAM_LEN(K), ctx->stream));
+    vs_gram_fold_args F;
+    F.partials = partials;
+    F.P = P;
+    F.K = K;
+    F.nsuper = 1;
+    F.npairs = 2;
+    F.super = SB;
+    F.st = 2;
+    F.gram = gram_dev;
+    F.counters = ctx->counters;
+    F.masked = 0;
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_SECOND_FOLD);
+        hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)(2 * SB * SB / 64)), dim3(VS2_FOLD_THREADS), 0, ctx->stream, F);
+    }
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
 extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                                       int flags, double* gram_dev) {
     return second_order_impl(ctx, f_dev, rows, k, l, flags, gram_dev, false, 0, 1, nullptr);

@@ -551,7 +551,7 @@ class Varsens(object):
             if self._fused_candidate(objective) or self._stream_rows:
                 kw['lazy'] = True   # the values are only produced if somebody asks for them
             elif self._fused is True:
-                raise Exception("fused=True needs first order only (second_order=False) and a device objective")
+                raise Exception("fused=True needs a device objective (with second_order: one output and k <= 32)")
             self.objective = Objective(self.k, self.n, self.sample, objective, verbose=verbose, **kw)
         self._ctx = self.objective._ctx
         self.compute_varsens()
@@ -590,10 +590,14 @@ class Varsens(object):
         return stream
 
     def _fused_candidate(self, objective):
-        """First order only and a device objective: the engine is asked whether its fused
-        evaluate+reduce kernels cover the (design, objective) pair (vs_eval_reduce_supported)."""
-        return (self._fused is not False and not self._second_order and
-                isinstance(objective, _objectives.DeviceObjective))
+        """A device objective whose f-values may never be needed: the engine is asked later whether its fused
+        evaluate+reduce kernels cover the (design, objective) pair -- vs_eval_reduce_supported for the first order
+        alone, vs_eval_reduce_both_supported (one output, k <= 32) when the second-order indices are wanted too."""
+        if self._fused is False or not isinstance(objective, _objectives.DeviceObjective):
+            return False
+        if not self._second_order:
+            return True
+        return int(self.k) <= 32 and int(objective.outputs(int(self.k))) == 1
 
     def compute_varsens(self):
         """E_2, var_y, U_j, U_nj, sens, sens_t, sens_2, sens_2n (varsens/saltelli.py:572-622)."""
@@ -612,15 +616,23 @@ class Varsens(object):
         fused = False
         if obj._f is None and obj._rows > 0 and self._fused_candidate(obj.objective_func):
             handle = obj._device_objective()
-            fused = ctx.eval_reduce_supported(obj.sample._design, handle)
+            design = obj.sample._design
+            # evaluate and reduce in one kernel: the 2n(k+1) values never reach HBM
+            if self._second_order:
+                fused = ctx.eval_reduce_both_supported(design, handle)
+                if fused:
+                    ctx.eval_reduce_first_second_order(design, handle, obj._row_begin, obj._rows, acc, gram, rank, world)
+            else:
+                fused = ctx.eval_reduce_supported(design, handle)
+                if fused:
+                    ctx.eval_reduce_first_order(design, handle, obj._row_begin, obj._rows, acc, rank, world)
             if fused:
-                # evaluate and reduce in one kernel: the 2n(k+1) values never reach HBM
-                ctx.eval_reduce_first_order(obj.sample._design, handle, obj._row_begin, obj._rows, acc, rank, world)
                 ctx.sync()
             handle.free()
             if not fused and self._fused is True:
                 raise Exception("fused=True: the fused kernels do not cover this design / objective "
-                                "(see vs_eval_reduce_first_order in include/varsens_hip.h)")
+                                "(see vs_eval_reduce_first_order / vs_eval_reduce_first_second_order in "
+                                "include/varsens_hip.h)")
         if fused:
             pass
         elif self._second_order:
