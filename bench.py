@@ -357,7 +357,7 @@ def main():
     s2, s2n = ctx.alloc(8 * k * l * k * l), ctx.alloc(8 * k * l * k * l)
     first_bo = ctx.alloc(8 * _native.first_order_len(k, l))
 
-    def api_default_step():
+    def api_two_kernel_step():
         i = counter[0]
         counter[0] += 1
         ctx.stream_select(0)
@@ -367,9 +367,25 @@ def main():
         ctx.finish_second_order(gram, first_bo, n, k, l, s2, s2n)
         return first_bo
 
-    t_api = recs_api = None
+    def api_fused_step():
+        """k <= 32, one output, built-in separable objective: evaluation and both reductions in ONE kernel"""
+        ctx.stream_select(0)
+        ctx.eval_reduce_first_second_order(design, objective, begin, rows, acc_bo, gram, rank, world)
+        ctx.finish_first_order(acc_bo, n, k, l, first_bo, world)
+        ctx.finish_second_order(gram, first_bo, n, k, l, s2, s2n)
+        return first_bo
+
+    t_api = recs_api = t_api2 = recs_api2 = None
+    api_fused = False
     if world == 1:   # the N > 1 form of this call adds the one all-reduce of record + Gram sums (saltelli.py: _finish)
-        t_api, recs_api, _ = timed(api_default_step, so_steps, 2, profile=True)
+        t_api2, recs_api2, _ = timed(api_two_kernel_step, so_steps, 2, profile=True)
+        s2_two = ctx.download(s2, (k * l, k * l))
+        api_fused = ctx.eval_reduce_both_supported(design, objective)
+        if api_fused:
+            t_api, recs_api, _ = timed(api_fused_step, so_steps, 2, profile=True)
+            s2_diff = float(np.max(np.abs(ctx.download(s2, (k * l, k * l)) - s2_two)))
+        else:
+            t_api, recs_api = t_api2, recs_api2
     # a linear fill of one f-value buffer, timed in this run: what the chip's store path takes for the same bytes
     # without any arithmetic (hipMemsetAsync); on the spare buffer: fbuf[0] still feeds the CPU baseline below
     ctx.memset(fbuf[1], 0)
@@ -482,13 +498,20 @@ def main():
                         "(49 TFLOP/s of 78.6); the S/T form is bound by the HBM stream"},
         }
         if t_api is not None:
+            two = {"value": N_total / (t_api2 / so_steps) / 1e9, "unit": "GSamples/s",
+                   "ms_per_pass": 1e3 * t_api2 / so_steps, "kernels_ms": averages(recs_api2),
+                   "note": "vs_eval + vs_reduce_first_second_order + the two finishing kernels, f-values rotating"}
             line["api_default"] = {
                 "value": N_total / (t_api / so_steps) / 1e9, "unit": "GSamples/s", "ms_per_pass": 1e3 * t_api / so_steps,
                 "kernels_ms": averages(recs_api),
-                "note": "Varsens(objective, scaling, k, n) with its default second_order=True: vs_eval + "
-                        "vs_reduce_first_second_order + vs_finish_first_order + vs_finish_second_order per pass "
-                        "(sens, sens_t, sens_2, sens_2n), f-values rotating; the headline `value` is the first-order "
-                        "pass north_star names"}
+                "path": "fused: vs_eval_reduce_first_second_order (no f-values in HBM)" if api_fused else "two kernels",
+                "two_kernel_path": two if api_fused else None,
+                "max_abs_diff_sens_2_vs_two_kernel_path": s2_diff if api_fused else None,
+                "note": "Varsens(objective, scaling, k, n) with its default second_order=True (sens, sens_t, sens_2, "
+                        "sens_2n per pass): the evaluation and both reductions in one kernel where the engine has one "
+                        "(built-in separable objective, one output, k <= 32), else vs_eval + "
+                        "vs_reduce_first_second_order; then vs_finish_first_order + vs_finish_second_order.  The "
+                        "headline `value` is the first-order pass north_star names"}
         line["both_orders_one_call"] = {
             "ms_per_call": 1e3 * t_bo / so_steps, "kernels_ms": avg_bo,
             "note": "vs_reduce_first_second_order on the same f-values: the first-order dot products ride on the "
