@@ -608,38 +608,44 @@ class Varsens(object):
         rank = self._comm.rank if self._comm is not None else 0
         flags = _native.REDUCE_NAN_TRIM if obj._nan_trim else 0
 
-        if self._stream_rows and obj._f is None and obj._rows > 0:
+        # Every decision below is the same on all ranks of a job (it depends on the design, the objective and the
+        # largest shard only): the all-reduce buffers must have one size everywhere, also on a rank without rows.
+        stream = bool(self._stream_rows) and obj._f is None
+        fused = False
+        # a fused kernel needs no f-values at all: preferred over streaming, unless the caller asked for row ranges
+        # of an explicit size
+        if obj._f is None and self._fused_candidate(obj.objective_func) and not (stream and self._rows_per_pass != 'auto'):
+            handle = obj._device_objective()
+            design = obj.sample._design
+            fused = (ctx.eval_reduce_both_supported(design, handle) if self._second_order
+                     else ctx.eval_reduce_supported(design, handle))
+            if not fused:
+                handle.free()
+                if self._fused is True:
+                    raise Exception("fused=True: the fused kernels do not cover this design / objective "
+                                    "(see vs_eval_reduce_first_order / vs_eval_reduce_first_second_order in "
+                                    "include/varsens_hip.h)")
+        if stream and not fused:
             return self._compute_streamed(self._stream_rows)
 
         nacc = _native.acc_len(k, l, world)
         acc, gram, whole = self._result_buffers(nacc, k * l)
-        fused = False
-        if obj._f is None and obj._rows > 0 and self._fused_candidate(obj.objective_func):
-            handle = obj._device_objective()
-            design = obj.sample._design
+        if fused and obj._rows > 0:
             # evaluate and reduce in one kernel: the 2n(k+1) values never reach HBM
             if self._second_order:
-                fused = ctx.eval_reduce_both_supported(design, handle)
-                if fused:
-                    ctx.eval_reduce_first_second_order(design, handle, obj._row_begin, obj._rows, acc, gram, rank, world)
+                ctx.eval_reduce_first_second_order(design, handle, obj._row_begin, obj._rows, acc, gram, rank, world)
             else:
-                fused = ctx.eval_reduce_supported(design, handle)
-                if fused:
-                    ctx.eval_reduce_first_order(design, handle, obj._row_begin, obj._rows, acc, rank, world)
-            if fused:
-                ctx.sync()
+                ctx.eval_reduce_first_order(design, handle, obj._row_begin, obj._rows, acc, rank, world)
+            ctx.sync()
             handle.free()
-            if not fused and self._fused is True:
-                raise Exception("fused=True: the fused kernels do not cover this design / objective "
-                                "(see vs_eval_reduce_first_order / vs_eval_reduce_first_second_order in "
-                                "include/varsens_hip.h)")
-        if fused:
-            pass
-        elif self._second_order:
-            # both reductions read the same blocks: one pass where the shape allows (k <= 32, one output)
-            ctx.reduce_first_second_order(obj._values(), obj._rows, k, l, acc, gram, flags, rank, world)
         else:
-            ctx.reduce_first_order(obj._values(), obj._rows, k, l, acc, flags, rank, world)
+            if fused:
+                handle.free()   # a rank without rows: the empty record of the reduction kernels
+            if self._second_order:
+                # both reductions read the same blocks: one pass where the shape allows
+                ctx.reduce_first_second_order(obj._values(), obj._rows, k, l, acc, gram, flags, rank, world)
+            else:
+                ctx.reduce_first_order(obj._values(), obj._rows, k, l, acc, flags, rank, world)
         self._finish(acc, nacc, gram, world, whole)
 
     def _result_buffers(self, nacc, K):
@@ -701,7 +707,7 @@ class Varsens(object):
         acc, gram, pass_buf = self._result_buffers(nacc, K)
         total, gram_total, total_buf = self._result_buffers(nacc, K)
         ctx.memset(total_buf, 0)
-        f = ctx.alloc(8 * 2 * (k + 1) * min(R, obj._rows) * l)
+        f = ctx.alloc(8 * 2 * (k + 1) * max(1, min(R, obj._rows)) * l)
         handle = obj._device_objective()
         for c in range(passes):
             begin = c * R
