@@ -112,6 +112,10 @@ extern "C" int vs_context_create(int device, vs_context** out) {
         delete ctx;
         return vs_fail(VS_ERR_HIP, "counter allocation failed");
     }
+    if (hipMemset(ctx->counters, 0, 64 * sizeof(uint32_t)) != hipSuccess) {   // tickets that folds hand back at zero
+        delete ctx;
+        return vs_fail(VS_ERR_HIP, "counter initialisation failed");
+    }
     *out = ctx;
     return VS_OK;
 }
@@ -130,6 +134,7 @@ extern "C" int vs_context_destroy(vs_context* ctx) {
     }
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->keep) hipFree(ctx->keep);
+    if (ctx->fold_scratch) hipFree(ctx->fold_scratch);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->counters) hipFree(ctx->counters);
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
@@ -269,6 +274,20 @@ int vs_workspace_keep(vs_context* ctx, size_t bytes) {
     }
     VS_HIP(hipMalloc(&ctx->keep, bytes));
     ctx->keep_bytes = bytes;
+    return VS_OK;
+}
+
+int vs_workspace_fold(vs_context* ctx, size_t bytes) {
+    if (bytes <= ctx->fold_scratch_bytes) return VS_OK;
+    if (ctx->fold_scratch) {
+        VS_HIP(hipStreamSynchronize(ctx->streams[0]));
+        VS_HIP(hipStreamSynchronize(ctx->streams[1]));
+        VS_HIP(hipFree(ctx->fold_scratch));
+        ctx->fold_scratch = nullptr;
+        ctx->fold_scratch_bytes = 0;
+    }
+    VS_HIP(hipMalloc(&ctx->fold_scratch, bytes));
+    ctx->fold_scratch_bytes = bytes;
     return VS_OK;
 }
 

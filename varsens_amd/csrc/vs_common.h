@@ -52,6 +52,9 @@ struct vs_context {
     // NaN-trim keep mask workspace (one byte per row)
     uint8_t* keep = nullptr;
     size_t keep_bytes = 0;
+    // segment sums of the two-stage folds (many partial records: the fused kernels' 2 x resident workgroups)
+    double* fold_scratch = nullptr;
+    size_t fold_scratch_bytes = 0;
     uint32_t* counters = nullptr;  // 64 x u32 scratch counters (device)
     uint32_t* counters_host = nullptr;  // pinned mirror
     // profiling
@@ -134,6 +137,9 @@ struct vs_launch_scope {
 int vs_workspace_partials(vs_context* ctx, size_t bytes);
 int vs_workspace_keep(vs_context* ctx, size_t bytes);
 int vs_workspace_scratch(vs_context* ctx, size_t bytes);
+int vs_workspace_fold(vs_context* ctx, size_t bytes);
+// segments of a two-stage fold over P partial records (1: single stage, the order of rounds 1-2)
+static inline uint32_t vs_fold_segments(uint32_t P) { return P >= 1024 ? 8u : P >= 512 ? 4u : 1u; }
 
 int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, const double* shift_dev,
                      int shift_stride, const double* f_dev, int rank, int max_ranks, double* acc_dev);

@@ -289,6 +289,7 @@ struct vs_fold_args {
     int rank, max_ranks;
     uint32_t* counters;
     int masked;
+    double* seg_sums;   // grid.y > 1: [grid.y][l*plen] sums of the segments of P (two-stage fold)
 };
 
 #define VS_FOLD_THREADS 1024
@@ -298,6 +299,10 @@ struct vs_fold_args {
 // flattened (l*plen) record with 16 waves striding over P.  The block that
 // finishes last (agent-scope ticket) lays the folded sums out as the rank's
 // accumulator record, so the whole fold is one launch.
+// grid.y = segments: with thousands of records (the fused kernels leave one per workgroup, twice the resident
+// set) three blocks walking all of them are latency-bound (0.039 ms for 2048 records of 133 doubles); block
+// (b, s) folds segment s of the records, the last block adds the segment sums in segment order (compensated,
+// like everything here) -- fixed order, bit-reproducible.  grid.y = 1 is the single-stage fold of rounds 1-2.
 enum { CNT_TICKET = 3 };
 
 __global__ void __launch_bounds__(VS_FOLD_THREADS)
@@ -310,14 +315,16 @@ fold_first_kernel(vs_fold_args A, double* folded /* [l*plen] scratch */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t col = (size_t)blockIdx.x * VS_FOLD_COLS + lane;
     double s = 0.0, comp = 0.0;
+    const uint32_t nseg = gridDim.y, per_seg = (A.P + nseg - 1) / nseg;
+    const uint32_t p_lo = blockIdx.y * per_seg, p_hi = p_lo + per_seg < A.P ? p_lo + per_seg : A.P;
     if (col < width) {
         constexpr uint32_t STEP = VS_FOLD_THREADS / 64, BATCH = 8;
-        for (uint32_t p0 = wave; p0 < A.P; p0 += STEP * BATCH) {
+        for (uint32_t p0 = p_lo + wave; p0 < p_hi; p0 += STEP * BATCH) {
             double x[BATCH];  // issue the loads of a batch together: the fold is latency-, not bandwidth-bound
 #pragma unroll
             for (uint32_t i = 0; i < BATCH; ++i) {
                 const uint32_t p = p0 + i * STEP;
-                x[i] = p < A.P ? A.partials[(size_t)p * width + col] : 0.0;
+                x[i] = p < p_hi ? A.partials[(size_t)p * width + col] : 0.0;
             }
 #pragma unroll
             for (uint32_t i = 0; i < BATCH; ++i) {
@@ -340,8 +347,12 @@ fold_first_kernel(vs_fold_args A, double* folded /* [l*plen] scratch */) {
             Cc += s_cmp[w][lane];
         }
         const double total = S + Cc;
-        __hip_atomic_store(&folded[col], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!A.masked && total != total) atomicOr(&A.counters[CNT_NANFLAG], 1u);
+        if (nseg == 1) {
+            __hip_atomic_store(&folded[col], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!A.masked && total != total) atomicOr(&A.counters[CNT_NANFLAG], 1u);
+        } else {
+            __hip_atomic_store(&A.seg_sums[(size_t)blockIdx.y * width + col], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     // publish, then take a ticket; the last block builds the record
     __syncthreads();
@@ -349,12 +360,27 @@ fold_first_kernel(vs_fold_args A, double* folded /* [l*plen] scratch */) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t t = atomicAdd(&A.counters[CNT_TICKET + (A.masked ? 1 : 0)], 1u);
-        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        s_last = (t == gridDim.x * gridDim.y - 1) ? 1u : 0u;
         if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     if (!s_last) return;
+    if (nseg > 1) {   // second stage: the segment sums of every column, in segment order
+        for (size_t c = threadIdx.x; c < width; c += VS_FOLD_THREADS) {
+            double S = 0.0, Cc = 0.0;
+            for (uint32_t sg = 0; sg < nseg; ++sg) {
+                const double x = __hip_atomic_load(&A.seg_sums[(size_t)sg * width + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double t = S + x;
+                Cc += (fabs(S) >= fabs(x)) ? (S - t) + x : (x - t) + S;
+                S = t;
+            }
+            const double total = S + Cc;
+            __hip_atomic_store(&folded[c], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!A.masked && total != total) atomicOr(&A.counters[CNT_NANFLAG], 1u);
+        }
+        __syncthreads();
+    }
 
     const int k = A.k, l = A.l;
     const size_t plen = VS_PLEN(k);
@@ -520,6 +546,7 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     F.rank = rank;
     F.max_ranks = max_ranks;
     F.counters = ctx->counters;
+    F.seg_sums = nullptr;   // at most one record per CU: single-stage fold
     const unsigned fold_blocks = (unsigned)((width + VS_FOLD_COLS - 1) / VS_FOLD_COLS);
 
     for (int pass = 0; pass < 2; ++pass) {
@@ -588,11 +615,18 @@ int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, c
     F.max_ranks = max_ranks;
     F.counters = ctx->counters;
     F.masked = 0;
+    const uint32_t nseg = vs_fold_segments(P);
+    F.seg_sums = nullptr;
+    if (nseg > 1) {
+        int rc = vs_workspace_fold(ctx, sizeof(double) * nseg * width);
+        if (rc) return rc;
+        F.seg_sums = ctx->fold_scratch;
+    }
     double* folded = ctx->partials + (size_t)P * width;
     const unsigned fold_blocks = (unsigned)((width + VS_FOLD_COLS - 1) / VS_FOLD_COLS);
     {
         vs_launch_scope scope(ctx, VS_KERNEL_FOLD);
-        hipLaunchKernelGGL(fold_first_kernel, dim3(fold_blocks), dim3(VS_FOLD_THREADS), 0, ctx->stream, F, folded);
+        hipLaunchKernelGGL(fold_first_kernel, dim3(fold_blocks, nseg), dim3(VS_FOLD_THREADS), 0, ctx->stream, F, folded);
     }
     VS_HIP(hipGetLastError());
     return VS_OK;

@@ -1245,43 +1245,90 @@ struct vs_gram_fold_args {
     double* gram;
     uint32_t* counters;
     int masked;
+    double* seg_sums;   // grid.y > 1: [grid.y][npairs * super^2] segment sums (two-stage fold)
 };
 
 #define VS2_FOLD_THREADS 1024
+enum { CNT_GRAM_TICKET = 5 };   // zero between folds (the last block of a two-stage fold puts it back)
 
 // block b folds 64 consecutive entries: 16 waves stride over the P partials (coalesced),
 // then wave 0 combines them in fixed order and scatters.
-__global__ void __launch_bounds__(VS2_FOLD_THREADS)
-gram_fold_kernel(vs_gram_fold_args A) {
-    __shared__ double s_sum[VS2_FOLD_THREADS / 64][64];
-    __shared__ double s_cmp[VS2_FOLD_THREADS / 64][64];
-    if (A.masked && A.counters[CNT_NANFLAG] == 0) return;
+// grid.y = segments (two-stage fold, as fold_first_kernel: thousands of partials behind the fused evaluate + both
+// orders kernels): block (b, s) leaves the sums of segment s in seg_sums, the block that takes the last ticket adds
+// them in segment order and scatters.  grid.y = 1: single stage.
+struct gram_entry {
+    bool live, mirror;
+    int gi, gj;
+};
+
+__device__ __forceinline__ gram_entry gram_entry_of(const vs_gram_fold_args& A, size_t col) {
     const int SB = A.super;
     const size_t tile_out = (size_t)SB * SB;
-    const size_t width = (size_t)A.npairs * tile_out;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t col = (size_t)blockIdx.x * 64 + lane;   // width is a multiple of 64
     const int pair = (int)(col / tile_out);
     const int e = (int)(col % tile_out);
     int SI = 0, SJ = 0;
     if (A.st != 2) pair_from_index(pair, A.nsuper, SI, SJ);
     const int li = e / SB, lj = e % SB;
     const int K = A.K;
+    gram_entry g;
     // st == 2 (gram_macro_st_kernel): tile 0 is S S^T, tile 1 T T^T, rows and columns u < K
-    const int gi = A.st == 2 ? li + pair * K : SI * SB + li, gj = A.st == 2 ? lj + pair * K : SJ * SB + lj;
+    g.gi = A.st == 2 ? li + pair * K : SI * SB + li;
+    g.gj = A.st == 2 ? lj + pair * K : SJ * SB + lj;
     // entries of mirror blocks (never computed) and of padding rows are skipped
-    const bool live = A.st == 2 ? (lj / 16) >= (li / 16) && li < K && lj < K
-                                : !(SI == SJ && (lj / 16) < (li / 16)) && gi < 2 * K && gj < 2 * K &&
-                                      !(A.st && (gi < K) != (gj < K));   // S.T products are by-products
+    g.live = A.st == 2 ? (lj / 16) >= (li / 16) && li < K && lj < K
+                       : !(SI == SJ && (lj / 16) < (li / 16)) && g.gi < 2 * K && g.gj < 2 * K &&
+                             !(A.st && (g.gi < K) != (g.gj < K));   // S.T products are by-products
+    g.mirror = !(SI == SJ && (li / 16) == (lj / 16));  // diagonal 16-blocks hold both triangles
+    return g;
+}
+
+__device__ __forceinline__ void gram_scatter(const vs_gram_fold_args& A, const gram_entry& g, double total) {
+    const int K = A.K, gi = g.gi, gj = g.gj;
+    if (!A.masked && total != total) atomicOr(&A.counters[CNT_NANFLAG], 1u);
+    if (A.st) {
+        double* M = A.gram + (gi < K ? 0 : (size_t)K * K);   // SS, then TT
+        const int i = gi < K ? gi : gi - K, j = gj < K ? gj : gj - K;
+        M[(size_t)i * K + j] = total;
+        if (g.mirror) M[(size_t)j * K + i] = total;
+        return;
+    }
+    double* DC = A.gram;
+    double* DD = DC + (size_t)K * K;
+    double* CC = DD + (size_t)K * K;
+    if (gi < K && gj < K) {
+        CC[(size_t)gi * K + gj] = total;
+        if (g.mirror) CC[(size_t)gj * K + gi] = total;
+    } else if (gi >= K && gj >= K) {
+        DD[(size_t)(gi - K) * K + (gj - K)] = total;
+        if (g.mirror) DD[(size_t)(gj - K) * K + (gi - K)] = total;
+    } else if (gi < K) {            // C_gi . D_gj
+        DC[(size_t)(gj - K) * K + gi] = total;
+    } else {                        // D_gi . C_gj
+        DC[(size_t)(gi - K) * K + gj] = total;
+    }
+}
+
+__global__ void __launch_bounds__(VS2_FOLD_THREADS)
+gram_fold_kernel(vs_gram_fold_args A) {
+    __shared__ double s_sum[VS2_FOLD_THREADS / 64][64];
+    __shared__ double s_cmp[VS2_FOLD_THREADS / 64][64];
+    __shared__ uint32_t s_last;
+    if (A.masked && A.counters[CNT_NANFLAG] == 0) return;
+    const size_t width = (size_t)A.npairs * A.super * A.super;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t col = (size_t)blockIdx.x * 64 + lane;   // width is a multiple of 64
+    const gram_entry g = gram_entry_of(A, col);
+    const uint32_t nseg = gridDim.y, per_seg = (A.P + nseg - 1) / nseg;
+    const uint32_t p_lo = blockIdx.y * per_seg, p_hi = p_lo + per_seg < A.P ? p_lo + per_seg : A.P;
     double s = 0.0, comp = 0.0;
-    if (live) {
+    if (g.live) {
         constexpr uint32_t STEP = VS2_FOLD_THREADS / 64, BATCH = 8;
-        for (uint32_t p0 = wave; p0 < A.P; p0 += STEP * BATCH) {
+        for (uint32_t p0 = p_lo + wave; p0 < p_hi; p0 += STEP * BATCH) {
             double x[BATCH];
 #pragma unroll
             for (uint32_t i = 0; i < BATCH; ++i) {
                 const uint32_t p = p0 + i * STEP;
-                x[i] = p < A.P ? A.partials[(size_t)p * width + col] : 0.0;
+                x[i] = p < p_hi ? A.partials[(size_t)p * width + col] : 0.0;
             }
 #pragma unroll
             for (uint32_t i = 0; i < BATCH; ++i) {
@@ -1294,39 +1341,44 @@ gram_fold_kernel(vs_gram_fold_args A) {
     s_sum[wave][lane] = s;
     s_cmp[wave][lane] = comp;
     __syncthreads();
-    if (wave != 0 || !live) return;
-    double S = 0.0, Cc = 0.0;
-    for (int w = 0; w < VS2_FOLD_THREADS / 64; ++w) {
-        const double x = s_sum[w][lane];
-        const double t = S + x;
-        Cc += (fabs(S) >= fabs(x)) ? (S - t) + x : (x - t) + S;
-        S = t;
-        Cc += s_cmp[w][lane];
+    if (wave == 0 && g.live) {
+        double S = 0.0, Cc = 0.0;
+        for (int w = 0; w < VS2_FOLD_THREADS / 64; ++w) {
+            const double x = s_sum[w][lane];
+            const double t = S + x;
+            Cc += (fabs(S) >= fabs(x)) ? (S - t) + x : (x - t) + S;
+            S = t;
+            Cc += s_cmp[w][lane];
+        }
+        const double total = S + Cc;   // = X_gi . X_gj (nseg > 1: over this block's segment)
+        if (nseg == 1) gram_scatter(A, g, total);
+        else __hip_atomic_store(&A.seg_sums[(size_t)blockIdx.y * width + col], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const double total = S + Cc;   // = X_gi . X_gj
-    if (!A.masked && total != total) atomicOr(&A.counters[CNT_NANFLAG], 1u);
-    const bool mirror = !(SI == SJ && (li / 16) == (lj / 16));  // diagonal 16-blocks hold both triangles
-    if (A.st) {
-        double* M = A.gram + (gi < K ? 0 : (size_t)K * K);   // SS, then TT
-        const int i = gi < K ? gi : gi - K, j = gj < K ? gj : gj - K;
-        M[(size_t)i * K + j] = total;
-        if (mirror) M[(size_t)j * K + i] = total;
-        return;
+    if (nseg == 1) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = atomicAdd(&A.counters[CNT_GRAM_TICKET], 1u);
+        s_last = (t == gridDim.x * gridDim.y - 1) ? 1u : 0u;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    double* DC = A.gram;
-    double* DD = DC + (size_t)K * K;
-    double* CC = DD + (size_t)K * K;
-    if (gi < K && gj < K) {
-        CC[(size_t)gi * K + gj] = total;
-        if (mirror) CC[(size_t)gj * K + gi] = total;
-    } else if (gi >= K && gj >= K) {
-        DD[(size_t)(gi - K) * K + (gj - K)] = total;
-        if (mirror) DD[(size_t)(gj - K) * K + (gi - K)] = total;
-    } else if (gi < K) {            // C_gi . D_gj
-        DC[(size_t)(gj - K) * K + gi] = total;
-    } else {                        // D_gi . C_gj
-        DC[(size_t)(gi - K) * K + gj] = total;
+    __syncthreads();
+    if (!s_last) return;
+    for (size_t c = threadIdx.x; c < width; c += VS2_FOLD_THREADS) {
+        const gram_entry e = gram_entry_of(A, c);
+        if (!e.live) continue;
+        double S = 0.0, Cc = 0.0;
+        for (uint32_t sg = 0; sg < nseg; ++sg) {
+            const double x = __hip_atomic_load(&A.seg_sums[(size_t)sg * width + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double t = S + x;
+            Cc += (fabs(S) >= fabs(x)) ? (S - t) + x : (x - t) + S;
+            S = t;
+        }
+        gram_scatter(A, e, S + Cc);
     }
+    if (threadIdx.x == 0) A.counters[CNT_GRAM_TICKET] = 0;   // ready for the next two-stage fold of this context
 }
 
 __global__ void __launch_bounds__(256)
@@ -1509,6 +1561,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     F.gram = st ? gram_dev : cd_dev;
     if (st) VS_HIP(hipMemsetAsync(gram_dev, 0, sizeof(double) * VS_GRAM_LEN(K), ctx->stream));
     F.counters = ctx->counters;
+    F.seg_sums = nullptr;
     const size_t lds_w = sizeof(double) * (nb_wave <= 4 ? (size_t)VS2_WAVE_LDS(nb_wave, false) : 0);   // wave-private tiles
     const size_t lds_m = sizeof(double) * 2 * 2 * VS2_MACRO * VS2_WPITCH;   // macro: two buffers of 256 rows
     const bool mwide = macro && l == 1 && aligned && ctx->tune.gram_wide != 0;   // two chunks per fetch, 256-byte runs
@@ -1648,9 +1701,16 @@ int vs_gram_fold_st(vs_context* ctx, const double* partials, uint32_t P, int K, 
     F.gram = gram_dev;
     F.counters = ctx->counters;
     F.masked = 0;
+    const uint32_t nseg = vs_fold_segments(P);
+    F.seg_sums = nullptr;
+    if (nseg > 1) {   // stream-ordered behind the first-order fold, which is done with the same scratch
+        int rc = vs_workspace_fold(ctx, sizeof(double) * nseg * 2 * SB * SB);
+        if (rc) return rc;
+        F.seg_sums = ctx->fold_scratch;
+    }
     {
         vs_launch_scope scope(ctx, VS_KERNEL_SECOND_FOLD);
-        hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)(2 * SB * SB / 64)), dim3(VS2_FOLD_THREADS), 0, ctx->stream, F);
+        hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)(2 * SB * SB / 64), nseg), dim3(VS2_FOLD_THREADS), 0, ctx->stream, F);
     }
     VS_HIP(hipGetLastError());
     return VS_OK;
@@ -1773,6 +1833,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     F.gram = gram_dev;
     F.counters = ctx->counters;
     F.masked = 0;
+    F.seg_sums = nullptr;
     {
         vs_launch_scope scope(ctx, VS_KERNEL_SECOND_FOLD);
         hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)(VS2_TILE_OUT / 64)), dim3(VS2_FOLD_THREADS), 0, ctx->stream, F);
