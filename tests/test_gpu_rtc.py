@@ -103,6 +103,36 @@ def test_separable_expression_equals_builtins_bit_for_bit(vs, k, n):
     assert v.sens.shape == (k, 1)
 
 
+@pytest.mark.parametrize("k,n,fold", [(6, 51200, "prod"), (32, 20001, "sum"), (17, 64, "prod"), (16, 3000, "sum")])
+def test_separable_expression_default_call_is_one_kernel(vs, k, n, fold):
+    """A user term function with k <= 32 through Varsens(...) with its second-order indices: the run-time compiled
+    fused evaluate + both-orders kernel (vs_user_gram), nothing written to HBM; results equal the built-in
+    objective's fused kernel (same term, same kernel body) and the two-kernel route."""
+    rng = np.random.RandomState(k + n)
+    a = rng.rand(k) * 5.0
+    if fold == "prod":
+        user = vs.objectives.SeparableExpression("return (fabs(4.0 * x - 2.0) + p[c]) / (1.0 + p[c]);", fold="prod", params=a)
+        built = vs.objectives.GFunction(a)
+    else:
+        user = vs.objectives.SeparableExpression("return p[c] * x;", fold="sum", params=a)
+        built = vs.objectives.Linear(a)
+    sc = vs.scale.Linear(-1.0, 2.0) if fold == "sum" else vs.scale.Identity()
+    u = vs.Varsens(user, sc, k, n, verbose=False, fused=True)
+    assert u.objective._f is None
+    b = vs.Varsens(built, sc, k, n, verbose=False, fused=True)
+    t = vs.Varsens(user, sc, k, n, verbose=False, fused=False)
+    assert t.objective._f is not None
+    for f in ("E_2", "var_y", "U_j", "U_nj"):
+        np.testing.assert_allclose(getattr(u, f), getattr(t, f), rtol=1e-12, err_msg=f)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        np.testing.assert_allclose(getattr(u, f), getattr(t, f), rtol=1e-9, atol=1e-11, err_msg=f)
+        # the g-function's built-in term takes its quotient from a rounded reciprocal (same bits as the division)
+        np.testing.assert_allclose(getattr(u, f), getattr(b, f), rtol=1e-9, atol=1e-11, err_msg=f)
+    # power scaling has no run-time compiled fused kernel: the two-kernel route by itself
+    w = vs.Varsens(user, vs.scale.Power(1.0, 10.0), k, min(n, 2000), verbose=False)
+    assert w.objective._f is not None
+
+
 def test_expression_compile_error_is_reported(vs):
     from varsens_amd._native import VarsensHipError
     s = vs.Sample(3, 8, vs.scale.Identity(), verbose=False)

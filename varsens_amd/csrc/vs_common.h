@@ -90,6 +90,8 @@ struct vs_objective {
     void* module = nullptr;    // hipModule_t of a run-time compiled objective
     void* function = nullptr;  // hipFunction_t (vs_user_eval)
     void* fused_function = nullptr;  // hipFunction_t (vs_user_fused): separable source objectives with k <= 128
+    void* gram_function = nullptr;   // hipFunction_t (vs_user_gram): ... with k <= 32, evaluate + both orders
+    size_t gram_lds = 0;
     bool eval_scan = false;    // vs_user_eval is the scan kernel (separable source objective): one 64-row block per workgroup
     int eval_threads = 256;    // launch shape of vs_user_eval / vs_user_fused
     size_t eval_lds = 0;       //   (eval_lds = 0: the 2k x 64 tile of the chain / general kernels)
@@ -110,6 +112,9 @@ int vs_rtc_launch_fused(vs_context* ctx, const vs_objective* o, const void* eval
 // launch shape of the scan kernels for k columns (vs_scan.hip); false: k is outside them
 bool vs_scan_shape(int k, bool fused, int* L, int* W, int* tlds, size_t* lds_bytes);
 int vs_rtc_fused_plan(vs_context* ctx, const vs_objective* o, uint64_t rows, unsigned* P_out);
+int vs_rtc_gram_plan(vs_context* ctx, const vs_objective* o, uint64_t rows, unsigned* P_out);
+int vs_rtc_launch_gram(vs_context* ctx, const vs_objective* o, const void* eval_args, size_t eval_args_bytes,
+                       unsigned P, const double* shift_dev, double* first_partials, double* gram_partials);
 
 int vs_fail(int code, const char* fmt, ...);
 

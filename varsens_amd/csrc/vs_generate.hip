@@ -851,15 +851,20 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
 int vs_scan_gram_launch(vs_context* ctx, const vs_eval_args& A, int nbh, unsigned* P_io, const double* shift_dev,
                         double* first_partials, double* gram_partials, bool plan_only);
 
-// the fused both-orders kernels: built-in separable objectives in scan form, one output, k <= 32
-static bool fused_both_route(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
-    return obj->l == 1 && obj->k <= 32 && obj->k == design->d.k && fused_route_for(ctx, design, obj) == FUSED_SCAN;
+// the fused both-orders kernels: separable objectives in scan form -- built-in or compiled at run time --, one
+// output, k <= 32
+static fused_route fused_both_route(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
+    if (obj->l != 1 || obj->k > 32 || obj->k != design->d.k) return FUSED_NONE;
+    const fused_route r = fused_route_for(ctx, design, obj);
+    if (r == FUSED_SCAN) return r;
+    if (r == FUSED_USER && obj->gram_function) return r;
+    return FUSED_NONE;
 }
 
 extern "C" int vs_eval_reduce_both_supported(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                                              int* supported) {
     VS_REQUIRE(ctx && design && obj && supported, "null argument");
-    *supported = fused_both_route(ctx, design, obj) ? 1 : 0;
+    *supported = fused_both_route(ctx, design, obj) != FUSED_NONE ? 1 : 0;
     return VS_OK;
 }
 
@@ -873,10 +878,11 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     VS_REQUIRE(row_count >= 1, "the fused path needs at least one row");
     VS_REQUIRE(rows_in_perm_slice(design, row_begin, row_count), "rows lie outside the design's shuffle slice");
     VS_HIP(hipSetDevice(ctx->device));
-    if (!fused_both_route(ctx, design, obj))
-        return vs_fail(VS_ERR_ARG, "the fused both-orders path covers G_FUNCTION / POLYNOMIAL / LINEAR objectives with one "
-                                   "output and k <= 32 (Halton indices below 2^32, scan evaluation order); use vs_eval + "
-                                   "vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
+    const fused_route route = fused_both_route(ctx, design, obj);
+    if (route == FUSED_NONE)
+        return vs_fail(VS_ERR_ARG, "the fused both-orders path covers G_FUNCTION / POLYNOMIAL / LINEAR and separable source "
+                                   "objectives with one output and k <= 32 (Halton indices below 2^32, scan evaluation "
+                                   "order); use vs_eval + vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
     const int k = obj->k;
     const int nbh = k <= 16 ? 1 : 2, SB = 16 * nbh;
     vs_eval_args A;
@@ -888,7 +894,8 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     A.rows = row_count;
     A.f = nullptr;
     unsigned P = 1;
-    int rc = vs_scan_gram_launch(ctx, A, nbh, &P, nullptr, nullptr, nullptr, true);
+    int rc = route == FUSED_USER ? vs_rtc_gram_plan(ctx, obj, row_count, &P)
+                                 : vs_scan_gram_launch(ctx, A, nbh, &P, nullptr, nullptr, nullptr, true);
     if (rc) return rc;
     // workspace: [P][plen] first-order records + [plen] folded (vs_fold_partials' layout) + the f-values of one design
     // row (the variance shift), then [P][2][SB][SB] Gram partials
@@ -902,7 +909,8 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     double* gram_partials = ctx->partials + first_doubles;
     rc = vs_eval(ctx, design, obj, row_begin, 1, shift_buf);   // f(M_1[row_begin]): a one-row evaluation
     if (rc) return rc;
-    rc = vs_scan_gram_launch(ctx, A, nbh, &P, shift_buf, ctx->partials, gram_partials, false);
+    rc = route == FUSED_USER ? vs_rtc_launch_gram(ctx, obj, &A, sizeof(A), P, shift_buf, ctx->partials, gram_partials)
+                             : vs_scan_gram_launch(ctx, A, nbh, &P, shift_buf, ctx->partials, gram_partials, false);
     if (rc) return rc;
     rc = vs_fold_partials(ctx, P, k, 1, row_count, shift_buf, (int)shift_stride, nullptr, rank, max_ranks, acc_dev);
     if (rc) return rc;

@@ -9,7 +9,8 @@
 
 // By default (VS_USER_EVAL_SCAN) the evaluation takes the segmented-scan form of vs_device_scan.h
 // instead (O(k) folds per row), and for k <= 128 a fused evaluate+reduce kernel vs_user_fused is built
-// beside it (VS_USER_FUSED); shapes VS_USER_*_L / _W / _TLDS come from the host.  The chain-scheme kernel
+// beside it (VS_USER_FUSED), for k <= 32 also the fused evaluate + both-orders kernel vs_user_gram (VS_USER_GRAM);
+// shapes VS_USER_*_L / _W / _TLDS / _NBH come from the host.  The chain-scheme kernel
 // below serves contexts in strict evaluation order.
 struct vs_user_term_t {
     static __device__ __forceinline__ double pre(int, const double* __restrict__) { return 0.0; }
@@ -26,6 +27,22 @@ vs_user_fused(vs_eval_args A, const double* shift_src, double* partials, unsigne
     vs_scan_body<vs_user_term_t, VS_USER_FOLD_KIND, VS_USER_FUSED_L, VS_USER_FUSED_W, true, VS_USER_FUSED_TLDS>(
         A, lds, shift_src, partials);
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the fold that follows (see scan_kernel)
+        counters[0] = 0;
+        counters[1] = 0xffffffffu;
+        counters[2] = 0;
+        counters[3] = 0;
+        counters[4] = 0;
+    }
+}
+#endif
+
+#if VS_USER_GRAM   // k <= 32: evaluate + both orders in one kernel (vs_scan_gram_body, vs_device_scan.h)
+extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS * 4)
+vs_user_gram(vs_eval_args A, const double* shift_src, double* first_partials, double* gram_partials, unsigned* counters) {
+    extern __shared__ double lds[];
+    vs_scan_gram_body<vs_user_term_t, VS_USER_FOLD_KIND, VS_USER_GRAM_L, VS_USER_GRAM_NBH, 0>(A, lds, shift_src,
+                                                                                             first_partials, gram_partials);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the folds that follow (see scan_kernel)
         counters[0] = 0;
         counters[1] = 0xffffffffu;
         counters[2] = 0;
