@@ -800,13 +800,40 @@ def test_fused_both_orders_matches_two_kernel_path(ctx, kind, k, n, mode):
     np.testing.assert_allclose(r2[4 + 3:4 + 3 + k], F[2:2 + k] @ F[0], rtol=1e-12)            # a . c_i
 
 
+@pytest.mark.parametrize("n", [1, 200, 4096, 100003, 1 << 20])
+def test_fused_both_orders_ishigami(ctx, n):
+    """BASELINE configs[2] (Ishigami, k = 3) through vs_eval_reduce_first_second_order: the thread-per-row fused kernel
+    with the 12 second-order products beside its 17 first-order sums."""
+    from varsens_amd import _native
+    k = 3
+    d = make_design(ctx, k, n, 1, np.full(3, -np.pi), np.full(3, np.pi))
+    obj = ctx.objective_create(_native.OBJ_ISHIGAMI, 3, 1, np.array([7.0, 0.1]))
+    assert ctx.eval_reduce_both_supported(d, obj)
+    nacc, ng = _native.acc_len(k, 1, 1), _native.gram_len(k)
+    f = ctx.alloc(8 * 8 * n)
+    ctx.eval(d, obj, 0, n, f)
+    acc1, acc2, g1, g2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc), ctx.alloc(8 * ng), ctx.alloc(8 * ng)
+    ctx.reduce_first_second_order(f, n, k, 1, acc1, g1)
+    ctx.eval_reduce_first_second_order(d, obj, 0, n, acc2, g2)
+    r1, r2 = ctx.download(acc1, (nacc,)), ctx.download(acc2, (nacc,))
+    G1, G2 = ctx.download(g1, (2, k, k)), ctx.download(g2, (2, k, k))
+    per = _native.acc_per_output(k)
+    np.testing.assert_allclose(r2[4:4 + per], r1[4:4 + per], rtol=1e-12, atol=1e-12 * np.abs(r1[4:4 + per]).max())
+    np.testing.assert_allclose(G2, G1, rtol=1e-12, atol=1e-12 * np.abs(G1).max())
+    assert np.array_equal(G2[0], G2[0].T) and np.array_equal(G2[1], G2[1].T)
+    F = ctx.download(f, (8, n))
+    S, T = F[2:5] + F[5:8], F[2:5] - F[5:8]
+    np.testing.assert_allclose(G2[0], S @ S.T, rtol=1e-12, atol=1e-12 * np.abs(G1).max())
+    np.testing.assert_allclose(G2[1], T @ T.T, rtol=1e-12, atol=1e-12 * np.abs(G1).max())
+
+
 def test_fused_both_orders_coverage(ctx):
     from varsens_amd import _native
     d = make_design(ctx, 40, 100)
     assert not ctx.eval_reduce_both_supported(d, ctx.objective_create(_native.OBJ_LINEAR, 40, 1, np.ones(40)))   # k > 32
     d8 = make_design(ctx, 8, 100)
     assert not ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 2, np.ones(16)))   # two outputs
-    assert not ctx.eval_reduce_both_supported(make_design(ctx, 3, 100), ctx.objective_create(_native.OBJ_ISHIGAMI, 3, 1, np.array([7.0, 0.1])))
+    assert not ctx.eval_reduce_both_supported(make_design(ctx, 3, 100), ctx.objective_create(_native.OBJ_INVERT, 3, 3, None))
     lin = ctx.objective_create(_native.OBJ_LINEAR, 8, 1, np.ones(8))
     assert ctx.eval_reduce_both_supported(d8, lin)
     acc, g = ctx.alloc(8 * _native.acc_len(8, 1, 1)), ctx.alloc(8 * _native.gram_len(8))

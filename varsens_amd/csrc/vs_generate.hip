@@ -759,7 +759,7 @@ int vs_scan_eval(vs_context* ctx, const vs_eval_args& A);
 int vs_scan_fused_plan(vs_context* ctx, const vs_eval_args& A, unsigned* P);
 int vs_scan_fused(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev);
 unsigned vs_fused_ishigami_workgroups(vs_context* ctx, uint64_t rows);
-int vs_fused_ishigami(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev);
+int vs_fused_ishigami(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev, double* gram_partials);
 int vs_ishigami_eval(vs_context* ctx, const vs_eval_args& A);
 
 static bool rows_in_perm_slice(const vs_design* g, uint64_t row_begin, uint64_t row_count) {
@@ -839,7 +839,7 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
     if (rc) return rc;
     switch (route) {
         case FUSED_SCAN: rc = vs_scan_fused(ctx, A, P, shift_buf); break;
-        case FUSED_ISHIGAMI: rc = vs_fused_ishigami(ctx, A, P, shift_buf); break;
+        case FUSED_ISHIGAMI: rc = vs_fused_ishigami(ctx, A, P, shift_buf, nullptr); break;
         case FUSED_USER: rc = vs_rtc_launch_fused(ctx, obj, &A, sizeof(A), P, shift_buf); break;
         default: break;
     }
@@ -856,7 +856,7 @@ int vs_scan_gram_launch(vs_context* ctx, const vs_eval_args& A, int nbh, unsigne
 static fused_route fused_both_route(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
     if (obj->l != 1 || obj->k > 32 || obj->k != design->d.k) return FUSED_NONE;
     const fused_route r = fused_route_for(ctx, design, obj);
-    if (r == FUSED_SCAN) return r;
+    if (r == FUSED_SCAN || r == FUSED_ISHIGAMI) return r;
     if (r == FUSED_USER && obj->gram_function) return r;
     return FUSED_NONE;
 }
@@ -880,8 +880,8 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     VS_HIP(hipSetDevice(ctx->device));
     const fused_route route = fused_both_route(ctx, design, obj);
     if (route == FUSED_NONE)
-        return vs_fail(VS_ERR_ARG, "the fused both-orders path covers G_FUNCTION / POLYNOMIAL / LINEAR and separable source "
-                                   "objectives with one output and k <= 32 (Halton indices below 2^32, scan evaluation "
+        return vs_fail(VS_ERR_ARG, "the fused both-orders path covers ISHIGAMI and G_FUNCTION / POLYNOMIAL / LINEAR / separable "
+                                   "source objectives with one output and k <= 32 (Halton indices below 2^32, scan evaluation "
                                    "order); use vs_eval + vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
     const int k = obj->k;
     const int nbh = k <= 16 ? 1 : 2, SB = 16 * nbh;
@@ -894,8 +894,10 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     A.rows = row_count;
     A.f = nullptr;
     unsigned P = 1;
-    int rc = route == FUSED_USER ? vs_rtc_gram_plan(ctx, obj, row_count, &P)
-                                 : vs_scan_gram_launch(ctx, A, nbh, &P, nullptr, nullptr, nullptr, true);
+    int rc = VS_OK;
+    if (route == FUSED_ISHIGAMI) P = vs_fused_ishigami_workgroups(ctx, row_count);
+    else if (route == FUSED_USER) rc = vs_rtc_gram_plan(ctx, obj, row_count, &P);
+    else rc = vs_scan_gram_launch(ctx, A, nbh, &P, nullptr, nullptr, nullptr, true);
     if (rc) return rc;
     // workspace: [P][plen] first-order records + [plen] folded (vs_fold_partials' layout) + the f-values of one design
     // row (the variance shift), then [P][2][SB][SB] Gram partials
@@ -909,8 +911,13 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     double* gram_partials = ctx->partials + first_doubles;
     rc = vs_eval(ctx, design, obj, row_begin, 1, shift_buf);   // f(M_1[row_begin]): a one-row evaluation
     if (rc) return rc;
-    rc = route == FUSED_USER ? vs_rtc_launch_gram(ctx, obj, &A, sizeof(A), P, shift_buf, ctx->partials, gram_partials)
-                             : vs_scan_gram_launch(ctx, A, nbh, &P, shift_buf, ctx->partials, gram_partials, false);
+    if (route == FUSED_ISHIGAMI) {   // its kernel writes 3 x 3 entries of every 16 x 16 block; the fold reads only those
+        rc = vs_fused_ishigami(ctx, A, P, shift_buf, gram_partials);
+    } else if (route == FUSED_USER) {
+        rc = vs_rtc_launch_gram(ctx, obj, &A, sizeof(A), P, shift_buf, ctx->partials, gram_partials);
+    } else {
+        rc = vs_scan_gram_launch(ctx, A, nbh, &P, shift_buf, ctx->partials, gram_partials, false);
+    }
     if (rc) return rc;
     rc = vs_fold_partials(ctx, P, k, 1, row_count, shift_buf, (int)shift_stride, nullptr, rank, max_ranks, acc_dev);
     if (rc) return rc;

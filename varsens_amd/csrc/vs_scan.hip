@@ -46,22 +46,20 @@ ishigami_eval_kernel(vs_eval_args A) {
     }
 }
 
-// fused evaluate + first-order reduce for Ishigami: 4*3 + 5 register sums per thread
+// fused evaluate + reduce for Ishigami: 4*3 + 5 register sums per thread; GRAM: also the second-order sums
+// s_i s_j and t_i t_j (i <= j; s = c + d, t = c - d, varsens/saltelli.py:612-619) -- 12 more -- so that the default
+// Varsens(...) call of BASELINE configs[2] is this one kernel.  Gram partial per workgroup: [S S^T, T T^T][16][16]
+// (gram_fold_kernel's st = 2 layout, 3 x 3 entries live).
+template <bool GRAM>
 __global__ void __launch_bounds__(256)
-fused_ishigami_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
-    __shared__ double wsum[4][17];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        counters[0] = 0;
-        counters[1] = 0xffffffffu;
-        counters[2] = 0;
-        counters[3] = 0;
-        counters[4] = 0;
-    }
+fused_ishigami_kernel(vs_eval_args A, const double* shift_src, double* partials, double* gram_partials, uint32_t* counters) {
+    constexpr int NS = GRAM ? 29 : 17;
+    __shared__ double wsum[4][NS];
     const double pa_ = A.params[0], pb_ = A.params[1];
     const double shift = shift_src[0];
-    double acc[17];
+    double acc[NS];
 #pragma unroll
-    for (int i = 0; i < 17; ++i) acc[i] = 0.0;
+    for (int i = 0; i < NS; ++i) acc[i] = 0.0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t lr = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lr < A.rows; lr += stride) {
         double v[8];
@@ -82,17 +80,52 @@ fused_ishigami_kernel(vs_eval_args A, const double* shift_src, double* partials,
             acc[VS_P_HEAD + 2 * 3 + i] = fma(a, d, acc[VS_P_HEAD + 2 * 3 + i]);
             acc[VS_P_HEAD + 3 * 3 + i] = fma(b, c, acc[VS_P_HEAD + 3 * 3 + i]);
         }
+        if (GRAM) {
+            double sv[3], tv[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sv[i] = v[2 + i] + v[5 + i];
+                tv[i] = v[2 + i] - v[5 + i];
+            }
+            int e = 17;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = i; j < 3; ++j) {
+                    acc[GRAM ? e : 0] = fma(sv[i], sv[j], acc[GRAM ? e : 0]);
+                    acc[GRAM ? e + 6 : 0] = fma(tv[i], tv[j], acc[GRAM ? e + 6 : 0]);
+                    ++e;
+                }
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 17; ++i) {
+    for (int i = 0; i < NS; ++i) {
         const double v = vs_wave_sum_dpp(acc[i]);
         if (lane == 63) wsum[wave][i] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 17)
-        partials[(size_t)blockIdx.x * 17 + threadIdx.x] =
-            ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+    if (threadIdx.x < NS) {
+        const double t = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+        if (threadIdx.x < 17) {
+            partials[(size_t)blockIdx.x * 17 + threadIdx.x] = t;
+        } else {
+            // entry e - 17 of the upper triangles (0,0) (0,1) (0,2) (1,1) (1,2) (2,2), S first: both triangles of the
+            // 16 x 16 block are read by the fold
+            const int e = ((int)threadIdx.x - 17) % 6, pair = ((int)threadIdx.x - 17) / 6;
+            const int i = e < 3 ? 0 : e < 5 ? 1 : 2, j = e < 3 ? e : e < 5 ? e - 2 : 2;
+            double* g = gram_partials + ((size_t)blockIdx.x * 2 + pair) * 256;
+            g[i * 16 + j] = t;
+            g[j * 16 + i] = t;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // counters of the folds that follow, at the end (see scan_kernel)
+        counters[0] = 0;
+        counters[1] = 0xffffffffu;
+        counters[2] = 0;
+        counters[3] = 0;
+        counters[4] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -204,10 +237,15 @@ unsigned vs_fused_ishigami_workgroups(vs_context* ctx, uint64_t rows) {
     return (unsigned)(P < 1 ? 1 : P);
 }
 
-int vs_fused_ishigami(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev) {
+// gram_partials: null = first order only, else [P][2][16][16] for the second-order sums too
+int vs_fused_ishigami(vs_context* ctx, const vs_eval_args& A, unsigned P, const double* shift_dev, double* gram_partials) {
     vs_launch_scope scope(ctx, VS_KERNEL_FUSED);
-    hipLaunchKernelGGL(fused_ishigami_kernel, dim3(P), dim3(256), 0, ctx->stream, A, shift_dev, ctx->partials,
-                       ctx->counters);
+    if (gram_partials)
+        hipLaunchKernelGGL(fused_ishigami_kernel<true>, dim3(P), dim3(256), 0, ctx->stream, A, shift_dev, ctx->partials,
+                           gram_partials, ctx->counters);
+    else
+        hipLaunchKernelGGL(fused_ishigami_kernel<false>, dim3(P), dim3(256), 0, ctx->stream, A, shift_dev, ctx->partials,
+                           (double*)nullptr, ctx->counters);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
