@@ -760,7 +760,10 @@ def test_fused_power_scaling_matches_two_kernel_path(ctx, kind, k, n, l):
 @pytest.mark.parametrize("kind,k,n,mode", [
     ("g", 6, 1024, 0), ("lin", 32, 4096, 0), ("poly", 32, 70001, 1), ("g", 17, 333, 0), ("lin", 16, 5000, 1),
     ("poly", 1, 64, 0), ("g", 3, 1, 0), ("lin", 9, 63, 0), ("g", 24, 65, 2), ("poly", 31, 20000, 0), ("lin", 12, 129, 2),
-    ("g", 32, 1 << 18, 0), ("lin", 2, 100003, 0), ("g", 8, 300000, 1), ("poly", 20, 640, 0)])
+    ("g", 32, 1 << 18, 0), ("lin", 2, 100003, 0), ("g", 8, 300000, 1), ("poly", 20, 640, 0),
+    # 113 .. 128 columns: the eight-wave kernel (137 KiB tile, nine accumulator tiles per wave)
+    ("poly", 128, 5000, 0), ("lin", 113, 700, 1), ("g", 120, 130, 0), ("lin", 125, 20000, 2), ("g", 128, 1, 0),
+    ("poly", 114, 64, 0), ("lin", 119, 63, 0), ("g", 127, 40000, 0), ("poly", 128, 1 << 17, 1)])
 def test_fused_both_orders_matches_two_kernel_path(ctx, kind, k, n, mode):
     """vs_eval_reduce_first_second_order (round 3: s/t rows of every 64-row block into an LDS tile, MFMA Gram and the
     first-order dot products in the evaluating workgroup) == vs_eval + vs_reduce_first_second_order up to summation
@@ -830,7 +833,9 @@ def test_fused_both_orders_ishigami(ctx, n):
 def test_fused_both_orders_coverage(ctx):
     from varsens_amd import _native
     d = make_design(ctx, 40, 100)
-    assert not ctx.eval_reduce_both_supported(d, ctx.objective_create(_native.OBJ_LINEAR, 40, 1, np.ones(40)))   # k > 32
+    assert not ctx.eval_reduce_both_supported(d, ctx.objective_create(_native.OBJ_LINEAR, 40, 1, np.ones(40)))   # 33 .. 112
+    assert not ctx.eval_reduce_both_supported(make_design(ctx, 112, 100), ctx.objective_create(_native.OBJ_LINEAR, 112, 1, np.ones(112)))
+    assert ctx.eval_reduce_both_supported(make_design(ctx, 113, 100), ctx.objective_create(_native.OBJ_LINEAR, 113, 1, np.ones(113)))
     d8 = make_design(ctx, 8, 100)
     assert not ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 2, np.ones(16)))   # two outputs
     assert not ctx.eval_reduce_both_supported(make_design(ctx, 3, 100), ctx.objective_create(_native.OBJ_INVERT, 3, 3, None))

@@ -44,10 +44,15 @@ def test_expression_ishigami_matches_builtin_and_truth(vs):
         out[0] = (s1 + p[0] * (s2 * s2)) + (p[1] * ((x3 * x3) * (x3 * x3))) * s1;
     """
     sc = vs.scale.Linear([-np.pi] * 3, [np.pi] * 3)
-    v1 = vs.Varsens(vs.objectives.Ishigami(7.0, 0.1), sc, 3, 1 << 16, verbose=False)
+    # (fused=False: the built-in objective's default call is its fused kernel, whose sums come in another order)
+    v1 = vs.Varsens(vs.objectives.Ishigami(7.0, 0.1), sc, 3, 1 << 16, verbose=False, fused=False)
     v2 = vs.Varsens(vs.objectives.Expression(body, params=[7.0, 0.1]), sc, 3, 1 << 16, verbose=False)
     assert np.array_equal(v1.objective.flat(), v2.objective.flat())
     assert np.array_equal(v1.sens, v2.sens) and np.array_equal(v1.sens_2, v2.sens_2)
+    v0 = vs.Varsens(vs.objectives.Ishigami(7.0, 0.1), sc, 3, 1 << 16, verbose=False)
+    assert v0.objective._f is None
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        np.testing.assert_allclose(getattr(v0, f), getattr(v2, f), rtol=1e-9, atol=1e-11, err_msg=f)
     V, S, ST = orc.ishigami_truth()
     np.testing.assert_allclose(v2.sens[:, 0], S, atol=0.01)
     np.testing.assert_allclose(v2.sens_t[:, 0], ST, atol=0.01)

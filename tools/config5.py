@@ -45,3 +45,21 @@ S = V / total
 ST = V * (np.prod(1.0 + V) / (1.0 + V)) / total
 print("var_y %.6e (analytic %.6e)  max|sens-S| %.2e  max|sens_t-ST| %.2e" %
       (fin[1, 0], total, np.max(np.abs(fin[2 + 2 * k:2 + 3 * k, 0] - S)), np.max(np.abs(fin[2 + 3 * k:, 0] - ST))))
+# the default call -- evaluation and both orders -- in ONE kernel, no f-values in HBM (vs_eval_reduce_first_second_order)
+f.free()
+if ctx.eval_reduce_both_supported(design, obj):
+    g2 = ctx.alloc(8 * _native.gram_len(k)); acc2 = ctx.alloc(8 * _native.acc_len(k, 1, 1))
+    for _ in range(2):
+        ctx.eval_reduce_first_second_order(design, obj, 0, n, acc2, g2)
+    ctx.sync()
+    ctx.profile_begin(64)
+    for _ in range(5):
+        ctx.eval_reduce_first_second_order(design, obj, 0, n, acc2, g2)
+    recs = ctx.profile_end()
+    fused = [ms for nm, ms in recs if nm == "fused"]
+    G1, G2 = ctx.download(gram, (2, k, k)), ctx.download(g2, (2, k, k))
+    print("fused evaluate + both orders: kernel %.3f ms (min %.3f), whole call %.3f ms of kernels; max rel. difference of "
+          "the Gram sums vs the two-kernel path %.1e" % (np.median(fused), min(fused), sum(ms for _, ms in recs) / 5.0,
+                                                         float(np.max(np.abs(G2 - G1)) / np.max(np.abs(G1)))), flush=True)
+    print("   = %.1f TFLOP/s of fp64 MFMA beside the evaluation arithmetic (pipe shared with the vector fp64 instructions)" %
+          (nbl * (nbl + 1) * (n / 4.0) * 2048 / np.median(fused) / 1e9))

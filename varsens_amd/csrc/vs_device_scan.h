@@ -241,6 +241,157 @@ __device__ __forceinline__ void vs_gram_epilogue(double* __restrict__ lds, int q
     }
 }
 
+// ---- the same for 65 .. 128 columns: eight waves x 16 columns, NBH = 8 (tile [258][68] = 137 KiB: one workgroup of
+// eight waves per CU, two waves per SIMD, 256 VGPRs).  Tile ownership of gram_st_kernel (vs_gram_st.hip): the wave with
+// block row R owns row R of S S^T (8 - R tiles) and row 7 - R of T T^T (R + 1): nine accumulator tiles, the diagonal
+// ones reuse the A fragments; body compiled per R (straight-line code, every tile a compile-time fact).  The host
+// sends 113 .. 128 columns here (all eight blocks live; rows from k on are zeros in the tile): with fewer live blocks
+// the waves' tile counts differ and the two-kernel route is faster (k = 96: 3.4-3.6 vs 3.35 ms at n = 2^22).
+struct vs_gram8_regs {
+    vs_d4 acc[9];
+    double pas, pbs, pat, pbt;   // a . s, b . s of the 16 rows of S block R; a . t, b . t of T block 7 - R
+};
+
+// Software pipeline over the eight 8-sample quarters of the block, pinned with sched_barrier (left alone every
+// ds_read_b128 was followed by s_waitcnt lgkmcnt(0) and its two MFMAs): the A fragments of S row R and T row 7 - R
+// and a, b of quarter h + 1 are read a quarter ahead (two register sets); the seven other operand blocks of quarter
+// h are read at its top and land behind the four MFMAs of the two diagonal tiles, which need the A fragments only.
+// (All eleven fragments a quarter ahead -- 88 VGPRs of fragments -- spilled inside the MFMA section.)
+struct vs_gram8_afrags {
+    vs_d2 as, at, av, bv;
+};
+
+template <int R>
+__device__ __forceinline__ void vs_gram8_consume_row(const double* __restrict__ tile, int lane, vs_gram8_regs& G) {
+    constexpr int P = VS_GT_PITCH, NB = 8, TR = NB - 1 - R;
+    const double* base = tile + (size_t)(lane & 15) * P + 2 * (lane >> 4);   // S block 0; T block 0 is 128 rows further
+    const double* rab = tile + (size_t)256 * P + 2 * (lane >> 4);
+    auto load_a = [&](int h, vs_gram8_afrags& F) {
+        F.av = *(const vs_d2*)(rab + 8 * h);
+        F.bv = *(const vs_d2*)(rab + P + 8 * h);
+        F.as = *(const vs_d2*)(base + (size_t)(16 * R) * P + 8 * h);
+        F.at = *(const vs_d2*)(base + (size_t)(128 + 16 * TR) * P + 8 * h);
+    };
+    vs_gram8_afrags F[2];
+    load_a(0, F[0]);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        vs_d2 b[7];
+#pragma unroll
+        for (int sl = 1; sl < NB - R; ++sl) b[sl - 1] = *(const vs_d2*)(base + (size_t)(16 * (R + sl)) * P + 8 * h);
+#pragma unroll
+        for (int j = 1; j <= R; ++j) b[NB - R - 1 + j - 1] = *(const vs_d2*)(base + (size_t)(128 + 16 * (TR + j)) * P + 8 * h);
+        if (h + 1 < 8) load_a(h + 1, F[(h + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const vs_gram8_afrags& A = F[h & 1];
+        G.acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[0], A.as[0], G.acc[0], 0, 0, 0);
+        G.acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[1], A.as[1], G.acc[0], 0, 0, 0);
+        G.acc[NB - R] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[0], A.at[0], G.acc[NB - R], 0, 0, 0);
+        G.acc[NB - R] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[1], A.at[1], G.acc[NB - R], 0, 0, 0);
+        G.pas = fma(A.av[0], A.as[0], G.pas);
+        G.pbs = fma(A.bv[0], A.as[0], G.pbs);
+        G.pas = fma(A.av[1], A.as[1], G.pas);
+        G.pbs = fma(A.bv[1], A.as[1], G.pbs);
+        G.pat = fma(A.av[0], A.at[0], G.pat);
+        G.pbt = fma(A.bv[0], A.at[0], G.pbt);
+        G.pat = fma(A.av[1], A.at[1], G.pat);
+        G.pbt = fma(A.bv[1], A.at[1], G.pbt);
+#pragma unroll
+        for (int sl = 1; sl < NB - R; ++sl) {
+            G.acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[0], b[sl - 1][0], G.acc[sl], 0, 0, 0);
+            G.acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[1], b[sl - 1][1], G.acc[sl], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 1; j <= R; ++j) {
+            G.acc[NB - R + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[0], b[NB - R - 1 + j - 1][0], G.acc[NB - R + j], 0, 0, 0);
+            G.acc[NB - R + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[1], b[NB - R - 1 + j - 1][1], G.acc[NB - R + j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the wave's nine tiles into the workgroup's partial [S S^T, T T^T][128][128] (upper 16-blocks)
+template <int R>
+__device__ __forceinline__ void vs_gram8_store_row(double* __restrict__ gout, int lane, int nbl, const vs_gram8_regs& G) {
+    constexpr int NB = 8, TR = NB - 1 - R, SB = 128;
+#pragma unroll
+    for (int sl = 0; sl < 9; ++sl) {
+        const bool ss = sl < NB - R;
+        const int rowblk = ss ? R : TR, blk = ss ? R + sl : TR + (sl - (NB - R));
+        if (rowblk < nbl && blk < nbl) {
+            double* o = gout + (ss ? 0 : (size_t)SB * SB);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                o[(size_t)(16 * rowblk + (lane >> 4) + 4 * v) * SB + 16 * blk + (lane & 15)] = G.acc[sl][v];
+        }
+    }
+}
+
+__device__ __forceinline__ void vs_gram8_consume(const double* __restrict__ tile, int q, int lane, vs_gram8_regs& G) {
+    switch (q) {
+        case 0: vs_gram8_consume_row<0>(tile, lane, G); break;
+        case 1: vs_gram8_consume_row<1>(tile, lane, G); break;
+        case 2: vs_gram8_consume_row<2>(tile, lane, G); break;
+        case 3: vs_gram8_consume_row<3>(tile, lane, G); break;
+        case 4: vs_gram8_consume_row<4>(tile, lane, G); break;
+        case 5: vs_gram8_consume_row<5>(tile, lane, G); break;
+        case 6: vs_gram8_consume_row<6>(tile, lane, G); break;
+        default: vs_gram8_consume_row<7>(tile, lane, G); break;
+    }
+}
+
+// `lds`: at least 2 * 256 + 8 doubles, free by now
+__device__ __forceinline__ void vs_gram8_epilogue(double* __restrict__ lds, int q, int lane, int nbl, vs_gram8_regs& G,
+                                                  const double (&head)[5], int k, double* __restrict__ gout,
+                                                  double* __restrict__ rec) {
+    double* dots = lds;          // [s rows 0..127, t rows 0..127][a, b]
+    double* hd = lds + 512;
+    G.pas += __shfl_xor(G.pas, 16, 64);
+    G.pas += __shfl_xor(G.pas, 32, 64);
+    G.pbs += __shfl_xor(G.pbs, 16, 64);
+    G.pbs += __shfl_xor(G.pbs, 32, 64);
+    G.pat += __shfl_xor(G.pat, 16, 64);
+    G.pat += __shfl_xor(G.pat, 32, 64);
+    G.pbt += __shfl_xor(G.pbt, 16, 64);
+    G.pbt += __shfl_xor(G.pbt, 32, 64);
+    __syncthreads();   // every wave is done with the tile
+    if (lane < 16) {
+        dots[(16 * q + lane) * 2 + 0] = G.pas;
+        dots[(16 * q + lane) * 2 + 1] = G.pbs;
+        dots[(128 + 16 * (7 - q) + lane) * 2 + 0] = G.pat;
+        dots[(128 + 16 * (7 - q) + lane) * 2 + 1] = G.pbt;
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int z = 0; z < 5; ++z) {
+            const double t = vs_wave_sum_dpp(head[z]);
+            if (lane == 63) hd[z] = t;
+        }
+    }
+    __syncthreads();
+    switch (q) {
+        case 0: vs_gram8_store_row<0>(gout, lane, nbl, G); break;
+        case 1: vs_gram8_store_row<1>(gout, lane, nbl, G); break;
+        case 2: vs_gram8_store_row<2>(gout, lane, nbl, G); break;
+        case 3: vs_gram8_store_row<3>(gout, lane, nbl, G); break;
+        case 4: vs_gram8_store_row<4>(gout, lane, nbl, G); break;
+        case 5: vs_gram8_store_row<5>(gout, lane, nbl, G); break;
+        case 6: vs_gram8_store_row<6>(gout, lane, nbl, G); break;
+        default: vs_gram8_store_row<7>(gout, lane, nbl, G); break;
+    }
+    const size_t plen = 5 + 4 * (size_t)k;
+    for (size_t e = threadIdx.x; e < plen; e += 512) {
+        double v = hd[e < 5 ? e : 0];
+        if (e >= 5) {
+            const int slot = (int)((e - 5) / k), j = (int)((e - 5) % k);
+            const int which = (slot == 0 || slot == 2) ? 0 : 1;
+            const double xs = dots[j * 2 + which], xt = dots[(128 + j) * 2 + which];
+            v = (slot == 0 || slot == 3) ? 0.5 * (xs + xt) : 0.5 * (xs - xt);
+        }
+        rec[e] = v;
+    }
+}
+
 // Everything behind the terms of one output: totals exchange, prefixes, suffix checkpoints, outputs.
 // ta/tb: the wave's 2L terms in registers (TLDS: in its LDS slab `tl` instead); Ta/Tb their totals.
 // NBH > 0 (FUSED): the outputs go into the Gram tile `gt` (tile + lane) instead of the 4L register sums.
@@ -619,6 +770,40 @@ __device__ __forceinline__ void vs_scan_gram_body(const vs_eval_args& A, double*
     const double head[5] = {acc.sab, acc.sa, acc.sb, acc.s1, acc.s2};
     vs_gram_epilogue<NBH>(tile, q, lane, G, head, k, gram_partials + (size_t)blockIdx.x * 2 * (16 * NBH) * (16 * NBH),
                           first_partials + (size_t)blockIdx.x * (5 + 4 * (size_t)k));
+}
+
+// 65 .. 128 columns: eight waves x 16 columns, one workgroup per CU (see vs_gram8_consume_row).
+// Partials: first_partials[blockIdx.x][5 + 4k], gram_partials[blockIdx.x][2][128][128].
+template <class Term, int FOLD, int GENV>
+__device__ __forceinline__ void vs_scan_gram8_body(const vs_eval_args& A, double* __restrict__ lds,
+                                                   const double* __restrict__ shift_src,
+                                                   double* __restrict__ first_partials,
+                                                   double* __restrict__ gram_partials) {
+    constexpr int T = VS_EVAL_ROWS, W = 8, L = 16, NBH = 8;
+    const int k = A.D.k;
+    const int nbl = (k + 15) >> 4;
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* tile = lds + 2 * W * T;
+    for (int e = threadIdx.x; e < VS_GT_DOUBLES(NBH); e += W * T) tile[e] = 0.0;   // rows k .. 127 stay zero
+    const double shift = shift_src[0];
+    vs_scan_acc<L> acc;
+    acc.sab = acc.sa = acc.sb = acc.s1 = acc.s2 = 0.0;
+    vs_gram8_regs G;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) G.acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
+    G.pas = G.pbs = G.pat = G.pbt = 0.0;
+    __syncthreads();
+    const vs_u64 nblocks = (A.rows + T - 1) / T;
+    for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+        vs_scan_block<Term, FOLD, L, W, true, false, false, GENV, NBH>(A, A.params, q, lane, rb, lds, nullptr, nullptr,
+                                                                       shift, acc, tile + lane);
+        __syncthreads();
+        vs_gram8_consume(tile, q, lane, G);
+    }
+    const double head[5] = {acc.sab, acc.sa, acc.sb, acc.s1, acc.s2};
+    vs_gram8_epilogue(tile, q, lane, nbl, G, head, k, gram_partials + (size_t)blockIdx.x * 2 * 128 * 128,
+                      first_partials + (size_t)blockIdx.x * (5 + 4 * (size_t)k));
 }
 
 #endif  // VS_DEVICE_SCAN_H

@@ -850,14 +850,18 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
 // vs_scan_gram.hip
 int vs_scan_gram_launch(vs_context* ctx, const vs_eval_args& A, int nbh, unsigned* P_io, const double* shift_dev,
                         double* first_partials, double* gram_partials, bool plan_only);
+// vs_scan_gram8.hip
+int vs_scan_gram8_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
+                         double* first_partials, double* gram_partials, bool plan_only);
 
-// the fused both-orders kernels: separable objectives in scan form -- built-in or compiled at run time --, one
-// output, k <= 32
+// the fused both-orders kernels, one output: separable objectives in scan form with k <= 32 -- built-in or compiled
+// at run time --, the built-in ones also with 113 .. 128 columns (eight-wave kernel, vs_scan_gram8.hip), Ishigami
 static fused_route fused_both_route(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
-    if (obj->l != 1 || obj->k > 32 || obj->k != design->d.k) return FUSED_NONE;
+    if (obj->l != 1 || obj->k != design->d.k) return FUSED_NONE;
     const fused_route r = fused_route_for(ctx, design, obj);
-    if (r == FUSED_SCAN || r == FUSED_ISHIGAMI) return r;
-    if (r == FUSED_USER && obj->gram_function) return r;
+    if (r == FUSED_ISHIGAMI) return r;
+    if (r == FUSED_SCAN && (obj->k <= 32 || (obj->k > 112 && obj->k <= 128 && ctx->tune.fused_both_wide != 0))) return r;
+    if (r == FUSED_USER && obj->gram_function && obj->k <= 32) return r;
     return FUSED_NONE;
 }
 
@@ -884,7 +888,8 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
                                    "source objectives with one output and k <= 32 (Halton indices below 2^32, scan evaluation "
                                    "order); use vs_eval + vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
     const int k = obj->k;
-    const int nbh = k <= 16 ? 1 : 2, SB = 16 * nbh;
+    const bool wide = route == FUSED_SCAN && k > 32;   // 113 .. 128 columns: the eight-wave kernel, partials of 128 x 128
+    const int nbh = k <= 16 ? 1 : k <= 32 ? 2 : 8, SB = 16 * nbh;
     vs_eval_args A;
     A.D = to_dev(design);
     A.kind = obj->kind;
@@ -897,6 +902,7 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     int rc = VS_OK;
     if (route == FUSED_ISHIGAMI) P = vs_fused_ishigami_workgroups(ctx, row_count);
     else if (route == FUSED_USER) rc = vs_rtc_gram_plan(ctx, obj, row_count, &P);
+    else if (wide) rc = vs_scan_gram8_launch(ctx, A, &P, nullptr, nullptr, nullptr, true);
     else rc = vs_scan_gram_launch(ctx, A, nbh, &P, nullptr, nullptr, nullptr, true);
     if (rc) return rc;
     // workspace: [P][plen] first-order records + [plen] folded (vs_fold_partials' layout) + the f-values of one design
@@ -915,6 +921,8 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
         rc = vs_fused_ishigami(ctx, A, P, shift_buf, gram_partials);
     } else if (route == FUSED_USER) {
         rc = vs_rtc_launch_gram(ctx, obj, &A, sizeof(A), P, shift_buf, ctx->partials, gram_partials);
+    } else if (wide) {
+        rc = vs_scan_gram8_launch(ctx, A, &P, shift_buf, ctx->partials, gram_partials, false);
     } else {
         rc = vs_scan_gram_launch(ctx, A, nbh, &P, shift_buf, ctx->partials, gram_partials, false);
     }

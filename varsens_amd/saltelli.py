@@ -592,12 +592,12 @@ class Varsens(object):
     def _fused_candidate(self, objective):
         """A device objective whose f-values may never be needed: the engine is asked later whether its fused
         evaluate+reduce kernels cover the (design, objective) pair -- vs_eval_reduce_supported for the first order
-        alone, vs_eval_reduce_both_supported (one output, k <= 32) when the second-order indices are wanted too."""
+        alone, vs_eval_reduce_both_supported (one output, k <= 128) when the second-order indices are wanted too."""
         if self._fused is False or not isinstance(objective, _objectives.DeviceObjective):
             return False
         if not self._second_order:
             return True
-        return int(self.k) <= 32 and int(objective.outputs(int(self.k))) == 1
+        return int(self.k) <= 128 and int(objective.outputs(int(self.k))) == 1
 
     def compute_varsens(self):
         """E_2, var_y, U_j, U_nj, sens, sens_t, sens_2, sens_2n (varsens/saltelli.py:572-622)."""
