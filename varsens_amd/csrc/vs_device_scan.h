@@ -241,49 +241,52 @@ __device__ __forceinline__ void vs_gram_epilogue(double* __restrict__ lds, int q
     }
 }
 
-// ---- the same for 65 .. 128 columns: eight waves x 16 columns, NBH = 8 (tile [258][68] = 137 KiB: one workgroup of
-// eight waves per CU, two waves per SIMD, 256 VGPRs).  Tile ownership of gram_st_kernel (vs_gram_st.hip): the wave with
-// block row R owns row R of S S^T (8 - R tiles) and row 7 - R of T T^T (R + 1): nine accumulator tiles, the diagonal
-// ones reuse the A fragments; body compiled per R (straight-line code, every tile a compile-time fact).  The host
-// sends 113 .. 128 columns here (all eight blocks live; rows from k on are zeros in the tile): with fewer live blocks
-// the waves' tile counts differ and the two-kernel route is faster (k = 96: 3.4-3.6 vs 3.35 ms at n = 2^22).
-struct vs_gram8_regs {
-    vs_d4 acc[9];
-    double pas, pbs, pat, pbt;   // a . s, b . s of the 16 rows of S block R; a . t, b . t of T block 7 - R
+// ---- the same beyond 32 columns: NB waves x 16 columns, tile of NB 16-row blocks per half, two waves per SIMD at 256
+// VGPRs.  NB = 8 (113 .. 128 columns; tile [258][68] = 137 KiB: one workgroup of eight waves per CU) and NB = 4
+// (49 .. 64 columns; 69 KiB: two workgroups of four waves per CU).  Tile ownership of gram_st_kernel
+// (vs_gram_st.hip): the wave with block row R owns row R of S S^T (NB - R tiles) and row NB-1-R of T T^T (R + 1):
+// NB + 1 accumulator tiles, the diagonal ones reuse the A fragments; body compiled per R (straight-line code, every
+// tile a compile-time fact).  All NB blocks are multiplied (rows from k on are zeros in the tile): with fewer live
+// blocks at NB = 8 the waves' tile counts would differ and the two-kernel route is faster (k = 96: 3.4-3.6 vs
+// 3.35 ms at n = 2^22; k = 48 at NB = 4: 1.42 vs 1.28), so the host sends 113 .. 128 and 49 .. 64 columns here.
+template <int NB>
+struct vs_gramn_regs {
+    vs_d4 acc[NB + 1];
+    double pas, pbs, pat, pbt;   // a . s, b . s of the 16 rows of S block R; a . t, b . t of T block NB-1-R
 };
 
 // Software pipeline over the eight 8-sample quarters of the block, pinned with sched_barrier (left alone every
-// ds_read_b128 was followed by s_waitcnt lgkmcnt(0) and its two MFMAs): the A fragments of S row R and T row 7 - R
-// and a, b of quarter h + 1 are read a quarter ahead (two register sets); the seven other operand blocks of quarter
+// ds_read_b128 was followed by s_waitcnt lgkmcnt(0) and its two MFMAs): the A fragments of S row R and T row NB-1-R
+// and a, b of quarter h + 1 are read a quarter ahead (two register sets); the NB - 1 other operand blocks of quarter
 // h are read at its top and land behind the four MFMAs of the two diagonal tiles, which need the A fragments only.
-// (All eleven fragments a quarter ahead -- 88 VGPRs of fragments -- spilled inside the MFMA section.)
-struct vs_gram8_afrags {
+// (All fragments a quarter ahead -- 88 VGPRs of fragments at NB = 8 -- spilled inside the MFMA section.)
+struct vs_gramn_afrags {
     vs_d2 as, at, av, bv;
 };
 
-template <int R>
-__device__ __forceinline__ void vs_gram8_consume_row(const double* __restrict__ tile, int lane, vs_gram8_regs& G) {
-    constexpr int P = VS_GT_PITCH, NB = 8, TR = NB - 1 - R;
-    const double* base = tile + (size_t)(lane & 15) * P + 2 * (lane >> 4);   // S block 0; T block 0 is 128 rows further
-    const double* rab = tile + (size_t)256 * P + 2 * (lane >> 4);
-    auto load_a = [&](int h, vs_gram8_afrags& F) {
+template <int R, int NB>
+__device__ __forceinline__ void vs_gramn_consume_row(const double* __restrict__ tile, int lane, vs_gramn_regs<NB>& G) {
+    constexpr int P = VS_GT_PITCH, TR = NB - 1 - R, HALF = 16 * NB;
+    const double* base = tile + (size_t)(lane & 15) * P + 2 * (lane >> 4);   // S block 0; T block 0 is HALF rows further
+    const double* rab = tile + (size_t)(2 * HALF) * P + 2 * (lane >> 4);
+    auto load_a = [&](int h, vs_gramn_afrags& F) {
         F.av = *(const vs_d2*)(rab + 8 * h);
         F.bv = *(const vs_d2*)(rab + P + 8 * h);
         F.as = *(const vs_d2*)(base + (size_t)(16 * R) * P + 8 * h);
-        F.at = *(const vs_d2*)(base + (size_t)(128 + 16 * TR) * P + 8 * h);
+        F.at = *(const vs_d2*)(base + (size_t)(HALF + 16 * TR) * P + 8 * h);
     };
-    vs_gram8_afrags F[2];
+    vs_gramn_afrags F[2];
     load_a(0, F[0]);
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
-        vs_d2 b[7];
+        vs_d2 b[NB - 1];
 #pragma unroll
         for (int sl = 1; sl < NB - R; ++sl) b[sl - 1] = *(const vs_d2*)(base + (size_t)(16 * (R + sl)) * P + 8 * h);
 #pragma unroll
-        for (int j = 1; j <= R; ++j) b[NB - R - 1 + j - 1] = *(const vs_d2*)(base + (size_t)(128 + 16 * (TR + j)) * P + 8 * h);
+        for (int j = 1; j <= R; ++j) b[NB - R - 1 + j - 1] = *(const vs_d2*)(base + (size_t)(HALF + 16 * (TR + j)) * P + 8 * h);
         if (h + 1 < 8) load_a(h + 1, F[(h + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        const vs_gram8_afrags& A = F[h & 1];
+        const vs_gramn_afrags& A = F[h & 1];
         G.acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[0], A.as[0], G.acc[0], 0, 0, 0);
         G.acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[1], A.as[1], G.acc[0], 0, 0, 0);
         G.acc[NB - R] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[0], A.at[0], G.acc[NB - R], 0, 0, 0);
@@ -310,15 +313,15 @@ __device__ __forceinline__ void vs_gram8_consume_row(const double* __restrict__ 
     }
 }
 
-// the wave's nine tiles into the workgroup's partial [S S^T, T T^T][128][128] (upper 16-blocks)
-template <int R>
-__device__ __forceinline__ void vs_gram8_store_row(double* __restrict__ gout, int lane, int nbl, const vs_gram8_regs& G) {
-    constexpr int NB = 8, TR = NB - 1 - R, SB = 128;
+// the wave's NB + 1 tiles into the workgroup's partial [S S^T, T T^T][16 NB][16 NB] (upper 16-blocks)
+template <int R, int NB>
+__device__ __forceinline__ void vs_gramn_store_row(double* __restrict__ gout, int lane, int nbl, const vs_gramn_regs<NB>& G) {
+    constexpr int TR = NB - 1 - R, SB = 16 * NB;
 #pragma unroll
-    for (int sl = 0; sl < 9; ++sl) {
+    for (int sl = 0; sl < NB + 1; ++sl) {
         const bool ss = sl < NB - R;
         const int rowblk = ss ? R : TR, blk = ss ? R + sl : TR + (sl - (NB - R));
-        if (rowblk < nbl && blk < nbl) {
+        if (rowblk < nbl && blk < nbl) {   // blocks from ceil(k / 16) on are all zeros: the fold never reads them
             double* o = gout + (ss ? 0 : (size_t)SB * SB);
 #pragma unroll
             for (int v = 0; v < 4; ++v)
@@ -327,25 +330,34 @@ __device__ __forceinline__ void vs_gram8_store_row(double* __restrict__ gout, in
     }
 }
 
-__device__ __forceinline__ void vs_gram8_consume(const double* __restrict__ tile, int q, int lane, vs_gram8_regs& G) {
-    switch (q) {
-        case 0: vs_gram8_consume_row<0>(tile, lane, G); break;
-        case 1: vs_gram8_consume_row<1>(tile, lane, G); break;
-        case 2: vs_gram8_consume_row<2>(tile, lane, G); break;
-        case 3: vs_gram8_consume_row<3>(tile, lane, G); break;
-        case 4: vs_gram8_consume_row<4>(tile, lane, G); break;
-        case 5: vs_gram8_consume_row<5>(tile, lane, G); break;
-        case 6: vs_gram8_consume_row<6>(tile, lane, G); break;
-        default: vs_gram8_consume_row<7>(tile, lane, G); break;
+// q < NB: one body per block row (the s_barrier count is the same in all of them: none)
+#define VS_GRAMN_DISPATCH(CALL)          \
+    switch (q) {                         \
+        case 0: CALL(0); break;          \
+        case 1: CALL(1); break;          \
+        case 2: CALL(2); break;          \
+        case 3: CALL(3); break;          \
+        case 4: CALL((NB > 4 ? 4 : 0)); break; \
+        case 5: CALL((NB > 4 ? 5 : 0)); break; \
+        case 6: CALL((NB > 4 ? 6 : 0)); break; \
+        default: CALL((NB > 4 ? 7 : 0)); break; \
     }
+
+template <int NB>
+__device__ __forceinline__ void vs_gramn_consume(const double* __restrict__ tile, int q, int lane, vs_gramn_regs<NB>& G) {
+#define VS_GRAMN_CONSUME(RR) vs_gramn_consume_row<RR, NB>(tile, lane, G)
+    VS_GRAMN_DISPATCH(VS_GRAMN_CONSUME)
+#undef VS_GRAMN_CONSUME
 }
 
-// `lds`: at least 2 * 256 + 8 doubles, free by now
-__device__ __forceinline__ void vs_gram8_epilogue(double* __restrict__ lds, int q, int lane, int nbl, vs_gram8_regs& G,
+// `lds`: at least 4 * 16 NB + 8 doubles, free by now
+template <int NB>
+__device__ __forceinline__ void vs_gramn_epilogue(double* __restrict__ lds, int q, int lane, int nbl, vs_gramn_regs<NB>& G,
                                                   const double (&head)[5], int k, double* __restrict__ gout,
                                                   double* __restrict__ rec) {
-    double* dots = lds;          // [s rows 0..127, t rows 0..127][a, b]
-    double* hd = lds + 512;
+    constexpr int HALF = 16 * NB;
+    double* dots = lds;          // [s rows 0..HALF-1, t rows 0..HALF-1][a, b]
+    double* hd = lds + 4 * HALF;
     G.pas += __shfl_xor(G.pas, 16, 64);
     G.pas += __shfl_xor(G.pas, 32, 64);
     G.pbs += __shfl_xor(G.pbs, 16, 64);
@@ -358,8 +370,8 @@ __device__ __forceinline__ void vs_gram8_epilogue(double* __restrict__ lds, int 
     if (lane < 16) {
         dots[(16 * q + lane) * 2 + 0] = G.pas;
         dots[(16 * q + lane) * 2 + 1] = G.pbs;
-        dots[(128 + 16 * (7 - q) + lane) * 2 + 0] = G.pat;
-        dots[(128 + 16 * (7 - q) + lane) * 2 + 1] = G.pbt;
+        dots[(HALF + 16 * (NB - 1 - q) + lane) * 2 + 0] = G.pat;
+        dots[(HALF + 16 * (NB - 1 - q) + lane) * 2 + 1] = G.pbt;
     }
     if (q == 0) {
 #pragma unroll
@@ -369,23 +381,16 @@ __device__ __forceinline__ void vs_gram8_epilogue(double* __restrict__ lds, int 
         }
     }
     __syncthreads();
-    switch (q) {
-        case 0: vs_gram8_store_row<0>(gout, lane, nbl, G); break;
-        case 1: vs_gram8_store_row<1>(gout, lane, nbl, G); break;
-        case 2: vs_gram8_store_row<2>(gout, lane, nbl, G); break;
-        case 3: vs_gram8_store_row<3>(gout, lane, nbl, G); break;
-        case 4: vs_gram8_store_row<4>(gout, lane, nbl, G); break;
-        case 5: vs_gram8_store_row<5>(gout, lane, nbl, G); break;
-        case 6: vs_gram8_store_row<6>(gout, lane, nbl, G); break;
-        default: vs_gram8_store_row<7>(gout, lane, nbl, G); break;
-    }
+#define VS_GRAMN_STORE(RR) vs_gramn_store_row<RR, NB>(gout, lane, nbl, G)
+    VS_GRAMN_DISPATCH(VS_GRAMN_STORE)
+#undef VS_GRAMN_STORE
     const size_t plen = 5 + 4 * (size_t)k;
-    for (size_t e = threadIdx.x; e < plen; e += 512) {
+    for (size_t e = threadIdx.x; e < plen; e += 64 * NB) {
         double v = hd[e < 5 ? e : 0];
         if (e >= 5) {
             const int slot = (int)((e - 5) / k), j = (int)((e - 5) % k);
             const int which = (slot == 0 || slot == 2) ? 0 : 1;
-            const double xs = dots[j * 2 + which], xt = dots[(128 + j) * 2 + which];
+            const double xs = dots[j * 2 + which], xt = dots[(HALF + j) * 2 + which];
             v = (slot == 0 || slot == 3) ? 0.5 * (xs + xt) : 0.5 * (xs - xt);
         }
         rec[e] = v;
@@ -772,26 +777,27 @@ __device__ __forceinline__ void vs_scan_gram_body(const vs_eval_args& A, double*
                           first_partials + (size_t)blockIdx.x * (5 + 4 * (size_t)k));
 }
 
-// 65 .. 128 columns: eight waves x 16 columns, one workgroup per CU (see vs_gram8_consume_row).
-// Partials: first_partials[blockIdx.x][5 + 4k], gram_partials[blockIdx.x][2][128][128].
-template <class Term, int FOLD, int GENV>
-__device__ __forceinline__ void vs_scan_gram8_body(const vs_eval_args& A, double* __restrict__ lds,
+// Beyond 32 columns: NB waves x 16 columns (see vs_gramn_consume_row).
+// Partials: first_partials[blockIdx.x][5 + 4k], gram_partials[blockIdx.x][2][16 NB][16 NB].
+template <class Term, int FOLD, int GENV, int NB>
+__device__ __forceinline__ void vs_scan_gramn_body(const vs_eval_args& A, double* __restrict__ lds,
                                                    const double* __restrict__ shift_src,
                                                    double* __restrict__ first_partials,
                                                    double* __restrict__ gram_partials) {
-    constexpr int T = VS_EVAL_ROWS, W = 8, L = 16, NBH = 8;
+    constexpr int T = VS_EVAL_ROWS, W = NB, L = 16, NBH = NB;
+    static_assert(NB == 4 || NB == 8, "64 or 128 index rows per half");
     const int k = A.D.k;
     const int nbl = (k + 15) >> 4;
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* tile = lds + 2 * W * T;
-    for (int e = threadIdx.x; e < VS_GT_DOUBLES(NBH); e += W * T) tile[e] = 0.0;   // rows k .. 127 stay zero
+    for (int e = threadIdx.x; e < VS_GT_DOUBLES(NBH); e += W * T) tile[e] = 0.0;   // rows k .. 16 NB - 1 stay zero
     const double shift = shift_src[0];
     vs_scan_acc<L> acc;
     acc.sab = acc.sa = acc.sb = acc.s1 = acc.s2 = 0.0;
-    vs_gram8_regs G;
+    vs_gramn_regs<NB> G;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) G.acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < NB + 1; ++i) G.acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
     G.pas = G.pbs = G.pat = G.pbt = 0.0;
     __syncthreads();
     const vs_u64 nblocks = (A.rows + T - 1) / T;
@@ -799,11 +805,11 @@ __device__ __forceinline__ void vs_scan_gram8_body(const vs_eval_args& A, double
         vs_scan_block<Term, FOLD, L, W, true, false, false, GENV, NBH>(A, A.params, q, lane, rb, lds, nullptr, nullptr,
                                                                        shift, acc, tile + lane);
         __syncthreads();
-        vs_gram8_consume(tile, q, lane, G);
+        vs_gramn_consume<NB>(tile, q, lane, G);
     }
     const double head[5] = {acc.sab, acc.sa, acc.sb, acc.s1, acc.s2};
-    vs_gram8_epilogue(tile, q, lane, nbl, G, head, k, gram_partials + (size_t)blockIdx.x * 2 * 128 * 128,
-                      first_partials + (size_t)blockIdx.x * (5 + 4 * (size_t)k));
+    vs_gramn_epilogue<NB>(tile, q, lane, nbl, G, head, k, gram_partials + (size_t)blockIdx.x * 2 * (16 * NB) * (16 * NB),
+                          first_partials + (size_t)blockIdx.x * (5 + 4 * (size_t)k));
 }
 
 #endif  // VS_DEVICE_SCAN_H
