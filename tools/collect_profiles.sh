@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): the committed profiles/rNN set.
 #   bench line; rocprofv3 --kernel-trace --stats of bench.py; counter passes (tools/pmc_run.py: one group per pass,
 #   never together with sys/hip/hsa traces) over bench.py, over the Gram kernels at k = 32 / 64 / 128 and over the
-#   config-5 evaluation; BASELINE configs[4] on one GPU (tools/config5.py) with its kernel stats.
+#   config-5 evaluation and over the fused evaluate + both-orders kernels (k = 32, k = 128); BASELINE configs[4] on one GPU (tools/config5.py) with its kernel stats.
 # Summaries land in gpurun_out/profiles/ ; copy the ones to be judged into profiles/rNN/.
 # Every profiled program follows `--` itself (no env/bash hop: the profiler's preload initialises the GPU).
 set -u
@@ -21,7 +21,9 @@ K=128 LOG2N=24 python3 $R/tools/pmc_run.py gram_k128_n24 --kernels gram_,first_h
 K=64 LOG2N=22 python3 $R/tools/pmc_run.py gram_k64_n22 --kernels gram_,first_head,reduce_first -- python3 $R/tools/gram_only.py
 K=32 LOG2N=22 python3 $R/tools/pmc_run.py gram_k32_n22 --kernels gram_,first_head,reduce_first -- python3 $R/tools/gram_only.py
 python3 $R/tools/pmc_run.py eval_k128_n24 --kernels scan_kernel -- python3 $R/tools/eval_one.py 128 24 eval poly
-for n in gram_k128_n24 gram_k64_n22 gram_k32_n22 eval_k128_n24; do cp $R/gpurun_out/pmc/$n.json $R/gpurun_out/pmc/${n}_kernel_stats.csv $OUT/; done
+K=32 LOG2N=22 KIND=lin python3 $R/tools/pmc_run.py fused_both_k32 --kernels scan_gram --groups issue,lds -- python3 $R/tools/fused_both.py
+K=128 LOG2N=24 KIND=poly python3 $R/tools/pmc_run.py fused_both_k128_n24 --kernels scan_gram --groups issue,lds -- python3 $R/tools/fused_both.py
+for n in gram_k128_n24 gram_k64_n22 gram_k32_n22 eval_k128_n24 fused_both_k32 fused_both_k128_n24; do cp $R/gpurun_out/pmc/$n.json $R/gpurun_out/pmc/${n}_kernel_stats.csv $OUT/; done
 echo "kernel pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python3 $R/tools/config5.py > $OUT/config5.log 2>&1
 cp $(find $OUT/stats5 -name '*kernel_stats.csv' | head -1) $OUT/config5_kernel_stats.csv
