@@ -543,9 +543,11 @@ def test_fused_both_orders_through_api(vs, golden):
             numpy.testing.assert_allclose(getattr(a, f), getattr(b, f), rtol=1e-12, err_msg=f)
         for f in ("sens", "sens_t", "sens_2", "sens_2n"):
             numpy.testing.assert_allclose(getattr(a, f), getattr(b, f), rtol=1e-9, atol=1e-11, err_msg=f)
-    # 65 .. 112 columns and several outputs: the two-kernel route by itself
+    # more than 128 columns and several outputs: the two-kernel route by itself
+    w = vs.Varsens(vs.objectives.Linear(numpy.ones(130)), vs.scale.Identity(), 130, 500, verbose=False)
+    assert w.objective._f is not None and w.sens_2.shape == (130, 1, 130, 1)
     w = vs.Varsens(vs.objectives.Linear(numpy.ones(70)), vs.scale.Identity(), 70, 500, verbose=False)
-    assert w.objective._f is not None and w.sens_2.shape == (70, 1, 70, 1)
+    assert w.objective._f is None and w.sens_2.shape == (70, 1, 70, 1)
     w = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 500, verbose=False)
     assert w.objective._f is not None and w.sens_2.shape == (6, 2, 6, 2)
     # Ishigami (BASELINE configs[2]): its own thread-per-row fused kernel carries the second-order sums too

@@ -766,7 +766,10 @@ def test_fused_power_scaling_matches_two_kernel_path(ctx, kind, k, n, l):
     ("poly", 114, 64, 0), ("lin", 119, 63, 0), ("g", 127, 40000, 0), ("poly", 128, 1 << 17, 1),
     # 49 .. 64 columns: four waves x 16 columns (69 KiB tile, five accumulator tiles per wave)
     ("lin", 64, 5000, 0), ("g", 49, 700, 1), ("poly", 52, 130, 0), ("lin", 60, 20000, 2), ("g", 64, 1, 0),
-    ("poly", 50, 64, 0), ("lin", 57, 63, 0), ("g", 63, 40000, 0), ("poly", 64, 1 << 17, 1)])
+    ("poly", 50, 64, 0), ("lin", 57, 63, 0), ("g", 63, 40000, 0), ("poly", 64, 1 << 17, 1),
+    # dead 16-row blocks in the tile (bodies compiled per count of live blocks): 3 of 4, 5 / 6 / 7 of 8
+    ("lin", 33, 700, 1), ("g", 40, 5000, 0), ("poly", 48, 130, 2), ("lin", 65, 3000, 0), ("g", 80, 64, 1),
+    ("poly", 81, 20000, 0), ("lin", 96, 4097, 2), ("g", 97, 1, 0), ("poly", 112, 1000, 0), ("lin", 100, 1 << 16, 0)])
 def test_fused_both_orders_matches_two_kernel_path(ctx, kind, k, n, mode):
     """vs_eval_reduce_first_second_order (round 3: s/t rows of every 64-row block into an LDS tile, MFMA Gram and the
     first-order dot products in the evaluating workgroup) == vs_eval + vs_reduce_first_second_order up to summation
@@ -835,12 +838,10 @@ def test_fused_both_orders_ishigami(ctx, n):
 
 def test_fused_both_orders_coverage(ctx):
     from varsens_amd import _native
-    d = make_design(ctx, 70, 100)
-    assert not ctx.eval_reduce_both_supported(d, ctx.objective_create(_native.OBJ_LINEAR, 70, 1, np.ones(70)))   # 33 .. 48, 65 .. 112
-    assert not ctx.eval_reduce_both_supported(make_design(ctx, 48, 100), ctx.objective_create(_native.OBJ_LINEAR, 48, 1, np.ones(48)))
-    assert ctx.eval_reduce_both_supported(make_design(ctx, 49, 100), ctx.objective_create(_native.OBJ_LINEAR, 49, 1, np.ones(49)))
-    assert not ctx.eval_reduce_both_supported(make_design(ctx, 112, 100), ctx.objective_create(_native.OBJ_LINEAR, 112, 1, np.ones(112)))
-    assert ctx.eval_reduce_both_supported(make_design(ctx, 113, 100), ctx.objective_create(_native.OBJ_LINEAR, 113, 1, np.ones(113)))
+    d = make_design(ctx, 129, 100)
+    assert not ctx.eval_reduce_both_supported(d, ctx.objective_create(_native.OBJ_LINEAR, 129, 1, np.ones(129)))   # k > 128
+    for kk in (33, 48, 49, 65, 112, 113, 128):
+        assert ctx.eval_reduce_both_supported(make_design(ctx, kk, 100), ctx.objective_create(_native.OBJ_LINEAR, kk, 1, np.ones(kk)))
     d8 = make_design(ctx, 8, 100)
     assert not ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 2, np.ones(16)))   # two outputs
     assert not ctx.eval_reduce_both_supported(make_design(ctx, 3, 100), ctx.objective_create(_native.OBJ_INVERT, 3, 3, None))
@@ -848,7 +849,7 @@ def test_fused_both_orders_coverage(ctx):
     assert ctx.eval_reduce_both_supported(d8, lin)
     acc, g = ctx.alloc(8 * _native.acc_len(8, 1, 1)), ctx.alloc(8 * _native.gram_len(8))
     with pytest.raises(_native.VarsensHipError):
-        ctx.eval_reduce_first_second_order(make_design(ctx, 70, 100), ctx.objective_create(_native.OBJ_LINEAR, 70, 1, np.ones(70)), 0, 100, acc, g)
+        ctx.eval_reduce_first_second_order(make_design(ctx, 129, 100), ctx.objective_create(_native.OBJ_LINEAR, 129, 1, np.ones(129)), 0, 100, acc, g)
     # a Sobol design and raw points go through the general column code
     from varsens_amd.saltelli import sobol_directions
     n = 3000

@@ -145,7 +145,7 @@ def test_evaluation_any_shape(k, n, kind, l, discard, begin_frac, mode):
     f.free(); obj.free(); d.free()
 
 
-FUSED_K = st.one_of(st.integers(1, 32), st.integers(49, 64), st.integers(113, 128), st.sampled_from([16, 17, 32, 49, 64, 113, 128]))
+FUSED_K = st.one_of(st.integers(1, 128), st.sampled_from([16, 17, 32, 33, 48, 49, 64, 65, 80, 81, 96, 97, 112, 113, 128]))
 
 
 @settings(**dict(COMMON, max_examples=_SOAK or 120))

@@ -242,13 +242,12 @@ __device__ __forceinline__ void vs_gram_epilogue(double* __restrict__ lds, int q
 }
 
 // ---- the same beyond 32 columns: NB waves x 16 columns, tile of NB 16-row blocks per half, two waves per SIMD at 256
-// VGPRs.  NB = 8 (113 .. 128 columns; tile [258][68] = 137 KiB: one workgroup of eight waves per CU) and NB = 4
-// (49 .. 64 columns; 69 KiB: two workgroups of four waves per CU).  Tile ownership of gram_st_kernel
+// VGPRs.  NB = 8 (65 .. 128 columns; tile [258][68] = 137 KiB: one workgroup of eight waves per CU) and NB = 4
+// (33 .. 64 columns; 69 KiB: two workgroups of four waves per CU).  Tile ownership of gram_st_kernel
 // (vs_gram_st.hip): the wave with block row R owns row R of S S^T (NB - R tiles) and row NB-1-R of T T^T (R + 1):
 // NB + 1 accumulator tiles, the diagonal ones reuse the A fragments; body compiled per R (straight-line code, every
-// tile a compile-time fact).  All NB blocks are multiplied (rows from k on are zeros in the tile): with fewer live
-// blocks at NB = 8 the waves' tile counts would differ and the two-kernel route is faster (k = 96: 3.4-3.6 vs
-// 3.35 ms at n = 2^22; k = 48 at NB = 4: 1.42 vs 1.28), so the host sends 113 .. 128 and 49 .. 64 columns here.
+// tile a compile-time fact), and per number NBL of live blocks (rows from k on are zeros in the tile; multiplying all
+// NB blocks whatever k is made k = 96 and k = 48 slower than the two-kernel route: 3.5 vs 3.35, 1.42 vs 1.28 ms).
 template <int NB>
 struct vs_gramn_regs {
     vs_d4 acc[NB + 1];
@@ -264,16 +263,19 @@ struct vs_gramn_afrags {
     vs_d2 as, at, av, bv;
 };
 
-template <int R, int NB>
+// NBL <= NB: live 16-row blocks (ceil(k / 16)); tiles with a block row or column from NBL on are all zeros and are
+// left out at compile time (the waves' tile counts then differ by at most one or two: k = 96: 6, 5, 5, 5, 5, 5, 5, 6)
+template <int R, int NB, int NBL>
 __device__ __forceinline__ void vs_gramn_consume_row(const double* __restrict__ tile, int lane, vs_gramn_regs<NB>& G) {
     constexpr int P = VS_GT_PITCH, TR = NB - 1 - R, HALF = 16 * NB;
+    constexpr bool S_LIVE = R < NBL, T_LIVE = TR < NBL;
     const double* base = tile + (size_t)(lane & 15) * P + 2 * (lane >> 4);   // S block 0; T block 0 is HALF rows further
     const double* rab = tile + (size_t)(2 * HALF) * P + 2 * (lane >> 4);
     auto load_a = [&](int h, vs_gramn_afrags& F) {
         F.av = *(const vs_d2*)(rab + 8 * h);
         F.bv = *(const vs_d2*)(rab + P + 8 * h);
-        F.as = *(const vs_d2*)(base + (size_t)(16 * R) * P + 8 * h);
-        F.at = *(const vs_d2*)(base + (size_t)(HALF + 16 * TR) * P + 8 * h);
+        if (S_LIVE) F.as = *(const vs_d2*)(base + (size_t)(16 * R) * P + 8 * h);
+        if (T_LIVE) F.at = *(const vs_d2*)(base + (size_t)(HALF + 16 * TR) * P + 8 * h);
     };
     vs_gramn_afrags F[2];
     load_a(0, F[0]);
@@ -281,33 +283,47 @@ __device__ __forceinline__ void vs_gramn_consume_row(const double* __restrict__ 
     for (int h = 0; h < 8; ++h) {
         vs_d2 b[NB - 1];
 #pragma unroll
-        for (int sl = 1; sl < NB - R; ++sl) b[sl - 1] = *(const vs_d2*)(base + (size_t)(16 * (R + sl)) * P + 8 * h);
+        for (int sl = 1; sl < NB - R; ++sl)
+            if (S_LIVE && R + sl < NBL) b[sl - 1] = *(const vs_d2*)(base + (size_t)(16 * (R + sl)) * P + 8 * h);
 #pragma unroll
-        for (int j = 1; j <= R; ++j) b[NB - R - 1 + j - 1] = *(const vs_d2*)(base + (size_t)(HALF + 16 * (TR + j)) * P + 8 * h);
+        for (int j = 1; j <= R; ++j)
+            if (T_LIVE && TR + j < NBL) b[NB - R - 1 + j - 1] = *(const vs_d2*)(base + (size_t)(HALF + 16 * (TR + j)) * P + 8 * h);
         if (h + 1 < 8) load_a(h + 1, F[(h + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
         const vs_gramn_afrags& A = F[h & 1];
-        G.acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[0], A.as[0], G.acc[0], 0, 0, 0);
-        G.acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[1], A.as[1], G.acc[0], 0, 0, 0);
-        G.acc[NB - R] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[0], A.at[0], G.acc[NB - R], 0, 0, 0);
-        G.acc[NB - R] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[1], A.at[1], G.acc[NB - R], 0, 0, 0);
-        G.pas = fma(A.av[0], A.as[0], G.pas);
-        G.pbs = fma(A.bv[0], A.as[0], G.pbs);
-        G.pas = fma(A.av[1], A.as[1], G.pas);
-        G.pbs = fma(A.bv[1], A.as[1], G.pbs);
-        G.pat = fma(A.av[0], A.at[0], G.pat);
-        G.pbt = fma(A.bv[0], A.at[0], G.pbt);
-        G.pat = fma(A.av[1], A.at[1], G.pat);
-        G.pbt = fma(A.bv[1], A.at[1], G.pbt);
+        if (S_LIVE) {
+            G.acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[0], A.as[0], G.acc[0], 0, 0, 0);
+            G.acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[1], A.as[1], G.acc[0], 0, 0, 0);
+        }
+        if (T_LIVE) {
+            G.acc[NB - R] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[0], A.at[0], G.acc[NB - R], 0, 0, 0);
+            G.acc[NB - R] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[1], A.at[1], G.acc[NB - R], 0, 0, 0);
+        }
+        if (S_LIVE) {
+            G.pas = fma(A.av[0], A.as[0], G.pas);
+            G.pbs = fma(A.bv[0], A.as[0], G.pbs);
+            G.pas = fma(A.av[1], A.as[1], G.pas);
+            G.pbs = fma(A.bv[1], A.as[1], G.pbs);
+        }
+        if (T_LIVE) {
+            G.pat = fma(A.av[0], A.at[0], G.pat);
+            G.pbt = fma(A.bv[0], A.at[0], G.pbt);
+            G.pat = fma(A.av[1], A.at[1], G.pat);
+            G.pbt = fma(A.bv[1], A.at[1], G.pbt);
+        }
 #pragma unroll
         for (int sl = 1; sl < NB - R; ++sl) {
-            G.acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[0], b[sl - 1][0], G.acc[sl], 0, 0, 0);
-            G.acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[1], b[sl - 1][1], G.acc[sl], 0, 0, 0);
+            if (S_LIVE && R + sl < NBL) {
+                G.acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[0], b[sl - 1][0], G.acc[sl], 0, 0, 0);
+                G.acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.as[1], b[sl - 1][1], G.acc[sl], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int j = 1; j <= R; ++j) {
-            G.acc[NB - R + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[0], b[NB - R - 1 + j - 1][0], G.acc[NB - R + j], 0, 0, 0);
-            G.acc[NB - R + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[1], b[NB - R - 1 + j - 1][1], G.acc[NB - R + j], 0, 0, 0);
+            if (T_LIVE && TR + j < NBL) {
+                G.acc[NB - R + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[0], b[NB - R - 1 + j - 1][0], G.acc[NB - R + j], 0, 0, 0);
+                G.acc[NB - R + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.at[1], b[NB - R - 1 + j - 1][1], G.acc[NB - R + j], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -343,9 +359,9 @@ __device__ __forceinline__ void vs_gramn_store_row(double* __restrict__ gout, in
         default: CALL((NB > 4 ? 7 : 0)); break; \
     }
 
-template <int NB>
+template <int NB, int NBL>
 __device__ __forceinline__ void vs_gramn_consume(const double* __restrict__ tile, int q, int lane, vs_gramn_regs<NB>& G) {
-#define VS_GRAMN_CONSUME(RR) vs_gramn_consume_row<RR, NB>(tile, lane, G)
+#define VS_GRAMN_CONSUME(RR) vs_gramn_consume_row<RR, NB, NBL>(tile, lane, G)
     VS_GRAMN_DISPATCH(VS_GRAMN_CONSUME)
 #undef VS_GRAMN_CONSUME
 }
@@ -779,15 +795,16 @@ __device__ __forceinline__ void vs_scan_gram_body(const vs_eval_args& A, double*
 
 // Beyond 32 columns: NB waves x 16 columns (see vs_gramn_consume_row).
 // Partials: first_partials[blockIdx.x][5 + 4k], gram_partials[blockIdx.x][2][16 NB][16 NB].
-template <class Term, int FOLD, int GENV, int NB>
+template <class Term, int FOLD, int GENV, int NB, int NBL>
 __device__ __forceinline__ void vs_scan_gramn_body(const vs_eval_args& A, double* __restrict__ lds,
                                                    const double* __restrict__ shift_src,
                                                    double* __restrict__ first_partials,
                                                    double* __restrict__ gram_partials) {
     constexpr int T = VS_EVAL_ROWS, W = NB, L = 16, NBH = NB;
     static_assert(NB == 4 || NB == 8, "64 or 128 index rows per half");
+    static_assert(NBL > NB / 2 && NBL <= NB, "live blocks");
     const int k = A.D.k;
-    const int nbl = (k + 15) >> 4;
+    const int nbl = NBL;   // = ceil(k / 16), the host's choice of instance
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* tile = lds + 2 * W * T;
@@ -805,7 +822,7 @@ __device__ __forceinline__ void vs_scan_gramn_body(const vs_eval_args& A, double
         vs_scan_block<Term, FOLD, L, W, true, false, false, GENV, NBH>(A, A.params, q, lane, rb, lds, nullptr, nullptr,
                                                                        shift, acc, tile + lane);
         __syncthreads();
-        vs_gramn_consume<NB>(tile, q, lane, G);
+        vs_gramn_consume<NB, NBL>(tile, q, lane, G);
     }
     const double head[5] = {acc.sab, acc.sa, acc.sb, acc.s1, acc.s2};
     vs_gramn_epilogue<NB>(tile, q, lane, nbl, G, head, k, gram_partials + (size_t)blockIdx.x * 2 * (16 * NB) * (16 * NB),

@@ -857,14 +857,12 @@ int vs_scan_gram4_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io,
                          double* first_partials, double* gram_partials, bool plan_only);
 
 // the fused both-orders kernels, one output: separable objectives in scan form with k <= 32 -- built-in or compiled
-// at run time --, the built-in ones also with 49 .. 64 and 113 .. 128 columns (vs_scan_gram4.hip, vs_scan_gram8.hip), Ishigami
+// at run time --, the built-in ones also with 33 .. 128 columns (vs_scan_gram4.hip, vs_scan_gram8*.hip), Ishigami
 static fused_route fused_both_route(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
     if (obj->l != 1 || obj->k != design->d.k) return FUSED_NONE;
     const fused_route r = fused_route_for(ctx, design, obj);
     if (r == FUSED_ISHIGAMI) return r;
-    // all 16-row blocks of the tile live: below that the waves' tile counts differ and the two-kernel route is faster
-    // (n = 2^22: k = 48 1.42 vs 1.28 ms, k = 96 3.5 vs 3.35; k = 56 1.49 vs 1.69, k = 64 1.57 vs 1.84, k = 120 4.16 vs 4.76)
-    const bool wide_k = (obj->k > 48 && obj->k <= 64) || (obj->k > 112 && obj->k <= 128);
+    const bool wide_k = obj->k > 32 && obj->k <= 128;   // four or eight waves x 16 columns, compiled per count of live blocks
     if (r == FUSED_SCAN && (obj->k <= 32 || (wide_k && ctx->tune.fused_both_wide != 0))) return r;
     if (r == FUSED_USER && obj->gram_function && obj->k <= 32) return r;
     return FUSED_NONE;
@@ -893,7 +891,7 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
                                    "source objectives with one output and k <= 32 (Halton indices below 2^32, scan evaluation "
                                    "order); use vs_eval + vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
     const int k = obj->k;
-    const bool wide = route == FUSED_SCAN && k > 32;   // 49 .. 64 / 113 .. 128 columns: four / eight waves x 16 columns
+    const bool wide = route == FUSED_SCAN && k > 32;   // 33 .. 64 / 65 .. 128 columns: four / eight waves x 16 columns
     const int nbh = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8, SB = 16 * nbh;
     vs_eval_args A;
     A.D = to_dev(design);

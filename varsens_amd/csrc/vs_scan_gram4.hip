@@ -1,4 +1,4 @@
-// Fused evaluate + first- and second-order reduce for the built-in separable objectives with 49 .. 64 columns, one
+// Fused evaluate + first- and second-order reduce for the built-in separable objectives with 33 .. 64 columns, one
 // output: four waves x 16 columns write s = c + d, t = c - d of every 64-row block into a
 // 69 KiB LDS tile and multiply it on the fp64 matrix cores, five accumulator tiles per wave (vs_device_scan.h:
 // vs_scan_gramn_body) -- compute_varsens (varsens/saltelli.py:572-622) without f-values in HBM.

@@ -27,8 +27,8 @@ int vs_scan_launch_lin(vs_context* ctx, const vs_eval_args& A, scan_shape s, uns
 int vs_scan_gram_launch(vs_context* ctx, const vs_eval_args& A, int nbh, unsigned* P_io, const double* shift_dev,
                         double* first_partials, double* gram_partials, bool plan_only);
 
-// the same beyond 32 columns: nb = 8 (113 .. 128 columns: eight waves, one workgroup per CU; vs_scan_gram8.hip) or
-// nb = 4 (49 .. 64 columns: four waves, two workgroups per CU; vs_scan_gram4.hip)
+// the same beyond 32 columns: nb = 8 (65 .. 128 columns: eight waves, one workgroup per CU; vs_scan_gram8*.hip, one
+// translation unit per objective kind) or nb = 4 (33 .. 64 columns: four waves, two workgroups per CU; vs_scan_gram4.hip)
 int vs_scan_gram8_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                          double* first_partials, double* gram_partials, bool plan_only);
 int vs_scan_gram4_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
@@ -207,12 +207,12 @@ static int launch_scan_gram_kind(vs_context* ctx, const vs_eval_args& A, int nbh
 }
 
 // ---- beyond 32 columns: NB waves x 16 columns, tile of 16 NB index rows per half, 256 VGPRs (vs_scan_gramn_body)
-template <int KIND, int GENV, int NB>
+template <int KIND, int GENV, int NB, int NBL>
 __global__ void __launch_bounds__(VS_EVAL_ROWS * NB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 scan_gramn_kernel(vs_eval_args A, const double* shift_src, double* first_partials, double* gram_partials,
                   uint32_t* counters) {
     extern __shared__ double scan_lds[];   // [2][NB][64] totals, then the tile [32 NB + 2][68]
-    vs_scan_gramn_body<builtin_term<KIND>, KIND, GENV, NB>(A, scan_lds, shift_src, first_partials, gram_partials);
+    vs_scan_gramn_body<builtin_term<KIND>, KIND, GENV, NB, NBL>(A, scan_lds, shift_src, first_partials, gram_partials);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         counters[0] = 0;
         counters[1] = 0xffffffffu;
@@ -222,12 +222,12 @@ scan_gramn_kernel(vs_eval_args A, const double* shift_src, double* first_partial
     }
 }
 
-template <int KIND, int GENV, int NB>
+template <int KIND, int GENV, int NB, int NBL>
 static int launch_scan_gramn_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                                double* first_partials, double* gram_partials, bool plan_only) {
     // NB = 8: 148 544 B, one workgroup per CU; NB = 4: 74 816 B, two
     const size_t lds = sizeof(double) * (2 * NB * VS_EVAL_ROWS + VS_GT_DOUBLES(NB));
-    const void* fn = (const void*)scan_gramn_kernel<KIND, GENV, NB>;
+    const void* fn = (const void*)scan_gramn_kernel<KIND, GENV, NB, NBL>;
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     if (plan_only) {
         const uint64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
@@ -238,24 +238,44 @@ static int launch_scan_gramn_g(vs_context* ctx, const vs_eval_args& A, unsigned*
     VS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         vs_launch_scope scope(ctx, VS_KERNEL_FUSED);
-        hipLaunchKernelGGL((scan_gramn_kernel<KIND, GENV, NB>), dim3(*P_io), dim3(VS_EVAL_ROWS * NB), lds, ctx->stream, A,
+        hipLaunchKernelGGL((scan_gramn_kernel<KIND, GENV, NB, NBL>), dim3(*P_io), dim3(VS_EVAL_ROWS * NB), lds, ctx->stream, A,
                            shift_dev, first_partials, gram_partials, ctx->counters);
     }
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
 
-template <int KIND, int NB>
-static int launch_scan_gramn_kind(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
-                                  double* first_partials, double* gram_partials, bool plan_only) {
+template <int KIND, int NB, int NBL>
+static int launch_scan_gramn_nbl(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
+                                 double* first_partials, double* gram_partials, bool plan_only) {
     const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0;
 #define VS_GRAMN_GENV(G) \
-    return launch_scan_gramn_g<KIND, G, NB>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
+    return launch_scan_gramn_g<KIND, G, NB, NBL>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY) VS_GRAMN_GENV(1);
     if (halton && A.D.scale_mode == VS_SCALE_LINEAR) VS_GRAMN_GENV(2);
     if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAMN_GENV(3);
     VS_GRAMN_GENV(0);
 #undef VS_GRAMN_GENV
+}
+
+// the instance for ceil(k / 16) live blocks (NB / 2 < live <= NB)
+template <int KIND, int NB>
+static int launch_scan_gramn_kind(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
+                                  double* first_partials, double* gram_partials, bool plan_only) {
+    const int nbl = (A.D.k + 15) / 16;
+#define VS_GRAMN_NBL(N)                                                                                              \
+    if (nbl == N) return launch_scan_gramn_nbl<KIND, NB, N>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
+    if constexpr (NB == 8) {
+        VS_GRAMN_NBL(5);
+        VS_GRAMN_NBL(6);
+        VS_GRAMN_NBL(7);
+        VS_GRAMN_NBL(8);
+    } else {
+        VS_GRAMN_NBL(3);
+        VS_GRAMN_NBL(4);
+    }
+#undef VS_GRAMN_NBL
+    return vs_fail(VS_ERR_ARG, "k=%d does not belong to the %d-block fused both-orders kernels", A.D.k, NB);
 }
 
 #endif  // VS_SCAN_KIND
