@@ -836,6 +836,26 @@ def test_fused_both_orders_ishigami(ctx, n):
     np.testing.assert_allclose(G2[1], T @ T.T, rtol=1e-12, atol=1e-12 * np.abs(G1).max())
 
 
+@pytest.mark.parametrize("k,n", [(6, 100003), (32, 1 << 16), (64, 50000), (128, 20000), (3, 70001)])
+def test_fused_both_orders_is_bit_reproducible(ctx, k, n):
+    """Fixed block-to-workgroup map, fixed fold order (two-stage folds included): the same call twice gives the same bits."""
+    from varsens_amd import _native
+    if k == 3:
+        d = make_design(ctx, 3, n, 1, np.full(3, -np.pi), np.full(3, np.pi))
+        obj = ctx.objective_create(_native.OBJ_ISHIGAMI, 3, 1, np.array([7.0, 0.1]))
+    else:
+        d = make_design(ctx, k, n)
+        obj = ctx.objective_create(_native.OBJ_G_FUNCTION, k, 1, np.linspace(0.0, 9.0, k))
+    nacc, ng = _native.acc_len(k, 1, 1), _native.gram_len(k)
+    out = []
+    for _ in range(3):
+        acc, g = ctx.alloc(8 * nacc), ctx.alloc(8 * ng)
+        ctx.eval_reduce_first_second_order(d, obj, 0, n, acc, g)
+        out.append((ctx.download(acc, (nacc,)), ctx.download(g, (2, k, k))))
+    for a, g in out[1:]:
+        assert np.array_equal(a, out[0][0]) and np.array_equal(g, out[0][1])
+
+
 def test_fused_both_orders_coverage(ctx):
     from varsens_amd import _native
     d = make_design(ctx, 129, 100)
