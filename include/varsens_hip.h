@@ -294,7 +294,7 @@ int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* design, const v
  * products off the same fragments: this rank's record (acc_dev, as vs_reduce_first_order) and Gram sums (gram_dev,
  * VS_GRAM_LEN(k) doubles, as vs_reduce_second_order) without any f-value in HBM.  Covers G_FUNCTION / POLYNOMIAL /
  * LINEAR objectives with ONE output and k <= 128 (every generator and scaling of the design), separable source
- * objectives with k <= 32 (identity or linear scaling) and ISHIGAMI; Halton indices below 2^32; not a context in strict
+ * objectives with k <= 128 (identity or linear scaling) and ISHIGAMI; Halton indices below 2^32; not a context in strict
  * evaluation order; VS_ERR_ARG otherwise -- vs_eval_reduce_both_supported tells in
  * advance, callers then use vs_eval + vs_reduce_first_second_order.  NaN values propagate.  Results equal the
  * two-kernel path's up to summation order (<= ~2e-13 relative on the sums).

@@ -108,9 +108,10 @@ def test_separable_expression_equals_builtins_bit_for_bit(vs, k, n):
     assert v.sens.shape == (k, 1)
 
 
-@pytest.mark.parametrize("k,n,fold", [(6, 51200, "prod"), (32, 20001, "sum"), (17, 64, "prod"), (16, 3000, "sum")])
+@pytest.mark.parametrize("k,n,fold", [(6, 51200, "prod"), (32, 20001, "sum"), (17, 64, "prod"), (16, 3000, "sum"),
+                                      (40, 3000, "sum"), (64, 2000, "prod"), (100, 1500, "sum"), (128, 700, "prod")])
 def test_separable_expression_default_call_is_one_kernel(vs, k, n, fold):
-    """A user term function with k <= 32 through Varsens(...) with its second-order indices: the run-time compiled
+    """A user term function with k <= 128 through Varsens(...) with its second-order indices: the run-time compiled
     fused evaluate + both-orders kernel (vs_user_gram), nothing written to HBM; results equal the built-in
     objective's fused kernel (same term, same kernel body) and the two-kernel route."""
     rng = np.random.RandomState(k + n)

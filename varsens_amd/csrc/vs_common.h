@@ -91,8 +91,10 @@ struct vs_objective {
     void* module = nullptr;    // hipModule_t of a run-time compiled objective
     void* function = nullptr;  // hipFunction_t (vs_user_eval)
     void* fused_function = nullptr;  // hipFunction_t (vs_user_fused): separable source objectives with k <= 128
-    void* gram_function = nullptr;   // hipFunction_t (vs_user_gram): ... with k <= 32, evaluate + both orders
+    void* gram_function = nullptr;   // hipFunction_t (vs_user_gram): ... evaluate + both orders
     size_t gram_lds = 0;
+    int gram_threads = 256;          //   its launch shape and the side of its Gram partials [2][gram_sb][gram_sb]
+    int gram_sb = 32;
     bool eval_scan = false;    // vs_user_eval is the scan kernel (separable source objective): one 64-row block per workgroup
     int eval_threads = 256;    // launch shape of vs_user_eval / vs_user_fused
     size_t eval_lds = 0;       //   (eval_lds = 0: the 2k x 64 tile of the chain / general kernels)

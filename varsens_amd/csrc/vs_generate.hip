@@ -864,7 +864,7 @@ static fused_route fused_both_route(const vs_context* ctx, const vs_design* desi
     if (r == FUSED_ISHIGAMI) return r;
     const bool wide_k = obj->k > 32 && obj->k <= 128;   // four or eight waves x 16 columns, compiled per count of live blocks
     if (r == FUSED_SCAN && (obj->k <= 32 || (wide_k && ctx->tune.fused_both_wide != 0))) return r;
-    if (r == FUSED_USER && obj->gram_function && obj->k <= 32) return r;
+    if (r == FUSED_USER && obj->gram_function) return r;
     return FUSED_NONE;
 }
 
@@ -892,7 +892,7 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
                                    "order); use vs_eval + vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
     const int k = obj->k;
     const bool wide = route == FUSED_SCAN && k > 32;   // 33 .. 64 / 65 .. 128 columns: four / eight waves x 16 columns
-    const int nbh = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8, SB = 16 * nbh;
+    const int nbh = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8, SB = 16 * nbh;   // (= obj->gram_sb of a source objective)
     vs_eval_args A;
     A.D = to_dev(design);
     A.kind = obj->kind;

@@ -9,7 +9,7 @@
 
 // By default (VS_USER_EVAL_SCAN) the evaluation takes the segmented-scan form of vs_device_scan.h
 // instead (O(k) folds per row), and for k <= 128 a fused evaluate+reduce kernel vs_user_fused is built
-// beside it (VS_USER_FUSED), for k <= 32 also the fused evaluate + both-orders kernel vs_user_gram (VS_USER_GRAM);
+// beside it (VS_USER_FUSED) and the fused evaluate + both-orders kernel vs_user_gram (VS_USER_GRAM);
 // shapes VS_USER_*_L / _W / _TLDS / _NBH come from the host.  The chain-scheme kernel
 // below serves contexts in strict evaluation order.
 struct vs_user_term_t {
@@ -36,12 +36,21 @@ vs_user_fused(vs_eval_args A, const double* shift_src, double* partials, unsigne
 }
 #endif
 
-#if VS_USER_GRAM   // k <= 32: evaluate + both orders in one kernel (vs_scan_gram_body, vs_device_scan.h)
+#if VS_USER_GRAM   // k <= 128: evaluate + both orders in one kernel (vs_scan_gram_body / vs_scan_gramn_body, vs_device_scan.h)
+#if VS_USER_GRAM_NBH <= 2
 extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS * 4)
+#else
+extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS * VS_USER_GRAM_NBH) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 vs_user_gram(vs_eval_args A, const double* shift_src, double* first_partials, double* gram_partials, unsigned* counters) {
     extern __shared__ double lds[];
+#if VS_USER_GRAM_NBH <= 2
     vs_scan_gram_body<vs_user_term_t, VS_USER_FOLD_KIND, VS_USER_GRAM_L, VS_USER_GRAM_NBH, 0>(A, lds, shift_src,
                                                                                              first_partials, gram_partials);
+#else   // 33 .. 128 columns: NBH waves x 16 columns, body compiled for VS_USER_GRAM_NBL live 16-row blocks
+    vs_scan_gramn_body<vs_user_term_t, VS_USER_FOLD_KIND, 0, VS_USER_GRAM_NBH, VS_USER_GRAM_NBL>(A, lds, shift_src,
+                                                                                                first_partials, gram_partials);
+#endif
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the folds that follow (see scan_kernel)
         counters[0] = 0;
         counters[1] = 0xffffffffu;
