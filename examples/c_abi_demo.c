@@ -58,6 +58,17 @@ int main(void) {
     CHECK(vs_download(ctx, out, first, sizeof(out)));
     printf("E_2 %.15g\nvar_y %.15g\n", out[0], out[1]);
     for (j = 0; j < K; ++j) printf("sens[%d] %.15g   sens_t[%d] %.15g\n", j, out[2 + 2 * K + j], j, out[2 + 3 * K + j]);
+    /* the same run in ONE kernel, no objective values in device memory (vs_eval_reduce_first_second_order) */
+    {
+        int ok = 0;
+        CHECK(vs_eval_reduce_both_supported(ctx, design, objective, &ok));
+        if (ok) {
+            CHECK(vs_eval_reduce_first_second_order(ctx, design, objective, 0, n, 0, 1, (double*)acc, (double*)gram));
+            CHECK(vs_finish_first_order(ctx, (const double*)acc, n, K, L, 1, (double*)first));
+            CHECK(vs_download(ctx, out, first, sizeof(out)));
+            for (j = 0; j < K; ++j) printf("fused_sens[%d] %.15g   fused_sens_t[%d] %.15g\n", j, out[2 + 2 * K + j], j, out[2 + 3 * K + j]);
+        }
+    }
     CHECK(vs_free(ctx, first));
     CHECK(vs_free(ctx, gram));
     CHECK(vs_free(ctx, acc));

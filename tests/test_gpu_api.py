@@ -751,6 +751,9 @@ def test_c_program_over_the_abi_reproduces_the_reference(vs, golden, tmp_path):
     for j in range(6):
         assert abs(vals["sens[%d]" % j] - g["sens"][j, 0]) <= 1e-10 * abs(g["sens"][j, 0]) + 1e-13
         assert abs(vals["sens_t[%d]" % j] - g["sens_t"][j, 0]) <= 1e-10 * abs(g["sens_t"][j, 0]) + 1e-13
+        # ... and the same from the one-kernel entry point (vs_eval_reduce_first_second_order)
+        assert abs(vals["fused_sens[%d]" % j] - g["sens"][j, 0]) <= 1e-10 * abs(g["sens"][j, 0]) + 1e-13
+        assert abs(vals["fused_sens_t[%d]" % j] - g["sens_t"][j, 0]) <= 1e-10 * abs(g["sens_t"][j, 0]) + 1e-13
 
 
 def test_sobol_large_design_uses_every_byte_table(vs):
