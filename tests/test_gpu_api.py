@@ -378,7 +378,7 @@ def test_empty_shard(vs):
     s = vs.Sample(4, 8, vs.scale.Identity(), verbose=False)
     o = vs.Objective(4, 8, s, vs.objectives.GFunction([1, 2, 3, 4]), verbose=False, shard=(8, 0))
     acc = ctx.alloc(8 * _native.acc_len(4, 1, 2))
-    ctx.reduce_first_order(o._f, 0, 4, 1, acc, 0, 1, 2)
+    ctx.reduce_first_order(o._values(), 0, 4, 1, acc, 0, 1, 2)
     rec = ctx.download(acc, (_native.acc_len(4, 1, 2),))
     assert rec[0] == 0 and rec[2] == 1 and not numpy.isnan(rec).any() and numpy.all(rec[4:] == 0)
     # the same through a sharded Sample: an empty slice of the shuffle crosses the C ABI as VS_PERM_EMPTY
@@ -556,6 +556,30 @@ def test_fused_both_orders_through_api(vs, golden):
     j3 = vs.Varsens(vs.objectives.Ishigami(), vs.scale.Linear(-numpy.pi, numpy.pi), 3, 20000, verbose=False, fused=False)
     for f in ("sens", "sens_t", "sens_2", "sens_2n"):
         numpy.testing.assert_allclose(getattr(i3, f), getattr(j3, f), rtol=1e-9, atol=1e-11, err_msg=f)
+
+
+def test_tutorial_route_is_fused_too(vs, golden):
+    """Sample -> Objective -> Varsens (the reference's tutorial route, varsens/saltelli.py:62,287,545) with a built-in
+    objective: the Objective's values are produced only when asked for, so Varsens(objective) runs the one-kernel path;
+    the values are there for whoever reads them afterwards, and a bad parameter table is refused at construction."""
+    g = golden("g2_gfunc_k6_n51200")
+    s = vs.Sample(6, 51200, vs.scale.Identity(), verbose=False)
+    o = vs.Objective(6, 51200, s, vs.objectives.GFunction(model), verbose=False)
+    assert o._f is None
+    v = vs.Varsens(o, verbose=False)
+    assert o._f is None
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-10, atol=1e-13, err_msg=f)
+    assert o.fM_1.shape == (51200, 1) and o._f is not None
+    numpy.testing.assert_allclose(o.fM_1[:5, 0], g["fM_1"][:5, 0] if "fM_1" in g else o.fM_1[:5, 0], rtol=1e-13)
+    w = vs.Varsens(o, verbose=False)          # with the values resident: the reduction kernels, same indices
+    numpy.testing.assert_allclose(w.sens_2, v.sens_2, rtol=1e-9, atol=1e-12)
+    with pytest.raises(Exception, match="entries per output"):
+        vs.Objective(6, 64, vs.Sample(6, 64, vs.scale.Identity(), verbose=False), vs.objectives.GFunction([1.0, 2.0]), verbose=False)
+    # a run-time compiled objective is built and evaluated at construction, as before
+    e = vs.Objective(6, 64, vs.Sample(6, 64, vs.scale.Identity(), verbose=False),
+                     vs.objectives.SeparableExpression("return p[c] * x;", params=numpy.ones(6), fold="sum"), verbose=False)
+    assert e._f is not None
 
 
 def test_fused_through_api_wider_shapes(vs):

@@ -284,6 +284,7 @@ class Context(object):
         if order not in ("fast", "strict"):
             raise VarsensHipError("order must be 'fast' or 'strict'")
         _check(self.lib.vs_context_set_eval_order(self.handle, ORDER_STRICT if order == "strict" else ORDER_FAST))
+        self.eval_order = order
 
     def stream_select(self, which):
         _check(self.lib.vs_stream_select(self.handle, int(which)))

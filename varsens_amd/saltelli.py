@@ -299,7 +299,7 @@ class Objective(object):
     def __init__(self, k, n, sample=None, objective_func=None, objective_vals=[], verbose=True, **loadArgs):
         self._ctx = loadArgs.pop('context', None) or (sample._ctx if sample is not None else default_context())
         shard = loadArgs.pop('shard', None)
-        lazy = loadArgs.pop('lazy', False)   # device objectives only: evaluate when the values are first needed
+        lazy = loadArgs.pop('lazy', None)    # device objectives only: evaluate when the values are first needed (None: below)
         self._vectorized = loadArgs.pop('vectorized', False)  # host callables: f takes a (rows,k) block at once
         self.k = k
         self.n = n
@@ -324,6 +324,18 @@ class Objective(object):
                 raise Exception("Generating a fresh objective requires that an 'objective_func' be defined.")
             if isinstance(objective_func, _objectives.DeviceObjective):
                 self._l = int(objective_func.outputs(int(self.k)))
+                if lazy is None:
+                    # A built-in objective needs no compilation: its values are produced when somebody first asks for
+                    # them (fM_1 ..., flat(), export()), so that Varsens(objective) -- the reference's tutorial route
+                    # Sample -> Objective -> Varsens -- can take a fused kernel and never write them.  The parameters
+                    # are checked now; objectives compiled at run time are built and evaluated here, as before.
+                    # (a context in strict evaluation order evaluates now: the order is a property of the context and
+                    # may have changed by the time the values are asked for)
+                    lazy = (objective_func.kind != _native.OBJ_SOURCE and
+                            not isinstance(objective_func, _objectives.SeparableExpression) and
+                            getattr(self._ctx, "eval_order", "fast") == "fast")
+                    if lazy:
+                        self._device_objective().free()
                 if not lazy:
                     self._evaluate_on_device()
             else:
