@@ -311,6 +311,7 @@ class Objective(object):
         self._l = None
         self._nan_trim = False  # only values that come through load() are trimmed (saltelli.py:474-495)
         self._host_cache = None
+        self._params = None
 
         if self.verbose: print("Generating Objective Values.")
         if len(objective_vals) > 0:
@@ -349,7 +350,9 @@ class Objective(object):
             return self._ctx.objective_create_separable(k, spec.term_body, spec.fold_sum, spec.params(k))
         if spec.kind == _native.OBJ_SOURCE:
             return self._ctx.objective_create_source(k, self._l, spec.body, spec.params(k))
-        return self._ctx.objective_create(spec.kind, k, self._l, spec.params(k))
+        if self._params is None:     # the parameter table as it was when the Objective was made (values may come later)
+            self._params = numpy.array(spec.params(k), dtype=numpy.float64, copy=True)
+        return self._ctx.objective_create(spec.kind, k, self._l, self._params)
 
     def _values(self):
         """The device buffer of f-values, evaluating now if that was deferred."""
