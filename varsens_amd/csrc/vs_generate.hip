@@ -856,7 +856,7 @@ int vs_scan_gram8_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io,
 int vs_scan_gram4_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                          double* first_partials, double* gram_partials, bool plan_only);
 
-// the fused both-orders kernels, one output: separable objectives in scan form with k <= 32 -- built-in or compiled
+// the fused both-orders kernels, one output: separable objectives in scan form with k <= 128 -- built-in or compiled
 // at run time --, the built-in ones also with 33 .. 128 columns (vs_scan_gram4.hip, vs_scan_gram8*.hip), Ishigami
 static fused_route fused_both_route(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
     if (obj->l != 1 || obj->k != design->d.k) return FUSED_NONE;
@@ -888,7 +888,7 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     const fused_route route = fused_both_route(ctx, design, obj);
     if (route == FUSED_NONE)
         return vs_fail(VS_ERR_ARG, "the fused both-orders path covers ISHIGAMI and G_FUNCTION / POLYNOMIAL / LINEAR / separable "
-                                   "source objectives with one output and k <= 32 (Halton indices below 2^32, scan evaluation "
+                                   "source objectives with one output and k <= 128 (Halton indices below 2^32, scan evaluation "
                                    "order); use vs_eval + vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
     const int k = obj->k;
     const bool wide = route == FUSED_SCAN && k > 32;   // 33 .. 64 / 65 .. 128 columns: four / eight waves x 16 columns

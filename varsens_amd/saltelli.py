@@ -566,7 +566,7 @@ class Varsens(object):
             if self._fused_candidate(objective) or self._stream_rows:
                 kw['lazy'] = True   # the values are only produced if somebody asks for them
             elif self._fused is True:
-                raise Exception("fused=True needs a device objective (with second_order: one output and k <= 32)")
+                raise Exception("fused=True needs a device objective (with second_order: one output and k <= 128)")
             self.objective = Objective(self.k, self.n, self.sample, objective, verbose=verbose, **kw)
         self._ctx = self.objective._ctx
         self.compute_varsens()
