@@ -856,8 +856,8 @@ int vs_scan_gram8_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io,
 int vs_scan_gram4_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                          double* first_partials, double* gram_partials, bool plan_only);
 
-// the fused both-orders kernels, one output: separable objectives in scan form with k <= 128 -- built-in or compiled
-// at run time --, the built-in ones also with 33 .. 128 columns (vs_scan_gram4.hip, vs_scan_gram8*.hip), Ishigami
+// the fused both-orders kernels, one output: separable objectives in scan form with k <= 128 -- built-in
+// (vs_scan_gram.hip, vs_scan_gram4.hip, vs_scan_gram8*.hip) or compiled at run time --, and Ishigami
 static fused_route fused_both_route(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
     if (obj->l != 1 || obj->k != design->d.k) return FUSED_NONE;
     const fused_route r = fused_route_for(ctx, design, obj);
