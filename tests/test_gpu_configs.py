@@ -162,6 +162,25 @@ def test_config2_against_the_reference_run(ctx, golden, capsys):
     rec2, fin2 = first_order(ctx, f2, n, n, k)
     np.testing.assert_allclose(fin2[:2 + 2 * k], fin[:2 + 2 * k], rtol=1e-13)
     np.testing.assert_allclose(fin2[2 + 2 * k:, 0], fin[2 + 2 * k:, 0], rtol=1e-10)
+    # ... and the whole of configs[1] in ONE kernel (vs_eval_reduce_first_second_order, no f-values in HBM): raw sums and
+    # indices held to the same exactly summed evaluation and to the reference's own outputs
+    d = ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 0, None, None, orc.seed1_permutation(n).astype(np.uint32))
+    o = ctx.objective_create(_native.OBJ_G_FUNCTION, k, 1, np.asarray(a, dtype=float))
+    assert ctx.eval_reduce_both_supported(d, o)
+    nacc = _native.acc_len(k, 1, 1)
+    acc3, gram3, first3 = ctx.alloc(8 * nacc), ctx.alloc(8 * 2 * k * k), ctx.alloc(8 * _native.first_order_len(k, 1))
+    ctx.eval_reduce_first_second_order(d, o, 0, n, acc3, gram3)
+    ctx.finish_first_order(acc3, n, k, 1, first3)
+    rec3, fin3 = ctx.download(acc3, (nacc,)), ctx.download(first3, (2 + 4 * k, 1))
+    body3 = rec3[4:4 + per]
+    for q, name in enumerate(("ac", "bd", "ad", "bc")):
+        np.testing.assert_allclose(body3[3 + q * k:3 + (q + 1) * k], ex[name][:, 0], rtol=1e-12, err_msg="fused " + name)
+    np.testing.assert_allclose(fin3[2 + 2 * k:2 + 3 * k, 0], want["sens"][:, 0], rtol=1e-10, err_msg="fused sens")
+    np.testing.assert_allclose(fin3[2 + 3 * k:2 + 4 * k, 0], want["sens_t"][:, 0], rtol=1e-10, err_msg="fused sens_t")
+    np.testing.assert_allclose(fin3[2 + 2 * k:2 + 3 * k, 0], g["sens"][:, 0], rtol=2e-9)
+    ctx.finish_second_order(gram3, first3, n, k, 1, s2, s2n)
+    np.testing.assert_allclose(ctx.download(s2, (k, 1, k, 1)), g["sens_2"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ctx.download(s2n, (k, 1, k, 1)), g["sens_2n"], rtol=1e-9, atol=1e-12)
 
 
 def test_config3_ishigami_k3_n2pow22(ctx):
@@ -189,6 +208,16 @@ def test_config3_ishigami_k3_n2pow22(ctx):
     V1, V3, V13 = 0.5 * (1 + 0.1 * np.pi ** 4 / 5) ** 2, 0.0, 8 * 0.01 * np.pi ** 8 / 225
     np.testing.assert_allclose(sens_2[0, 2], (V1 + V3 + V13) / V, atol=5e-3)
     np.testing.assert_allclose(sens_2[0, 2], sens_2[2, 0], rtol=1e-12)
+    # configs[2] in one kernel (the default call's route): same record and Gram sums up to summation order
+    d = ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 1, lo, hi, orc.seed1_permutation(n).astype(np.uint32))
+    o = ctx.objective_create(_native.OBJ_ISHIGAMI, k, 1, np.array([7.0, 0.1]))
+    nacc = _native.acc_len(k, 1, 1)
+    acc3, gram3 = ctx.alloc(8 * nacc), ctx.alloc(8 * 2 * k * k)
+    ctx.eval_reduce_first_second_order(d, o, 0, n, acc3, gram3)
+    per = _native.acc_per_output(k)
+    np.testing.assert_allclose(ctx.download(acc3, (nacc,))[4:4 + per], rec[4:4 + per], rtol=1e-11)
+    G1 = ctx.download(gram, (2, k, k))
+    np.testing.assert_allclose(ctx.download(gram3, (2, k, k)), G1, rtol=1e-11, atol=1e-12 * np.abs(G1).max())
 
 
 def test_config4_linear_k32_n2pow22_properties(ctx):
@@ -311,6 +340,28 @@ def test_config5_whole_polynomial_k128_n2pow24(ctx):
     np.testing.assert_allclose(fin8[:2 + 2 * k], fin[:2 + 2 * k], rtol=1e-13)
     np.testing.assert_allclose(fin8[2 + 2 * k:], fin[2 + 2 * k:], rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(total_gram, G, rtol=1e-12, atol=1e-12 * np.abs(G).max())
+    # configs[4] without its 34.6 GB of f-values: the one-kernel call (eight waves x 16 columns, 137 KiB tile), whole and
+    # as the 8-rank split -- records and Gram sums equal the two-kernel path's up to summation order
+    d = ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 0, None, None, orc.seed1_permutation(n).astype(np.uint32))
+    o = ctx.objective_create(_native.OBJ_POLYNOMIAL, k, 1, beta)
+    assert ctx.eval_reduce_both_supported(d, o)
+    per = _native.acc_per_output(k)
+    acc1, g1 = ctx.alloc(8 * _native.acc_len(k, 1, 1)), ctx.alloc(8 * 2 * k * k)
+    ctx.eval_reduce_first_second_order(d, o, 0, n, acc1, g1)
+    np.testing.assert_allclose(ctx.download(acc1, (_native.acc_len(k, 1, 1),))[4:4 + per], rec[4:4 + per], rtol=1e-11)
+    np.testing.assert_allclose(ctx.download(g1, (2, k, k)), G, rtol=1e-11, atol=1e-12 * np.abs(G).max())
+    fused_rec, fused_gram = np.zeros(nacc), np.zeros((2, k, k))
+    for rank in range(world):
+        b, cnt = shard_rows(n, world, rank)
+        acc, gs = ctx.alloc(8 * nacc), ctx.alloc(8 * 2 * k * k)
+        ctx.eval_reduce_first_second_order(d, o, b, cnt, acc, gs, rank, world)
+        fused_rec += ctx.download(acc, (nacc,))
+        fused_gram += ctx.download(gs, (2, k, k))
+    ctx.finish_first_order(ctx.upload(fused_rec), n, k, 1, out, world)
+    finf = ctx.download(out, (2 + 4 * k, 1))
+    np.testing.assert_allclose(finf[:2 + 2 * k], fin[:2 + 2 * k], rtol=1e-11)
+    np.testing.assert_allclose(finf[2 + 2 * k:], fin[2 + 2 * k:], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(fused_gram, G, rtol=1e-11, atol=1e-12 * np.abs(G).max())
 
 
 def test_model_study_shape_k100_l10():
