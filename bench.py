@@ -123,18 +123,26 @@ def spawn_ranks(world, argv=None, script=None):
     import socket
     import subprocess
     argv = list(sys.argv[1:] if argv is None else argv)
-    probe = socket.socket()
-    probe.bind(("127.0.0.1", 0))
-    port = probe.getsockname()[1]
-    probe.close()
+    # The rendezvous port is bound HERE and stays bound: the listening socket itself goes to rank 0 (an inherited
+    # descriptor, VARSENS_RENDEZVOUS_FD), the other ranks get its number.  Nothing is probed, closed and hoped to be
+    # still free when rank 0 comes up; connections made before rank 0 accepts wait in the listen queue.
+    listener = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    listener.bind(("127.0.0.1", 0))
+    listener.listen(max(world, 8))
+    port = listener.getsockname()[1]
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                    LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only does dmabuf IPC (RCCL needs it)
         env.pop("TORCHELASTIC_RUN_ID", None)                 # the children rendezvous over dist.TcpRendezvous
+        env.pop("VARSENS_RENDEZVOUS_FD", None)
+        if rank == 0:
+            env["VARSENS_RENDEZVOUS_FD"] = str(listener.fileno())
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr.fileno()))
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr.fileno(),
+                                      pass_fds=(listener.fileno(),) if rank == 0 else ()))
+    listener.close()    # rank 0 holds the only other copy: when it ends, late peers get "connection refused", not a hang
     import threading
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
@@ -312,6 +320,16 @@ def main():
         return group.max(dt), recs, res
 
     ctx.eval(design, objective, begin, rows, fbuf[F_BUFFERS - 1])   # batch "-1" of the pipeline
+    # Before anything is timed: does the exchange sum what it should?  One untimed pass; this rank's record goes
+    # through the all-reduce of the timed steps (RCCL, or the host exchange of a rehearsal) AND, as it was before the
+    # exchange, through the rendezvous to be summed on the host in rank order.  `ranks_in_record` is the record's
+    # own rank counter (every rank writes 1.0): it must come out as n_gpus.
+    ctx.reduce_first_order(fbuf[F_BUFFERS - 1], rows, k, l, accs[0], 0, rank, world)
+    ctx.sync()
+    record_before = ctx.download(accs[0], (nacc,))
+    comm.allreduce(accs[0], nacc)
+    ctx.sync()
+    check = dist.exchange_check(group, record_before, ctx.download(accs[0], (nacc,)))
     # DVFS: a GPU that was idle needs ~0.2 s of work to reach its sustained clock; bring it there
     # before the W warm-up steps so that the K timed steps do not depend on how small K and W are
     # (a fixed COUNT, not a wall-clock loop: every rank must issue the same number of all-reduces)
@@ -445,6 +463,7 @@ def main():
                        "k": k, "n_per_gpu": rows, "n_global": n, "l": l,
                        "samples_per_step": N_total, "sharding": "rows/%d" % world},
             "exchange": exchange,
+            "exchange_check": check,
             "stages_ms": avg,
             "stages_note": "reduce_first (and allreduce): HIP events inside the timed region, the only launches bracketed "
                            "there; eval, fold, finish: from a second pass of the same step with every launch bracketed "
@@ -455,6 +474,9 @@ def main():
             "model_evals_per_s": N_total / t_eval,  # rank 0's kernel time, all ranks' evaluations
             "reduce_gsamples_per_s_per_gpu": N_local / t_red / 1e9,
             "max_abs_err_sens_vs_analytic": max_err,
+            # the finished indices of the last timed step (the same global problem gives the same numbers at every N
+            # under --strong: tests/test_gpu_api.py::test_two_ranks_over_rccl compares them)
+            "sens": [float(x) for x in sens], "sens_t": [float(x) for x in result[2 + 3 * k:2 + 4 * k, 0]],
             "fused_path": fused,
             "single_buffer": {"value": N_total / (t_single / args.steps) / 1e9, "unit": "GSamples/s",
                               "ms_per_step": 1e3 * t_single / args.steps, "stages_ms": avg_single,
@@ -524,11 +546,16 @@ def main():
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
             cpu, _ = cpu_baseline(k, blocks, n_small, cores)
             line["cpu_baseline"] = cpu
-        # a run that ended on the host fallback is not a scaling number: its line goes to stderr only
-        print(json.dumps(line), flush=True, file=sys.stderr if host_fallback else sys.stdout)
+        # a run that ended on the host fallback, or whose exchange did not sum every rank's record, is not a scaling
+        # number: its line goes to stderr only
+        print(json.dumps(line), flush=True, file=sys.stderr if (host_fallback or not check["ok"]) else sys.stdout)
     comm.close()
     ctx.close()
     group.close()
+    if not check["ok"]:
+        sys.stderr.write("bench.py: the exchange did NOT return the sum of the %d ranks' records: %s\n"
+                         % (world, json.dumps(check)))
+        sys.exit(4)
     if host_fallback:
         sys.stderr.write("bench.py: --gpus %d ended on the HOST FALLBACK exchange (RCCL did not initialise); the "
                          "line above (stderr only) is not a scaling number\n" % world)

@@ -61,6 +61,21 @@ WORKER = textwrap.dedent("""
     total = g.sum_array(rec)
     assert total[0] == n and total[2] == 2
 
+    # the check bench.py runs before it times anything (dist.exchange_check): a true sum passes; an exchange that
+    # leaves a rank out, one that returns different bits per rank and one that is off in a single entry do not
+    good = dist.exchange_check(g, rec, total)
+    assert good["ok"] and good["ranks_in_record"] == 2 and good["max_rel_diff_vs_host_sum"] <= 1e-15
+    assert good["identical_on_all_ranks"] and good["doubles"] == rec.size
+    alone = dist.exchange_check(g, rec, rec)                 # "all-reduce" that did nothing: one rank in the record
+    assert not alone["ok"] and alone["ranks_in_record"] == 1
+    skew = total.copy()
+    skew[5] *= 1.0 + 1e-9 * g.rank                           # rank 1 ends with other bits than rank 0
+    assert not dist.exchange_check(g, rec, skew)["identical_on_all_ranks"]
+    off = total.copy()
+    off[7] += 1e-6 * abs(off[7]) + 1e-9
+    bad = dist.exchange_check(g, rec, off)
+    assert not bad["ok"] and bad["max_rel_diff_vs_host_sum"] > 1e-8 and bad["ranks_in_record"] == 2
+
     # finish exactly as finish_first_kernel does (pooled variance over the rank slots)
     slots = total[4 + l * per:].reshape(g.world, slot)
     cnt = slots[:, 0].sum()

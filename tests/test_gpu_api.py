@@ -571,7 +571,9 @@ def test_tutorial_route_is_fused_too(vs, golden):
     for f in ("sens", "sens_t", "sens_2", "sens_2n"):
         numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-10, atol=1e-13, err_msg=f)
     assert o.fM_1.shape == (51200, 1) and o._f is not None
-    numpy.testing.assert_allclose(o.fM_1[:5, 0], g["fM_1"][:5, 0] if "fM_1" in g else o.fM_1[:5, 0], rtol=1e-13)
+    # the reference's own first values (its numpy.prod folds left to right; the default order here is reassociated)
+    numpy.testing.assert_allclose(o.fM_1[:8, 0], g["fM_1_head"][:, 0], rtol=1e-13)
+    numpy.testing.assert_allclose(o.fN_j[:, :4, 0], g["fN_j_head"][:, :, 0], rtol=1e-13)
     w = vs.Varsens(o, verbose=False)          # with the values resident: the reduction kernels, same indices
     numpy.testing.assert_allclose(w.sens_2, v.sens_2, rtol=1e-9, atol=1e-12)
     with pytest.raises(Exception, match="entries per output"):
@@ -580,6 +582,32 @@ def test_tutorial_route_is_fused_too(vs, golden):
     e = vs.Objective(6, 64, vs.Sample(6, 64, vs.scale.Identity(), verbose=False),
                      vs.objectives.SeparableExpression("return p[c] * x;", params=numpy.ones(6), fold="sum"), verbose=False)
     assert e._f is not None
+
+
+def test_deferred_objective_keeps_the_order_it_was_made_in(vs):
+    """An Objective whose values are deferred computes what it would have computed at construction: the parameter
+    table is copied and the context's evaluation order recorded, so switching the context to the strict order
+    afterwards changes neither the values nor the route Varsens(objective) takes."""
+    from varsens_amd import _native
+    k, n = 32, 3000
+    a = numpy.linspace(0.0, 9.0, k)
+    ctx = _native.Context(0)
+    try:
+        s = vs.Sample(k, n, vs.scale.Identity(), verbose=False, context=ctx)
+        now = vs.Objective(k, n, s, vs.objectives.GFunction(a), verbose=False, lazy=False)
+        later = vs.Objective(k, n, s, vs.objectives.GFunction(a), verbose=False)
+        assert later._f is None and later._order == "fast"
+        ctx.set_eval_order("strict")
+        v = vs.Varsens(later, verbose=False)
+        assert later._f is None, "the one-kernel route of the fast order was still taken"
+        assert numpy.array_equal(later.flat(), now.flat())       # the scan order's bits, not the strict fold's
+        assert ctx.eval_order == "strict"                         # and the context is left as the caller set it
+        made_strict = vs.Objective(k, n, s, vs.objectives.GFunction(a), verbose=False)
+        assert made_strict._f is not None and not numpy.array_equal(made_strict.flat(), now.flat())
+        w = vs.Varsens(now, verbose=False)
+        numpy.testing.assert_allclose(v.sens, w.sens, rtol=1e-9, atol=1e-12)
+    finally:
+        ctx.close()
 
 
 def test_fused_through_api_wider_shapes(vs):
@@ -617,29 +645,38 @@ def test_fused_through_api_wider_shapes(vs):
 
 # ---------------------------------------------------------------- multi-process flow (rehearsal on one GPU)
 
-@pytest.mark.parametrize("rows_per_pass", [0, 3000, 10000])   # 10000 = rank 0's shard, one less than rank 1's
-def test_two_process_sharded_run_equals_single_process(vs, tmp_path, rows_per_pass):
-    """examples/multi_gpu.py with 2 ranks sharing GPU 0 and the records crossing the host (gloo): the
-    sharded Objective + Varsens(comm=...) flow gives the single-process result.  The RCCL exchange
-    itself needs >= 2 GPUs and is exercised by the driver's scaling runs."""
-    import os
-    import socket
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    out = str(tmp_path / "two.npz")
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "examples", "multi_gpu.py"), "--k", "6",
-                                       "--n", "20001", "--host-exchange", "--shared-device", "--out", out,
-                                       "--rows-per-pass", str(rows_per_pass)],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+def _wait_all(procs, timeout=300):
+    outs = []
     for p in procs:
-        o, _ = p.communicate(timeout=300)
-        assert p.returncode == 0, o
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except Exception:
+            p.kill()
+            o, _ = p.communicate()
+        outs.append(o)
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d:\n%s" % (rank, o[-4000:])
+    return outs
+
+
+def _bench_env():
+    import os
+    return {k: v for k, v in os.environ.items()
+            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+                         "VARSENS_RENDEZVOUS_FD")}
+
+
+@pytest.mark.parametrize("rows_per_pass", [0, 3000, 10000])   # 10000 = rank 0's shard, one less than rank 1's
+def test_two_process_sharded_run_equals_single_process(vs, tmp_path, spawn_ranks, rows_per_pass):
+    """examples/multi_gpu.py with 2 ranks sharing GPU 0 and the records crossing the host: the
+    sharded Objective + Varsens(comm=...) flow gives the single-process result.  The RCCL exchange
+    itself needs >= 2 GPUs: test_two_ranks_over_rccl below."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "two.npz")
+    _wait_all(spawn_ranks(2, [os.path.join(root, "examples", "multi_gpu.py"), "--k", "6", "--n", "20001",
+                              "--host-exchange", "--shared-device", "--out", out,
+                              "--rows-per-pass", str(rows_per_pass)]))
     two = numpy.load(out)
     a = numpy.array(model, dtype=float)
     one = vs.Varsens(vs.objectives.GFunction([a, a[::-1]]), vs.scale.Identity(), 6, 20001, verbose=False)
@@ -652,17 +689,16 @@ def test_two_process_sharded_run_equals_single_process(vs, tmp_path, rows_per_pa
 def test_bench_launches_its_own_ranks(vs):
     """`python3 bench.py --gpus 2` with NO launcher (the shape of the driver's N=1 command): the parent starts the
     two ranks itself over the torch-free rendezvous and relays exactly one result line.  Both ranks share GPU 0
-    and the records cross the host -- RCCL refuses two ranks on one device; the RCCL leg needs >= 2 GPUs."""
+    and the records cross the host -- RCCL refuses two ranks on one device; the RCCL leg needs >= 2 GPUs
+    (test_two_ranks_over_rccl)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items()
-           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--exchange", "host",
                         "--shared-device", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                       env=_bench_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [x for x in p.stdout.splitlines() if x.strip()]
     assert len(lines) == 1, p.stdout
@@ -673,6 +709,57 @@ def test_bench_launches_its_own_ranks(vs):
     assert line["config"]["n_global"] == 2 * line["config"]["n_per_gpu"]
     assert line["max_abs_err_sens_vs_analytic"] < 1e-3      # quasi-Monte Carlo error of 2^23 draws in 32 dimensions
     assert "rehearsal" in line["exchange"]
+    # the line says how many ranks its exchange summed and how far it is from the host's own sum of their records
+    chk = line["exchange_check"]
+    assert chk["ok"] and chk["ranks_in_record"] == 2 == chk["ranks_expected"]
+    assert chk["max_rel_diff_vs_host_sum"] <= 1e-13 and chk["identical_on_all_ranks"]
+
+
+def test_two_ranks_over_rccl(vs, tmp_path, spawn_ranks):
+    """The one exchange the multi-GPU design rests on, with two ranks on two GPUs over RCCL (skipped on a one-GPU
+    box; the reference's counterpart is the PBS fan-out, varsens/cluster/accre-submit.sh:27, accre-job.sh:13).
+    (1) `python3 bench.py --gpus 2 --strong`: the line reports an RCCL exchange whose record counts two ranks and
+    equals the host's rank-ordered sum of the two records, and the finished sens equal the one-GPU run of the same
+    global problem to 1e-10.  (2) examples/multi_gpu.py without --host-exchange: record AND Gram sums cross in one
+    ncclAllReduce; sens, sens_t, sens_2, sens_2n equal the single-process analysis to 1e-10."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from varsens_amd import _native
+    if _native.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs: RCCL refuses two ranks on one device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for gpus in (2, 1):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--strong",
+                            "--log2n", "20", "--steps", "3", "--warmup", "1", "--prewarm-steps", "0",
+                            "--no-cpu-baseline"],
+                           env=_bench_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-4000:]
+        out = [x for x in p.stdout.splitlines() if x.strip()]
+        assert len(out) == 1, p.stdout
+        lines[gpus] = json.loads(out[0])
+    two, one = lines[2], lines[1]
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "rccl" in two["exchange"].lower()
+    assert "fallback" not in two["exchange"].lower()
+    chk = two["exchange_check"]
+    assert chk["ok"] and chk["ranks_in_record"] == 2 and chk["identical_on_all_ranks"], chk
+    assert chk["max_rel_diff_vs_host_sum"] <= 1e-13, chk
+    assert two["config"]["n_global"] == one["config"]["n_global"] == 1 << 20
+    numpy.testing.assert_allclose(two["sens"], one["sens"], rtol=1e-10, atol=1e-13)
+    numpy.testing.assert_allclose(two["sens_t"], one["sens_t"], rtol=1e-10, atol=1e-13)
+
+    out = str(tmp_path / "rccl.npz")
+    _wait_all(spawn_ranks(2, [os.path.join(root, "examples", "multi_gpu.py"), "--k", "6", "--n", "20001",
+                              "--out", out]))
+    got = numpy.load(out)
+    a = numpy.array(model, dtype=float)
+    ref = vs.Varsens(vs.objectives.GFunction([a, a[::-1]]), vs.scale.Identity(), 6, 20001, verbose=False)
+    for f in ("E_2", "var_y"):
+        numpy.testing.assert_allclose(got[f], getattr(ref, f), rtol=1e-13)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(got[f], getattr(ref, f), rtol=1e-10, atol=1e-13)
 
 
 def test_sobol_with_opaque_scaling_and_discard(vs):

@@ -313,3 +313,38 @@ def test_fused_is_bit_reproducible(ctx):
     first = ctx.download(acc, (nacc,))
     ctx.eval_reduce_first_order(d, obj, 0, n, acc)
     same(ctx.download(acc, (nacc,)), first)
+
+
+# ------------------------------------------------------------------ fused evaluate + BOTH orders, straight against the oracle
+
+def gram_expected(F):
+    """S S^T and T T^T (S = C + D, T = C - D; index row u = output * k + column) of ORACLE f-values, in numpy."""
+    k, n, l = F[2].shape
+    C = F[2].transpose(2, 0, 1).reshape(l * k, n)
+    D = F[3].transpose(2, 0, 1).reshape(l * k, n)
+    S, T = C + D, C - D
+    return S @ S.T, T @ T.T
+
+
+@pytest.mark.parametrize("kind", ["g_function", "linear", "polynomial"])
+@pytest.mark.parametrize("k,n", [(6, 4096), (24, 1000), (32, 4096), (48, 4096), (64, 777), (96, 2048), (128, 4096)])
+def test_fused_both_orders_against_the_oracle(ctx, kind, k, n):
+    """vs_eval_reduce_first_second_order with NO device-produced value on the expected side: the
+    Gram sums against S S^T / T T^T of the oracle's evaluation (orc.evaluate_scan; the one-kernel call folds its
+    columns in its own segment shape, a few ulp per value from the oracle's -- far inside the bars), the record
+    against the exactly rounded sums of the same values.  Replaces varsens/saltelli.py:329-355, 577-619."""
+    from varsens_amd import _native
+    P = params_for(kind, k, 1, 5 * k + n)
+    d = design(ctx, k, n)
+    obj = ctx.objective_create(KINDS[kind], k, 1, P)
+    assert ctx.eval_reduce_both_supported(d, obj)
+    nacc, ng = _native.acc_len(k, 1, 1), _native.gram_len(k)
+    acc, g = ctx.alloc(8 * nacc), ctx.alloc(8 * ng)
+    ctx.eval_reduce_first_second_order(d, obj, 0, n, acc, g)
+    S = orc.build_sample(k, n)
+    F = orc.evaluate_scan(kind, P, S[0], S[1], fused=True)
+    check_record(ctx.download(acc, (nacc,)), F, k, 1, rtol=1e-12)
+    G = ctx.download(g, (2, k, k))
+    SS, TT = gram_expected(F)
+    np.testing.assert_allclose(G[0], SS, rtol=1e-11, atol=1e-12 * np.abs(SS).max())
+    np.testing.assert_allclose(G[1], TT, rtol=1e-11, atol=1e-12 * np.abs(SS).max())

@@ -94,8 +94,10 @@ def main():
                     agg[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
                     pmc.setdefault(row["Kernel_Name"], {}).update(
                         grid_size=int(row["Grid_Size"]), workgroup_size=int(row.get("Workgroup_Size", 0) or 0),
-                        vgpr=int(row.get("VGPR_Count", 0) or 0), accum_vgpr=int(row.get("Accum_VGPR_Count", 0) or 0),
-                        sgpr=int(row.get("SGPR_Count", 0) or 0), lds_bytes=int(row.get("LDS_Block_Size", 0) or 0),
+                        rocprof_vgpr_count=int(row.get("VGPR_Count", 0) or 0),
+                        rocprof_accum_vgpr_count=int(row.get("Accum_VGPR_Count", 0) or 0),
+                        rocprof_sgpr_count=int(row.get("SGPR_Count", 0) or 0),
+                        lds_bytes=int(row.get("LDS_Block_Size", 0) or 0),
                         scratch_bytes=int(row.get("Scratch_Size", 0) or 0))
             for (kname, c), v in agg.items():
                 pmc[kname][c] = sum(v) / len(v)
@@ -116,7 +118,15 @@ def main():
             c["lds_conflict_per_active"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_ACTIVE_INST_LDS"]
         if "FETCH_SIZE" in c:
             c["hbm_bytes"] = (2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
-    json.dump({"command": cmd, "env": {k: os.environ[k] for k in ("K", "LOG2N") if k in os.environ},
+    units = {"rocprof_vgpr_count": "rocprofv3's VGPR_Count column as it stands; on gfx950 it reads HALF the allocated "
+                                   "vector registers per lane (60 for a kernel whose code object says .vgpr_count 119, "
+                                   "allocated in blocks of 8 = 120) -- the registers, spills and scratch of a kernel are "
+                                   "read off the code object by tools/spill_report.py, not from here",
+             "rocprof_accum_vgpr_count": "rocprofv3's Accum_VGPR_Count column, same unit",
+             "rocprof_sgpr_count": "rocprofv3's SGPR_Count column", "lds_bytes": "bytes per workgroup",
+             "scratch_bytes": "bytes per lane", "FETCH_SIZE, WRITE_SIZE": "KB", "hbm_bytes": "bytes per launch",
+             "SQ_*": "per launch, summed over the chip (see the docstring of tools/pmc_run.py)"}
+    json.dump({"command": cmd, "units": units, "env": {k: os.environ[k] for k in ("K", "LOG2N") if k in os.environ},
                "failed_groups": failed, "kernels": pmc}, open(os.path.join(out, name + ".json"), "w"), indent=1)
     shutil.rmtree(work, ignore_errors=True)
     print("pmc_run %s: %d kernels, failed groups: %s" % (name, len(pmc), failed or "none"), flush=True)

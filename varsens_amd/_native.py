@@ -286,6 +286,23 @@ class Context(object):
         _check(self.lib.vs_context_set_eval_order(self.handle, ORDER_STRICT if order == "strict" else ORDER_FAST))
         self.eval_order = order
 
+    def eval_order_scope(self, order):
+        """Context manager: evaluate in `order` inside, the context's own order again outside (an Objective whose
+        values were deferred evaluates in the order its context had when it was made)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            before = getattr(self, "eval_order", "fast")
+            if before != order:
+                self.set_eval_order(order)
+            try:
+                yield
+            finally:
+                if before != order:
+                    self.set_eval_order(before)
+        return scope()
+
     def stream_select(self, which):
         _check(self.lib.vs_stream_select(self.handle, int(which)))
 

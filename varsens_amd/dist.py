@@ -15,8 +15,9 @@ pickled values through it).  A job started by ``torch.distributed.run`` finds
 that port taken by the launcher's own store, so there the same plumbing rides
 on torch.distributed's CPU ``gloo`` group.  ``VARSENS_RENDEZVOUS=tcp|gloo``
 overrides the choice (tcp under torchrun listens on MASTER_PORT+1 unless
-``VARSENS_RENDEZVOUS_PORT`` names the port).  Nothing on the data path touches
-either.
+``VARSENS_RENDEZVOUS_PORT`` names the port; ``VARSENS_RENDEZVOUS_FD`` on rank 0
+is a listening socket the launcher bound and passed down, see bench.py).
+Nothing on the data path touches either.
 """
 import os
 import pickle
@@ -88,14 +89,18 @@ class TcpRendezvous(object):
     """All-gather of small picklable values over one TCP connection per rank to a store thread on
     rank 0.  Every rank must take part in every round, in the same order (as with any collective)."""
 
-    def __init__(self, rank, world, addr, port, timeout=300.0):
+    def __init__(self, rank, world, addr, port, timeout=300.0, listener=None):
+        """`listener`: a socket already bound to (addr, port) and listening, handed to rank 0 by whoever
+        started the ranks (bench.py's parent binds port 0 and passes the descriptor on), so that the port
+        is never free between its choice and its use."""
         self.rank, self.world = rank, world
         self._server = None
         if rank == 0:
-            listener = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            listener.bind((addr, port))
-            listener.listen(world)
+            if listener is None:
+                listener = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                listener.bind((addr, port))
+                listener.listen(world)
             listener.settimeout(timeout)
             self._server = threading.Thread(target=self._serve, args=(listener, timeout), daemon=True)
             self._server.start()
@@ -179,7 +184,12 @@ class HostGroup(object):
                     port = int(os.environ["VARSENS_RENDEZVOUS_PORT"])
                 elif "TORCHELASTIC_RUN_ID" in os.environ:
                     port += 1
-                self._tcp = TcpRendezvous(self.rank, self.world, addr, port)
+                listener = None
+                if self.rank == 0 and "VARSENS_RENDEZVOUS_FD" in os.environ:
+                    # the launcher's bound, listening socket (inherited descriptor): take it over
+                    listener = socket.socket(fileno=int(os.environ.pop("VARSENS_RENDEZVOUS_FD")))
+                    port = listener.getsockname()[1]
+                self._tcp = TcpRendezvous(self.rank, self.world, addr, port, listener=listener)
                 self._tcp.all_gather(None)
             elif self.backend == "gloo":
                 self._init_gloo()
@@ -253,6 +263,32 @@ class HostGroup(object):
         if self._dist is not None and self._dist.is_initialized():
             self._dist.destroy_process_group()
         self._dist = None
+
+
+def exchange_check(group, before, after):
+    """Does an all-reduce result hold the sum over ALL ranks?  `before`: this rank's record as it
+    went into the exchange, `after`: what came out (host float64 arrays of equal length on every
+    rank).  Every rank's `before` crosses the rendezvous and is summed in rank order on the host;
+    the report says how many ranks the record counts (entry [2], 1 per rank going in), how far the
+    exchanged record is from that host sum -- relative to the sum of magnitudes, so that a
+    cancelling entry cannot hide a missing addend -- and whether every rank holds the same bits.
+    A collective: every rank calls it and gets the same report."""
+    before = numpy.ascontiguousarray(before, dtype=numpy.float64)
+    after = numpy.ascontiguousarray(after, dtype=numpy.float64)
+    parts = group.gather_objects(before)
+    outs = group.gather_objects(after)
+    want = numpy.zeros_like(parts[0])
+    size = numpy.zeros_like(parts[0])
+    for part in parts:
+        want += part
+        size += numpy.abs(part)
+    diff = numpy.abs(outs[0] - want)
+    rel = float(numpy.max(numpy.where(size > 0.0, diff / numpy.where(size > 0.0, size, 1.0), diff))) if want.size else 0.0
+    same = all(numpy.array_equal(o, outs[0]) for o in outs[1:])
+    ranks = float(outs[0][2]) if want.size > 2 else float("nan")
+    return {"ranks_in_record": ranks, "ranks_expected": group.world, "max_rel_diff_vs_host_sum": rel,
+            "identical_on_all_ranks": bool(same), "doubles": int(want.size),
+            "ok": bool(ranks == group.world and rel <= 1e-13 and same)}
 
 
 class RcclComm(object):

@@ -312,6 +312,7 @@ class Objective(object):
         self._nan_trim = False  # only values that come through load() are trimmed (saltelli.py:474-495)
         self._host_cache = None
         self._params = None
+        self._order = None      # device objectives: the context's evaluation order at construction
 
         if self.verbose: print("Generating Objective Values.")
         if len(objective_vals) > 0:
@@ -325,13 +326,16 @@ class Objective(object):
                 raise Exception("Generating a fresh objective requires that an 'objective_func' be defined.")
             if isinstance(objective_func, _objectives.DeviceObjective):
                 self._l = int(objective_func.outputs(int(self.k)))
+                self._order = getattr(self._ctx, "eval_order", "fast")
                 if lazy is None:
                     # A built-in objective needs no compilation: its values are produced when somebody first asks for
                     # them (fM_1 ..., flat(), export()), so that Varsens(objective) -- the reference's tutorial route
                     # Sample -> Objective -> Varsens -- can take a fused kernel and never write them.  The parameters
                     # are checked now; objectives compiled at run time are built and evaluated here, as before.
-                    # (a context in strict evaluation order evaluates now: the order is a property of the context and
-                    # may have changed by the time the values are asked for)
+                    # What will be computed is fixed NOW: the parameter table is copied (_device_objective) and the
+                    # evaluation order of the context is recorded (_order) -- values asked for after the context was
+                    # switched to the other order are still produced in this one.  (A context in strict order
+                    # evaluates now, as the reference does.)
                     lazy = (objective_func.kind != _native.OBJ_SOURCE and
                             not isinstance(objective_func, _objectives.SeparableExpression) and
                             getattr(self._ctx, "eval_order", "fast") == "fast")
@@ -366,8 +370,9 @@ class Objective(object):
         self._l = int(spec.outputs(k))
         handle = self._device_objective()
         self._f = self._ctx.alloc(8 * 2 * (k + 1) * self._rows * self._l)
-        self._ctx.eval(self.sample._design, handle, self._row_begin, self._rows, self._f)
-        self._ctx.sync()
+        with self._ctx.eval_order_scope(self._order):      # the order of the day the Objective was made
+            self._ctx.eval(self.sample._design, handle, self._row_begin, self._rows, self._f)
+            self._ctx.sync()
         handle.free()
 
     def _evaluate_on_host(self):
@@ -616,6 +621,13 @@ class Varsens(object):
 
     def compute_varsens(self):
         """E_2, var_y, U_j, U_nj, sens, sens_t, sens_2, sens_2n (varsens/saltelli.py:572-622)."""
+        # whatever still has to be evaluated (fused kernels, streamed row ranges, deferred values) is evaluated in the
+        # order the Objective was made in, not in the one the context may have been switched to since
+        order = self.objective._order or getattr(self._ctx, "eval_order", "fast")
+        with self._ctx.eval_order_scope(order):
+            return self._compute_varsens()
+
+    def _compute_varsens(self):
         if self.verbose: print("Final sensitivity calculation")
         ctx, obj = self._ctx, self.objective
         k, n, l = int(self.k), int(self.n), int(obj._l)
