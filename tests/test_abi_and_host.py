@@ -236,3 +236,43 @@ def test_varsens_takes_the_stream_plan_from_the_largest_shard():
     assert v._max_rows_over_ranks(mine) == 777
     v._comm = None
     assert v._max_rows_over_ranks(mine) == mine
+
+
+# ------------------------------------------------------------------ what the compiler made of the kernels
+
+# Kernels allowed to keep a few spilled registers: fallback shapes only (the NaN-masked pass, odd row counts, more
+# than 128 index rows), each with the most it may have -- so that a regression shows.  Every other kernel of the
+# library -- the north-star reduction, every scan / fused kernel, the Gram kernels of all BASELINE configurations --
+# must have none (DESIGN said "no spills" where the code objects said 11 .. 67).
+SPILL_ALLOWED = {"gram_macro_kernel": 4, "gram_macro_st_kernel": 10, "gram_diag_wave_kernel": 69}
+
+
+def test_hot_kernels_do_not_spill():
+    """tools/spill_report.py over the objects of the build (code-object metadata: .vgpr_spill_count,
+    .private_segment_fixed_size): no spilled vector register and no scratch in any product-path kernel."""
+    import glob
+    import importlib.util
+    import shutil
+    from varsens_amd import build as b
+    if not os.path.isdir("/opt/rocm/lib/llvm/bin") or shutil.which("c++filt") is None:
+        pytest.skip("needs the ROCm LLVM tools")
+    objs = glob.glob(os.path.join(ROOT, "build", "obj", "*.o"))
+    if len(objs) < len(b.SOURCES) or b.needs_build():
+        b.build(force=True, verbose=False)
+    spec = importlib.util.spec_from_file_location("spill_report", os.path.join(ROOT, "tools", "spill_report.py"))
+    sr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sr)
+    rows = sr.report()
+    assert len(rows) > 400, "the report lost kernels: %d" % len(rows)
+    names = " ".join(r["kernel"] for r in rows)
+    for must in ("reduce_first_kernel", "scan_kernel<3, 8, 4, true", "scan_gram_kernel", "scan_gramn_kernel",
+                 "gram_st_kernel<8, 8, true, true, true>", "gram_diag_wide_kernel", "fold_first_kernel"):
+        assert must in names, must
+    bad = []
+    for r in rows:
+        base = re.sub(r"^void (\(anonymous namespace\)::)?", "", r["kernel"]).split("<")[0].split("(")[0]
+        limit = SPILL_ALLOWED.get(base, 0)
+        if r["vgpr_spill"] > limit or (limit == 0 and r["scratch_bytes"] > 0):
+            bad.append("%s: %d spilled VGPRs, %d B scratch (allowed %d)" % (r["kernel"], r["vgpr_spill"],
+                                                                           r["scratch_bytes"], limit))
+    assert not bad, "\n".join(bad)

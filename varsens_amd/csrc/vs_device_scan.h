@@ -93,11 +93,48 @@ __device__ __forceinline__ void vs_scan_col_load(vs_scan_col& C, const vs_design
 }
 
 // Per-wave state carried across the row blocks of a persistent workgroup (fused reduce only).
-template <int L>
+// The five head sums sab, sa, sb, s1, s2 (numbered 0..4) are functions of a and b, which every wave of the
+// workgroup computes with the same bits: sum z is kept by wave z mod W, in its slot z / W -- ceil(5 / W) doubles per
+// lane instead of five, all of them in wave 0 (rounds 1-3), where they were what the 128-register fused kernel
+// spilled to scratch and carried through it once per block.  Each sum is still one per-lane chain over the
+// workgroup's blocks followed by one wave sum: same bits whoever keeps it.
+#define VS_HEAD_SLOTS(W) ((5 + (W) - 1) / (W))
+template <int L, int W = 1>
 struct vs_scan_acc {
     double v[L][4];   // ac, bd, ad, bc of the wave's L columns
-    double sab, sa, sb, s1, s2;
+    double h[VS_HEAD_SLOTS(W)];
 };
+
+template <int L, int W>
+__device__ __forceinline__ void vs_head_add(vs_scan_acc<L, W>& acc, int q, double a, double b, double shift) {
+    const double dx = a - shift, dy = b - shift;
+#pragma unroll
+    for (int z = 0; z < 5; ++z) {
+        if (W == 1 || q == z % W) {   // q is wave-uniform: a scalar branch
+            double& h = acc.h[z / W];
+            if (z == 0) h = fma(a, b, h);
+            else if (z == 1) h += a;
+            else if (z == 2) h += b;
+            else if (z == 3) h += dx + dy;
+            else {
+                h = fma(dx, dx, h);
+                h = fma(dy, dy, h);
+            }
+        }
+    }
+}
+
+// wave sums of the head sums this wave keeps, into out[z] (global or LDS) by lane 63
+template <int L, int W>
+__device__ __forceinline__ void vs_head_store(const vs_scan_acc<L, W>& acc, int q, int lane, double* __restrict__ out) {
+#pragma unroll
+    for (int z = 0; z < 5; ++z) {
+        if (W == 1 || q == z % W) {
+            const double t = vs_wave_sum_dpp(acc.h[z / W]);
+            if (lane == 63) out[z] = t;
+        }
+    }
+}
 
 // One 64-row block.  Term::eval(x, c, params) is the per-coordinate term; FOLD is VS_OBJ_LINEAR
 // (sum) or anything else (product).  `tot` is this block's LDS slab [2][W][64].
@@ -177,10 +214,10 @@ __device__ __forceinline__ void vs_gram_consume(const double* __restrict__ tile,
 
 // End of the kernel: the workgroup's Gram partial [S S^T, T T^T][16 NBH][16 NBH] (upper 16-blocks; the layout
 // gram_fold_kernel reads with st = 2) and its first-order record (layout of reduce_first_kernel's partials).
-// `lds`: at least 2 * 256 + 128 + 8 doubles, free by now; head[5]: sab, sa, sb, s1, s2 (meaningful in wave 0).
-template <int NBH>
+// `lds`: at least 2 * 256 + 128 + 8 doubles, free by now; `acc`: the head sums sab, sa, sb, s1, s2 (vs_scan_acc).
+template <int NBH, int L>
 __device__ __forceinline__ void vs_gram_epilogue(double* __restrict__ lds, int q, int lane, vs_gram_regs& G,
-                                                 const double (&head)[5], int k, double* __restrict__ gout,
+                                                 const vs_scan_acc<L, 4>& acc, int k, double* __restrict__ gout,
                                                  double* __restrict__ rec) {
     constexpr int SB = 16 * NBH;
     const int part = q >> 1, odd = q & 1;
@@ -201,13 +238,7 @@ __device__ __forceinline__ void vs_gram_epilogue(double* __restrict__ lds, int q
 #pragma unroll
         for (int v = 0; v < 4; ++v) red2[part * 256 + ((lane >> 4) + 4 * v) * 16 + (lane & 15)] = share[v];
     }
-    if (q == 0) {
-#pragma unroll
-        for (int z = 0; z < 5; ++z) {
-            const double t = vs_wave_sum_dpp(head[z]);
-            if (lane == 63) hd[z] = t;
-        }
-    }
+    vs_head_store(acc, q, lane, hd);
     __syncthreads();
     double* o = gout + (size_t)part * SB * SB;
 #pragma unroll
@@ -367,9 +398,9 @@ __device__ __forceinline__ void vs_gramn_consume(const double* __restrict__ tile
 }
 
 // `lds`: at least 4 * 16 NB + 8 doubles, free by now
-template <int NB>
+template <int NB, int L>
 __device__ __forceinline__ void vs_gramn_epilogue(double* __restrict__ lds, int q, int lane, int nbl, vs_gramn_regs<NB>& G,
-                                                  const double (&head)[5], int k, double* __restrict__ gout,
+                                                  const vs_scan_acc<L, NB>& acc, int k, double* __restrict__ gout,
                                                   double* __restrict__ rec) {
     constexpr int HALF = 16 * NB;
     double* dots = lds;          // [s rows 0..HALF-1, t rows 0..HALF-1][a, b]
@@ -389,13 +420,7 @@ __device__ __forceinline__ void vs_gramn_epilogue(double* __restrict__ lds, int 
         dots[(HALF + 16 * (NB - 1 - q) + lane) * 2 + 0] = G.pat;
         dots[(HALF + 16 * (NB - 1 - q) + lane) * 2 + 1] = G.pbt;
     }
-    if (q == 0) {
-#pragma unroll
-        for (int z = 0; z < 5; ++z) {
-            const double t = vs_wave_sum_dpp(head[z]);
-            if (lane == 63) hd[z] = t;
-        }
-    }
+    vs_head_store(acc, q, lane, hd);
     __syncthreads();
 #define VS_GRAMN_STORE(RR) vs_gramn_store_row<RR, NB>(gout, lane, nbl, G)
     VS_GRAMN_DISPATCH(VS_GRAMN_STORE)
@@ -416,12 +441,14 @@ __device__ __forceinline__ void vs_gramn_epilogue(double* __restrict__ lds, int 
 // Everything behind the terms of one output: totals exchange, prefixes, suffix checkpoints, outputs.
 // ta/tb: the wave's 2L terms in registers (TLDS: in its LDS slab `tl` instead); Ta/Tb their totals.
 // NBH > 0 (FUSED): the outputs go into the Gram tile `gt` (tile + lane) instead of the 4L register sums.
-template <int FOLD, int L, int W, bool FUSED, bool TLDS, int NBH = 0>
+// SLDS > 0 (FUSED): the 4 sums of the wave's LAST SLDS columns live in its LDS slab `sl` ([4 SLDS][64] + lane)
+// instead of registers (see vs_scan_body).
+template <int FOLD, int L, int W, bool FUSED, bool TLDS, int NBH = 0, int SLDS = 0>
 __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L], const double (&tb)[TLDS ? 1 : L],
                                                const double* __restrict__ tl, double Ta, double Tb,
                                                double* __restrict__ tot, int q, int lane, double* __restrict__ f,
-                                               vs_u64 rows, int k, bool valid, double shift, vs_scan_acc<L>& acc,
-                                               double* __restrict__ gt = nullptr) {
+                                               vs_u64 rows, int k, bool valid, double shift, vs_scan_acc<L, W>& acc,
+                                               double* __restrict__ gt = nullptr, double* __restrict__ sl = nullptr) {
     constexpr int T = VS_EVAL_ROWS;
     constexpr int SUB = L < VS_SCAN_SUB ? L : VS_SCAN_SUB;
     constexpr int NSUB = L / SUB;
@@ -512,10 +539,19 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
                 }
             } else if (FUSED) {
                 if (valid) {  // columns beyond k hold the identity; their sums are dropped at the end
-                    acc.v[jj][0] = fma(a, cj, acc.v[jj][0]);
-                    acc.v[jj][1] = fma(b, dj, acc.v[jj][1]);
-                    acc.v[jj][2] = fma(a, dj, acc.v[jj][2]);
-                    acc.v[jj][3] = fma(b, cj, acc.v[jj][3]);
+                    if (SLDS > 0 && jj >= L - SLDS) {
+                        double* s4 = sl + (size_t)(4 * (jj - (L - SLDS))) * VS_EVAL_ROWS;
+                        s4[0 * VS_EVAL_ROWS] = fma(a, cj, s4[0 * VS_EVAL_ROWS]);
+                        s4[1 * VS_EVAL_ROWS] = fma(b, dj, s4[1 * VS_EVAL_ROWS]);
+                        s4[2 * VS_EVAL_ROWS] = fma(a, dj, s4[2 * VS_EVAL_ROWS]);
+                        s4[3 * VS_EVAL_ROWS] = fma(b, cj, s4[3 * VS_EVAL_ROWS]);
+                        __builtin_amdgcn_wave_barrier();   // see the zeroing of the slab in vs_scan_body
+                    } else {
+                        acc.v[jj][0] = fma(a, cj, acc.v[jj][0]);
+                        acc.v[jj][1] = fma(b, dj, acc.v[jj][1]);
+                        acc.v[jj][2] = fma(a, dj, acc.v[jj][2]);
+                        acc.v[jj][3] = fma(b, cj, acc.v[jj][3]);
+                    }
                 }
             } else if (i < k && valid) {
                 // wave-uniform plane address + lane: scalar base and one vector offset per store.  (The scalar-base
@@ -525,7 +561,10 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
                 VS_STORE(f + (vs_u64)(2 + k + i) * rows + lane, dj);
             }
         }
-        if (!FUSED && L >= 16) __builtin_amdgcn_sched_barrier(0);   // one sub-block's suffixes alive at a time
+        // one sub-block's suffixes alive at a time.  Also in the fused first-order kernel: left alone the scheduler
+        // forms every c_j, d_j of the segment first and multiplies afterwards, with all of them alive beside the 4 L sums
+        // (18 of the 30 spilled dwords of the 8 x 4 kernel came from that).
+        if ((!FUSED && L >= 16) || (FUSED && NBH == 0)) __builtin_amdgcn_sched_barrier(0);
     }
 #undef VS_TA
 #undef VS_TB
@@ -533,26 +572,19 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
         gt[(size_t)(32 * NBH) * VS_GT_PITCH] = valid ? a : 0.0;
         gt[(size_t)(32 * NBH + 1) * VS_GT_PITCH] = valid ? b : 0.0;
     }
-    if (FUSED && q == 0 && valid) {
-        const double dx = a - shift, dy = b - shift;
-        acc.sab = fma(a, b, acc.sab);
-        acc.sa += a;
-        acc.sb += b;
-        acc.s1 += dx + dy;
-        acc.s2 = fma(dx, dx, acc.s2);
-        acc.s2 = fma(dy, dy, acc.s2);
-    }
+    if (FUSED && valid) vs_head_add(acc, q, a, b, shift);
 }
 
 // One 64-row block.  MULTI (evaluation only, l > 1): the scaled coordinates of the segment stay in
 // registers and every output o builds its own terms from them (parameters params + o*k, plane o of
 // the f-values; the two totals slabs alternate per output, one barrier each) -- the generator runs
 // once per row whatever l is.  Otherwise one output (`params`, `fplane` are that output's).
-template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV, int NBH = 0>
+template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV, int NBH = 0, int SLDS = 0>
 __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const double* __restrict__ params,
                                               int q, int lane, vs_u64 rb, double* __restrict__ tot,
                                               double* __restrict__ tl, double* __restrict__ fplane, double shift,
-                                              vs_scan_acc<L>& acc, double* __restrict__ gt = nullptr) {
+                                              vs_scan_acc<L, W>& acc, double* __restrict__ gt = nullptr,
+                                              double* __restrict__ sl = nullptr) {
     constexpr int T = VS_EVAL_ROWS;
     // q is loop-invariant in the persistent walk; tied to the block index here, or the optimiser hoists
     // every column's addresses and masks (all derived from q) out of that loop and spills scalars for
@@ -638,7 +670,8 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
 #ifdef VS_SCAN_STAMPS
         asm("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(stamp1) : "v"(Ta), "v"(Tb));
 #endif
-        vs_scan_finish<FOLD, L, W, FUSED, TLDS, NBH>(ta, tb, tl, Ta, Tb, tot, q, lane, f, rows, k, valid, shift, acc, gt);
+        vs_scan_finish<FOLD, L, W, FUSED, TLDS, NBH, SLDS>(ta, tb, tl, Ta, Tb, tot, q, lane, f, rows, k, valid, shift, acc,
+                                                           gt, sl);
 #ifdef VS_SCAN_STAMPS
         if constexpr (!FUSED) {
             if ((blockIdx.x & 511) == 0 && lane == 0) {
@@ -678,12 +711,13 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
 }
 
 // LDS doubles a workgroup of the scan kernels needs: totals slabs (two, or one when the terms take
-// the room) + the wave-private term slabs
-template <int L, int W, bool TLDS>
+// the room) + the wave-private term slabs + the wave-private slabs of the sums kept in LDS (SLDS columns per wave)
+template <int L, int W, bool TLDS, int SLDS = 0>
 struct vs_scan_lds {
     static constexpr int slabs = TLDS ? 1 : 2;
     static constexpr int totals = slabs * 2 * W * VS_EVAL_ROWS;
-    static constexpr int doubles = totals + (TLDS ? 2 * L * W * VS_EVAL_ROWS : 0);
+    static constexpr int terms = TLDS ? 2 * L * W * VS_EVAL_ROWS : 0;
+    static constexpr int doubles = totals + terms + 4 * SLDS * W * VS_EVAL_ROWS;
 };
 
 // The whole kernel body.  grid.x workgroups walk the 64-row blocks (FUSED: persistent; else one block
@@ -691,7 +725,13 @@ struct vs_scan_lds {
 // (every output is its own plane of f-values / its own record; params + o*k are its parameters).
 // FUSED: one partial record per workgroup and output, layout and fold of reduce_first_kernel
 // (partials[(blockIdx.x * l + o) * VS_PLEN(k)], VS_PLEN = 5 + 4k).
-template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI = false, int GENV = 0>
+// SLDS (FUSED): the 4 sums of the last SLDS of a wave's L columns are kept in a wave-private LDS slab ([4 SLDS][64]
+// doubles per wave, read - fma - write once per block) instead of registers.  The fused kernel of 25 .. 32 columns
+// (four waves x 8 columns, held to 128 registers for four waves per SIMD) is ten registers short of its 4 L = 32
+// sums + 2 L terms + the generator's temporaries: rounds 1-3 let the compiler spill -- five of the sums went through
+// scratch memory once per block, each reload behind `s_waitcnt vmcnt(0)`.  Two columns' sums in LDS (4 KiB per wave):
+// no scratch, same bits (the same fma chain per lane, whichever memory holds the running value).
+template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI = false, int GENV = 0, int SLDS = 0>
 __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __restrict__ lds,
                                              const double* __restrict__ shift_src, double* __restrict__ partials) {
     constexpr int T = VS_EVAL_ROWS;
@@ -702,12 +742,22 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
     const double* params = A.params + (size_t)o * k;
     double* fplane = FUSED ? nullptr : A.f + (vs_u64)o * (2 * (vs_u64)k + 2) * A.rows;
     const double shift = FUSED ? shift_src[(size_t)o * (2 * (size_t)k + 2)] : 0.0;  // f_o(M_1[row]) of a one-row evaluation
-    double* tl = lds + vs_scan_lds<L, W, TLDS>::totals + (size_t)q * (2 * L * T) + lane;
-    vs_scan_acc<L> acc;
+    double* tl = lds + vs_scan_lds<L, W, TLDS, SLDS>::totals + (size_t)q * (2 * L * T) + lane;
+    double* sl = lds + vs_scan_lds<L, W, TLDS, SLDS>::totals + vs_scan_lds<L, W, TLDS, SLDS>::terms +
+                 (size_t)q * (4 * SLDS * T) + lane;
+    vs_scan_acc<L, W> acc;
     if (FUSED) {
 #pragma unroll
         for (int j = 0; j < L; ++j) acc.v[j][0] = acc.v[j][1] = acc.v[j][2] = acc.v[j][3] = 0.0;
-        acc.sab = acc.sa = acc.sb = acc.s1 = acc.s2 = 0.0;
+#pragma unroll
+        for (int z = 0; z < VS_HEAD_SLOTS(W); ++z) acc.h[z] = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4 * SLDS; ++e) sl[(size_t)e * T] = 0.0;   // a lane only ever touches its own entries
+        // A plain store with no barrier between it and the loads of the design constants that follow makes the
+        // compiler treat those loads as possibly clobbered: they turn from scalar into vector loads (and the "+s"
+        // ties on them no longer compile).  A wave barrier costs no instruction and ends that analysis, as the
+        // workgroup barrier does behind the totals.
+        if (SLDS > 0) __builtin_amdgcn_wave_barrier();
     }
     const vs_u64 nblocks = (A.rows + T - 1) / T;
     int parity = 0;
@@ -716,8 +766,9 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
     // (one slab: a second barrier closes the block instead.)
     if (FUSED) {
         for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-            vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, false, GENV>(A, params, q, lane, rb, lds + parity * (2 * W * T),
-                                                                      tl, fplane, shift, acc);
+            vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, false, GENV, 0, SLDS>(A, params, q, lane, rb,
+                                                                               lds + parity * (2 * W * T), tl, fplane, shift,
+                                                                               acc, nullptr, sl);
             if (TLDS) __syncthreads();
             else parity ^= 1;
         }
@@ -736,22 +787,12 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
             const int i = VS_SCAN_COLUMN(q, j, W);
 #pragma unroll
             for (int z = 0; z < 4; ++z) {
-                const double v = vs_wave_sum_dpp(acc.v[j][z]);
+                const double mine = (SLDS > 0 && j >= L - SLDS) ? sl[(size_t)(4 * (j - (L - SLDS)) + z) * T] : acc.v[j][z];
+                const double v = vs_wave_sum_dpp(mine);
                 if (lane == 63 && i < k) out[5 + (size_t)z * k + i] = v;
             }
         }
-        if (q == 0) {
-            const double t0 = vs_wave_sum_dpp(acc.sab), t1 = vs_wave_sum_dpp(acc.sa),
-                         t2 = vs_wave_sum_dpp(acc.sb), t3 = vs_wave_sum_dpp(acc.s1),
-                         t4 = vs_wave_sum_dpp(acc.s2);
-            if (lane == 63) {
-                out[0] = t0;
-                out[1] = t1;
-                out[2] = t2;
-                out[3] = t3;
-                out[4] = t4;
-            }
-        }
+        vs_head_store(acc, q, lane, out);
     }
 }
 
@@ -775,8 +816,9 @@ __device__ __forceinline__ void vs_scan_gram_body(const vs_eval_args& A, double*
     double* tile = lds + 2 * W * T;
     for (int e = threadIdx.x; e < VS_GT_DOUBLES(NBH); e += W * T) tile[e] = 0.0;   // rows k .. 16 NBH - 1 stay zero
     const double shift = shift_src[0];
-    vs_scan_acc<L> acc;
-    acc.sab = acc.sa = acc.sb = acc.s1 = acc.s2 = 0.0;
+    vs_scan_acc<L, W> acc;
+#pragma unroll
+    for (int z = 0; z < VS_HEAD_SLOTS(W); ++z) acc.h[z] = 0.0;
     vs_gram_regs G;
     G.d = G.o = (vs_d4){0.0, 0.0, 0.0, 0.0};
     G.pa = G.pb = 0.0;
@@ -788,8 +830,7 @@ __device__ __forceinline__ void vs_scan_gram_body(const vs_eval_args& A, double*
         __syncthreads();
         vs_gram_consume<NBH>(tile, q, lane, G);
     }
-    const double head[5] = {acc.sab, acc.sa, acc.sb, acc.s1, acc.s2};
-    vs_gram_epilogue<NBH>(tile, q, lane, G, head, k, gram_partials + (size_t)blockIdx.x * 2 * (16 * NBH) * (16 * NBH),
+    vs_gram_epilogue<NBH>(tile, q, lane, G, acc, k, gram_partials + (size_t)blockIdx.x * 2 * (16 * NBH) * (16 * NBH),
                           first_partials + (size_t)blockIdx.x * (5 + 4 * (size_t)k));
 }
 
@@ -810,8 +851,9 @@ __device__ __forceinline__ void vs_scan_gramn_body(const vs_eval_args& A, double
     double* tile = lds + 2 * W * T;
     for (int e = threadIdx.x; e < VS_GT_DOUBLES(NBH); e += W * T) tile[e] = 0.0;   // rows k .. 16 NB - 1 stay zero
     const double shift = shift_src[0];
-    vs_scan_acc<L> acc;
-    acc.sab = acc.sa = acc.sb = acc.s1 = acc.s2 = 0.0;
+    vs_scan_acc<L, W> acc;
+#pragma unroll
+    for (int z = 0; z < VS_HEAD_SLOTS(W); ++z) acc.h[z] = 0.0;
     vs_gramn_regs<NB> G;
 #pragma unroll
     for (int i = 0; i < NB + 1; ++i) G.acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
@@ -824,8 +866,7 @@ __device__ __forceinline__ void vs_scan_gramn_body(const vs_eval_args& A, double
         __syncthreads();
         vs_gramn_consume<NB, NBL>(tile, q, lane, G);
     }
-    const double head[5] = {acc.sab, acc.sa, acc.sb, acc.s1, acc.s2};
-    vs_gramn_epilogue<NB>(tile, q, lane, nbl, G, head, k, gram_partials + (size_t)blockIdx.x * 2 * (16 * NB) * (16 * NB),
+    vs_gramn_epilogue<NB>(tile, q, lane, nbl, G, acc, k, gram_partials + (size_t)blockIdx.x * 2 * (16 * NB) * (16 * NB),
                           first_partials + (size_t)blockIdx.x * (5 + 4 * (size_t)k));
 }
 

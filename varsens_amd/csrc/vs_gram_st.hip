@@ -71,9 +71,14 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
     static_assert(R < NB, "block row");
     constexpr int TR = NB - 1 - R;                   // block row of T T^T
     constexpr int NSLOT = NB + 1;                    // accumulator tiles per wave
-    // tiles per pipeline group: three; two where the nine-tile kernel also carries the first-order sums (at three its
-    // 256 registers ran out and a thread-constant was reloaded from scratch once per stage, behind a vmcnt(0))
-    constexpr int GS = 3;
+    // tiles per pipeline group: three.  (Where the nine-tile kernel also carries the first-order sums its 256 registers
+    // ran out in round 3 and a thread constant went through scratch once per stage; the constants are now rebuilt where
+    // they are used -- stash(), the epilogue -- and nothing is spilled at three tiles per group or at two;
+    // VS_ST_GS_FIRST8 = 2 is the measurement knob for the latter.)
+#ifndef VS_ST_GS_FIRST8
+#define VS_ST_GS_FIRST8 3
+#endif
+    constexpr int GS = (FIRST && NB == 8) ? VS_ST_GS_FIRST8 : 3;
     constexpr int NGS = (NSLOT + GS - 1) / GS;       // groups per sub-tile: 3 (slots 0-2, 3-5, 6-8) or 2 (0-2, 3-4)
     constexpr int NG = 2 * NGS;                      // groups per stage and wave
     // One fetch in flight.  Two (a second register set, the stage loop unrolled by two so that the set is a
@@ -103,7 +108,8 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
             poff[ONE ? 0 : j] = ((uint64_t)o * (2 * (uint64_t)A.k + 2) + (j >= 4 ? 2 + A.k : 2) + (uint64_t)jj) * rows;
         }
     }
-    double* wr = tiles + (piece >> 3) * SUB + lrow * VS2_WPITCH + 2 * (piece & 7);   // + RSTEP j rows: s; + NROWS rows: t
+    // LDS write address of the stash: tiles + (piece >> 3) * SUB + lrow * VS2_WPITCH + 2 * (piece & 7) (+ RSTEP j rows:
+    // s; + NROWS rows: t) -- rebuilt inside stash() (see there)
     const double* rd = tiles + 2 * grp * SUB + (lane & 15) * VS2_WPITCH + 2 * (lane >> 4);   // + 16 blk rows (+ NROWS: t)
 
     vs_d4 acc[NSLOT];
@@ -153,6 +159,14 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
         }
     };
     auto stash = [&](int b, int set) {
+        // The write address is rebuilt from the thread index at every stash (five integer instructions) instead of
+        // living in a register between stashes: at nine accumulator tiles plus the first-order sums the 256 registers
+        // ran out, the compiler kept this thread constant in scratch and reloaded it once per stage behind
+        // `s_waitcnt vmcnt(0)` (round 3's code object: 11 spilled dwords, 20 B of scratch).
+        int t = tid;
+        asm volatile("" : "+v"(t));   // not loop-invariant as far as the compiler can tell
+        const int lrow_w = t / PIECES, piece_w = t % PIECES;
+        double* wr = tiles + (piece_w >> 3) * SUB + lrow_w * VS2_WPITCH + 2 * (piece_w & 7);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const vs_d2 c = raw[set][j], d = raw[set][4 + j];   // the c and d loads of the same rows and samples
@@ -160,8 +174,8 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
             *(vs_d2*)(wr + b * STAGE + (NROWS + RSTEP * j) * VS2_WPITCH) = c - d;
         }
         // sample pair p of a sub-tile goes into the padding of that sub-tile's row p: a at [16,17], b at [18,19]
-        if (FIRST && abth)
-            *(vs_d2*)(tiles + b * STAGE + (piece >> 3) * SUB + (piece & 7) * VS2_WPITCH + 16 + 2 * lrow) = rawab[set];
+        if (FIRST && t < 2 * PIECES)
+            *(vs_d2*)(tiles + b * STAGE + (piece_w >> 3) * SUB + (piece_w & 7) * VS2_WPITCH + 16 + 2 * lrow_w) = rawab[set];
     };
 
     // fragments of one group of GS tiles; every address is a compile-time offset from `rd + off`
@@ -291,6 +305,11 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
     for (uint64_t i = 0; i < mine; ++i) stage_iter(i, (int)(i & 1));
 #undef ST_PIN
 
+    // what the epilogue needs of the thread index is rebuilt here, so that nothing of it is carried (or spilled)
+    // across the stage loop
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63;
     if (FIRST) {
         // the four lane groups of a wave hold the same index rows over different samples
         pas += __shfl_xor(pas, 16, 64);
@@ -302,18 +321,18 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
         pbt += __shfl_xor(pbt, 16, 64);
         pbt += __shfl_xor(pbt, 32, 64);
         double* red = tiles + grp * 4 * NROWS;   // the tiles are free: [wave group][s rows, then t rows][2]
-        if (lane < 16) {
-            red[(16 * R + lane) * 2 + 0] = pas;
-            red[(16 * R + lane) * 2 + 1] = pbs;
-            red[(NROWS + 16 * TR + lane) * 2 + 0] = pat;
-            red[(NROWS + 16 * TR + lane) * 2 + 1] = pbt;
+        if (lane_e < 16) {
+            red[(16 * R + lane_e) * 2 + 0] = pas;
+            red[(16 * R + lane_e) * 2 + 1] = pbs;
+            red[(NROWS + 16 * TR + lane_e) * 2 + 0] = pat;
+            red[(NROWS + 16 * TR + lane_e) * 2 + 1] = pbt;
         }
         __syncthreads();
         const int k = A.k;
         const size_t plen = VS_PLEN(k);
         constexpr int NGRP = NB == 8 ? 1 : 2, TPG = 512 / NGRP;   // one record per wave group
         double* rec = A.first_partials + ((size_t)blockIdx.x * NGRP + grp) * plen;
-        for (size_t e = tid % TPG; e < plen; e += TPG) {
+        for (size_t e = tid_e % TPG; e < plen; e += TPG) {
             double v = 0.0;
             if (e >= VS_P_HEAD) {   // the five scalar sums come from first_head_kernel's records
                 // record layout: head, ac[k], bd[k], ad[k], bc[k]
@@ -338,7 +357,7 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
             double* o = out + (ss ? 0 : NROWS * NROWS);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int row = (lane >> 4) + 4 * v, col = lane & 15;   // f64 C/D layout
+                const int row = (lane_e >> 4) + 4 * v, col = lane_e & 15;   // f64 C/D layout
                 o[(rowblk * 16 + row) * NROWS + (blk * 16 + col)] = acc[sl][v];
             }
         }

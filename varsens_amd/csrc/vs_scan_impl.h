@@ -64,12 +64,22 @@ struct builtin_term {
 
 // GENV: 1 / 2 = Halton indices below 2^32 with identity / linear scaling (straight-line column code);
 //       0 = any generator and scaling (fused: except power scaling); 3 = fused, power scaling
+// columns per wave whose four sums the fused kernel keeps in LDS instead of registers (vs_scan_body): what the
+// four-waves-per-SIMD shape is short of, so that nothing goes to scratch
+#define VS_SCAN_SUMS_IN_LDS(L, W, FUSED, GENV) ((FUSED) && (L) == 8 && (W) == 4 ? VS_SCAN_SLDS_84(GENV) : 0)
+// (Halton with identity / linear scaling: one column; the general generator paths and the one with pow() behind a
+// call need more room)
+#ifndef VS_SCAN_SLDS_84
+#define VS_SCAN_SLDS_84(GENV) ((GENV) == 1 || (GENV) == 2 ? 1 : (GENV) == 0 ? 2 : 4)
+#endif
+
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
 __global__ void __launch_bounds__(VS_EVAL_ROWS* W)
 __attribute__((amdgpu_waves_per_eu(VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI))))
 scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
-    extern __shared__ double scan_lds[];  // totals slabs [2 families][W][64] (+ term slabs), vs_scan_lds
-    vs_scan_body<builtin_term<KIND>, KIND, L, W, FUSED, TLDS, MULTI, GENV>(A, scan_lds, shift_src, partials);
+    extern __shared__ double scan_lds[];  // totals slabs [2 families][W][64] (+ term slabs, + sum slabs), vs_scan_lds
+    vs_scan_body<builtin_term<KIND>, KIND, L, W, FUSED, TLDS, MULTI, GENV, VS_SCAN_SUMS_IN_LDS(L, W, FUSED, GENV)>(
+        A, scan_lds, shift_src, partials);
     // counters of the fold that follows (see reduce_first_kernel).  At the END of the kernel: a global
     // store in front of the row loop would make every load of design constants "possibly clobbered"
     // and keep it out of the scalar cache.
@@ -84,7 +94,7 @@ scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t*
 
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
 static int launch_scan_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
-    const size_t lds = sizeof(double) * vs_scan_lds<L, W, TLDS>::doubles;
+    const size_t lds = sizeof(double) * vs_scan_lds<L, W, TLDS, VS_SCAN_SUMS_IN_LDS(L, W, FUSED, GENV)>::doubles;
     const void* fn = (const void*)scan_kernel<KIND, L, W, FUSED, TLDS, MULTI, GENV>;
     if (lds > 64 * 1024) VS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
