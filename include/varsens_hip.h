@@ -34,8 +34,9 @@ extern "C" {
 /* 2: perm slices per rank, vs_accumulate, vs_context_set_eval_order, vs_eval_reduce_supported.
  * 3: the second-order sums are S S^T and T T^T (VS_GRAM_LEN doubles) instead of D C^T, D D^T, C C^T.
  * 4: VS_PERM_EMPTY, vs_profile_select.
- * 5: vs_eval_reduce_first_second_order, vs_eval_reduce_both_supported. */
-#define VS_ABI_VERSION 5
+ * 5: vs_eval_reduce_first_second_order, vs_eval_reduce_both_supported.
+ * 6: vs_eval_reduce_first_second_order takes objectives with several outputs; vs_design_desc_validate. */
+#define VS_ABI_VERSION 6
 
 typedef enum vs_status {
     VS_OK = 0,
@@ -185,6 +186,13 @@ typedef struct vs_design_desc {
  * Fisher-Yates from the last row down, masked-rejection draws.  Feed it to vs_design_desc.perm. */
 int vs_seed1_permutation(uint32_t* out, uint64_t n);
 
+/* Host helper (no GPU involved; ABI 6): every check vs_design_create makes on a descriptor before anything is
+ * uploaded -- k, n, generator, scale mode and its bounds (scale.py:33,62), raw points / direction numbers where the
+ * generator needs them, and the shuffle slice of a rank (perm_begin, perm_count incl. VS_PERM_EMPTY; every entry must
+ * be a row of the second half, saltelli.py:100-101).  *perm_entries (may be NULL): the number of entries of
+ * desc->perm that will be read.  VS_OK or VS_ERR_ARG with vs_last_error(). */
+int vs_design_desc_validate(const vs_design_desc* desc, uint64_t* perm_entries);
+
 int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_design** out);
 int vs_design_destroy(vs_context* ctx, vs_design* design);
 
@@ -292,9 +300,13 @@ int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* design, const v
 /* Fused path for BOTH orders: the same evaluation walk writes s = c + d, t = c - d of every 64-row block into an
  * LDS tile, and the workgroup multiplies it on the fp64 matrix cores (S S^T, T T^T) and takes the first-order dot
  * products off the same fragments: this rank's record (acc_dev, as vs_reduce_first_order) and Gram sums (gram_dev,
- * VS_GRAM_LEN(k) doubles, as vs_reduce_second_order) without any f-value in HBM.  Covers G_FUNCTION / POLYNOMIAL /
- * LINEAR objectives with ONE output and k <= 128 (every generator and scaling of the design), separable source
- * objectives with k <= 128 (identity or linear scaling) and ISHIGAMI; Halton indices below 2^32; not a context in strict
+ * VS_GRAM_LEN(k l) doubles, as vs_reduce_second_order) without any f-value in HBM.  Covers G_FUNCTION / POLYNOMIAL /
+ * LINEAR objectives with one output and k <= 128 (every generator and scaling of the design) and with SEVERAL outputs
+ * (ABI 6; the reference's two-output known-answer test, varsens/tests/test_g_function.py:77-88): 2 .. 8 outputs and
+ * k l <= 64 index rows, or 2 or 4 outputs and k l <= 128, identity or linear scaling -- the generator runs once per
+ * design row, every output builds its terms from the same coordinates, index row = column * l + output of ONE tile, so
+ * that sens_2[:, o, :, o'] of every pair of outputs comes out of the same pass; separable source objectives with one
+ * output and k <= 128 (identity or linear scaling); ISHIGAMI.  Halton indices below 2^32; not a context in strict
  * evaluation order; VS_ERR_ARG otherwise -- vs_eval_reduce_both_supported tells in
  * advance, callers then use vs_eval + vs_reduce_first_second_order.  NaN values propagate.  Results equal the
  * two-kernel path's up to summation order (<= ~2e-13 relative on the sums).

@@ -1,0 +1,163 @@
+// Driver of the sanitizer leg (python -m varsens_amd.build --asan-host): the host-only entry points of the C ABI
+// under AddressSanitizer + UndefinedBehaviorSanitizer, no GPU.  Prints one line per check; the CPU test
+// (tests/test_abi_and_host.py::test_host_entry_points_under_sanitizers) compares the permutation checksums with the
+// oracle's and expects exit status 0 -- any sanitizer report ends the program with a non-zero status
+// (-fno-sanitize-recover=all).
+//   * vs_seed1_permutation (varsens/saltelli.py:100-101) into buffers of EXACTLY n entries (heap: a write past the end
+//     is a report), n on both sides of the 2048-swap batches;
+//   * vs_design_desc_validate (varsens/saltelli.py:62-108): well-formed descriptors, every refusal, a rank's slice of
+//     the shuffle in a buffer of exactly perm_count entries, VS_PERM_EMPTY with a one-entry buffer that must not be
+//     read beyond, perm_count = 0 (= n entries).
+#include <cinttypes>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "varsens_hip.h"
+
+static int failures = 0;
+#define CHECK(cond)                                                      \
+    do {                                                                 \
+        if (!(cond)) {                                                   \
+            std::printf("FAILED %s:%d %s\n", __FILE__, __LINE__, #cond); \
+            ++failures;                                                  \
+        }                                                                \
+    } while (0)
+
+static uint64_t fnv(const uint32_t* p, uint64_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t i = 0; i < n; ++i)
+        for (int b = 0; b < 4; ++b) {
+            h ^= (p[i] >> (8 * b)) & 0xffu;
+            h *= 1099511628211ull;
+        }
+    return h;
+}
+
+int main() {
+    CHECK(vs_abi_version() == VS_ABI_VERSION);
+    CHECK(std::strlen(vs_last_error()) == 0);
+
+    // ---- the seed-1 shuffle
+    const uint64_t sizes[] = {0, 1, 2, 3, 5, 13, 1024, 2047, 2048, 2049, 2050, 4097, 100003, 1u << 20};
+    for (uint64_t n : sizes) {
+        uint32_t* out = n ? static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * n)) : nullptr;   // exactly n entries
+        const int rc = vs_seed1_permutation(out, n);
+        CHECK(rc == VS_OK);
+        std::vector<uint8_t> seen(n, 0);
+        bool perm = true;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (out[i] >= n || seen[out[i]]) perm = false;
+            else seen[out[i]] = 1;
+        }
+        CHECK(perm);
+        std::printf("perm %" PRIu64 " %016" PRIx64 "\n", n, fnv(out, n));
+        std::free(out);
+    }
+    CHECK(vs_seed1_permutation(nullptr, 0) == VS_OK);
+    CHECK(vs_seed1_permutation(nullptr, 7) == VS_ERR_ARG);
+    CHECK(std::strstr(vs_last_error(), "null") != nullptr);
+    uint32_t one[1];
+    CHECK(vs_seed1_permutation(one, 0x100000000ull) == VS_ERR_ARG);
+
+    // ---- descriptors
+    const int k = 5;
+    const uint64_t n = 1000;
+    std::vector<double> lo(k, -1.0), hi(k, 2.0);
+    vs_design_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.generator = VS_GEN_HALTON;
+    d.k = k;
+    d.n = n;
+    d.first_index = 1 + 20 * k;
+    d.scale_mode = VS_SCALE_IDENTITY;
+    uint64_t entries = 99;
+    CHECK(vs_design_desc_validate(&d, &entries) == VS_OK && entries == 0);
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_OK);
+    CHECK(vs_design_desc_validate(nullptr, &entries) == VS_ERR_ARG);
+
+    // the whole shuffle: perm_count = 0 means n entries, all read
+    uint32_t* whole = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * n));
+    CHECK(vs_seed1_permutation(whole, n) == VS_OK);
+    d.perm = whole;
+    d.perm_begin = 0;
+    d.perm_count = 0;
+    CHECK(vs_design_desc_validate(&d, &entries) == VS_OK && entries == n);
+    // a rank's slice in a buffer of exactly that many entries
+    const uint64_t begin = 334, count = 333;
+    uint32_t* slice = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * count));
+    std::memcpy(slice, whole + begin, sizeof(uint32_t) * count);
+    d.perm = slice;
+    d.perm_begin = begin;
+    d.perm_count = count;
+    CHECK(vs_design_desc_validate(&d, &entries) == VS_OK && entries == count);
+    d.perm_begin = n - count + 1;   // the slice runs past the last row
+    CHECK(vs_design_desc_validate(&d, &entries) == VS_ERR_ARG);
+    CHECK(std::strstr(vs_last_error(), "exceeds") != nullptr);
+    d.perm_begin = begin;
+    slice[count - 1] = (uint32_t)n;   // not a row of the second half
+    CHECK(vs_design_desc_validate(&d, &entries) == VS_ERR_ARG);
+    CHECK(std::strstr(vs_last_error(), "not a row") != nullptr);
+    // an empty slice (a rank without rows): perm must be non-null and is NOT read -- a one-entry buffer holding garbage
+    uint32_t* none = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t)));
+    none[0] = 0xffffffffu;
+    d.perm = none;
+    d.perm_begin = n;
+    d.perm_count = VS_PERM_EMPTY;
+    CHECK(vs_design_desc_validate(&d, &entries) == VS_OK && entries == 0);
+    d.perm_begin = 17;
+    CHECK(vs_design_desc_validate(&d, &entries) == VS_OK && entries == 0);
+    d.perm = nullptr;
+    d.perm_begin = d.perm_count = 0;
+
+    // scaling, generators, ranges
+    d.scale_mode = VS_SCALE_LINEAR;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    d.lower = lo.data();
+    d.upper = hi.data();
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_OK);
+    d.scale_mode = VS_SCALE_POWER;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_OK);
+    d.scale_mode = 3;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    d.scale_mode = -1;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    d.scale_mode = VS_SCALE_IDENTITY;
+    d.generator = VS_GEN_RAW;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    std::vector<double> raw(2 * n * k, 0.25);
+    d.raw = raw.data();
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_OK);
+    d.generator = VS_GEN_SOBOL;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    std::vector<uint32_t> dirs(32 * k, 1u);
+    d.sobol_directions = dirs.data();
+    d.first_index = 4096;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_OK);
+    d.first_index = (1ull << 32) - 2 * n + 1;   // the last index would be 2^32
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    d.first_index = ~0ull - 5;                   // first_index + 2n wraps around
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    d.first_index = 4096;
+    d.generator = 7;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    d.generator = VS_GEN_HALTON;
+    d.k = 0;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    d.k = 4097;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    d.k = k;
+    d.n = 0;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    d.n = 1ull << 32;
+    CHECK(vs_design_desc_validate(&d, nullptr) == VS_ERR_ARG);
+    CHECK(std::strstr(vs_last_error(), "out of range") != nullptr);
+
+    std::free(whole);
+    std::free(slice);
+    std::free(none);
+    std::printf("%s\n", failures ? "host checks FAILED" : "host checks ok");
+    return failures ? 1 : 0;
+}

@@ -276,3 +276,50 @@ def test_hot_kernels_do_not_spill():
             bad.append("%s: %d spilled VGPRs, %d B scratch (allowed %d)" % (r["kernel"], r["vgpr_spill"],
                                                                            r["scratch_bytes"], limit))
     assert not bad, "\n".join(bad)
+
+
+def test_host_entry_points_under_sanitizers():
+    """SURVEY.md section 5 (sanitizers: CPU build only on this pool): the host-only entry points of the C ABI --
+    vs_seed1_permutation (varsens/saltelli.py:100-101), vs_design_desc_validate (every descriptor check of
+    vs_design_create incl. a rank's shuffle slice and VS_PERM_EMPTY), the error store -- built from
+    varsens_amd/csrc/vs_host.cpp with g++ -fsanitize=address,undefined and driven by tests/host_asan_main.cpp:
+    exit status 0, no sanitizer report, and the permutations are the oracle's."""
+    import shutil
+    import subprocess
+    from varsens_amd import build as b
+    from oracle import saltelli_oracle as orc
+    if shutil.which("g++") is None and shutil.which("clang++") is None:
+        pytest.skip("no host C++ compiler")
+    exe = b.build_asan_host(verbose=False)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "host checks ok" in p.stdout and "FAILED" not in p.stdout
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
+
+    def fnv(a):
+        h = 1469598103934665603
+        for byte in np.asarray(a, dtype="<u4").tobytes():
+            h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    seen = {}
+    for line in p.stdout.splitlines():
+        if line.startswith("perm "):
+            _, n, h = line.split()
+            seen[int(n)] = int(h, 16)
+    assert set(seen) >= {0, 1, 2, 5, 13, 1024, 2048, 2049, 100003}
+    for n in (0, 1, 2, 3, 5, 13, 1024, 2047, 2048, 2049, 2050, 4097, 100003):
+        assert seen[n] == fnv(orc.seed1_permutation(n)), n
+
+
+def test_descriptor_checks_through_the_binding(native):
+    """vs_design_desc_validate over ctypes (the product library, no GPU call): what Sample(...) relies on."""
+    import ctypes as C
+    lib = native.load_library()
+    d = native.DesignDesc()
+    d.generator, d.k, d.n, d.first_index, d.scale_mode = native.GEN_HALTON, 4, 50, 81, native.SCALE_IDENTITY
+    entries = C.c_uint64(7)
+    assert lib.vs_design_desc_validate(C.byref(d), C.byref(entries)) == 0 and entries.value == 0
+    d.k = 0
+    assert lib.vs_design_desc_validate(C.byref(d), None) == -1
+    assert b"out of range" in lib.vs_last_error()

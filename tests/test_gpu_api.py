@@ -220,6 +220,8 @@ def test_double_g_function(vs, golden):
         assert abs(truth[i] - estimate[5 - i][1]) < 0.005
     g = golden("g3_gfunc2_k6_n1024")
     v = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 1024, verbose=False)
+    # the default call of a two-output model is ONE kernel (round 4): no f-value was written
+    assert v.objective._f is None
     assert v.sens_2.shape == (6, 2, 6, 2)
     for f in ("E_2", "var_y", "U_j", "U_nj"):
         numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-13)
@@ -345,7 +347,9 @@ def test_accuracy_profile_reproduces_the_published_curve(vs):
 def test_accuracy_profile_errors_equal_the_oracles(vs):
     """f4 as a parity row: for the SAME random models the device's per-model numbers -- S_i var_y and the error
     sum_i (V_i - S_i var_y)^2 of varsens/profile/parameters.py:51-76 -- equal the reference arithmetic's (oracle:
-    row-by-row g-function, numpy compute_varsens) to 1e-10.  Dims 6 and 24 at three of the published n."""
+    row-by-row g-function, numpy compute_varsens) to 1e-10.  Dims 6 and 24 at three of the published n, dims 48 and 96
+    (round 4: they were in the committed tables only) at one each, dim 192 -- beyond the fused kernels, the two-kernel
+    route -- at n = 320."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location(
@@ -353,7 +357,7 @@ def test_accuracy_profile_errors_equal_the_oracles(vs):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     rng = numpy.random.RandomState(4)
-    for k, n in ((6, 80), (6, 1280), (6, 20480), (24, 80), (24, 1280), (24, 5120)):
+    for k, n in ((6, 80), (6, 1280), (6, 20480), (24, 80), (24, 1280), (24, 5120), (48, 1280), (96, 640), (192, 320)):
         s = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
         S = orc.build_sample(k, n)
         for _ in range(3):
@@ -514,8 +518,15 @@ def test_fused_first_order_through_api(vs, golden):
     # what the fused kernels do not cover takes the two-kernel path by itself, or says so when fused=True was asked
     with pytest.raises(Exception, match="fused=True"):
         vs.Varsens(vs.objectives.Invert(), vs.scale.Identity(), 3, 64, verbose=False, second_order=False, fused=True)
-    with pytest.raises(Exception, match="fused=True needs"):   # second order with two outputs: no fused kernel
-        vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 64, verbose=False, fused=True)
+    wide = numpy.linspace(0.0, 9.0, 70)
+    with pytest.raises(Exception, match="fused=True needs"):   # second order with 2 x 70 index rows: no fused kernel
+        vs.Varsens(vs.objectives.GFunction([wide, wide[::-1]]), vs.scale.Identity(), 70, 64, verbose=False, fused=True)
+    three = numpy.linspace(0.0, 9.0, 30)
+    with pytest.raises(Exception, match="fused=True: the fused kernels do not cover"):   # 3 outputs beyond 64 index rows
+        vs.Varsens(vs.objectives.GFunction([three, three[::-1], three]), vs.scale.Identity(), 30, 64, verbose=False,
+                   fused=True)
+    two = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 64, verbose=False, fused=True)
+    assert two.objective._f is None and two.sens_2.shape == (6, 2, 6, 2)
     vi = vs.Varsens(vs.objectives.Invert(), vs.scale.Identity(), 3, 64, verbose=False, second_order=False)
     assert vi.sens.shape == (3, 3)
 
@@ -548,8 +559,27 @@ def test_fused_both_orders_through_api(vs, golden):
     assert w.objective._f is not None and w.sens_2.shape == (130, 1, 130, 1)
     w = vs.Varsens(vs.objectives.Linear(numpy.ones(70)), vs.scale.Identity(), 70, 500, verbose=False)
     assert w.objective._f is None and w.sens_2.shape == (70, 1, 70, 1)
+    # several outputs (round 4): one kernel up to 64 index rows (2 .. 8 outputs) and up to 128 (2 or 4); three outputs
+    # beyond 64 rows and power scaling take the two-kernel route by themselves
     w = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 500, verbose=False)
-    assert w.objective._f is not None and w.sens_2.shape == (6, 2, 6, 2)
+    assert w.objective._f is None and w.sens_2.shape == (6, 2, 6, 2)
+    w2 = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 500, verbose=False, fused=False)
+    assert w2.objective._f is not None
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(w, f), getattr(w2, f), rtol=1e-9, atol=1e-11, err_msg=f)
+    c32 = numpy.arange(1.0, 33.0)
+    w = vs.Varsens(vs.objectives.Linear([c32, c32[::-1], 2.0 * c32, c32 ** 2]), vs.scale.Linear(-1.0, 2.0), 32, 3000, verbose=False)
+    assert w.objective._f is None and w.sens_2.shape == (32, 4, 32, 4)
+    w2 = vs.Varsens(vs.objectives.Linear([c32, c32[::-1], 2.0 * c32, c32 ** 2]), vs.scale.Linear(-1.0, 2.0), 32, 3000, verbose=False,
+                    fused=False)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(w, f), getattr(w2, f), rtol=1e-9, atol=1e-11, err_msg=f)
+    numpy.testing.assert_allclose(w.sens[:, 0], w.sens[:, 2], rtol=1e-9)     # output 2 = 2 x output 0: the same indices
+    c30 = numpy.linspace(0.0, 9.0, 30)
+    w = vs.Varsens(vs.objectives.GFunction([c30, c30[::-1], c30]), vs.scale.Identity(), 30, 500, verbose=False)
+    assert w.objective._f is not None and w.sens_2.shape == (30, 3, 30, 3)
+    w = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Power(1.0, 10.0), 6, 500, verbose=False)
+    assert w.objective._f is not None
     # Ishigami (BASELINE configs[2]): its own thread-per-row fused kernel carries the second-order sums too
     i3 = vs.Varsens(vs.objectives.Ishigami(), vs.scale.Linear(-numpy.pi, numpy.pi), 3, 20000, verbose=False)
     assert i3.objective._f is None

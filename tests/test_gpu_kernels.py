@@ -863,7 +863,15 @@ def test_fused_both_orders_coverage(ctx):
     for kk in (33, 48, 49, 65, 112, 113, 128):
         assert ctx.eval_reduce_both_supported(make_design(ctx, kk, 100), ctx.objective_create(_native.OBJ_LINEAR, kk, 1, np.ones(kk)))
     d8 = make_design(ctx, 8, 100)
-    assert not ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 2, np.ones(16)))   # two outputs
+    # several outputs (round 4): 2 .. 8 up to 64 index rows, 2 or 4 up to 128 (tests/test_gpu_scan.py holds their parity)
+    assert ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 2, np.ones(16)))
+    assert ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 8, np.ones(64)))
+    assert not ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 9, np.ones(72)))    # nine outputs
+    assert not ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 16, np.ones(128)))  # 16 outputs
+    d30 = make_design(ctx, 30, 100)
+    assert ctx.eval_reduce_both_supported(d30, ctx.objective_create(_native.OBJ_LINEAR, 30, 4, np.ones(120)))
+    assert not ctx.eval_reduce_both_supported(d30, ctx.objective_create(_native.OBJ_LINEAR, 30, 3, np.ones(90)))   # 3 outputs > 64 rows
+    assert not ctx.eval_reduce_both_supported(d30, ctx.objective_create(_native.OBJ_LINEAR, 30, 5, np.ones(150)))  # > 128 rows
     assert not ctx.eval_reduce_both_supported(make_design(ctx, 3, 100), ctx.objective_create(_native.OBJ_INVERT, 3, 3, None))
     lin = ctx.objective_create(_native.OBJ_LINEAR, 8, 1, np.ones(8))
     assert ctx.eval_reduce_both_supported(d8, lin)

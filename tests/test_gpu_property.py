@@ -148,16 +148,27 @@ def test_evaluation_any_shape(k, n, kind, l, discard, begin_frac, mode):
 FUSED_K = st.one_of(st.integers(1, 128), st.sampled_from([16, 17, 32, 33, 48, 49, 64, 65, 80, 81, 96, 97, 112, 113, 128]))
 
 
-@settings(**dict(COMMON, max_examples=_SOAK or 120))
+def fused_both_takes(k, l, mode):
+    """include/varsens_hip.h, vs_eval_reduce_first_second_order: several outputs of a built-in separable objective --
+    2 .. 8 outputs up to 64 index rows, 2 or 4 outputs up to 128, no power scaling"""
+    if l == 1:
+        return k <= 128
+    return mode != 2 and ((k * l <= 64 and l <= 8) or (k * l <= 128 and l in (2, 4)))
+
+
+@settings(**dict(COMMON, max_examples=_SOAK or 160))
 @given(k=FUSED_K, n=st.one_of(st.integers(1, 300), st.sampled_from([63, 64, 65, 127, 128, 129, 1000, 4097])),
        kind=st.sampled_from(["g", "lin", "poly"]), mode=st.sampled_from([0, 1, 2]), begin_frac=st.floats(0, 1),
-       discard=st.integers(0, 40), slot=st.integers(0, 2))
-def test_fused_both_orders_any_shape(k, n, kind, mode, begin_frac, discard, slot):
+       discard=st.integers(0, 40), slot=st.integers(0, 2), l=st.sampled_from([1, 1, 2, 3, 4]))
+def test_fused_both_orders_any_shape(k, n, kind, mode, begin_frac, discard, slot, l):
     """vs_eval_reduce_first_second_order == vs_eval + vs_reduce_first_second_order on any window of the design's rows,
-    every kernel family (four waves x 4 / 8 columns, four and eight waves x 16), every scaling, any variance slot."""
+    every kernel family (four waves x 4 / 8 columns, four and eight waves x 16; with several outputs four waves x 2 / 4 / 8
+    and eight x 8 columns), every scaling, any variance slot, one to four outputs."""
     from varsens_amd import _native
+    if l > 1:
+        k = max(1, min(k, 128 // l))
     c = ctx()
-    rng = np.random.RandomState(k * 977 + n)
+    rng = np.random.RandomState(k * 977 + n + l)
     lo = hi = None
     if mode == 1:
         lo = rng.rand(k) - 0.5
@@ -166,29 +177,35 @@ def test_fused_both_orders_any_shape(k, n, kind, mode, begin_frac, discard, slot
         lo, hi = np.full(k, 1e-2), 0.5 + 0.5 * rng.rand(k)
     perm = orc.seed1_permutation(n).astype(np.uint32)
     d = c.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k, discard), mode, lo, hi, perm)
-    params = 0.5 + rng.rand(k)
+    params = 0.5 + rng.rand(l, k)
     code = {"g": _native.OBJ_G_FUNCTION, "lin": _native.OBJ_LINEAR, "poly": _native.OBJ_POLYNOMIAL}[kind]
-    obj = c.objective_create(code, k, 1, params)
-    assert c.eval_reduce_both_supported(d, obj)
+    obj = c.objective_create(code, k, l, params)
+    takes = fused_both_takes(k, l, mode)
+    assert c.eval_reduce_both_supported(d, obj) == takes
+    if not takes:
+        obj.free(); d.free()
+        return
+    K = k * l
     begin = int(begin_frac * (n - 1))
     count = n - begin
     ranks = 3
-    nacc, ng = _native.acc_len(k, 1, ranks), _native.gram_len(k)
-    f = c.alloc(8 * 2 * (k + 1) * count)
+    nacc, ng = _native.acc_len(k, l, ranks), _native.gram_len(K)
+    f = c.alloc(8 * 2 * (k + 1) * count * l)
     c.eval(d, obj, begin, count, f)
     acc1, acc2, g1, g2 = c.alloc(8 * nacc), c.alloc(8 * nacc), c.alloc(8 * ng), c.alloc(8 * ng)
-    c.reduce_first_second_order(f, count, k, 1, acc1, g1, 0, slot, ranks)
+    c.reduce_first_second_order(f, count, k, l, acc1, g1, 0, slot, ranks)
     c.eval_reduce_first_second_order(d, obj, begin, count, acc2, g2, slot, ranks)
     r1, r2 = c.download(acc1, (nacc,)), c.download(acc2, (nacc,))
-    G1, G2 = c.download(g1, (2, k, k)), c.download(g2, (2, k, k))
+    G1, G2 = c.download(g1, (2, K, K)), c.download(g2, (2, K, K))
     per = _native.acc_per_output(k)
-    scale = max(1.0, float(np.abs(r1[4:4 + per]).max()))
-    np.testing.assert_allclose(r2[:4 + per], r1[:4 + per], rtol=1e-11, atol=1e-12 * scale)
-    # variance slots: count exact, mean and m2 to rounding (m2 is a difference of sums: absolute tolerance from its scale)
-    s1, s2 = r1[4 + per:].reshape(ranks, 3), r2[4 + per:].reshape(ranks, 3)
+    scale = max(1.0, float(np.abs(r1[4:4 + l * per]).max()))
+    np.testing.assert_allclose(r2[:4 + l * per], r1[:4 + l * per], rtol=1e-11, atol=1e-12 * scale)
+    # variance slots (count, mean[l], m2[l]): count exact, mean and m2 to rounding (m2 is a difference of sums: absolute
+    # tolerance from its scale)
+    s1, s2 = r1[4 + l * per:].reshape(ranks, 1 + 2 * l), r2[4 + l * per:].reshape(ranks, 1 + 2 * l)
     assert np.array_equal(s1[:, 0], s2[:, 0])
-    np.testing.assert_allclose(s2[:, 1], s1[:, 1], rtol=1e-10, atol=1e-12)
-    np.testing.assert_allclose(s2[:, 2], s1[:, 2], rtol=1e-7, atol=1e-9 * scale)
+    np.testing.assert_allclose(s2[:, 1:1 + l], s1[:, 1:1 + l], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(s2[:, 1 + l:], s1[:, 1 + l:], rtol=1e-7, atol=1e-9 * scale)
     np.testing.assert_allclose(G2, G1, rtol=1e-11, atol=1e-12 * max(1.0, float(np.abs(G1).max())))
     for b in (f, acc1, acc2, g1, g2, obj, d):
         b.free()

@@ -348,3 +348,102 @@ def test_fused_both_orders_against_the_oracle(ctx, kind, k, n):
     SS, TT = gram_expected(F)
     np.testing.assert_allclose(G[0], SS, rtol=1e-11, atol=1e-12 * np.abs(SS).max())
     np.testing.assert_allclose(G[1], TT, rtol=1e-11, atol=1e-12 * np.abs(SS).max())
+
+
+def fused_both_takes(k, l):
+    """What include/varsens_hip.h promises for several outputs of a built-in separable objective (identity / linear
+    scaling): 2 .. 8 outputs up to 64 index rows, 2 or 4 outputs up to 128."""
+    K = k * l
+    if l == 1:
+        return k <= 128
+    return (K <= 64 and l <= 8) or (K <= 128 and l in (2, 4))
+
+
+@pytest.mark.parametrize("kind", ["g_function", "linear", "polynomial"])
+@pytest.mark.parametrize("k,n,l", [(6, 1024, 2), (6, 4096, 3), (3, 700, 5), (2, 500, 8), (8, 64, 2),      # <= 16 index rows
+                                   (16, 1000, 2), (4, 777, 7), (10, 3000, 3), (5, 1, 6),                   # <= 32
+                                   (32, 4096, 2), (21, 1500, 3), (12, 2048, 5), (8, 129, 8), (17, 640, 2),  # <= 64
+                                   (64, 2048, 2), (32, 3000, 4), (40, 1000, 2), (17, 5000, 4), (48, 300, 2),
+                                   (25, 4096, 4), (56, 700, 2), (64, 1, 2)])                               # <= 128
+def test_fused_both_orders_several_outputs_against_the_oracle(ctx, kind, k, n, l):
+    """The one-kernel default call with SEVERAL outputs (the reference's two-output known-answer test,
+    varsens/tests/test_g_function.py:77-88; sens_2[:, o, :, o'] slices of varsens/examples/varsens_earm_scipy.py:179-186):
+    record and Gram sums (index row = column * l + output) against the oracle's evaluation, no device value on the
+    expected side; and against the two-kernel route.  Replaces varsens/saltelli.py:329-355, 577-619."""
+    from varsens_amd import _native
+    P = params_for(kind, k, l, 3 * k + n + l)
+    d = design(ctx, k, n)
+    obj = ctx.objective_create(KINDS[kind], k, l, P)
+    assert ctx.eval_reduce_both_supported(d, obj) == fused_both_takes(k, l)
+    K = k * l
+    nacc, ng = _native.acc_len(k, l, 1), _native.gram_len(K)
+    acc, g = ctx.alloc(8 * nacc), ctx.alloc(8 * ng)
+    ctx.eval_reduce_first_second_order(d, obj, 0, n, acc, g)
+    S = orc.build_sample(k, n)
+    F = orc.evaluate_scan(kind, P, S[0], S[1], fused=True)
+    rec = ctx.download(acc, (nacc,))
+    check_record(rec, F, k, l, rtol=1e-12)
+    G = ctx.download(g, (2, K, K))
+    SS, TT = gram_expected_rows(F)
+    np.testing.assert_allclose(G[0], SS, rtol=1e-11, atol=1e-12 * np.abs(SS).max())
+    np.testing.assert_allclose(G[1], TT, rtol=1e-11, atol=1e-12 * np.abs(SS).max())
+    assert np.array_equal(G[0], G[0].T) and np.array_equal(G[1], G[1].T)
+    # the two-kernel route on the device's own f-values
+    f = ctx.alloc(8 * 2 * (k + 1) * n * l)
+    ctx.eval(d, obj, 0, n, f)
+    acc1, g1 = ctx.alloc(8 * nacc), ctx.alloc(8 * ng)
+    ctx.reduce_first_second_order(f, n, k, l, acc1, g1)
+    r1, G1 = ctx.download(acc1, (nacc,)), ctx.download(g1, (2, K, K))
+    per = _native.acc_per_output(k)
+    np.testing.assert_allclose(rec[4:4 + l * per], r1[4:4 + l * per], rtol=1e-12)
+    np.testing.assert_allclose(G, G1, rtol=1e-12, atol=1e-13 * np.abs(G1).max())
+    # bit-reproducible from call to call
+    acc2, g2 = ctx.alloc(8 * nacc), ctx.alloc(8 * ng)
+    ctx.eval_reduce_first_second_order(d, obj, 0, n, acc2, g2)
+    assert np.array_equal(ctx.download(acc2, (nacc,)), rec) and np.array_equal(ctx.download(g2, (2, K, K)), G)
+
+
+def gram_expected_rows(F):
+    """S S^T and T T^T with index row m = column * l + output (the layout of sens_2[k, l, k, l] flattened)."""
+    k, n, l = F[2].shape
+    C = F[2].transpose(0, 2, 1).reshape(k * l, n)
+    D = F[3].transpose(0, 2, 1).reshape(k * l, n)
+    S, T = C + D, C - D
+    return S @ S.T, T @ T.T
+
+
+@pytest.mark.parametrize("k,l,mode,generator", [(6, 2, 1, None), (20, 3, 1, None), (30, 4, 1, None), (6, 2, 0, "sobol"),
+                                                (40, 2, 1, "sobol"), (5, 3, 2, None), (33, 2, 2, None)])
+def test_fused_both_orders_several_outputs_designs(ctx, k, l, mode, generator):
+    """Linear scaling and the Sobol generator take the several-output kernels too (the general column code); power
+    scaling has no such instance: the engine says so and the two-kernel route serves."""
+    from varsens_amd import _native
+    from varsens_amd.saltelli import sobol_directions
+    n = 2500
+    lo = hi = None
+    if mode == 1:
+        lo, hi = np.linspace(-1, 0.5, k), np.linspace(1, 3, k)
+    elif mode == 2:
+        lo, hi = np.full(k, 1e-2), np.linspace(0.5, 1.0, k)
+    d = design(ctx, k, n, mode, lo, hi, generator=generator, dirs=sobol_directions(k) if generator else None)
+    P = params_for("g_function", k, l, k + l)
+    obj = ctx.objective_create(KINDS["g_function"], k, l, P)
+    K = k * l
+    nacc, ng = _native.acc_len(k, l, 1), _native.gram_len(K)
+    assert ctx.eval_reduce_both_supported(d, obj) == (mode != 2)
+    f = ctx.alloc(8 * 2 * (k + 1) * n * l)
+    ctx.eval(d, obj, 0, n, f)
+    acc1, g1 = ctx.alloc(8 * nacc), ctx.alloc(8 * ng)
+    ctx.reduce_first_second_order(f, n, k, l, acc1, g1)
+    if mode == 2:
+        with pytest.raises(Exception, match="fused both-orders path covers"):
+            ctx.eval_reduce_first_second_order(d, obj, 0, n, acc1, g1)
+        return
+    acc, g = ctx.alloc(8 * nacc), ctx.alloc(8 * ng)
+    ctx.eval_reduce_first_second_order(d, obj, 0, n, acc, g)
+    per = _native.acc_per_output(k)
+    r, r1 = ctx.download(acc, (nacc,)), ctx.download(acc1, (nacc,))
+    np.testing.assert_allclose(r[4:4 + l * per], r1[4:4 + l * per], rtol=1e-12)
+    np.testing.assert_allclose(r[4 + l * per:], r1[4 + l * per:], rtol=1e-9, atol=1e-9 * np.abs(r1[4 + l * per:]).max())
+    G, G1 = ctx.download(g, (2, K, K)), ctx.download(g1, (2, K, K))
+    np.testing.assert_allclose(G, G1, rtol=1e-12, atol=1e-13 * np.abs(G1).max())

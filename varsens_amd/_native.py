@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARSENS_HIP_LIB") or os.path.join(_HERE, "libvarsens_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 COMM_ID_BYTES = 128
 
 GEN_HALTON, GEN_SOBOL, GEN_RAW = 0, 1, 2
@@ -107,6 +107,7 @@ SIGNATURES = {
     "vs_halton_fill": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "vs_sobol_fill": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "vs_seed1_permutation": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "vs_design_desc_validate": (C.c_int, [C.POINTER(DesignDesc), C.POINTER(C.c_uint64)]),
     "vs_design_create": (C.c_int, [C.c_void_p, C.POINTER(DesignDesc), C.POINTER(C.c_void_p)]),
     "vs_design_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vs_sample_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),

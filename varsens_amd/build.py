@@ -1,6 +1,8 @@
 """Build libvarsens_hip.so in-tree with hipcc for gfx950.
 
     python -m varsens_amd.build [--force]
+    python -m varsens_amd.build --asan-host     the host-only part (csrc/vs_host.cpp) under AddressSanitizer and
+                                                UBSan with the driver tests/host_asan_main.cpp: build/asan/host_asan
 """
 import glob
 import os
@@ -12,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvarsens_hip.so")
-SOURCES = ["vs_api.hip", "vs_generate.hip", "vs_scan.hip", "vs_scan_g.hip", "vs_scan_poly.hip", "vs_scan_lin.hip", "vs_scan_gram.hip", "vs_scan_gram8.hip", "vs_scan_gram8_g.hip", "vs_scan_gram8_poly.hip", "vs_scan_gram8_lin.hip", "vs_scan_gram4.hip", "vs_reduce.hip", "vs_second.hip", "vs_gram_st.hip", "vs_comm.hip", "vs_rtc.hip"]
+SOURCES = ["vs_host.cpp", "vs_api.hip", "vs_generate.hip", "vs_scan.hip", "vs_scan_g.hip", "vs_scan_poly.hip", "vs_scan_lin.hip", "vs_scan_gram.hip", "vs_scan_gram8.hip", "vs_scan_gram8_g.hip", "vs_scan_gram8_poly.hip", "vs_scan_gram8_lin.hip", "vs_scan_gram4.hip", "vs_scan_gramm_g.hip", "vs_scan_gramm_poly.hip", "vs_scan_gramm_lin.hip", "vs_reduce.hip", "vs_second.hip", "vs_gram_st.hip", "vs_comm.hip", "vs_rtc.hip"]
 # device sources hiprtc needs at run time, embedded into the library as C++ raw strings
 EMBED = {"vs_device_gen.h": "vs_rtc_embed_gen.inc", "vs_device_scan.h": "vs_rtc_embed_scan.inc",
          "vs_rtc_kernel.h": "vs_rtc_embed_kernel.inc", "vs_rtc_kernel_sep.h": "vs_rtc_embed_kernel_sep.inc"}
@@ -77,7 +79,7 @@ def build(force=False, verbose=True):
         cflags = [f for f in FLAGS if f != "-shared"] + os.environ.get("VS_EXTRA_CFLAGS", "").split()
 
         def compile_one(src):
-            obj = os.path.join(objdir, src.replace(".hip", ".o"))
+            obj = os.path.join(objdir, src.replace(".hip", ".o").replace(".cpp", ".o"))
             if force or _deps_newer(obj):
                 cmd = [hipcc] + cflags + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
                 if verbose:
@@ -96,5 +98,30 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_asan_host(verbose=True):
+    """The sanitizer leg (GPU sanitizers are not available on the pool): everything of the library
+    that runs without a GPU -- the error store, the seed-1 shuffle, the descriptor checks -- is one plain C++ file;
+    g++ builds it with -fsanitize=address,undefined together with the driver program.  Returns the executable."""
+    gxx = shutil.which("g++") or shutil.which("clang++")
+    if gxx is None:
+        raise RuntimeError("no host C++ compiler for the sanitizer build")
+    outdir = os.path.join(ROOT, "build", "asan")
+    os.makedirs(outdir, exist_ok=True)
+    exe = os.path.join(outdir, "host_asan")
+    srcs = [os.path.join(CSRC, "vs_host.cpp"), os.path.join(ROOT, "tests", "host_asan_main.cpp")]
+    deps = srcs + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    if os.path.isfile(exe) and all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
+        return exe
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=all", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", exe]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return exe
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--asan-host" in sys.argv:
+        print(build_asan_host())
+    else:
+        build(force="--force" in sys.argv)

@@ -136,6 +136,31 @@ __device__ __forceinline__ void vs_head_store(const vs_scan_acc<L, W>& acc, int 
     }
 }
 
+// Several outputs in one kernel (the fused both-orders kernels): the head sums of output O live in LDS, heads[5 O ..
+// 5 O + 4], kept by wave O mod W -- per block one wave sum of each of the five and one read-add-write by lane 63 (some
+// thirty instructions of the block's thousands).  In registers (5 LMAX sums spread over the waves like the single
+// output's, or per output) they either cost the eight-wave kernel the registers it does not have, or the compiler
+// merged the waves' branches into one update through a selected address and moved the whole array to scratch.
+template <int O, int W>
+__device__ __forceinline__ void vs_head_add_lds(double* __restrict__ heads, int q, int lane, bool valid, double a, double b,
+                                                double shift) {
+    if (q == O % W) {
+        const double dx = a - shift, dy = b - shift;
+        const double v0 = valid ? a * b : 0.0, v1 = valid ? a : 0.0, v2 = valid ? b : 0.0, v3 = valid ? dx + dy : 0.0,
+                     v4 = valid ? fma(dx, dx, dy * dy) : 0.0;
+        const double t0 = vs_wave_sum_dpp(v0), t1 = vs_wave_sum_dpp(v1), t2 = vs_wave_sum_dpp(v2), t3 = vs_wave_sum_dpp(v3),
+                     t4 = vs_wave_sum_dpp(v4);
+        if (lane == 63) {
+            double* h = heads + 5 * O;
+            h[0] += t0;
+            h[1] += t1;
+            h[2] += t2;
+            h[3] += t3;
+            h[4] += t4;
+        }
+    }
+}
+
 // One 64-row block.  Term::eval(x, c, params) is the per-coordinate term; FOLD is VS_OBJ_LINEAR
 // (sum) or anything else (product).  `tot` is this block's LDS slab [2][W][64].
 // FUSED = false: stores the 2k+2 values (planar f-values, non-temporal); FUSED = true: adds the
@@ -166,6 +191,12 @@ __device__ __forceinline__ void vs_head_store(const vs_scan_acc<L, W>& acc, int 
 #define VS_GT_PITCH 68
 #define VS_GT_ROWS(NBH) (32 * (NBH) + 2)
 #define VS_GT_DOUBLES(NBH) (VS_GT_ROWS(NBH) * VS_GT_PITCH)
+// with up to LMAX outputs: two rows (a_o, b_o) per output behind the index rows
+#define VS_GT_DOUBLES_M(NBH, LMAX) ((32 * (NBH) + 2 * (LMAX)) * VS_GT_PITCH)
+// LDS doubles of those kernels: totals slabs (one; two with several outputs), the tile, the outputs' variance shifts and
+// head sums
+#define VS_GT_LDS_DOUBLES(W, NBH, LMAX) \
+    (((LMAX) > 1 ? 2 : 1) * 2 * (W) * VS_EVAL_ROWS + VS_GT_DOUBLES_M(NBH, LMAX) + ((LMAX) > 1 ? 6 * (LMAX) : 0))
 typedef double vs_d2 __attribute__((ext_vector_type(2)));
 typedef double vs_d4 __attribute__((ext_vector_type(4)));
 
@@ -178,13 +209,16 @@ struct vs_gram_regs {
     double pa, pb;
 };
 
+// abrow: tile row (behind the 2 HALF index rows) of the a the lane's index row belongs to (b one row further): 0 with
+// one output; with several, 2 x the output of index row m = column * l + output -- a per-lane row (see vs_gram_abrow)
 template <int NBH>
-__device__ __forceinline__ void vs_gram_consume(const double* __restrict__ tile, int q, int lane, vs_gram_regs& G) {
+__device__ __forceinline__ void vs_gram_consume(const double* __restrict__ tile, int q, int lane, vs_gram_regs& G,
+                                                int abrow = 0) {
     constexpr int P = VS_GT_PITCH, HALF = 16 * NBH;
     const int part = q >> 1, odd = q & 1;
     const double* base = tile + (size_t)(part * HALF + (lane & 15)) * P + 2 * (lane >> 4);   // block 0 of S or of T
     const double* rx = base + (NBH == 2 ? 16 * odd * P : 0);                                  // the wave's own block
-    const double* rab = tile + (size_t)(2 * HALF) * P + 2 * (lane >> 4);                      // a; b one row further
+    const double* rab = tile + (size_t)(2 * HALF + abrow) * P + 2 * (lane >> 4);              // a; b one row further
     // eight quarters of 8 samples: lane group g = lane >> 4 holds samples 8 h + 2 g, + 1 of its index row
     auto diag = [&](int h) {
         const vs_d2 x = *(const vs_d2*)(rx + 8 * h);
@@ -214,16 +248,19 @@ __device__ __forceinline__ void vs_gram_consume(const double* __restrict__ tile,
 
 // End of the kernel: the workgroup's Gram partial [S S^T, T T^T][16 NBH][16 NBH] (upper 16-blocks; the layout
 // gram_fold_kernel reads with st = 2) and its first-order record (layout of reduce_first_kernel's partials).
-// `lds`: at least 2 * 256 + 128 + 8 doubles, free by now; `acc`: the head sums sab, sa, sb, s1, s2 (vs_scan_acc).
+// `lds`: at least 2 * 256 + 128 + 8 doubles, free by now; `acc`: the head sums sab, sa, sb, s1, s2 (vs_scan_acc) of the
+// one output.  l outputs: index row m = column * l + output; rec holds l records of 5 + 4k.
+// heads: null with one output (the sums are in `acc`), else the LDS sums of vs_head_add_lds
 template <int NBH, int L>
 __device__ __forceinline__ void vs_gram_epilogue(double* __restrict__ lds, int q, int lane, vs_gram_regs& G,
-                                                 const vs_scan_acc<L, 4>& acc, int k, double* __restrict__ gout,
-                                                 double* __restrict__ rec) {
+                                                 const vs_scan_acc<L, 4>& acc, const double* __restrict__ heads, int k, int l,
+                                                 double* __restrict__ gout, double* __restrict__ rec) {
     constexpr int SB = 16 * NBH;
     const int part = q >> 1, odd = q & 1;
     double* red2 = lds;               // [part][16][16]: the odd waves' share of a tile the even waves store
     double* dots = lds + 512;         // [wave][16 rows][a, b]
-    double* hd = lds + 512 + 128;     // the five head sums
+    double* hdl = lds + 512 + 128;    // the five head sums (one output)
+    const double* hd = heads ? heads : hdl;
     G.pa += __shfl_xor(G.pa, 16, 64);
     G.pa += __shfl_xor(G.pa, 32, 64);
     G.pb += __shfl_xor(G.pb, 16, 64);
@@ -238,7 +275,7 @@ __device__ __forceinline__ void vs_gram_epilogue(double* __restrict__ lds, int q
 #pragma unroll
         for (int v = 0; v < 4; ++v) red2[part * 256 + ((lane >> 4) + 4 * v) * 16 + (lane & 15)] = share[v];
     }
-    vs_head_store(acc, q, lane, hd);
+    if (!heads) vs_head_store(acc, q, lane, hdl);
     __syncthreads();
     double* o = gout + (size_t)part * SB * SB;
 #pragma unroll
@@ -253,10 +290,12 @@ __device__ __forceinline__ void vs_gram_epilogue(double* __restrict__ lds, int q
     }
     // record: head, ac[k], bd[k], ad[k], bc[k] with a.c = (a.s + a.t) / 2, a.d = (a.s - a.t) / 2
     const size_t plen = 5 + 4 * (size_t)k;
-    for (size_t e = threadIdx.x; e < plen; e += 256) {
-        double v = hd[e < 5 ? e : 0];
+    for (size_t ee = threadIdx.x; ee < plen * l; ee += 256) {
+        const int out = (int)(ee / plen);
+        const size_t e = ee - out * plen;
+        double v = hd[5 * out + (e < 5 ? e : 0)];
         if (e >= 5) {
-            const int slot = (int)((e - 5) / k), j = (int)((e - 5) % k);
+            const int slot = (int)((e - 5) / k), j = (int)((e - 5) % k) * l + out;   // j: the index row
             const int which = (slot == 0 || slot == 2) ? 0 : 1;
             double xs, xt;
             if (NBH == 2) {   // s row j: wave j >> 4, t row j: wave 2 + (j >> 4)
@@ -268,7 +307,7 @@ __device__ __forceinline__ void vs_gram_epilogue(double* __restrict__ lds, int q
             }
             v = (slot == 0 || slot == 3) ? 0.5 * (xs + xt) : 0.5 * (xs - xt);
         }
-        rec[e] = v;
+        rec[ee] = v;
     }
 }
 
@@ -292,19 +331,38 @@ struct vs_gramn_regs {
 // (All fragments a quarter ahead -- 88 VGPRs of fragments at NB = 8 -- spilled inside the MFMA section.)
 struct vs_gramn_afrags {
     vs_d2 as, at, av, bv;
+    vs_d2 avt, bvt;   // several outputs: a, b of the T rows' outputs (av, bv: of the S rows')
 };
 
 // NBL <= NB: live 16-row blocks (ceil(k / 16)); tiles with a block row or column from NBL on are all zeros and are
 // left out at compile time (the waves' tile counts then differ by at most one or two: k = 96: 6, 5, 5, 5, 5, 5, 5, 6)
-template <int R, int NB, int NBL>
-__device__ __forceinline__ void vs_gramn_consume_row(const double* __restrict__ tile, int lane, vs_gramn_regs<NB>& G) {
+// MULTI: several outputs -- the a, b a lane's index row meets are those of the row's output: tile rows abs (S rows of
+// block R) and abt (T rows of block NB-1-R) behind the 2 HALF index rows, per lane (vs_gram_abrow)
+// (NB = 8 takes 2 or 4 outputs only: the output of a row then repeats every 16 rows, abs == abt, and one pair of
+// fragments serves both -- with two pairs the nine-tile body no longer fits its 256 registers)
+template <int R, int NB, int NBL, bool MULTI = false>
+__device__ __forceinline__ void vs_gramn_consume_row(const double* __restrict__ tile, int lane, vs_gramn_regs<NB>& G,
+                                                     int abs = 0, int abt = 0) {
+    constexpr bool TWO = MULTI && NB < 8;   // separate a, b fragments for the T rows
     constexpr int P = VS_GT_PITCH, TR = NB - 1 - R, HALF = 16 * NB;
     constexpr bool S_LIVE = R < NBL, T_LIVE = TR < NBL;
     const double* base = tile + (size_t)(lane & 15) * P + 2 * (lane >> 4);   // S block 0; T block 0 is HALF rows further
-    const double* rab = tile + (size_t)(2 * HALF) * P + 2 * (lane >> 4);
+    // MULTI: an offset of zero the compiler cannot see through, different text in every block row's body: otherwise the
+    // a, b fragments of the first quarter -- the same addresses in all NB bodies -- are hoisted above the dispatch on
+    // the wave index and one of them is carried through it in scratch (the nine-tile body has no register to spare)
+    int zero = 0;
+    if (MULTI) asm("; block row %1" : "+s"(zero) : "n"(R));
+    const double* rab = tile + (size_t)(2 * HALF + (MULTI ? abs : 0)) * P + 2 * (lane >> 4) + zero;
+    const double* rabt = tile + (size_t)(2 * HALF + (MULTI ? abt : 0)) * P + 2 * (lane >> 4) + zero;
     auto load_a = [&](int h, vs_gramn_afrags& F) {
-        F.av = *(const vs_d2*)(rab + 8 * h);
-        F.bv = *(const vs_d2*)(rab + P + 8 * h);
+        if (!TWO || S_LIVE) {
+            F.av = *(const vs_d2*)(rab + 8 * h);
+            F.bv = *(const vs_d2*)(rab + P + 8 * h);
+        }
+        if (TWO && T_LIVE) {
+            F.avt = *(const vs_d2*)(rabt + 8 * h);
+            F.bvt = *(const vs_d2*)(rabt + P + 8 * h);
+        }
         if (S_LIVE) F.as = *(const vs_d2*)(base + (size_t)(16 * R) * P + 8 * h);
         if (T_LIVE) F.at = *(const vs_d2*)(base + (size_t)(HALF + 16 * TR) * P + 8 * h);
     };
@@ -337,10 +395,11 @@ __device__ __forceinline__ void vs_gramn_consume_row(const double* __restrict__ 
             G.pbs = fma(A.bv[1], A.as[1], G.pbs);
         }
         if (T_LIVE) {
-            G.pat = fma(A.av[0], A.at[0], G.pat);
-            G.pbt = fma(A.bv[0], A.at[0], G.pbt);
-            G.pat = fma(A.av[1], A.at[1], G.pat);
-            G.pbt = fma(A.bv[1], A.at[1], G.pbt);
+            const vs_d2 ta_ = TWO ? A.avt : A.av, tb_ = TWO ? A.bvt : A.bv;
+            G.pat = fma(ta_[0], A.at[0], G.pat);
+            G.pbt = fma(tb_[0], A.at[0], G.pbt);
+            G.pat = fma(ta_[1], A.at[1], G.pat);
+            G.pbt = fma(tb_[1], A.at[1], G.pbt);
         }
 #pragma unroll
         for (int sl = 1; sl < NB - R; ++sl) {
@@ -390,21 +449,26 @@ __device__ __forceinline__ void vs_gramn_store_row(double* __restrict__ gout, in
         default: CALL((NB > 4 ? 7 : 0)); break; \
     }
 
-template <int NB, int NBL>
-__device__ __forceinline__ void vs_gramn_consume(const double* __restrict__ tile, int q, int lane, vs_gramn_regs<NB>& G) {
-#define VS_GRAMN_CONSUME(RR) vs_gramn_consume_row<RR, NB, NBL>(tile, lane, G)
+template <int NB, int NBL, bool MULTI = false>
+__device__ __forceinline__ void vs_gramn_consume(const double* __restrict__ tile, int q, int lane, vs_gramn_regs<NB>& G,
+                                                 int abs = 0, int abt = 0) {
+#define VS_GRAMN_CONSUME(RR) vs_gramn_consume_row<RR, NB, NBL, MULTI>(tile, lane, G, abs, abt)
     VS_GRAMN_DISPATCH(VS_GRAMN_CONSUME)
 #undef VS_GRAMN_CONSUME
 }
 
-// `lds`: at least 4 * 16 NB + 8 doubles, free by now
+// tile row offset (behind the index rows) of the a that index row m = column * l + output meets: 2 x output
+__device__ __forceinline__ int vs_gram_abrow(int m, int l) { return 2 * (m % l); }
+
+// `lds`: at least 4 * 16 NB + 8 doubles, free by now; l outputs: index row m = column * l + output, l records
 template <int NB, int L>
 __device__ __forceinline__ void vs_gramn_epilogue(double* __restrict__ lds, int q, int lane, int nbl, vs_gramn_regs<NB>& G,
-                                                  const vs_scan_acc<L, NB>& acc, int k, double* __restrict__ gout,
-                                                  double* __restrict__ rec) {
+                                                  const vs_scan_acc<L, NB>& acc, const double* __restrict__ heads, int k,
+                                                  int l, double* __restrict__ gout, double* __restrict__ rec) {
     constexpr int HALF = 16 * NB;
     double* dots = lds;          // [s rows 0..HALF-1, t rows 0..HALF-1][a, b]
-    double* hd = lds + 4 * HALF;
+    double* hdl = lds + 4 * HALF;
+    const double* hd = heads ? heads : hdl;
     G.pas += __shfl_xor(G.pas, 16, 64);
     G.pas += __shfl_xor(G.pas, 32, 64);
     G.pbs += __shfl_xor(G.pbs, 16, 64);
@@ -420,21 +484,23 @@ __device__ __forceinline__ void vs_gramn_epilogue(double* __restrict__ lds, int 
         dots[(HALF + 16 * (NB - 1 - q) + lane) * 2 + 0] = G.pat;
         dots[(HALF + 16 * (NB - 1 - q) + lane) * 2 + 1] = G.pbt;
     }
-    vs_head_store(acc, q, lane, hd);
+    if (!heads) vs_head_store(acc, q, lane, hdl);
     __syncthreads();
 #define VS_GRAMN_STORE(RR) vs_gramn_store_row<RR, NB>(gout, lane, nbl, G)
     VS_GRAMN_DISPATCH(VS_GRAMN_STORE)
 #undef VS_GRAMN_STORE
     const size_t plen = 5 + 4 * (size_t)k;
-    for (size_t e = threadIdx.x; e < plen; e += 64 * NB) {
-        double v = hd[e < 5 ? e : 0];
+    for (size_t ee = threadIdx.x; ee < plen * l; ee += 64 * NB) {
+        const int out = (int)(ee / plen);
+        const size_t e = ee - out * plen;
+        double v = hd[5 * out + (e < 5 ? e : 0)];
         if (e >= 5) {
-            const int slot = (int)((e - 5) / k), j = (int)((e - 5) % k);
+            const int slot = (int)((e - 5) / k), j = (int)((e - 5) % k) * l + out;   // j: the index row
             const int which = (slot == 0 || slot == 2) ? 0 : 1;
             const double xs = dots[j * 2 + which], xt = dots[(HALF + j) * 2 + which];
             v = (slot == 0 || slot == 3) ? 0.5 * (xs + xt) : 0.5 * (xs - xt);
         }
-        rec[e] = v;
+        rec[ee] = v;
     }
 }
 
@@ -443,12 +509,15 @@ __device__ __forceinline__ void vs_gramn_epilogue(double* __restrict__ lds, int 
 // NBH > 0 (FUSED): the outputs go into the Gram tile `gt` (tile + lane) instead of the 4L register sums.
 // SLDS > 0 (FUSED): the 4 sums of the wave's LAST SLDS columns live in its LDS slab `sl` ([4 SLDS][64] + lane)
 // instead of registers (see vs_scan_body).
-template <int FOLD, int L, int W, bool FUSED, bool TLDS, int NBH = 0, int SLDS = 0>
+// Several outputs in the Gram tile (NBH > 0, HOUT >= 0 = the output): column i of this output is index row i * rmul + radd
+// (rmul = l, radd = output), its a, b go to rows abrow, abrow + 1 behind the index rows, its head sums to LDS (`heads`).
+template <int FOLD, int L, int W, bool FUSED, bool TLDS, int NBH = 0, int SLDS = 0, int HOUT = -1>
 __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L], const double (&tb)[TLDS ? 1 : L],
                                                const double* __restrict__ tl, double Ta, double Tb,
                                                double* __restrict__ tot, int q, int lane, double* __restrict__ f,
                                                vs_u64 rows, int k, bool valid, double shift, vs_scan_acc<L, W>& acc,
-                                               double* __restrict__ gt = nullptr, double* __restrict__ sl = nullptr) {
+                                               double* __restrict__ gt = nullptr, double* __restrict__ sl = nullptr,
+                                               int rmul = 1, int radd = 0, int abrow = 0, double* __restrict__ heads = nullptr) {
     constexpr int T = VS_EVAL_ROWS;
     constexpr int SUB = L < VS_SCAN_SUB ? L : VS_SCAN_SUB;
     constexpr int NSUB = L / SUB;
@@ -534,8 +603,9 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
             pb = vs_fold<FOLD>(pb, ub[j]);
             if (NBH > 0) {
                 if (i < k) {  // rows past the block's last design row are zeros in the tile
-                    gt[(size_t)i * VS_GT_PITCH] = valid ? cj + dj : 0.0;
-                    gt[(size_t)(16 * NBH + i) * VS_GT_PITCH] = valid ? cj - dj : 0.0;
+                    const int m = i * rmul + radd;
+                    gt[(size_t)m * VS_GT_PITCH] = valid ? cj + dj : 0.0;
+                    gt[(size_t)(16 * NBH + m) * VS_GT_PITCH] = valid ? cj - dj : 0.0;
                 }
             } else if (FUSED) {
                 if (valid) {  // columns beyond k hold the identity; their sums are dropped at the end
@@ -564,27 +634,73 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
         // one sub-block's suffixes alive at a time.  Also in the fused first-order kernel: left alone the scheduler
         // forms every c_j, d_j of the segment first and multiplies afterwards, with all of them alive beside the 4 L sums
         // (18 of the 30 spilled dwords of the 8 x 4 kernel came from that).
-        if ((!FUSED && L >= 16) || (FUSED && NBH == 0)) __builtin_amdgcn_sched_barrier(0);
+        if ((!FUSED && L >= 16) || (FUSED && (NBH == 0 || HOUT >= 0))) __builtin_amdgcn_sched_barrier(0);
     }
 #undef VS_TA
 #undef VS_TB
     if (NBH > 0 && q == 0) {
-        gt[(size_t)(32 * NBH) * VS_GT_PITCH] = valid ? a : 0.0;
-        gt[(size_t)(32 * NBH + 1) * VS_GT_PITCH] = valid ? b : 0.0;
+        gt[(size_t)(32 * NBH + abrow) * VS_GT_PITCH] = valid ? a : 0.0;
+        gt[(size_t)(32 * NBH + abrow + 1) * VS_GT_PITCH] = valid ? b : 0.0;
     }
-    if (FUSED && valid) vs_head_add(acc, q, a, b, shift);
+    if constexpr (HOUT >= 0) vs_head_add_lds<HOUT, W>(heads, q, lane, valid, a, b, shift);
+    else if (FUSED && valid) vs_head_add(acc, q, a, b, shift);
+}
+
+// The outputs of the fused both-orders kernels with several outputs, one after the other from the coordinates xa, xb of
+// the wave's L columns (O is a compile-time fact: head sums, totals slab and tile rows are static), guarded by the
+// wave-uniform O < l.  The two totals slabs alternate per output, one barrier each -- a wave reaches output O + 2
+// only behind the barrier of O + 1, which every wave passes after it has read the totals of O.
+template <int O, class Term, int FOLD, int L, int W, int NBH, int LMAX>
+__device__ __forceinline__ void vs_scan_gram_outputs(const vs_eval_args& A, const double* __restrict__ params, int q, int lane,
+                                                     double* __restrict__ tot, vs_u64 rows, int k, int lk, bool valid,
+                                                     const double (&xa)[L], const double (&xb)[L],
+                                                     double* __restrict__ shifts, vs_scan_acc<L, W>& acc,
+                                                     double* __restrict__ gt) {
+    if constexpr (O < LMAX) {
+        constexpr int T = VS_EVAL_ROWS;
+        if (O < A.l) {
+            const double ident = FOLD == VS_OBJ_LINEAR ? 0.0 : 1.0;
+            const double* po = params + (size_t)O * k;
+            double ua[L], ub[L];
+            double Ta = ident, Tb = ident;
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                const int c = VS_SCAN_COLUMN(q, j, W);
+                ua[j] = ub[j] = ident;
+                if (c < k) {
+                    const double pre = Term::pre(c, po), pre2 = Term::pre2(c, po, lk);
+                    ua[j] = Term::eval(xa[j], c, po, pre, pre2);
+                    ub[j] = Term::eval(xb[j], c, po, pre, pre2);
+                }
+                Ta = vs_fold<FOLD>(Ta, ua[j]);
+                Tb = vs_fold<FOLD>(Tb, ub[j]);
+            }
+            // shifts: LDS, [LMAX] variance shifts, then the [5 LMAX] head sums
+            vs_scan_finish<FOLD, L, W, true, false, NBH, 0, O>(
+                ua, ub, nullptr, Ta, Tb, tot + (O & 1) * (2 * W * T), q, lane, nullptr, rows, k, valid, shifts[O], acc, gt,
+                nullptr, A.l, O, 2 * O, shifts + LMAX);
+            // ends the compiler's search for stores that might clobber the design constants loaded further down (see
+            // the zeroing of the sums' slab in vs_scan_body): no instruction
+            __builtin_amdgcn_wave_barrier();
+        }
+        vs_scan_gram_outputs<O + 1, Term, FOLD, L, W, NBH, LMAX>(A, params, q, lane, tot, rows, k, lk, valid, xa, xb, shifts, acc,
+                                                                gt);
+    }
 }
 
 // One 64-row block.  MULTI (evaluation only, l > 1): the scaled coordinates of the segment stay in
 // registers and every output o builds its own terms from them (parameters params + o*k, plane o of
 // the f-values; the two totals slabs alternate per output, one barrier each) -- the generator runs
 // once per row whatever l is.  Otherwise one output (`params`, `fplane` are that output's).
-template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV, int NBH = 0, int SLDS = 0>
+// MULTI with NBH > 0 (the fused both-orders kernels, up to LMAX outputs): every output's s, t rows go into the one
+// Gram tile (index row = column * l + output), its a, b into their own two tile rows; `shifts`: LMAX variance shifts.
+template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV, int NBH = 0, int SLDS = 0,
+          int LMAX = 1>
 __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const double* __restrict__ params,
                                               int q, int lane, vs_u64 rb, double* __restrict__ tot,
                                               double* __restrict__ tl, double* __restrict__ fplane, double shift,
                                               vs_scan_acc<L, W>& acc, double* __restrict__ gt = nullptr,
-                                              double* __restrict__ sl = nullptr) {
+                                              double* __restrict__ sl = nullptr, double* __restrict__ shifts = nullptr) {
     constexpr int T = VS_EVAL_ROWS;
     // q is loop-invariant in the persistent walk; tied to the block index here, or the optimiser hoists
     // every column's addresses and masks (all derived from q) out of that loop and spills scalars for
@@ -684,6 +800,8 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
             }
         }
 #endif
+    } else if constexpr (NBH > 0) {
+        vs_scan_gram_outputs<0, Term, FOLD, L, W, NBH, LMAX>(A, params, q, lane, tot, rows, k, lk, valid, ta, tb, shifts, acc, gt);
     } else {
         const vs_u64 plane = (2 * (vs_u64)k + 2) * rows;
         for (int o = 0; o < A.l; ++o) {
@@ -802,58 +920,80 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
 // the tile of block n + 1 only behind that block's first barrier, which every wave reaches after its MFMAs of block n;
 // one totals slab for the same reason).  LDS: [2][4][64] totals, then the tile.
 // Partials: first_partials[blockIdx.x][5 + 4k], gram_partials[blockIdx.x][2][16 NBH][16 NBH].
-template <class Term, int FOLD, int L, int NBH, int GENV>
+// LMAX > 1: the instance for 2 .. LMAX outputs (A.l of them; k l <= 16 NBH index rows, m = column * l + output): the
+// generator runs once per row, every output builds its terms from the same coordinates and writes its rows into the one
+// tile, a_o and b_o into rows of their own behind the index rows; a lane's first-order dot products take the a, b of
+// its index row's output.  LDS: totals [slabs][2][4][64] (one slab; two with several outputs), then the tile
+// [32 NBH + 2 LMAX][68].  Partials: first_partials[blockIdx.x][l][5 + 4k], gram_partials as before (16 NBH >= k l).
+template <class Term, int FOLD, int L, int NBH, int GENV, int LMAX = 1>
 __device__ __forceinline__ void vs_scan_gram_body(const vs_eval_args& A, double* __restrict__ lds,
                                                   const double* __restrict__ shift_src,
                                                   double* __restrict__ first_partials,
                                                   double* __restrict__ gram_partials) {
     constexpr int T = VS_EVAL_ROWS, W = 4;
+    constexpr bool MULTI = LMAX > 1;
     static_assert(NBH == 1 || NBH == 2, "16 or 32 index rows per half");
-    static_assert(L * W >= 16 * NBH || L * W >= 8, "columns");
-    const int k = A.D.k;
+    static_assert(L * W >= 16 * NBH || L * W >= 8 || MULTI, "columns");
+    const int k = A.D.k, l = MULTI ? A.l : 1;
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* tile = lds + 2 * W * T;
-    for (int e = threadIdx.x; e < VS_GT_DOUBLES(NBH); e += W * T) tile[e] = 0.0;   // rows k .. 16 NBH - 1 stay zero
-    const double shift = shift_src[0];
+    double* tile = lds + (MULTI ? 2 : 1) * 2 * W * T;
+    for (int e = threadIdx.x; e < VS_GT_DOUBLES_M(NBH, LMAX); e += W * T) tile[e] = 0.0;   // rows k l .. 16 NBH - 1 stay zero
+    // the outputs' variance shifts: one scalar register pair with one output; with several, LDS behind the tile (LMAX
+    // pairs of scalar registers between the blocks were more than the kernel has), and behind them the head sums
+    double* shifts = tile + VS_GT_DOUBLES_M(NBH, LMAX);
+    if (MULTI && (int)threadIdx.x < LMAX) shifts[threadIdx.x] = (int)threadIdx.x < l ? shift_src[(size_t)threadIdx.x * (2 * (size_t)k + 2)] : 0.0;
+    if (MULTI && (int)threadIdx.x < 5 * LMAX) shifts[LMAX + threadIdx.x] = 0.0;
+    const double shift0 = shift_src[0];
     vs_scan_acc<L, W> acc;
 #pragma unroll
     for (int z = 0; z < VS_HEAD_SLOTS(W); ++z) acc.h[z] = 0.0;
     vs_gram_regs G;
     G.d = G.o = (vs_d4){0.0, 0.0, 0.0, 0.0};
     G.pa = G.pb = 0.0;
+    // the wave's index rows: block (q & 1) of its half at NBH = 2, block 0 at NBH = 1
+    const int abrow = MULTI ? vs_gram_abrow((NBH == 2 ? 16 * (q & 1) : 0) + (lane & 15), l) : 0;
     __syncthreads();
     const vs_u64 nblocks = (A.rows + T - 1) / T;
     for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-        vs_scan_block<Term, FOLD, L, W, true, false, false, GENV, NBH>(A, A.params, q, lane, rb, lds, nullptr, nullptr,
-                                                                       shift, acc, tile + lane);
+        vs_scan_block<Term, FOLD, L, W, true, false, MULTI, GENV, NBH, 0, LMAX>(A, A.params, q, lane, rb, lds, nullptr,
+                                                                                nullptr, shift0, acc, tile + lane,
+                                                                                nullptr, shifts);
         __syncthreads();
-        vs_gram_consume<NBH>(tile, q, lane, G);
+        vs_gram_consume<NBH>(tile, q, lane, G, abrow);
     }
-    vs_gram_epilogue<NBH>(tile, q, lane, G, acc, k, gram_partials + (size_t)blockIdx.x * 2 * (16 * NBH) * (16 * NBH),
-                          first_partials + (size_t)blockIdx.x * (5 + 4 * (size_t)k));
+    vs_gram_epilogue<NBH>(tile, q, lane, G, acc, MULTI ? shifts + LMAX : nullptr, k, l, gram_partials + (size_t)blockIdx.x * 2 * (16 * NBH) * (16 * NBH),
+                          first_partials + (size_t)blockIdx.x * l * (5 + 4 * (size_t)k));
 }
 
 // Beyond 32 columns: NB waves x 16 columns (see vs_gramn_consume_row).
 // Partials: first_partials[blockIdx.x][5 + 4k], gram_partials[blockIdx.x][2][16 NB][16 NB].
-template <class Term, int FOLD, int GENV, int NB, int NBL>
+// LMAX > 1: the instance for 2 .. LMAX outputs (see vs_scan_gram_body): NB waves x 8 columns (k <= 8 NB: at least two
+// outputs share the 16 NB index rows), NBL = ceil(k l / 16) live blocks.
+template <class Term, int FOLD, int GENV, int NB, int NBL, int LMAX = 1>
 __device__ __forceinline__ void vs_scan_gramn_body(const vs_eval_args& A, double* __restrict__ lds,
                                                    const double* __restrict__ shift_src,
                                                    double* __restrict__ first_partials,
                                                    double* __restrict__ gram_partials) {
-    constexpr int T = VS_EVAL_ROWS, W = NB, L = 16, NBH = NB;
+    constexpr bool MULTI = LMAX > 1;
+    constexpr int T = VS_EVAL_ROWS, W = NB, L = MULTI ? 8 : 16, NBH = NB;
     static_assert(NB == 4 || NB == 8, "64 or 128 index rows per half");
     static_assert(NBL > NB / 2 && NBL <= NB, "live blocks");
-    const int k = A.D.k;
-    const int nbl = NBL;   // = ceil(k / 16), the host's choice of instance
+    const int k = A.D.k, l = MULTI ? A.l : 1;
+    const int nbl = NBL;   // = ceil(k l / 16), the host's choice of instance
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* tile = lds + 2 * W * T;
-    for (int e = threadIdx.x; e < VS_GT_DOUBLES(NBH); e += W * T) tile[e] = 0.0;   // rows k .. 16 NB - 1 stay zero
-    const double shift = shift_src[0];
+    double* tile = lds + (MULTI ? 2 : 1) * 2 * W * T;
+    for (int e = threadIdx.x; e < VS_GT_DOUBLES_M(NBH, LMAX); e += W * T) tile[e] = 0.0;   // rows k l .. 16 NB - 1 stay zero
+    double* shifts = tile + VS_GT_DOUBLES_M(NBH, LMAX);   // shifts and head sums: see vs_scan_gram_body
+    if (MULTI && (int)threadIdx.x < LMAX) shifts[threadIdx.x] = (int)threadIdx.x < l ? shift_src[(size_t)threadIdx.x * (2 * (size_t)k + 2)] : 0.0;
+    if (MULTI && (int)threadIdx.x < 5 * LMAX) shifts[LMAX + threadIdx.x] = 0.0;
+    const double shift0 = shift_src[0];
     vs_scan_acc<L, W> acc;
 #pragma unroll
     for (int z = 0; z < VS_HEAD_SLOTS(W); ++z) acc.h[z] = 0.0;
+    const int abs = MULTI ? vs_gram_abrow(16 * q + (lane & 15), l) : 0;              // S rows of block q
+    const int abt = MULTI ? vs_gram_abrow(16 * (NB - 1 - q) + (lane & 15), l) : 0;   // T rows of block NB-1-q
     vs_gramn_regs<NB> G;
 #pragma unroll
     for (int i = 0; i < NB + 1; ++i) G.acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
@@ -861,13 +1001,14 @@ __device__ __forceinline__ void vs_scan_gramn_body(const vs_eval_args& A, double
     __syncthreads();
     const vs_u64 nblocks = (A.rows + T - 1) / T;
     for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-        vs_scan_block<Term, FOLD, L, W, true, false, false, GENV, NBH>(A, A.params, q, lane, rb, lds, nullptr, nullptr,
-                                                                       shift, acc, tile + lane);
+        vs_scan_block<Term, FOLD, L, W, true, false, MULTI, GENV, NBH, 0, LMAX>(A, A.params, q, lane, rb, lds, nullptr,
+                                                                                nullptr, shift0, acc, tile + lane,
+                                                                                nullptr, shifts);
         __syncthreads();
-        vs_gramn_consume<NB, NBL>(tile, q, lane, G);
+        vs_gramn_consume<NB, NBL, MULTI>(tile, q, lane, G, abs, abt);
     }
-    vs_gramn_epilogue<NB>(tile, q, lane, nbl, G, acc, k, gram_partials + (size_t)blockIdx.x * 2 * (16 * NB) * (16 * NB),
-                          first_partials + (size_t)blockIdx.x * (5 + 4 * (size_t)k));
+    vs_gramn_epilogue<NB>(tile, q, lane, nbl, G, acc, MULTI ? shifts + LMAX : nullptr, k, l, gram_partials + (size_t)blockIdx.x * 2 * (16 * NB) * (16 * NB),
+                          first_partials + (size_t)blockIdx.x * l * (5 + 4 * (size_t)k));
 }
 
 #endif  // VS_DEVICE_SCAN_H

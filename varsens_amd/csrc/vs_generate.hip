@@ -204,33 +204,14 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
     VS_REQUIRE(ctx && desc && out, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     *out = nullptr;
+    // every check of the descriptor: vs_host.cpp (host only; the sanitizer leg of the CPU tests runs it)
+    uint64_t perm_count = 0;
+    {
+        const int bad = vs_design_desc_validate(desc, &perm_count);
+        if (bad) return bad;
+    }
     const int k = desc->k;
     const uint64_t n = desc->n;
-    VS_REQUIRE(k >= 1 && k <= 4096, "k=%d out of range [1,4096]", k);
-    VS_REQUIRE(n >= 1 && n <= 0xffffffffull, "n=%llu out of range [1,2^32)", (unsigned long long)n);
-    VS_REQUIRE(desc->generator >= VS_GEN_HALTON && desc->generator <= VS_GEN_RAW, "unknown generator %d",
-               desc->generator);
-    VS_REQUIRE(desc->scale_mode >= VS_SCALE_IDENTITY && desc->scale_mode <= VS_SCALE_POWER,
-               "unknown scale mode %d", desc->scale_mode);
-    if (desc->scale_mode != VS_SCALE_IDENTITY)
-        VS_REQUIRE(desc->lower && desc->upper, "lower/upper bounds are required for this scale mode");
-    if (desc->generator == VS_GEN_RAW) VS_REQUIRE(desc->raw, "raw points are required for VS_GEN_RAW");
-    if (desc->generator == VS_GEN_SOBOL) {
-        VS_REQUIRE(desc->sobol_directions, "direction numbers are required for VS_GEN_SOBOL");
-        VS_REQUIRE(desc->first_index + 2 * n <= (1ull << 32), "Sobol indices must stay below 2^32");
-    }
-    // the shuffle may be given for a slice of rows only (a rank's shard): perm_count entries from row perm_begin
-    const uint64_t perm_count = !desc->perm ? 0
-                                : desc->perm_count == VS_PERM_EMPTY ? 0   // a rank without rows: nothing is read
-                                : desc->perm_count ? desc->perm_count : n;
-    if (desc->perm) {
-        VS_REQUIRE(desc->perm_begin <= n && perm_count <= n - desc->perm_begin,
-                   "perm slice [%llu,+%llu) exceeds n=%llu", (unsigned long long)desc->perm_begin,
-                   (unsigned long long)perm_count, (unsigned long long)n);
-        for (uint64_t i = 0; i < perm_count; ++i)
-            VS_REQUIRE(desc->perm[i] < n, "perm[%llu]=%u is not a row of the second half",
-                       (unsigned long long)(desc->perm_begin + i), desc->perm[i]);
-    }
 
     VS_HIP(hipSetDevice(ctx->device));
     vs_design* g = new vs_design();
@@ -855,11 +836,30 @@ int vs_scan_gram8_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io,
                          double* first_partials, double* gram_partials, bool plan_only);
 int vs_scan_gram4_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                          double* first_partials, double* gram_partials, bool plan_only);
+// vs_scan_gram.hip -> vs_scan_gramm_*.hip: several outputs
+int vs_scan_gram_multi_lmax(int nb);
+int vs_scan_gram_multi_launch(vs_context* ctx, const vs_eval_args& A, int nb, unsigned* P_io, const double* shift_dev,
+                              double* first_partials, double* gram_partials, bool plan_only);
 
-// the fused both-orders kernels, one output: separable objectives in scan form with k <= 128 -- built-in
-// (vs_scan_gram.hip, vs_scan_gram4.hip, vs_scan_gram8*.hip) or compiled at run time --, and Ishigami
+// 16-row blocks per half of the fused both-orders kernel that takes K index rows
+static int fused_both_blocks(int K) { return K <= 16 ? 1 : K <= 32 ? 2 : K <= 64 ? 4 : 8; }
+
+// the fused both-orders kernels: separable objectives in scan form with k l <= 128 index rows -- built-in
+// (vs_scan_gram.hip, vs_scan_gram4.hip, vs_scan_gram8*.hip; several outputs: vs_scan_gramm_*.hip) or, with one output,
+// compiled at run time --, and Ishigami
 static fused_route fused_both_route(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
-    if (obj->l != 1 || obj->k != design->d.k) return FUSED_NONE;
+    if (obj->k != design->d.k) return FUSED_NONE;
+    if (obj->l != 1) {
+        // several outputs of a built-in separable objective: 2 .. 8 outputs (2 or 4 beyond 64 index rows -- the eight-wave
+        // kernel), identity or linear scaling
+        const long K = (long)obj->k * obj->l;
+        if (K > 128 || fused_route_for(ctx, design, obj) != FUSED_SCAN || design->d.scale_mode == VS_SCALE_POWER ||
+            ctx->tune.fused_both_wide == 0)
+            return FUSED_NONE;
+        const int nb = fused_both_blocks((int)K);
+        if (obj->l > vs_scan_gram_multi_lmax(nb) || (nb == 8 && 16 % obj->l != 0)) return FUSED_NONE;
+        return FUSED_SCAN;
+    }
     const fused_route r = fused_route_for(ctx, design, obj);
     if (r == FUSED_ISHIGAMI) return r;
     const bool wide_k = obj->k > 32 && obj->k <= 128;   // four or eight waves x 16 columns, compiled per count of live blocks
@@ -887,16 +887,18 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     VS_HIP(hipSetDevice(ctx->device));
     const fused_route route = fused_both_route(ctx, design, obj);
     if (route == FUSED_NONE)
-        return vs_fail(VS_ERR_ARG, "the fused both-orders path covers ISHIGAMI and G_FUNCTION / POLYNOMIAL / LINEAR / separable "
+        return vs_fail(VS_ERR_ARG, "the fused both-orders path covers ISHIGAMI, G_FUNCTION / POLYNOMIAL / LINEAR with k l <= 128 "
+                                   "(several outputs: 2 .. 8, 2 or 4 beyond 64 index rows, no power scaling) and separable "
                                    "source objectives with one output and k <= 128 (Halton indices below 2^32, scan evaluation "
                                    "order); use vs_eval + vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
-    const int k = obj->k;
-    const bool wide = route == FUSED_SCAN && k > 32;   // 33 .. 64 / 65 .. 128 columns: four / eight waves x 16 columns
-    const int nbh = k <= 16 ? 1 : k <= 32 ? 2 : k <= 64 ? 4 : 8, SB = 16 * nbh;   // (= obj->gram_sb of a source objective)
+    const int k = obj->k, l = obj->l, K = k * l;
+    const bool multi = l > 1;                          // (FUSED_SCAN only)
+    const bool wide = route == FUSED_SCAN && K > 32;   // 33 .. 64 / 65 .. 128 index rows: four / eight waves
+    const int nbh = fused_both_blocks(K), SB = 16 * nbh;   // (= obj->gram_sb of a source objective)
     vs_eval_args A;
     A.D = to_dev(design);
     A.kind = obj->kind;
-    A.l = 1;
+    A.l = l;
     A.params = obj->params;
     A.row_begin = row_begin;
     A.rows = row_count;
@@ -905,26 +907,29 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     int rc = VS_OK;
     if (route == FUSED_ISHIGAMI) P = vs_fused_ishigami_workgroups(ctx, row_count);
     else if (route == FUSED_USER) rc = vs_rtc_gram_plan(ctx, obj, row_count, &P);
+    else if (multi) rc = vs_scan_gram_multi_launch(ctx, A, nbh, &P, nullptr, nullptr, nullptr, true);
     else if (wide) rc = nbh == 8 ? vs_scan_gram8_launch(ctx, A, &P, nullptr, nullptr, nullptr, true)
                                  : vs_scan_gram4_launch(ctx, A, &P, nullptr, nullptr, nullptr, true);
     else rc = vs_scan_gram_launch(ctx, A, nbh, &P, nullptr, nullptr, nullptr, true);
     if (rc) return rc;
-    // workspace: [P][plen] first-order records + [plen] folded (vs_fold_partials' layout) + the f-values of one design
-    // row (the variance shift), then [P][2][SB][SB] Gram partials
-    const size_t plen = VS_PLEN(k), shift_stride = 2 * (size_t)k + 2;
-    size_t first_doubles = (size_t)P * plen + plen + shift_stride;
+    // workspace: [P][l][plen] first-order records + [l][plen] folded (vs_fold_partials' layout) + the f-values of one
+    // design row (the variance shifts: l planes of 2k+2), then [P][2][SB][SB] Gram partials
+    const size_t plen = VS_PLEN(k), width = (size_t)l * plen, shift_stride = 2 * (size_t)k + 2;
+    size_t first_doubles = (size_t)P * width + width + (size_t)l * shift_stride;
     first_doubles = (first_doubles + 1) & ~(size_t)1;
     const size_t gram_doubles = (size_t)P * 2 * SB * SB;
     rc = vs_workspace_partials(ctx, sizeof(double) * (first_doubles + gram_doubles));
     if (rc) return rc;
-    double* shift_buf = ctx->partials + (size_t)P * plen + plen;
+    double* shift_buf = ctx->partials + (size_t)P * width + width;
     double* gram_partials = ctx->partials + first_doubles;
-    rc = vs_eval(ctx, design, obj, row_begin, 1, shift_buf);   // f(M_1[row_begin]): a one-row evaluation
+    rc = vs_eval(ctx, design, obj, row_begin, 1, shift_buf);   // f_o(M_1[row_begin]): a one-row evaluation
     if (rc) return rc;
     if (route == FUSED_ISHIGAMI) {   // its kernel writes 3 x 3 entries of every 16 x 16 block; the fold reads only those
         rc = vs_fused_ishigami(ctx, A, P, shift_buf, gram_partials);
     } else if (route == FUSED_USER) {
         rc = vs_rtc_launch_gram(ctx, obj, &A, sizeof(A), P, shift_buf, ctx->partials, gram_partials);
+    } else if (multi) {
+        rc = vs_scan_gram_multi_launch(ctx, A, nbh, &P, shift_buf, ctx->partials, gram_partials, false);
     } else if (wide) {
         rc = nbh == 8 ? vs_scan_gram8_launch(ctx, A, &P, shift_buf, ctx->partials, gram_partials, false)
                       : vs_scan_gram4_launch(ctx, A, &P, shift_buf, ctx->partials, gram_partials, false);
@@ -932,9 +937,9 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
         rc = vs_scan_gram_launch(ctx, A, nbh, &P, shift_buf, ctx->partials, gram_partials, false);
     }
     if (rc) return rc;
-    rc = vs_fold_partials(ctx, P, k, 1, row_count, shift_buf, (int)shift_stride, nullptr, rank, max_ranks, acc_dev);
+    rc = vs_fold_partials(ctx, P, k, l, row_count, shift_buf, (int)shift_stride, nullptr, rank, max_ranks, acc_dev);
     if (rc) return rc;
-    return vs_gram_fold_st(ctx, gram_partials, P, k, SB, gram_dev);
+    return vs_gram_fold_st(ctx, gram_partials, P, K, SB, gram_dev);
 }
 
 extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,

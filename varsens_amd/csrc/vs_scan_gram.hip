@@ -18,3 +18,29 @@ int vs_scan_gram_launch(vs_context* ctx, const vs_eval_args& A, int nbh, unsigne
     }
     return vs_fail(VS_ERR_ARG, "objective kind %d is not separable", A.kind);
 }
+
+// ---- several outputs: vs_scan_gramm_g.hip, vs_scan_gramm_poly.hip, vs_scan_gramm_lin.hip
+int vs_scan_gram_multi_launch_g(vs_context* ctx, const vs_eval_args& A, int nb, unsigned* P_io, const double* shift_dev,
+                                double* first_partials, double* gram_partials, bool plan_only);
+int vs_scan_gram_multi_launch_poly(vs_context* ctx, const vs_eval_args& A, int nb, unsigned* P_io, const double* shift_dev,
+                                   double* first_partials, double* gram_partials, bool plan_only);
+int vs_scan_gram_multi_launch_lin(vs_context* ctx, const vs_eval_args& A, int nb, unsigned* P_io, const double* shift_dev,
+                                  double* first_partials, double* gram_partials, bool plan_only);
+
+int vs_scan_gram_multi_lmax(int nb) {
+    return nb == 8 ? VS_GRAM_LMAX_8 : (nb == 1 || nb == 2 || nb == 4) ? VS_GRAM_LMAX_SMALL : 0;
+}
+
+int vs_scan_gram_multi_launch(vs_context* ctx, const vs_eval_args& A, int nb, unsigned* P_io, const double* shift_dev,
+                              double* first_partials, double* gram_partials, bool plan_only) {
+    VS_REQUIRE(A.l >= 2 && A.l <= vs_scan_gram_multi_lmax(nb), "l=%d outputs do not fit the %d-block kernel", A.l, nb);
+    switch (A.kind) {
+        case VS_OBJ_G_FUNCTION:
+            return vs_scan_gram_multi_launch_g(ctx, A, nb, P_io, shift_dev, first_partials, gram_partials, plan_only);
+        case VS_OBJ_POLYNOMIAL:
+            return vs_scan_gram_multi_launch_poly(ctx, A, nb, P_io, shift_dev, first_partials, gram_partials, plan_only);
+        case VS_OBJ_LINEAR:
+            return vs_scan_gram_multi_launch_lin(ctx, A, nb, P_io, shift_dev, first_partials, gram_partials, plan_only);
+    }
+    return vs_fail(VS_ERR_ARG, "objective kind %d is not separable", A.kind);
+}

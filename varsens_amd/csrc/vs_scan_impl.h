@@ -34,6 +34,15 @@ int vs_scan_gram8_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io,
 int vs_scan_gram4_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                          double* first_partials, double* gram_partials, bool plan_only);
 
+// several outputs (2 .. lmax, k l <= 128) in the fused both-orders kernels: nb = 1, 2 (four waves, 16 / 32 index rows per
+// half), 4 (four waves, 64) in vs_scan_gramm.hip, 8 (eight waves, 128) in vs_scan_gramm8_*.hip; vs_scan_gram_multi_lmax:
+// the most outputs the instance of `nb` takes (0: none)
+int vs_scan_gram_multi_lmax(int nb);
+int vs_scan_gram_multi_launch(vs_context* ctx, const vs_eval_args& A, int nb, unsigned* P_io, const double* shift_dev,
+                              double* first_partials, double* gram_partials, bool plan_only);
+#define VS_GRAM_LMAX_SMALL 8   // nb = 1, 2, 4
+#define VS_GRAM_LMAX_8 4       // nb = 8: the 160 KiB of LDS hold the tile, two totals slabs and four (a, b) row pairs
+
 #ifdef VS_SCAN_KIND
 template <int KIND>
 struct builtin_term {
@@ -157,12 +166,12 @@ static int launch_scan_kind(vs_context* ctx, const vs_eval_args& A, scan_shape s
 }
 
 // ---- fused evaluate + both orders: four waves x L columns, tile of 16 NBH index rows per half (vs_device_scan.h)
-template <int KIND, int L, int NBH, int GENV>
+template <int KIND, int L, int NBH, int GENV, int LMAX = 1>
 __global__ void __launch_bounds__(VS_EVAL_ROWS * 4) __attribute__((amdgpu_waves_per_eu(4)))
 scan_gram_kernel(vs_eval_args A, const double* shift_src, double* first_partials, double* gram_partials,
                  uint32_t* counters) {
-    extern __shared__ double scan_lds[];   // [2][4][64] totals, then the tile [32 NBH + 2][68]
-    vs_scan_gram_body<builtin_term<KIND>, KIND, L, NBH, GENV>(A, scan_lds, shift_src, first_partials, gram_partials);
+    extern __shared__ double scan_lds[];   // [slabs][2][4][64] totals, then the tile [32 NBH + 2 LMAX][68]
+    vs_scan_gram_body<builtin_term<KIND>, KIND, L, NBH, GENV, LMAX>(A, scan_lds, shift_src, first_partials, gram_partials);
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // counters of the folds that follow, at the END (see scan_kernel)
         counters[0] = 0;
         counters[1] = 0xffffffffu;
@@ -172,11 +181,11 @@ scan_gram_kernel(vs_eval_args A, const double* shift_src, double* first_partials
     }
 }
 
-template <int KIND, int L, int NBH, int GENV>
+template <int KIND, int L, int NBH, int GENV, int LMAX = 1>
 static int launch_scan_gram_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                               double* first_partials, double* gram_partials, bool plan_only) {
-    const size_t lds = sizeof(double) * (2 * 4 * VS_EVAL_ROWS + VS_GT_DOUBLES(NBH));
-    const void* fn = (const void*)scan_gram_kernel<KIND, L, NBH, GENV>;
+    const size_t lds = sizeof(double) * VS_GT_LDS_DOUBLES(4, NBH, LMAX);
+    const void* fn = (const void*)scan_gram_kernel<KIND, L, NBH, GENV, LMAX>;
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     if (plan_only) {
         // twice the resident set (as the first-order fused kernels; 0.61 vs 0.65 ms at k = 32, n = 2^22) -- but every
@@ -188,22 +197,27 @@ static int launch_scan_gram_g(vs_context* ctx, const vs_eval_args& A, unsigned* 
     }
     {
         vs_launch_scope scope(ctx, VS_KERNEL_FUSED);
-        hipLaunchKernelGGL((scan_gram_kernel<KIND, L, NBH, GENV>), dim3(*P_io), dim3(VS_EVAL_ROWS * 4), lds, ctx->stream, A,
-                           shift_dev, first_partials, gram_partials, ctx->counters);
+        hipLaunchKernelGGL((scan_gram_kernel<KIND, L, NBH, GENV, LMAX>), dim3(*P_io), dim3(VS_EVAL_ROWS * 4), lds, ctx->stream,
+                           A, shift_dev, first_partials, gram_partials, ctx->counters);
     }
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
 
-template <int KIND, int L, int NBH>
+// several outputs: no instance with pow() (power scaling takes vs_eval + vs_reduce_first_second_order)
+template <int KIND, int L, int NBH, int LMAX = 1>
 static int launch_scan_gram_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                                double* first_partials, double* gram_partials, bool plan_only) {
     const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0;
 #define VS_GRAM_GENV(G) \
-    return launch_scan_gram_g<KIND, L, NBH, G>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
+    return launch_scan_gram_g<KIND, L, NBH, G, LMAX>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY) VS_GRAM_GENV(1);
     if (halton && A.D.scale_mode == VS_SCALE_LINEAR) VS_GRAM_GENV(2);
-    if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAM_GENV(3);
+    if constexpr (LMAX == 1) {
+        if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAM_GENV(3);
+    } else {
+        if (A.D.scale_mode == VS_SCALE_POWER) return vs_fail(VS_ERR_ARG, "no fused both-orders kernel for several outputs with power scaling");
+    }
     VS_GRAM_GENV(0);
 #undef VS_GRAM_GENV
 }
@@ -217,12 +231,12 @@ static int launch_scan_gram_kind(vs_context* ctx, const vs_eval_args& A, int nbh
 }
 
 // ---- beyond 32 columns: NB waves x 16 columns, tile of 16 NB index rows per half, 256 VGPRs (vs_scan_gramn_body)
-template <int KIND, int GENV, int NB, int NBL>
+template <int KIND, int GENV, int NB, int NBL, int LMAX = 1>
 __global__ void __launch_bounds__(VS_EVAL_ROWS * NB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 scan_gramn_kernel(vs_eval_args A, const double* shift_src, double* first_partials, double* gram_partials,
                   uint32_t* counters) {
-    extern __shared__ double scan_lds[];   // [2][NB][64] totals, then the tile [32 NB + 2][68]
-    vs_scan_gramn_body<builtin_term<KIND>, KIND, GENV, NB, NBL>(A, scan_lds, shift_src, first_partials, gram_partials);
+    extern __shared__ double scan_lds[];   // [slabs][2][NB][64] totals, then the tile [32 NB + 2 LMAX][68]
+    vs_scan_gramn_body<builtin_term<KIND>, KIND, GENV, NB, NBL, LMAX>(A, scan_lds, shift_src, first_partials, gram_partials);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         counters[0] = 0;
         counters[1] = 0xffffffffu;
@@ -232,12 +246,14 @@ scan_gramn_kernel(vs_eval_args A, const double* shift_src, double* first_partial
     }
 }
 
-template <int KIND, int GENV, int NB, int NBL>
+template <int KIND, int GENV, int NB, int NBL, int LMAX = 1>
 static int launch_scan_gramn_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                                double* first_partials, double* gram_partials, bool plan_only) {
-    // NB = 8: 148 544 B, one workgroup per CU; NB = 4: 74 816 B, two
-    const size_t lds = sizeof(double) * (2 * NB * VS_EVAL_ROWS + VS_GT_DOUBLES(NB));
-    const void* fn = (const void*)scan_gramn_kernel<KIND, GENV, NB, NBL>;
+    // one output: NB = 8: 148 544 B, one workgroup per CU; NB = 4: 74 816 B, two.  Several: a second totals slab and
+    // 2 (LMAX - 1) more tile rows (NB = 8, LMAX = 4: 160 032 B of the 163 840)
+    const size_t lds = sizeof(double) * VS_GT_LDS_DOUBLES(NB, NB, LMAX);
+    static_assert(sizeof(double) * VS_GT_LDS_DOUBLES(NB, NB, LMAX) <= 160 * 1024, "the tile does not fit the LDS of a CU");
+    const void* fn = (const void*)scan_gramn_kernel<KIND, GENV, NB, NBL, LMAX>;
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     if (plan_only) {
         const uint64_t cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
@@ -248,33 +264,37 @@ static int launch_scan_gramn_g(vs_context* ctx, const vs_eval_args& A, unsigned*
     VS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         vs_launch_scope scope(ctx, VS_KERNEL_FUSED);
-        hipLaunchKernelGGL((scan_gramn_kernel<KIND, GENV, NB, NBL>), dim3(*P_io), dim3(VS_EVAL_ROWS * NB), lds, ctx->stream, A,
-                           shift_dev, first_partials, gram_partials, ctx->counters);
+        hipLaunchKernelGGL((scan_gramn_kernel<KIND, GENV, NB, NBL, LMAX>), dim3(*P_io), dim3(VS_EVAL_ROWS * NB), lds,
+                           ctx->stream, A, shift_dev, first_partials, gram_partials, ctx->counters);
     }
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
 
-template <int KIND, int NB, int NBL>
+template <int KIND, int NB, int NBL, int LMAX = 1>
 static int launch_scan_gramn_nbl(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                                  double* first_partials, double* gram_partials, bool plan_only) {
     const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0;
 #define VS_GRAMN_GENV(G) \
-    return launch_scan_gramn_g<KIND, G, NB, NBL>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
+    return launch_scan_gramn_g<KIND, G, NB, NBL, LMAX>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY) VS_GRAMN_GENV(1);
     if (halton && A.D.scale_mode == VS_SCALE_LINEAR) VS_GRAMN_GENV(2);
-    if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAMN_GENV(3);
+    if constexpr (LMAX == 1) {
+        if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAMN_GENV(3);
+    } else {
+        if (A.D.scale_mode == VS_SCALE_POWER) return vs_fail(VS_ERR_ARG, "no fused both-orders kernel for several outputs with power scaling");
+    }
     VS_GRAMN_GENV(0);
 #undef VS_GRAMN_GENV
 }
 
-// the instance for ceil(k / 16) live blocks (NB / 2 < live <= NB)
-template <int KIND, int NB>
+// the instance for ceil(k l / 16) live blocks (NB / 2 < live <= NB)
+template <int KIND, int NB, int LMAX = 1>
 static int launch_scan_gramn_kind(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                                   double* first_partials, double* gram_partials, bool plan_only) {
-    const int nbl = (A.D.k + 15) / 16;
+    const int nbl = (A.D.k * (LMAX > 1 ? A.l : 1) + 15) / 16;
 #define VS_GRAMN_NBL(N)                                                                                              \
-    if (nbl == N) return launch_scan_gramn_nbl<KIND, NB, N>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
+    if (nbl == N) return launch_scan_gramn_nbl<KIND, NB, N, LMAX>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
     if constexpr (NB == 8) {
         VS_GRAMN_NBL(5);
         VS_GRAMN_NBL(6);
@@ -285,7 +305,18 @@ static int launch_scan_gramn_kind(vs_context* ctx, const vs_eval_args& A, unsign
         VS_GRAMN_NBL(4);
     }
 #undef VS_GRAMN_NBL
-    return vs_fail(VS_ERR_ARG, "k=%d does not belong to the %d-block fused both-orders kernels", A.D.k, NB);
+    return vs_fail(VS_ERR_ARG, "k=%d, l=%d does not belong to the %d-block fused both-orders kernels", A.D.k, A.l, NB);
+}
+
+// several outputs, up to 64 index rows per half: the four-wave kernels of nb = 1, 2 (2 / 4 columns per wave) and 4 (8)
+template <int KIND>
+static int launch_scan_gram_multi_kind(vs_context* ctx, const vs_eval_args& A, int nb, unsigned* P_io, const double* shift_dev,
+                                       double* first_partials, double* gram_partials, bool plan_only) {
+    constexpr int LM = VS_GRAM_LMAX_SMALL;
+    if (nb == 1) return launch_scan_gram_lw<KIND, 2, 1, LM>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only);
+    if (nb == 2) return launch_scan_gram_lw<KIND, 4, 2, LM>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only);
+    if (nb == 4) return launch_scan_gramn_kind<KIND, 4, LM>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only);
+    return vs_fail(VS_ERR_ARG, "nb=%d is not a four-wave fused both-orders kernel", nb);
 }
 
 #endif  // VS_SCAN_KIND

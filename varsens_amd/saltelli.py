@@ -571,7 +571,7 @@ class Varsens(object):
             if self._fused_candidate(objective) or self._stream_rows:
                 kw['lazy'] = True   # the values are only produced if somebody asks for them
             elif self._fused is True:
-                raise Exception("fused=True needs a device objective (with second_order: one output and k <= 128)")
+                raise Exception("fused=True needs a device objective (with second_order: k * outputs <= 128)")
             self.objective = Objective(self.k, self.n, self.sample, objective, verbose=verbose, **kw)
         self._ctx = self.objective._ctx
         self.compute_varsens()
@@ -612,12 +612,12 @@ class Varsens(object):
     def _fused_candidate(self, objective):
         """A device objective whose f-values may never be needed: the engine is asked later whether its fused
         evaluate+reduce kernels cover the (design, objective) pair -- vs_eval_reduce_supported for the first order
-        alone, vs_eval_reduce_both_supported (one output, k <= 128) when the second-order indices are wanted too."""
+        alone, vs_eval_reduce_both_supported (k l <= 128 index rows) when the second-order indices are wanted too."""
         if self._fused is False or not isinstance(objective, _objectives.DeviceObjective):
             return False
         if not self._second_order:
             return True
-        return int(self.k) <= 128 and int(objective.outputs(int(self.k))) == 1
+        return int(self.k) * int(objective.outputs(int(self.k))) <= 128
 
     def compute_varsens(self):
         """E_2, var_y, U_j, U_nj, sens, sens_t, sens_2, sens_2n (varsens/saltelli.py:572-622)."""
