@@ -559,8 +559,8 @@ def test_fused_both_orders_through_api(vs, golden):
     assert w.objective._f is not None and w.sens_2.shape == (130, 1, 130, 1)
     w = vs.Varsens(vs.objectives.Linear(numpy.ones(70)), vs.scale.Identity(), 70, 500, verbose=False)
     assert w.objective._f is None and w.sens_2.shape == (70, 1, 70, 1)
-    # several outputs (round 4): one kernel up to 64 index rows (2 .. 8 outputs) and up to 128 (2 or 4); three outputs
-    # beyond 64 rows and power scaling take the two-kernel route by themselves
+    # several outputs (round 4): one kernel up to 32 index rows (2 .. 8 outputs), up to 64 with k >= 16 and up to 128
+    # with 2 or 4 outputs; three outputs beyond 64 rows and power scaling take the two-kernel route by themselves
     w = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 500, verbose=False)
     assert w.objective._f is None and w.sens_2.shape == (6, 2, 6, 2)
     w2 = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 500, verbose=False, fused=False)

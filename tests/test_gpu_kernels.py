@@ -863,9 +863,10 @@ def test_fused_both_orders_coverage(ctx):
     for kk in (33, 48, 49, 65, 112, 113, 128):
         assert ctx.eval_reduce_both_supported(make_design(ctx, kk, 100), ctx.objective_create(_native.OBJ_LINEAR, kk, 1, np.ones(kk)))
     d8 = make_design(ctx, 8, 100)
-    # several outputs (round 4): 2 .. 8 up to 64 index rows, 2 or 4 up to 128 (tests/test_gpu_scan.py holds their parity)
+    # several outputs (round 4): 2 .. 8 up to 32 index rows, k >= 16 up to 64, 2 or 4 up to 128 (tests/test_gpu_scan.py holds their parity)
     assert ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 2, np.ones(16)))
-    assert ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 8, np.ones(64)))
+    assert ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 4, np.ones(32)))
+    assert not ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 8, np.ones(64)))    # 64 rows, k < 16
     assert not ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 9, np.ones(72)))    # nine outputs
     assert not ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 16, np.ones(128)))  # 16 outputs
     d30 = make_design(ctx, 30, 100)

@@ -851,13 +851,18 @@ static fused_route fused_both_route(const vs_context* ctx, const vs_design* desi
     if (obj->k != design->d.k) return FUSED_NONE;
     if (obj->l != 1) {
         // several outputs of a built-in separable objective: 2 .. 8 outputs (2 or 4 beyond 64 index rows -- the eight-wave
-        // kernel), identity or linear scaling
+        // kernel; at least 16 columns from 33 index rows on), identity or linear scaling
         const long K = (long)obj->k * obj->l;
         if (K > 128 || fused_route_for(ctx, design, obj) != FUSED_SCAN || design->d.scale_mode == VS_SCALE_POWER ||
             ctx->tune.fused_both_wide == 0)
             return FUSED_NONE;
         const int nb = fused_both_blocks((int)K);
         if (obj->l > vs_scan_gram_multi_lmax(nb) || (nb == 8 && 16 % obj->l != 0)) return FUSED_NONE;
+        // 33 .. 64 index rows with fewer than 16 columns (five or more outputs, or 3 x 11 .. 15): the four-wave kernel
+        // spends its time in the outputs' barriers and walks and loses to vs_eval + vs_reduce_first_second_order
+        // (profiles/r04/fused_both_several_outputs_sweep.txt: k=8 l=8 3.25 vs 2.54 ms, k=12 l=3 1.74 vs 1.55; from 16
+        // columns on it wins: k=16 l=4 2.37 vs 2.49, k=20 l=3 2.25 vs 2.49, k=32 l=2 2.19 vs 2.46)
+        if (nb == 4 && obj->k < 16) return FUSED_NONE;
         return FUSED_SCAN;
     }
     const fused_route r = fused_route_for(ctx, design, obj);
@@ -888,7 +893,8 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     const fused_route route = fused_both_route(ctx, design, obj);
     if (route == FUSED_NONE)
         return vs_fail(VS_ERR_ARG, "the fused both-orders path covers ISHIGAMI, G_FUNCTION / POLYNOMIAL / LINEAR with k l <= 128 "
-                                   "(several outputs: 2 .. 8, 2 or 4 beyond 64 index rows, no power scaling) and separable "
+                                   "(several outputs: 2 .. 8 up to 32 index rows, k >= 16 beyond, 2 or 4 outputs beyond 64 rows, "
+                                   "no power scaling) and separable "
                                    "source objectives with one output and k <= 128 (Halton indices below 2^32, scan evaluation "
                                    "order); use vs_eval + vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
     const int k = obj->k, l = obj->l, K = k * l;

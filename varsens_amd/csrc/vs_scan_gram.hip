@@ -28,7 +28,7 @@ int vs_scan_gram_multi_launch_lin(vs_context* ctx, const vs_eval_args& A, int nb
                                   double* first_partials, double* gram_partials, bool plan_only);
 
 int vs_scan_gram_multi_lmax(int nb) {
-    return nb == 8 ? VS_GRAM_LMAX_8 : (nb == 1 || nb == 2 || nb == 4) ? VS_GRAM_LMAX_SMALL : 0;
+    return nb == 8 ? VS_GRAM_LMAX_8 : nb == 4 ? VS_GRAM_LMAX_4 : (nb == 1 || nb == 2) ? VS_GRAM_LMAX_SMALL : 0;
 }
 
 int vs_scan_gram_multi_launch(vs_context* ctx, const vs_eval_args& A, int nb, unsigned* P_io, const double* shift_dev,

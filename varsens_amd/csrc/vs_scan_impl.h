@@ -40,7 +40,8 @@ int vs_scan_gram4_launch(vs_context* ctx, const vs_eval_args& A, unsigned* P_io,
 int vs_scan_gram_multi_lmax(int nb);
 int vs_scan_gram_multi_launch(vs_context* ctx, const vs_eval_args& A, int nb, unsigned* P_io, const double* shift_dev,
                               double* first_partials, double* gram_partials, bool plan_only);
-#define VS_GRAM_LMAX_SMALL 8   // nb = 1, 2, 4
+#define VS_GRAM_LMAX_SMALL 8   // nb = 1, 2
+#define VS_GRAM_LMAX_4 4       // nb = 4: only with 16 or more columns (the host's choice, vs_generate.hip), i.e. up to 4 outputs
 #define VS_GRAM_LMAX_8 4       // nb = 8: the 160 KiB of LDS hold the tile, two totals slabs and four (a, b) row pairs
 
 #ifdef VS_SCAN_KIND
@@ -315,7 +316,8 @@ static int launch_scan_gram_multi_kind(vs_context* ctx, const vs_eval_args& A, i
     constexpr int LM = VS_GRAM_LMAX_SMALL;
     if (nb == 1) return launch_scan_gram_lw<KIND, 2, 1, LM>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only);
     if (nb == 2) return launch_scan_gram_lw<KIND, 4, 2, LM>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only);
-    if (nb == 4) return launch_scan_gramn_kind<KIND, 4, LM>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only);
+    if (nb == 4)
+        return launch_scan_gramn_kind<KIND, 4, VS_GRAM_LMAX_4>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only);
     return vs_fail(VS_ERR_ARG, "nb=%d is not a four-wave fused both-orders kernel", nb);
 }
 
