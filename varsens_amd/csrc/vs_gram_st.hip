@@ -126,7 +126,19 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
     asm volatile("" : "+s"(G));
     uint64_t mine = 0;
     for (uint64_t v = blockIdx.x; v < nvisits; v += G) mine += (VISIT * v + VISIT <= nst) ? VISIT : nst - VISIT * v;
+#if defined(VS_ST_REPEAT) && VS_ST_REPEAT > 1
+    // diagnostic build (tools/gram_cache_vs_hbm.sh): every workgroup walks its stages VS_ST_REPEAT times, so that a
+    // design small enough for the 256 MB Infinity Cache gives a launch as long as a large one (sums x VS_ST_REPEAT:
+    // timing only)
+    const uint64_t mine_once = mine;
+    mine *= VS_ST_REPEAT;
+    auto stage_of = [&](uint64_t i) {
+        i %= mine_once;
+        return VISIT * (blockIdx.x + (i / VISIT) * (uint64_t)G) + (i % VISIT);
+    };
+#else
     auto stage_of = [&](uint64_t i) { return VISIT * (blockIdx.x + (i / VISIT) * (uint64_t)G) + (i % VISIT); };
+#endif
 
     vs_d2 raw[DEPTH][8];
     // FIRST: a (plane 0) and b (plane 1) of the stage: threads 0 .. PIECES-1 and PIECES .. 2 PIECES-1 (lrow 0 and 1)
