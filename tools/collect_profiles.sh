@@ -23,7 +23,11 @@ K=32 LOG2N=22 python3 $R/tools/pmc_run.py gram_k32_n22 --kernels gram_,first_hea
 python3 $R/tools/pmc_run.py eval_k128_n24 --kernels scan_kernel -- python3 $R/tools/eval_one.py 128 24 eval poly
 K=32 LOG2N=22 KIND=lin python3 $R/tools/pmc_run.py fused_both_k32 --kernels scan_gram --groups issue,lds -- python3 $R/tools/fused_both.py
 K=128 LOG2N=24 KIND=poly python3 $R/tools/pmc_run.py fused_both_k128_n24 --kernels scan_gram --groups issue,lds -- python3 $R/tools/fused_both.py
-for n in gram_k128_n24 gram_k64_n22 gram_k32_n22 eval_k128_n24 fused_both_k32 fused_both_k128_n24; do cp $R/gpurun_out/pmc/$n.json $R/gpurun_out/pmc/${n}_kernel_stats.csv $OUT/; done
+# several outputs in the one-kernel call (round 4): k = 32 x 4 outputs (eight waves), k = 16 x 2 (four waves, 32 index rows)
+K=32 L=4 LOG2N=22 KIND=lin python3 $R/tools/pmc_run.py fused_both_k32_l4 --kernels scan_gram --groups issue,lds -- python3 $R/tools/fused_both.py
+K=16 L=2 LOG2N=22 KIND=poly python3 $R/tools/pmc_run.py fused_both_k16_l2 --kernels scan_gram --groups issue,lds -- python3 $R/tools/fused_both.py
+python3 $R/tools/pmc_run.py fused_first_k32 --kernels scan_kernel --groups issue,lds,mem -- python3 $R/tools/eval_one.py 32 22 fused lin
+for n in gram_k128_n24 gram_k64_n22 gram_k32_n22 eval_k128_n24 fused_both_k32 fused_both_k128_n24 fused_both_k32_l4 fused_both_k16_l2 fused_first_k32; do cp $R/gpurun_out/pmc/$n.json $R/gpurun_out/pmc/${n}_kernel_stats.csv $OUT/; done
 echo "kernel pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python3 $R/tools/config5.py > $OUT/config5.log 2>&1
 cp $(find $OUT/stats5 -name '*kernel_stats.csv' | head -1) $OUT/config5_kernel_stats.csv

@@ -288,7 +288,11 @@ def exchange_check(group, before, after):
     ranks = float(outs[0][2]) if want.size > 2 else float("nan")
     return {"ranks_in_record": ranks, "ranks_expected": group.world, "max_rel_diff_vs_host_sum": rel,
             "identical_on_all_ranks": bool(same), "doubles": int(want.size),
-            "ok": bool(ranks == group.world and rel <= 1e-13 and same)}
+            # `identical_on_all_ranks` is reported, not required: a collective library may in principle sum in another
+            # order on another rank; what must hold is that every rank's record is in the sum
+            "ok": bool(ranks == group.world and rel <= 1e-12 and
+                       all(float(numpy.max(numpy.abs(o - outs[0]))) <= 1e-12 * max(1.0, float(numpy.max(size)))
+                           for o in outs[1:]))}
 
 
 class RcclComm(object):
