@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # data-sheet fp64 matrix rate (the guide lists no fp64 figure); tools/mfma_f64_peak.hip measures 77.6
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "bench_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04", "bench_pmc.json")
 F_BUFFERS = 3
 
 
@@ -487,7 +487,7 @@ def main():
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic("void reduce_first_kernel", k, args.log2n),
-                         "traffic_source": "profiles/r03/bench_pmc.json (separate rocprofv3 --pmc passes, tools/pmc_run.py)",
+                         "traffic_source": "profiles/r04/bench_pmc.json (separate rocprofv3 --pmc passes, tools/pmc_run.py)",
                          "algorithmic_bytes_per_launch": 8 * N_local,
                          "avg_launch_ms": avg["reduce_first"],
                          "input_last_written": "one step earlier (3 rotating buffers): not an Infinity-Cache number"},
