@@ -847,8 +847,9 @@ struct vs_scan_lds {
 // doubles per wave, read - fma - write once per block) instead of registers.  The fused kernel of 25 .. 32 columns
 // (four waves x 8 columns, held to 128 registers for four waves per SIMD) is ten registers short of its 4 L = 32
 // sums + 2 L terms + the generator's temporaries: rounds 1-3 let the compiler spill -- five of the sums went through
-// scratch memory once per block, each reload behind `s_waitcnt vmcnt(0)`.  Two columns' sums in LDS (4 KiB per wave):
-// no scratch, same bits (the same fma chain per lane, whichever memory holds the running value).
+// scratch memory once per block, each reload behind `s_waitcnt vmcnt(0)`.  With the sums of its last column (two or
+// four columns for the general generator paths; VS_SCAN_SUMS_IN_LDS, vs_scan_impl.h) in LDS, 2 KiB per wave and
+// column: no scratch, same bits (the same fma chain per lane, whichever memory holds the running value).
 template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI = false, int GENV = 0, int SLDS = 0>
 __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __restrict__ lds,
                                              const double* __restrict__ shift_src, double* __restrict__ partials) {
