@@ -240,11 +240,12 @@ def test_varsens_takes_the_stream_plan_from_the_largest_shard():
 
 # ------------------------------------------------------------------ what the compiler made of the kernels
 
-# Kernels allowed to keep a few spilled registers: fallback shapes only (the NaN-masked pass, odd row counts, more
-# than 128 index rows), each with the most it may have -- so that a regression shows.  Every other kernel of the
+# Kernels allowed to keep a few spilled registers: two fallback kernels of vs_second.hip only (the NaN-masked pass and
+# odd row counts beyond 64 index rows, more than 128 index rows: three to ten dwords of row pointers, stored once and
+# reloaded in front of each fetch), each with the most it may have -- so that a regression shows.  Every other kernel of the
 # library -- the north-star reduction, every scan / fused kernel, the Gram kernels of all BASELINE configurations --
 # must have none (DESIGN said "no spills" where the code objects said 11 .. 67).
-SPILL_ALLOWED = {"gram_macro_kernel": 4, "gram_macro_st_kernel": 10, "gram_diag_wave_kernel": 69}
+SPILL_ALLOWED = {"gram_macro_kernel": 4, "gram_macro_st_kernel": 10}
 
 
 def test_hot_kernels_do_not_spill():

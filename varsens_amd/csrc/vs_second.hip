@@ -125,7 +125,12 @@ __device__ __forceinline__ void gram_first_record(const vs_gram_args& A, double*
 // Waves per SIMD (= resident workgroups per CU) by the number of live 16-row blocks: with few index rows a wave
 // has little in flight (16 sample rows x 16 NB index rows), so the small shapes -- BASELINE configs[1], [2] have
 // 12 and 6 index rows -- run more waves: they are bound by bytes in flight, not by the matrix pipe.
-#define VS2_WAVES_PER_SIMD(NB, FIRST) ((FIRST) ? ((NB) == 1 ? 5 : (NB) == 2 ? 3 : 2) : ((NB) == 1 ? 8 : (NB) == 2 ? 6 : 3))
+// Round 4: without the first-order sums the kernel ran 6 / 3 / 3 waves per SIMD at 2 / 3 / 4 live blocks -- 80 and 168
+// registers, where the code objects showed 2 and 43-69 spilled dwords (the run-time tile set of four blocks keeps ten
+// accumulator tiles): 5 / 3 / 2 waves now, nothing spilled; measured at n = 2^22 (profiles/r04/ab_wave_occupancy.txt):
+// k=10 l=3 0.508 -> 0.391 ms, k=6 l=2 0.154 -> 0.140, k=16 l=2 0.400 -> 0.410.
+#define VS2_WAVES_PER_SIMD(NB, FIRST) \
+    ((FIRST) ? ((NB) == 1 ? 5 : (NB) == 2 ? 3 : 2) : ((NB) == 1 ? 8 : (NB) == 2 ? 5 : (NB) == 3 ? 3 : 2))
 // LDS doubles per workgroup: the four wave tiles (16 NB rows each), and the epilogue's scratch
 #define VS2_WAVE_LDS(NB, FIRST) \
     ((4 * 16 * (NB) * VS2_WPITCH) > 1024 + ((FIRST) ? 16 * (NB) * 16 * 2 + 80 : 0) \
