@@ -745,6 +745,33 @@ def test_bench_launches_its_own_ranks(vs):
     assert chk["max_rel_diff_vs_host_sum"] <= 1e-13 and chk["identical_on_all_ranks"]
 
 
+def test_strong_scaling_rehearsal_equals_one_rank(vs):
+    """The comparison test_two_ranks_over_rccl makes on a multi-GPU box, rehearsed on one GPU: `bench.py --gpus 2
+    --strong` (both ranks on GPU 0, records crossing the host) and `--gpus 1 --strong` solve the same global problem and
+    their result lines carry the same finished indices to 1e-10."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for gpus, extra in ((2, ["--exchange", "host", "--shared-device"]), (1, [])):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--strong", "--log2n", "18",
+                            "--steps", "3", "--warmup", "1", "--prewarm-steps", "0", "--no-cpu-baseline"] + extra,
+                           env=_bench_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-4000:]
+        out = [x for x in p.stdout.splitlines() if x.strip()]
+        assert len(out) == 1, p.stdout
+        lines[gpus] = json.loads(out[0])
+    two, one = lines[2], lines[1]
+    assert two["scaling"] == one["scaling"] == "strong"
+    assert two["config"]["n_global"] == one["config"]["n_global"] == 1 << 18
+    assert two["config"]["n_per_gpu"] == 1 << 17 and one["config"]["n_per_gpu"] == 1 << 18
+    assert two["exchange_check"]["ranks_in_record"] == 2 and one["exchange_check"]["ranks_in_record"] == 1
+    numpy.testing.assert_allclose(two["sens"], one["sens"], rtol=1e-10, atol=1e-13)
+    numpy.testing.assert_allclose(two["sens_t"], one["sens_t"], rtol=1e-10, atol=1e-13)
+
+
 def test_two_ranks_over_rccl(vs, tmp_path, spawn_ranks):
     """The one exchange the multi-GPU design rests on, with two ranks on two GPUs over RCCL (skipped on a one-GPU
     box; the reference's counterpart is the PBS fan-out, varsens/cluster/accre-submit.sh:27, accre-job.sh:13).
