@@ -521,9 +521,9 @@ def test_fused_first_order_through_api(vs, golden):
     wide = numpy.linspace(0.0, 9.0, 70)
     with pytest.raises(Exception, match="fused=True needs"):   # second order with 2 x 70 index rows: no fused kernel
         vs.Varsens(vs.objectives.GFunction([wide, wide[::-1]]), vs.scale.Identity(), 70, 64, verbose=False, fused=True)
-    three = numpy.linspace(0.0, 9.0, 30)
-    with pytest.raises(Exception, match="fused=True: the fused kernels do not cover"):   # 3 outputs beyond 64 index rows
-        vs.Varsens(vs.objectives.GFunction([three, three[::-1], three]), vs.scale.Identity(), 30, 64, verbose=False,
+    three = numpy.linspace(0.0, 9.0, 40)
+    with pytest.raises(Exception, match="fused=True: the fused kernels do not cover"):   # 3 outputs beyond 112 index rows
+        vs.Varsens(vs.objectives.GFunction([three, three[::-1], three]), vs.scale.Identity(), 40, 64, verbose=False,
                    fused=True)
     two = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 64, verbose=False, fused=True)
     assert two.objective._f is None and two.sens_2.shape == (6, 2, 6, 2)
@@ -560,7 +560,7 @@ def test_fused_both_orders_through_api(vs, golden):
     w = vs.Varsens(vs.objectives.Linear(numpy.ones(70)), vs.scale.Identity(), 70, 500, verbose=False)
     assert w.objective._f is None and w.sens_2.shape == (70, 1, 70, 1)
     # several outputs (round 4): one kernel up to 32 index rows (2 .. 8 outputs), up to 64 with k >= 16 and up to 128
-    # with 2 or 4 outputs; three outputs beyond 64 rows and power scaling take the two-kernel route by themselves
+    # with 2 or 4 outputs (3 up to 112 rows); three outputs beyond 112 rows and power scaling take the two-kernel route
     w = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 500, verbose=False)
     assert w.objective._f is None and w.sens_2.shape == (6, 2, 6, 2)
     w2 = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 500, verbose=False, fused=False)
@@ -575,9 +575,12 @@ def test_fused_both_orders_through_api(vs, golden):
     for f in ("sens", "sens_t", "sens_2", "sens_2n"):
         numpy.testing.assert_allclose(getattr(w, f), getattr(w2, f), rtol=1e-9, atol=1e-11, err_msg=f)
     numpy.testing.assert_allclose(w.sens[:, 0], w.sens[:, 2], rtol=1e-9)     # output 2 = 2 x output 0: the same indices
+    c40 = numpy.linspace(0.0, 9.0, 40)
+    w = vs.Varsens(vs.objectives.GFunction([c40, c40[::-1], c40]), vs.scale.Identity(), 40, 500, verbose=False)
+    assert w.objective._f is not None and w.sens_2.shape == (40, 3, 40, 3)
     c30 = numpy.linspace(0.0, 9.0, 30)
     w = vs.Varsens(vs.objectives.GFunction([c30, c30[::-1], c30]), vs.scale.Identity(), 30, 500, verbose=False)
-    assert w.objective._f is not None and w.sens_2.shape == (30, 3, 30, 3)
+    assert w.objective._f is None and w.sens_2.shape == (30, 3, 30, 3)
     w = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Power(1.0, 10.0), 6, 500, verbose=False)
     assert w.objective._f is not None
     # Ishigami (BASELINE configs[2]): its own thread-per-row fused kernel carries the second-order sums too

@@ -871,7 +871,9 @@ def test_fused_both_orders_coverage(ctx):
     assert not ctx.eval_reduce_both_supported(d8, ctx.objective_create(_native.OBJ_LINEAR, 8, 16, np.ones(128)))  # 16 outputs
     d30 = make_design(ctx, 30, 100)
     assert ctx.eval_reduce_both_supported(d30, ctx.objective_create(_native.OBJ_LINEAR, 30, 4, np.ones(120)))
-    assert not ctx.eval_reduce_both_supported(d30, ctx.objective_create(_native.OBJ_LINEAR, 30, 3, np.ones(90)))   # 3 outputs > 64 rows
+    assert ctx.eval_reduce_both_supported(d30, ctx.objective_create(_native.OBJ_LINEAR, 30, 3, np.ones(90)))       # 3 outputs, 90 rows
+    d40 = make_design(ctx, 40, 100)
+    assert not ctx.eval_reduce_both_supported(d40, ctx.objective_create(_native.OBJ_LINEAR, 40, 3, np.ones(120)))  # 3 outputs > 112 rows
     assert not ctx.eval_reduce_both_supported(d30, ctx.objective_create(_native.OBJ_LINEAR, 30, 5, np.ones(150)))  # > 128 rows
     assert not ctx.eval_reduce_both_supported(make_design(ctx, 3, 100), ctx.objective_create(_native.OBJ_INVERT, 3, 3, None))
     lin = ctx.objective_create(_native.OBJ_LINEAR, 8, 1, np.ones(8))

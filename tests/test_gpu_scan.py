@@ -352,11 +352,11 @@ def test_fused_both_orders_against_the_oracle(ctx, kind, k, n):
 
 def fused_both_takes(k, l):
     """What include/varsens_hip.h promises for several outputs of a built-in separable objective (identity / linear
-    scaling): 2 .. 8 outputs up to 32 index rows, k >= 16 up to 64, 2 or 4 outputs up to 128."""
+    scaling): 2 .. 8 outputs up to 32 index rows, k >= 16 up to 64, 2 or 4 outputs up to 128 (3 up to 112)."""
     K = k * l
     if l == 1:
         return k <= 128
-    return (K <= 32 and l <= 8) or (K <= 64 and k >= 16) or (64 < K <= 128 and l in (2, 4))
+    return (K <= 32 and l <= 8) or (K <= 64 and k >= 16) or (64 < K <= 128 and (l in (2, 4) or (l == 3 and K <= 112)))
 
 
 @pytest.mark.parametrize("kind", ["g_function", "linear", "polynomial"])
@@ -365,7 +365,8 @@ def fused_both_takes(k, l):
                                    (32, 4096, 2), (21, 1500, 3), (12, 2048, 5), (8, 129, 8), (17, 640, 2), (16, 3000, 4),
                                    (16, 777, 3), (15, 500, 3),                                             # <= 64
                                    (64, 2048, 2), (32, 3000, 4), (40, 1000, 2), (17, 5000, 4), (48, 300, 2),
-                                   (25, 4096, 4), (56, 700, 2), (64, 1, 2)])                               # <= 128
+                                   (25, 4096, 4), (56, 700, 2), (64, 1, 2), (30, 3000, 3), (37, 900, 3), (22, 4096, 3),
+                                   (38, 500, 3)])                                                          # <= 128
 def test_fused_both_orders_several_outputs_against_the_oracle(ctx, kind, k, n, l):
     """The one-kernel default call with SEVERAL outputs (the reference's two-output known-answer test,
     varsens/tests/test_g_function.py:77-88; sens_2[:, o, :, o'] slices of varsens/examples/varsens_earm_scipy.py:179-186):

@@ -338,12 +338,13 @@ struct vs_gramn_afrags {
 // left out at compile time (the waves' tile counts then differ by at most one or two: k = 96: 6, 5, 5, 5, 5, 5, 5, 6)
 // MULTI: several outputs -- the a, b a lane's index row meets are those of the row's output: tile rows abs (S rows of
 // block R) and abt (T rows of block NB-1-R) behind the 2 HALF index rows, per lane (vs_gram_abrow)
-// (NB = 8 takes 2 or 4 outputs only: the output of a row then repeats every 16 rows, abs == abt, and one pair of
-// fragments serves both -- with two pairs the nine-tile body no longer fits its 256 registers)
+// (NB = 8 with all eight blocks live -- 113 .. 128 index rows -- takes 2 or 4 outputs only: the output of a row then
+// repeats every 16 rows, abs == abt, and one pair of fragments serves both; with two pairs the nine-tile body no longer
+// fits its 256 registers.  Up to seven live blocks there is room: three outputs are taken too.)
 template <int R, int NB, int NBL, bool MULTI = false>
 __device__ __forceinline__ void vs_gramn_consume_row(const double* __restrict__ tile, int lane, vs_gramn_regs<NB>& G,
                                                      int abs = 0, int abt = 0) {
-    constexpr bool TWO = MULTI && NB < 8;   // separate a, b fragments for the T rows
+    constexpr bool TWO = MULTI && (NB < 8 || NBL < 8);   // separate a, b fragments for the T rows
     constexpr int P = VS_GT_PITCH, TR = NB - 1 - R, HALF = 16 * NB;
     constexpr bool S_LIVE = R < NBL, T_LIVE = TR < NBL;
     const double* base = tile + (size_t)(lane & 15) * P + 2 * (lane >> 4);   // S block 0; T block 0 is HALF rows further

@@ -857,7 +857,8 @@ static fused_route fused_both_route(const vs_context* ctx, const vs_design* desi
             ctx->tune.fused_both_wide == 0)
             return FUSED_NONE;
         const int nb = fused_both_blocks((int)K);
-        if (obj->l > vs_scan_gram_multi_lmax(nb) || (nb == 8 && 16 % obj->l != 0)) return FUSED_NONE;
+        // eight waves: 2 or 4 outputs; three up to 112 index rows (seven live blocks: vs_gramn_consume_row)
+        if (obj->l > vs_scan_gram_multi_lmax(nb) || (nb == 8 && 16 % obj->l != 0 && K > 112)) return FUSED_NONE;
         // 33 .. 64 index rows with fewer than 16 columns (five or more outputs, or 3 x 11 .. 15): the four-wave kernel
         // spends its time in the outputs' barriers and walks and loses to vs_eval + vs_reduce_first_second_order
         // (profiles/r04/fused_both_several_outputs_sweep.txt: k=8 l=8 3.25 vs 2.54 ms, k=12 l=3 1.74 vs 1.55; from 16
@@ -893,7 +894,7 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     const fused_route route = fused_both_route(ctx, design, obj);
     if (route == FUSED_NONE)
         return vs_fail(VS_ERR_ARG, "the fused both-orders path covers ISHIGAMI, G_FUNCTION / POLYNOMIAL / LINEAR with k l <= 128 "
-                                   "(several outputs: 2 .. 8 up to 32 index rows, k >= 16 beyond, 2 or 4 outputs beyond 64 rows, "
+                                   "(several outputs: 2 .. 8 up to 32 index rows, k >= 16 beyond, 2 .. 4 outputs beyond 64 rows -- 3 only up to 112 --, "
                                    "no power scaling) and separable "
                                    "source objectives with one output and k <= 128 (Halton indices below 2^32, scan evaluation "
                                    "order); use vs_eval + vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
