@@ -272,6 +272,27 @@ def config2():
          fvals_sha=sha(o.flat()), **result_fields(v))
 
 
+def several_outputs():
+    """G16, G17 (round 4): models with several outputs at the sizes of the one-kernel default call's several-output kernels,
+    run by the reference itself -- its objective returns a list per row (varsens/saltelli.py:329-355), compute_varsens
+    gives sens_2[k, l, k, l] (:612-622).
+    G16: linear, k = 24, three outputs (72 index rows: the eight-wave kernel), scale.linear(-1, 2), n = 2048;
+    G17: g-function, k = 16, two outputs (32 index rows: a four-wave kernel), identity, n = 2048."""
+    ref, rscale = load_reference()
+    k, l, n = 24, 3, 2048
+    C = np.arange(1, k + 1, dtype=float)[None, :] * (1.0 + np.arange(l))[:, None] + np.arange(l)[:, None] ** 2
+    lo, hi = np.full(k, -1.0), np.full(k, 2.0)
+    s, o, v = run3(ref, k, n, lambda x: rscale.linear(x, lo, hi), lambda x: [float(np.dot(c, x)) for c in C])
+    save("g16_linear3_k24_n2048", k=k, n=n, l=l, c=C, lower=lo, upper=hi, fM_1_head=o.fM_1[:8], **result_fields(v))
+    k, l, n = 16, 2, 2048
+    A = np.stack([np.linspace(0.0, 9.0, k), np.linspace(9.0, 0.5, k)])
+
+    def g2(x):
+        return [float(np.prod((np.abs(4.0 * x - 2.0) + a) / (1.0 + a))) for a in A]
+    s, o, v = run3(ref, k, n, lambda x: x, g2)
+    save("g17_gfunc2_k16_n2048", k=k, n=n, l=l, a=A, fM_1_head=o.fM_1[:8], fvals_sha=sha(o.flat()), **result_fields(v))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference checkout not found at %s" % REF)
@@ -281,7 +302,10 @@ if __name__ == "__main__":
         nan_fm_only()
     elif "--config2" in sys.argv:   # minutes of reference time: generated on its own
         config2()
+    elif "--several-outputs" in sys.argv:
+        several_outputs()
     else:
         main()
         nan_fm_only()
         wire_formats()
+        several_outputs()

@@ -229,6 +229,31 @@ def test_double_g_function(vs, golden):
         numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-10, atol=1e-13)
 
 
+def test_several_outputs_goldens_through_the_one_kernel_call(vs, golden):
+    """G16 / G17 (round 4): the REFERENCE's own runs of a three-output linear model (k = 24, scale.linear: 72 index rows, the
+    eight-wave several-output kernel) and a two-output g-function (k = 16: 32 index rows, a four-wave one) against the
+    default call -- one kernel, no f-values -- at the north-star's 1e-10 on every index incl. the cross-output blocks
+    sens_2[:, o, :, o'] (varsens/saltelli.py:612-622; varsens/examples/varsens_earm_scipy.py:179-186 reads such slices)."""
+    g = golden("g16_linear3_k24_n2048")
+    v = vs.Varsens(vs.objectives.Linear(g["c"]), vs.scale.Linear(g["lower"], g["upper"]), 24, 2048, verbose=False)
+    assert v.objective._f is None and v.sens_2.shape == (24, 3, 24, 3)
+    for f in ("E_2", "var_y", "U_j", "U_nj"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-12, err_msg=f)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-10, atol=1e-12, err_msg=f)
+    numpy.testing.assert_allclose(v.objective.fM_1[:8], g["fM_1_head"], rtol=1e-14)      # (now evaluated: on request)
+    w = vs.Varsens(vs.objectives.Linear(g["c"]), vs.scale.Linear(g["lower"], g["upper"]), 24, 2048, verbose=False, fused=False)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(w, f), g[f], rtol=1e-10, atol=1e-12, err_msg=f)
+    g = golden("g17_gfunc2_k16_n2048")
+    v = vs.Varsens(vs.objectives.GFunction(g["a"]), vs.scale.Identity(), 16, 2048, verbose=False)
+    assert v.objective._f is None and v.sens_2.shape == (16, 2, 16, 2)
+    for f in ("E_2", "var_y", "U_j", "U_nj"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-12, err_msg=f)
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, f), g[f], rtol=1e-10, atol=1e-12, err_msg=f)
+
+
 def test_ishigami_linear_polynomial_golden(vs, golden):
     g = golden("g4_ishigami_k3_n4096")
     v = vs.Varsens(vs.objectives.Ishigami(7.0, 0.1), vs.scale.Linear(g["lower"], g["upper"]), 3, 4096, verbose=False)

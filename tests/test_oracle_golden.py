@@ -91,6 +91,27 @@ def test_two_outputs(golden):
     assert R["sens_2"].shape == (6, 2, 6, 2)
 
 
+def test_several_outputs_at_kernel_sizes(golden):
+    """G16 / G17 (round 4): the reference's own runs of a three-output linear model (k = 24, linear scaling) and a
+    two-output g-function (k = 16) -- the oracle reproduces them; the GPU's one-kernel call is held to the same
+    fixtures in tests/test_gpu_api.py."""
+    g = golden("g16_linear3_k24_n2048")
+    C, lo, hi = g["c"], g["lower"], g["upper"]
+    rows = lambda X: np.stack([orc.linear_rows(X, c) for c in C], axis=-1)
+    S, F, R = run(24, 2048, lambda x: orc.scale_linear(x, lo, hi), rows)
+    assert F[0].shape == (2048, 3) and R["sens_2"].shape == (24, 3, 24, 3)
+    np.testing.assert_allclose(F[0][:8], g["fM_1_head"], rtol=4e-15)      # numpy.dot vs the oracle's left-to-right sum
+    for f in FIELDS:
+        np.testing.assert_allclose(R[f], g[f], rtol=1e-10, atol=1e-12)
+    g = golden("g17_gfunc2_k16_n2048")
+    A = g["a"]
+    rows = lambda X: np.stack([orc.g_function_rows(X, a) for a in A], axis=-1)
+    S, F, R = run(16, 2048, None, rows)
+    assert sha(orc.flat_objective(*F)) == str(g["fvals_sha"])
+    for f in FIELDS:
+        same(R[f], g[f])
+
+
 def test_ishigami(golden):
     g = golden("g4_ishigami_k3_n4096")
     lo, hi = g["lower"], g["upper"]
