@@ -774,16 +774,16 @@ def test_bench_launches_its_own_ranks(vs):
 
 
 def test_strong_scaling_rehearsal_equals_one_rank(vs):
-    """The comparison test_two_ranks_over_rccl makes on a multi-GPU box, rehearsed on one GPU: `bench.py --gpus 2
-    --strong` (both ranks on GPU 0, records crossing the host) and `--gpus 1 --strong` solve the same global problem and
-    their result lines carry the same finished indices to 1e-10."""
+    """The comparison test_two_ranks_over_rccl makes on a multi-GPU box, rehearsed on one GPU: `bench.py --gpus 4 / 2
+    --strong` (all ranks on GPU 0, records crossing the host) and `--gpus 1 --strong` solve the same global problem and
+    their result lines carry the same finished indices to 1e-10; the exchange counted 4 / 2 / 1 ranks."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lines = {}
-    for gpus, extra in ((2, ["--exchange", "host", "--shared-device"]), (1, [])):
+    for gpus, extra in ((4, ["--exchange", "host", "--shared-device"]), (2, ["--exchange", "host", "--shared-device"]), (1, [])):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--strong", "--log2n", "18",
                             "--steps", "3", "--warmup", "1", "--prewarm-steps", "0", "--no-cpu-baseline"] + extra,
                            env=_bench_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
@@ -791,13 +791,16 @@ def test_strong_scaling_rehearsal_equals_one_rank(vs):
         out = [x for x in p.stdout.splitlines() if x.strip()]
         assert len(out) == 1, p.stdout
         lines[gpus] = json.loads(out[0])
-    two, one = lines[2], lines[1]
-    assert two["scaling"] == one["scaling"] == "strong"
-    assert two["config"]["n_global"] == one["config"]["n_global"] == 1 << 18
-    assert two["config"]["n_per_gpu"] == 1 << 17 and one["config"]["n_per_gpu"] == 1 << 18
-    assert two["exchange_check"]["ranks_in_record"] == 2 and one["exchange_check"]["ranks_in_record"] == 1
-    numpy.testing.assert_allclose(two["sens"], one["sens"], rtol=1e-10, atol=1e-13)
-    numpy.testing.assert_allclose(two["sens_t"], one["sens_t"], rtol=1e-10, atol=1e-13)
+    four, two, one = lines[4], lines[2], lines[1]
+    assert four["scaling"] == two["scaling"] == one["scaling"] == "strong"
+    assert four["config"]["n_global"] == two["config"]["n_global"] == one["config"]["n_global"] == 1 << 18
+    assert four["config"]["n_per_gpu"] == 1 << 16 and two["config"]["n_per_gpu"] == 1 << 17 and one["config"]["n_per_gpu"] == 1 << 18
+    assert [x["exchange_check"]["ranks_in_record"] for x in (four, two, one)] == [4, 2, 1]
+    assert len(four["stages_ms_per_rank"]) == 4
+    for many in (four, two):
+        assert many["exchange_check"]["ok"]
+        numpy.testing.assert_allclose(many["sens"], one["sens"], rtol=1e-10, atol=1e-13)
+        numpy.testing.assert_allclose(many["sens_t"], one["sens_t"], rtol=1e-10, atol=1e-13)
 
 
 def test_two_ranks_over_rccl(vs, tmp_path, spawn_ranks):
