@@ -152,13 +152,13 @@ def test_scan_eval_row_shards_and_scalings(ctx):
     same(whole, blocks_of(orc.evaluate_scan("g_function", P, S[0], S[1])))
     _, _, part = device_blocks(ctx, d, "g_function", k, 1, P, n, begin=130, count=211)
     same(part, whole[:, 130:341])
-    # power scaling: device pow within a few ulp of libm's
+    # power scaling: lower * exp(x ln r) on the device within two ulp of numpy's pow per coordinate
     plo, phi = np.full(k, 0.5), np.linspace(2.0, 50.0, k)
     Sp = orc.build_sample(k, n, lambda x: orc.scale_power(x, plo, phi))
     _, _, got = device_blocks(ctx, design(ctx, k, n, _native.SCALE_POWER, plo, phi), "polynomial", k, 1,
                               params_for("polynomial", k, 1, 0), n)
     want = blocks_of(orc.evaluate_scan("polynomial", params_for("polynomial", k, 1, 0), Sp[0], Sp[1]))
-    np.testing.assert_allclose(got, want, rtol=1e-13)
+    np.testing.assert_allclose(got, want, rtol=1e-13)   # (a product of k terms 1 + beta (x - 1/2): the ulps add up)
     # raw points
     rng = np.random.RandomState(5)
     raw = rng.rand(2 * n, k)

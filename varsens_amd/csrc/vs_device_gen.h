@@ -200,7 +200,7 @@ struct vs_design_dev {
     int sobol_bits;  // Gray-code bits in use (VS_GEN_SOBOL)
     vs_u64 n, first_index;
     const double* lower;
-    const double* width;
+    const double* width;    // LINEAR: upper - lower [k]; POWER: ratio [k], then ln ratio as hi [k] and lo [k]
     const vs_u32* perm;     // entries of rows [perm_begin, perm_begin + perm_count) of the seed-1 shuffle, or null
     vs_u64 perm_begin;
     const double* raw;
@@ -222,9 +222,24 @@ __device__ __forceinline__ vs_u64 vs_perm_at(const vs_design_dev& D, vs_u64 r) {
     return D.perm ? (vs_u64)D.perm[r - D.perm_begin] : r;
 }
 
+// Power scaling, lower * (upper / lower)^x (scale.py:62), as lower * exp(x ln r): ln r comes from the host as a
+// double-double (lhi + llo, logl of the ratio the reference forms), y = RN(x lhi), e = the rounding error of that
+// product + x llo, and exp(y + e) = exp(y) (1 + e) to first order (|e| < 1e-15): one exp per point instead of a pow
+// (about a third of its instructions), 1-2 ulp from libm's pow.  A ratio without a finite logarithm keeps pow().
+__device__ __forceinline__ double vs_power_scale(double lower, double ratio, double lhi, double llo, double p) {
+    if (lhi - lhi == 0.0) {   // finite: wave-uniform
+        const double y = p * lhi;
+        const double e = fma(p, lhi, -y) + p * llo;
+        const double r = exp(y);
+        return lower * fma(r, e, r);
+    }
+    return lower * pow(ratio, p);
+}
+
 __device__ __forceinline__ double vs_apply_scale(const vs_design_dev& D, double p, int c) {
     if (D.scale_mode == VS_SCALE_LINEAR) return p * D.width[c] + D.lower[c];   // scale.py:33
-    if (D.scale_mode == VS_SCALE_POWER) return D.lower[c] * pow(D.width[c], p); // scale.py:62
+    if (D.scale_mode == VS_SCALE_POWER)                                        // scale.py:62
+        return vs_power_scale(D.lower[c], D.width[c], D.width[D.k + c], D.width[2 * D.k + c], p);
     return p;
 }
 

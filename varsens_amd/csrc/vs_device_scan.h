@@ -45,8 +45,8 @@ __device__ __forceinline__ void vs_unit_pair(const vs_design_dev& D, const vs_ba
     }
 }
 
-__device__ __attribute__((noinline, const)) double vs_scale_power(double lower, double ratio, double p) {
-    return lower * pow(ratio, p);  // scale.py:62
+__device__ __attribute__((noinline, const)) double vs_scale_power(double lower, double ratio, double lhi, double llo, double p) {
+    return vs_power_scale(lower, ratio, lhi, llo, p);  // scale.py:62 (vs_device_gen.h)
 }
 
 // POWER = false (the fused kernels' general variant, GENV 0): no power scaling in the kernel at all -- a call
@@ -56,7 +56,8 @@ __device__ __attribute__((noinline, const)) double vs_scale_power(double lower, 
 template <bool POWER>
 __device__ __forceinline__ double vs_apply_scale_compact(const vs_design_dev& D, double p, int c) {
     if (D.scale_mode == VS_SCALE_LINEAR) return p * D.width[c] + D.lower[c];   // scale.py:33
-    if (POWER && D.scale_mode == VS_SCALE_POWER) return vs_scale_power(D.lower[c], D.width[c], p);
+    if (POWER && D.scale_mode == VS_SCALE_POWER)
+        return vs_scale_power(D.lower[c], D.width[c], D.width[D.k + c], D.width[2 * D.k + c], p);
     return p;
 }
 

@@ -229,14 +229,27 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
     } while (0)
 
     if (desc->scale_mode != VS_SCALE_IDENTITY) {
-        std::vector<double> lo(desc->lower, desc->lower + k), w(k);
-        for (int c = 0; c < k; ++c)
+        // width: LINEAR upper - lower; POWER the ratio r = RN(upper / lower) as the reference forms it, and behind the k
+        // ratios ln r as a double-double (hi[k], lo[k]; logl of the rounded ratio): the kernels take lower * r^x as
+        // lower * exp(x ln r) with the product's rounding error carried along (vs_power_scale, vs_device_gen.h) -- one
+        // exp instead of a pow per point, 1-2 ulp from numpy's pow.  A ratio whose logarithm is not finite (zero,
+        // negative, infinite bounds) keeps pow() and its conventions.
+        const bool power = desc->scale_mode == VS_SCALE_POWER;
+        std::vector<double> lo(desc->lower, desc->lower + k), w(power ? 3 * (size_t)k : (size_t)k);
+        for (int c = 0; c < k; ++c) {
             w[c] = desc->scale_mode == VS_SCALE_LINEAR ? desc->upper[c] - desc->lower[c]   // scale.py:33
                                                        : desc->upper[c] / desc->lower[c];  // scale.py:62
+            if (power) {
+                const long double L = logl((long double)w[c]);
+                const double hi = (double)L;
+                w[k + c] = hi;
+                w[2 * (size_t)k + c] = std::isfinite(hi) ? (double)(L - (long double)hi) : 0.0;
+            }
+        }
         VS_TRY(hipMalloc(&g->lower, sizeof(double) * k));
-        VS_TRY(hipMalloc(&g->width, sizeof(double) * k));
+        VS_TRY(hipMalloc(&g->width, sizeof(double) * w.size()));
         VS_TRY(hipMemcpyAsync(g->lower, lo.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
-        VS_TRY(hipMemcpyAsync(g->width, w.data(), sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+        VS_TRY(hipMemcpyAsync(g->width, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, ctx->stream));
         VS_TRY(hipStreamSynchronize(ctx->stream));
     }
     if (desc->perm) {
