@@ -104,8 +104,9 @@ def test_scan_eval_default_route(ctx, kind, k, n, l):
 def test_g_function_quotient_is_the_correctly_rounded_one(ctx):
     """The scan kernels take (|4x-2| + a) / (1 + a) from a host-rounded reciprocal by Markstein's fma sequence: the
     bits must be those of the division (numpy's, the reference's) for every parameter the host admits -- tiny, huge,
-    many-ones significands -- and a parameter it does not admit (1 + a with an all-ones significand, a = -1) must
-    route the objective to the kernels that divide."""
+    many-ones significands -- and for a parameter it does not admit (1 + a with an all-ones significand, a = -1, inf)
+    that column alone divides (round 4: the objective stays on the scan kernels and the fused paths; until round 3 one
+    such parameter sent it to the O(k^2) chain kernels)."""
     from varsens_amd import _native
     k, n = 24, 20000
     a = np.array([0.0, 0.5, 3.0, 9.0, 99.0, 99.0, 1e-12, 1e-300, 1e6, 2.0 ** 52, 1.0 / 3.0, 2.0 / 3.0, 0.1, 0.7,
@@ -121,9 +122,14 @@ def test_g_function_quotient_is_the_correctly_rounded_one(ctx):
         b = a.copy()
         b[5] = bad
         _, obj, got = device_blocks(ctx, d, "g_function", k, 1, b[None, :], n)
-        assert not ctx.eval_reduce_supported(d, obj)
+        assert ctx.eval_reduce_supported(d, obj) and ctx.eval_reduce_both_supported(d, obj)
         with np.errstate(all="ignore"):
-            same(got, strict_blocks("g_function", b[None, :], S))
+            same(got, blocks_of(orc.evaluate_scan("g_function", b[None, :], S[0], S[1])))
+            if np.isfinite(bad) and bad != -1.0:     # the fused kernels on the same objective: finite sums
+                nacc = _native.acc_len(k, 1, 1)
+                acc = ctx.alloc(8 * nacc)
+                ctx.eval_reduce_first_order(d, obj, 0, n, acc)
+                check_record(ctx.download(acc, (nacc,)), orc.evaluate_scan("g_function", b[None, :], S[0], S[1], fused=True), k, 1)
 
 
 @pytest.mark.parametrize("kind,k,n,l", [("g_function", 6, 1024, 1), ("g_function", 6, 1000, 2), ("linear", 1, 7, 1),

@@ -101,8 +101,9 @@ struct vs_objective {
     int fused_threads = 0;
     size_t fused_lds = 0;
     bool scratch_tile = false; // compiled for the HBM scratch tile (k beyond the LDS budget)
-    // G_FUNCTION: the l*k correctly rounded reciprocals 1 / (1 + a) follow the parameters in `params`; false when
-    // some 1 + a is not a plain normal number (then the scan kernels, which divide through them, are not used)
+    // G_FUNCTION: the l*k correctly rounded reciprocals 1 / (1 + a) follow the parameters in `params` (0 where 1 + a is
+    // not a plain normal number or has an all-ones significand: that column divides); true when every column is plain --
+    // then the scan kernels' specialised column code, which carries no division, may serve the objective
     bool recip_ok = false;
 };
 

@@ -256,6 +256,8 @@ __device__ __forceinline__ double vs_m2(const vs_design_dev& D, vs_u64 r, int c)
 struct vs_eval_args {
     vs_design_dev D;
     int kind, l;
+    int plain_recip;   // host side only -- G_FUNCTION: every 1 + a has a Markstein-safe reciprocal (else: general column code)
+    int reserved;
     const double* params;
     vs_u64 row_begin, rows;
     double* f;

@@ -396,8 +396,12 @@ extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, cons
         // quotient from the correctly rounded reciprocal r = RN(1 / (1 + a)), computed here in IEEE double, by
         // Markstein's fma sequence -- two steps of q += fma(-q, d, n) * r give RN(n / d) exactly when r is the correctly
         // rounded reciprocal of a normal d whose significand is not all ones and nothing leaves the normal range
-        // (checked below; otherwise the objective keeps to the kernels that divide).  The reciprocals follow the
-        // l*k parameters in the same device buffer.
+        // (checked below).  The reciprocals follow the l*k parameters in the same device buffer; a column whose
+        // parameter does not meet the conditions gets the reciprocal 0, on which the scan kernels' GENERAL column code
+        // divides for that column alone; the specialised column code (Halton, identity / linear scaling) carries no
+        // division -- the branch costs its g-function kernels 1-4 % -- and serves objectives whose columns are all plain
+        // (round 4; until round 3 one such parameter -- a = 7 - 1 ulp is enough: 1 + a is the largest double below 8 --
+        // sent the whole objective to the O(k^2) chain kernels and past every fused path).
         std::vector<double> host(params, params + nparams);
         if (kind == VS_OBJ_G_FUNCTION) {
             bool ok = true;
@@ -408,9 +412,9 @@ extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, cons
                 const bool plain = std::isfinite(params[i]) && std::isfinite(d) && fabs(d) > 0x1p-200 && fabs(d) < 0x1p200 &&
                                    fabs(params[i]) < 0x1p200 && (bits & 0x000fffffffffffffull) != 0x000fffffffffffffull;
                 ok = ok && plain;
-                host.push_back(plain ? 1.0 / d : 0.0);
+                host.push_back(plain ? 1.0 / d : 0.0);   // 0: this column divides (builtin_term::eval, general column code)
             }
-            o->recip_ok = ok;
+            o->recip_ok = ok;   // all columns plain: the specialised column code (no division compiled in) may be used
         }
         if (hipMalloc(&o->params, sizeof(double) * host.size()) != hipSuccess ||
             hipMemcpyAsync(o->params, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, ctx->stream) !=
@@ -776,7 +780,7 @@ enum fused_route { FUSED_NONE = 0, FUSED_SCAN, FUSED_ISHIGAMI, FUSED_USER };
 static fused_route fused_route_for(const vs_context* ctx, const vs_design* design, const vs_objective* obj) {
     const bool separable = obj->kind == VS_OBJ_G_FUNCTION || obj->kind == VS_OBJ_POLYNOMIAL || obj->kind == VS_OBJ_LINEAR;
     // power scaling: the built-in objectives have fused instances for it (GENV 3); a run-time compiled one does not
-    const bool scan_ok = design_compact(design) && ctx->tune.eval_mode != 1 && (obj->kind != VS_OBJ_G_FUNCTION || obj->recip_ok);
+    const bool scan_ok = design_compact(design) && ctx->tune.eval_mode != 1;
     if (separable && scan_ok && vs_scan_covers(obj->kind, obj->k, true)) return FUSED_SCAN;
     if (obj->kind == VS_OBJ_ISHIGAMI) return FUSED_ISHIGAMI;
     if (obj->kind == VS_OBJ_SOURCE && obj->fused_function && scan_ok && design->d.scale_mode != VS_SCALE_POWER)
@@ -811,6 +815,8 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
     vs_eval_args A;
     A.D = to_dev(design);
     A.kind = obj->kind;
+    A.plain_recip = obj->recip_ok ? 1 : 0;
+    A.reserved = 0;
     A.l = l;
     A.params = obj->params;
     A.row_begin = row_begin;
@@ -918,6 +924,8 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     vs_eval_args A;
     A.D = to_dev(design);
     A.kind = obj->kind;
+    A.plain_recip = obj->recip_ok ? 1 : 0;
+    A.reserved = 0;
     A.l = l;
     A.params = obj->params;
     A.row_begin = row_begin;
@@ -979,6 +987,8 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
     vs_eval_args A;
     A.D = to_dev(design);
     A.kind = obj->kind;
+    A.plain_recip = obj->recip_ok ? 1 : 0;
+    A.reserved = 0;
     A.l = obj->l;
     A.params = obj->params;
     A.row_begin = row_begin;
@@ -989,7 +999,7 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
     // separable built-ins: the segmented scan (O(k) folds per row, association order of
     // vs_device_scan.h) wherever it applies; the chain scheme (strict left-to-right folds, O(k^2)) beyond
     // 256 columns, for Halton indices beyond 2^32, and when the context asks for the strict order
-    if (vs_scan_covers(obj->kind, obj->k, false) && (obj->kind != VS_OBJ_G_FUNCTION || obj->recip_ok) &&
+    if (vs_scan_covers(obj->kind, obj->k, false) &&
         design_compact(design) && ctx->tune.eval_scratch != 1 &&
         ctx->tune.eval_mode != 1)
         return vs_scan_eval(ctx, A);

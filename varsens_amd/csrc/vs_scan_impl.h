@@ -45,7 +45,9 @@ int vs_scan_gram_multi_launch(vs_context* ctx, const vs_eval_args& A, int nb, un
 #define VS_GRAM_LMAX_8 4       // nb = 8: the 160 KiB of LDS hold the tile, two totals slabs and four (a, b) row pairs
 
 #ifdef VS_SCAN_KIND
-template <int KIND>
+// DIV: the column code may meet a reciprocal of 0 (a parameter whose 1 + a Markstein's theorem does not cover) and then
+// divides; compiled into the general column code only (GENV 0 and 3), where such objectives are routed
+template <int KIND, bool DIV = false>
 struct builtin_term {
     static __device__ __forceinline__ double pre(int c, const double* __restrict__ p) { return p[c]; }
     // G_FUNCTION: r = RN(1 / (1 + a)), stored behind the l*k parameters by vs_objective_create
@@ -58,6 +60,7 @@ struct builtin_term {
             // the correctly rounded reciprocal (two steps; the second is exact for every normal n / d -- the host
             // admits only such d).  Same bits as vs_term<G>'s division; 5 fp64 instructions instead of ~13.
             const double n = fabs(4.0 * x - 2.0) + pc, d = 1.0 + pc;
+            if (DIV && r == 0.0) return n / d;   // wave-uniform: a column the theorem does not cover (host: r = 0)
             double q = n * r;
             q = fma(fma(-q, d, n), r, q);
             return fma(fma(-q, d, n), r, q);
@@ -88,7 +91,7 @@ __global__ void __launch_bounds__(VS_EVAL_ROWS* W)
 __attribute__((amdgpu_waves_per_eu(VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI))))
 scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
     extern __shared__ double scan_lds[];  // totals slabs [2 families][W][64] (+ term slabs, + sum slabs), vs_scan_lds
-    vs_scan_body<builtin_term<KIND>, KIND, L, W, FUSED, TLDS, MULTI, GENV, VS_SCAN_SUMS_IN_LDS(L, W, FUSED, GENV)>(
+    vs_scan_body<builtin_term<KIND, GENV == 0 || GENV == 3>, KIND, L, W, FUSED, TLDS, MULTI, GENV, VS_SCAN_SUMS_IN_LDS(L, W, FUSED, GENV)>(
         A, scan_lds, shift_src, partials);
     // counters of the fold that follows (see reduce_first_kernel).  At the END of the kernel: a global
     // store in front of the row loop would make every load of design constants "possibly clobbered"
@@ -126,7 +129,8 @@ static int launch_scan_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io,
 // kernels accept) with identity or linear scaling; Sobol, raw points and power scaling take the general one
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
 static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
-    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0;
+    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0 &&
+                        (A.kind != VS_OBJ_G_FUNCTION || A.plain_recip != 0);   // else: the column code that can divide
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY)
         return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 1>(ctx, A, P_io, shift_dev, plan_only);
     if (halton && A.D.scale_mode == VS_SCALE_LINEAR)
@@ -172,7 +176,7 @@ __global__ void __launch_bounds__(VS_EVAL_ROWS * 4) __attribute__((amdgpu_waves_
 scan_gram_kernel(vs_eval_args A, const double* shift_src, double* first_partials, double* gram_partials,
                  uint32_t* counters) {
     extern __shared__ double scan_lds[];   // [slabs][2][4][64] totals, then the tile [32 NBH + 2 LMAX][68]
-    vs_scan_gram_body<builtin_term<KIND>, KIND, L, NBH, GENV, LMAX>(A, scan_lds, shift_src, first_partials, gram_partials);
+    vs_scan_gram_body<builtin_term<KIND, GENV == 0 || GENV == 3>, KIND, L, NBH, GENV, LMAX>(A, scan_lds, shift_src, first_partials, gram_partials);
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // counters of the folds that follow, at the END (see scan_kernel)
         counters[0] = 0;
         counters[1] = 0xffffffffu;
@@ -209,7 +213,8 @@ static int launch_scan_gram_g(vs_context* ctx, const vs_eval_args& A, unsigned* 
 template <int KIND, int L, int NBH, int LMAX = 1>
 static int launch_scan_gram_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                                double* first_partials, double* gram_partials, bool plan_only) {
-    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0;
+    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0 &&
+                        (A.kind != VS_OBJ_G_FUNCTION || A.plain_recip != 0);   // else: the column code that can divide
 #define VS_GRAM_GENV(G) \
     return launch_scan_gram_g<KIND, L, NBH, G, LMAX>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY) VS_GRAM_GENV(1);
@@ -237,7 +242,7 @@ __global__ void __launch_bounds__(VS_EVAL_ROWS * NB) __attribute__((amdgpu_waves
 scan_gramn_kernel(vs_eval_args A, const double* shift_src, double* first_partials, double* gram_partials,
                   uint32_t* counters) {
     extern __shared__ double scan_lds[];   // [slabs][2][NB][64] totals, then the tile [32 NB + 2 LMAX][68]
-    vs_scan_gramn_body<builtin_term<KIND>, KIND, GENV, NB, NBL, LMAX>(A, scan_lds, shift_src, first_partials, gram_partials);
+    vs_scan_gramn_body<builtin_term<KIND, GENV == 0 || GENV == 3>, KIND, GENV, NB, NBL, LMAX>(A, scan_lds, shift_src, first_partials, gram_partials);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         counters[0] = 0;
         counters[1] = 0xffffffffu;
@@ -275,7 +280,8 @@ static int launch_scan_gramn_g(vs_context* ctx, const vs_eval_args& A, unsigned*
 template <int KIND, int NB, int NBL, int LMAX = 1>
 static int launch_scan_gramn_nbl(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                                  double* first_partials, double* gram_partials, bool plan_only) {
-    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0;
+    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0 &&
+                        (A.kind != VS_OBJ_G_FUNCTION || A.plain_recip != 0);   // else: the column code that can divide
 #define VS_GRAMN_GENV(G) \
     return launch_scan_gramn_g<KIND, G, NB, NBL, LMAX>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY) VS_GRAMN_GENV(1);
