@@ -187,14 +187,16 @@ __device__ __attribute__((noinline)) double vs_sobol_point(vs_u64 i, const vs_u3
 // The same point from per-column byte tables (built once per design on the host): tab[b][v] is the
 // XOR of the direction integers selected by the bits of byte value v at byte position b of the Gray
 // code -- three or four cached 4-byte reads and XORs instead of ~3 vector instructions per bit.
-__device__ __forceinline__ double vs_sobol_point_tab(vs_u64 i, const vs_u32* __restrict__ tab, int nbits) {
+__device__ __forceinline__ vs_u32 vs_sobol_bits_tab(vs_u64 i, const vs_u32* __restrict__ tab, int nbits) {
     const vs_u32 g = (vs_u32)(i ^ (i >> 1));
     vs_u32 x = tab[g & 255u] ^ tab[256 + ((g >> 8) & 255u)];
     if (nbits > 16) x ^= tab[512 + ((g >> 16) & 255u)];
     if (nbits > 24) x ^= tab[768 + (g >> 24)];
-    return (double)x * (1.0 / 4294967296.0);
+    return x;
 }
-
+__device__ __forceinline__ double vs_sobol_point_tab(vs_u64 i, const vs_u32* __restrict__ tab, int nbits) {
+    return (double)vs_sobol_bits_tab(i, tab, nbits) * (1.0 / 4294967296.0);
+}
 struct vs_design_dev {
     int generator, k, scale_mode;
     int sobol_bits;  // Gray-code bits in use (VS_GEN_SOBOL)

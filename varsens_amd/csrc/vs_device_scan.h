@@ -32,12 +32,42 @@
 // whose column loop is unrolled L times: only the compact generator paths are inlined (Halton below
 // 2^32 -- the host sends designs whose indices reach 2^32 to the chain kernel --, Sobol byte tables,
 // raw points), and pow() of the power scaling sits behind one out-of-line copy.
+// Sobol points of the 64 CONSECUTIVE indices base .. base + 63 of a block's M_1 rows (base a multiple of 64: the lane
+// index is the low six bits).  Bit j of the Gray code is i_j ^ i_{j+1}: from bit 6 on it is the block's alone, bit 5 is
+// lane bit 5 ^ bit 6 of the base, bits 0 .. 4 are the lane's.  So the three upper bytes of the Gray code are wave-uniform --
+// their table entries come through the scalar cache -- and only byte 0 is looked up per lane: one gather instead of
+// three or four (round 4: the table gathers are what a Sobol design costs beyond 32 columns, 512 KB of tables at k = 128).
+struct vs_sobol_block {
+    bool fast;     // wave-uniform: the block's M_1 indices are base + lane
+    vs_u32 gb;     // Gray code of the base (bits 6 .. 31 are those of every index of the block)
+    vs_u32 b0;     // this lane's byte 0 of the Gray code
+};
+
+__device__ __forceinline__ vs_sobol_block vs_sobol_block_of(const vs_design_dev& D, vs_u64 r, int lane) {
+    vs_sobol_block S;
+    // lane 0 of a block is always a row of the design (rows are clamped from the block's end): its index is the base
+    const vs_u32 base = (vs_u32)__builtin_amdgcn_readfirstlane((int)(vs_u32)(D.first_index + r));
+    S.fast = D.generator == VS_GEN_SOBOL && (base & 63u) == 0;
+    S.gb = base ^ (base >> 1);
+    S.b0 = ((((vs_u32)lane ^ ((vs_u32)lane >> 1)) ^ ((base >> 1) & 32u)) & 63u) | (S.gb & 192u);
+    return S;
+}
+
+__device__ __forceinline__ vs_u32 vs_sobol_bits_block(const vs_sobol_block& S, const vs_u32* __restrict__ tab, int nbits) {
+    vs_u32 xh = tab[256 + ((S.gb >> 8) & 255u)];           // uniform addresses: scalar loads
+    if (nbits > 16) xh ^= tab[512 + ((S.gb >> 16) & 255u)];
+    if (nbits > 24) xh ^= tab[768 + (S.gb >> 24)];
+    return xh ^ tab[S.b0];
+}
+
 __device__ __forceinline__ void vs_unit_pair(const vs_design_dev& D, const vs_base& B, vs_u64 r, vs_u64 src2, int c,
-                                             double& x1, double& x2) {
+                                             double& x1, double& x2, const vs_sobol_block& SB) {
     if (D.generator == VS_GEN_HALTON) {  // B = D.bases[c], fetched one column ahead by the caller
         vs_radical_inverse_pair((vs_u32)(D.first_index + r), (vs_u32)(D.first_index + src2), B, x1, x2);
     } else if (D.generator == VS_GEN_SOBOL) {
-        x1 = vs_sobol_point_tab(D.first_index + r, D.sobol_tabs + 1024 * c, D.sobol_bits);
+        // (the scan kernels take Sobol points from vs_scan_block's table look-ups, issued for all columns at once)
+        if (SB.fast) x1 = (double)vs_sobol_bits_block(SB, D.sobol_tabs + 1024 * c, D.sobol_bits) * (1.0 / 4294967296.0);
+        else x1 = vs_sobol_point_tab(D.first_index + r, D.sobol_tabs + 1024 * c, D.sobol_bits);
         x2 = vs_sobol_point_tab(D.first_index + src2, D.sobol_tabs + 1024 * c, D.sobol_bits);
     } else {
         x1 = D.raw[r * (vs_u64)D.k + c];
@@ -738,6 +768,36 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     // GENV 1 / 2: Halton below 2^32 with identity / linear scaling -- straight-line code per column;
     // GENV 0: any generator and scaling, decided by (wave-uniform) branches per column (fused: no power scaling);
     // GENV 3: as 0, power scaling included also when fused.
+    // Sobol designs (the general column code): a point is the XOR of three or four table entries, i.e. gathers.  The
+    // look-ups of ALL the wave's columns are issued here, ahead of the column loop, which then only converts (taken
+    // column by column between the scheduling barriers below, a wave sat their latency out once per column), and the M_1
+    // point of a block with aligned consecutive indices takes one look-up instead of three (vs_sobol_block).  Measured
+    // (round 4, tools/sobol_vs_halton.py): fused first order k = 32, n = 2^22 0.493 -> 0.448 ms (Halton: 0.378), k = 64,
+    // n = 2^21 0.84 (Halton 0.46), k = 128, n = 2^20 0.883 -> 0.863 (0.443).  What is left is the texture path itself: a
+    // 64-lane dword gather costs it ~54 clocks whatever the addresses (nibble tables -- one cache line per look-up, twice
+    // as many look-ups -- were SLOWER: 0.95 ms at k = 128), and it is one unit per CU where Halton's digit loops run on
+    // four SIMDs: 4 gathers = ~217 clocks per column and block against ~115.  Next: the GF(2) product on the vector ALU
+    // (23 bits x 2.5 instructions per point, direction integers as scalar operands), no gathers at all.
+    vs_sobol_block sobol_block = {false, 0u, 0u};
+    vs_u32 sx1[L], sx2[L];
+    bool sobol = false;
+    if constexpr (GENV == 0 || GENV == 3) {
+        sobol = A.D.generator == VS_GEN_SOBOL;   // wave-uniform
+        if (sobol) {
+            sobol_block = vs_sobol_block_of(A.D, r, lane);
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                const int c = VS_SCAN_COLUMN(q, j, W);
+                sx1[j] = sx2[j] = 0u;
+                if (c < k) {
+                    const vs_u32* tab = A.D.sobol_tabs + 1024 * c;
+                    sx1[j] = sobol_block.fast ? vs_sobol_bits_block(sobol_block, tab, A.D.sobol_bits)
+                                              : vs_sobol_bits_tab(A.D.first_index + r, tab, A.D.sobol_bits);
+                    sx2[j] = vs_sobol_bits_tab(A.D.first_index + A.D.n + src2, tab, A.D.sobol_bits);
+                }
+            }
+        }
+    }
     vs_scan_col Cnext;
     const int lk = A.l * k;
     vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, VS_SCAN_COLUMN(q, 0, W), k, lk);
@@ -754,7 +814,12 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
                 t1 = GENV == 2 ? x1 * C.w + C.lo : x1;   // scale.py:33
                 t2 = GENV == 2 ? x2 * C.w + C.lo : x2;
             } else {
-                vs_unit_pair(A.D, C.B, r, A.D.n + src2, c, x1, x2);
+                if (sobol) {
+                    x1 = (double)sx1[j] * (1.0 / 4294967296.0);
+                    x2 = (double)sx2[j] * (1.0 / 4294967296.0);
+                } else {
+                    vs_unit_pair(A.D, C.B, r, A.D.n + src2, c, x1, x2, sobol_block);
+                }
                 t1 = vs_apply_scale_compact<!FUSED || GENV == 3>(A.D, x1, c);
                 t2 = vs_apply_scale_compact<!FUSED || GENV == 3>(A.D, x2, c);
             }
