@@ -776,8 +776,10 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     // n = 2^21 0.84 (Halton 0.46), k = 128, n = 2^20 0.883 -> 0.863 (0.443).  What is left is the texture path itself: a
     // 64-lane dword gather costs it ~54 clocks whatever the addresses (nibble tables -- one cache line per look-up, twice
     // as many look-ups -- were SLOWER: 0.95 ms at k = 128), and it is one unit per CU where Halton's digit loops run on
-    // four SIMDs: 4 gathers = ~217 clocks per column and block against ~115.  Next: the GF(2) product on the vector ALU
-    // (23 bits x 2.5 instructions per point, direction integers as scalar operands), no gathers at all.
+    // four SIMDs.  The other way round -- the M_2 point as a GF(2) product on the vector ALU, three instructions per
+    // Gray-code bit with the direction integers as scalar operands, no look-up -- was tried too and is worse still
+    // (k = 32 fused 0.621 ms, k = 64 1.036, k = 128 1.085): the fused kernels have no vector-ALU slack to take 69 more
+    // instructions per point, the look-ups at least run beside it.  (profiles/r04/sobol_vs_halton.txt)
     vs_sobol_block sobol_block = {false, 0u, 0u};
     vs_u32 sx1[L], sx2[L];
     bool sobol = false;
