@@ -216,7 +216,7 @@ def main():
 
     from varsens_amd import _native
     from varsens_amd.saltelli import seed1_permutation
-    ctx = _native.Context(0 if args.shared_device else group.local_rank)
+    ctx = _native.Context(dist.device_for_rank(group.local_rank, args.shared_device))
     world, rank = group.world, group.rank
     exchange = "none (single GPU)" if world == 1 else "rccl all-reduce (xGMI)"
     host_fallback = False

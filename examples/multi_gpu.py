@@ -30,7 +30,7 @@ def main():
     args = ap.parse_args()
 
     group = dist.HostGroup()
-    ctx = _native.Context(0 if args.shared_device else group.local_rank)
+    ctx = _native.Context(dist.device_for_rank(group.local_rank, args.shared_device))
     comm = dist.HostExchange(ctx, group) if args.host_exchange else dist.RcclComm(ctx, group)
 
     a = np.array([0, 0.5, 3, 9, 99, 99], dtype=float)[:args.k] if args.k <= 6 else np.linspace(0, 9, args.k)

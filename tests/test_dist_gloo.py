@@ -165,3 +165,19 @@ def test_a_dead_rank_is_noticed_not_waited_for(tmp_path):
     procs[1].communicate(timeout=60)
     assert procs[1].returncode == 7
     assert procs[0].returncode == 5 and "noticed" in out0, out0
+
+
+def test_device_for_rank_follows_the_visible_devices(monkeypatch):
+    """LOCAL_RANK is the ordinal where a rank sees the whole node; a launcher that narrows each rank's view to its own
+    card leaves one visible device, number 0 -- and a rank that sees none says so."""
+    from varsens_amd import _native, dist
+    monkeypatch.setattr(_native, "device_count", lambda: 8)
+    assert [dist.device_for_rank(r) for r in range(8)] == list(range(8))
+    monkeypatch.setattr(_native, "device_count", lambda: 1)
+    assert [dist.device_for_rank(r) for r in range(8)] == [0] * 8
+    monkeypatch.setattr(_native, "device_count", lambda: 2)
+    assert [dist.device_for_rank(r) for r in range(4)] == [0, 1, 0, 1]
+    assert dist.device_for_rank(5, shared_device=True) == 0
+    monkeypatch.setattr(_native, "device_count", lambda: 0)
+    with pytest.raises(Exception, match="sees no GPU"):
+        dist.device_for_rank(0)

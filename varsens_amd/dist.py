@@ -265,6 +265,20 @@ class HostGroup(object):
         self._dist = None
 
 
+def device_for_rank(local_rank, shared_device=False):
+    """The device ordinal a rank opens: its LOCAL_RANK where the process sees every GPU of the node (torchrun, bench.py's
+    own launcher), ordinal LOCAL_RANK mod visible-count where the launcher has narrowed each rank's view to its own
+    card(s) (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank: every rank then sees ONE device, number 0).  Two ranks
+    that end up on one card are caught where it matters: RCCL refuses duplicate devices."""
+    from . import _native
+    if shared_device:
+        return 0
+    visible = _native.device_count()
+    if visible < 1:
+        raise Exception("rank with LOCAL_RANK=%d sees no GPU" % local_rank)
+    return local_rank % visible
+
+
 def exchange_check(group, before, after):
     """Does an all-reduce result hold the sum over ALL ranks?  `before`: this rank's record as it
     went into the exchange, `after`: what came out (host float64 arrays of equal length on every
