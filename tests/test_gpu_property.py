@@ -7,6 +7,7 @@ import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
 
 from oracle import saltelli_oracle as orc
+from varsens_amd.saltelli import sobol_directions
 
 pytestmark = pytest.mark.gpu
 
@@ -23,6 +24,10 @@ def ctx():
 EDGE_ROWS = st.one_of(st.integers(1, 70), st.sampled_from([63, 64, 65, 127, 128, 129, 511, 512, 513, 2047, 2048, 2049, 4097]),
                       st.integers(71, 6000))
 EDGE_K = st.one_of(st.integers(1, 12), st.sampled_from([15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 70, 80, 81, 96, 97, 112, 113, 127, 128]))
+# None: a Halton design (two draws of three); else the first index of a Sobol design -- 64-aligned (the M_1 points of an
+# aligned block share their upper Gray-code bytes), off by one, across byte boundaries of the Gray code, anywhere
+SOBOL_FIRST = st.one_of(st.none(), st.none(), st.sampled_from([0, 1, 64, 4096, 4097, 65535, 65536, (1 << 24) - 64, 1 << 24]),
+                        st.integers(0, 1 << 26))
 # VS_PROPERTY_EXAMPLES=N: a soak run with N random examples per test instead of the fixed 150 / 100
 _SOAK = int(os.environ.get("VS_PROPERTY_EXAMPLES", "0"))
 COMMON = dict(deadline=None, max_examples=_SOAK or 150, suppress_health_check=list(HealthCheck), derandomize=not _SOAK,
@@ -109,18 +114,24 @@ def test_both_orders_any_shape(k, rows, seed, trim):
 @settings(**COMMON)
 @given(k=EDGE_K, n=st.one_of(st.integers(1, 200), st.sampled_from([63, 64, 65, 128, 1000])),
        kind=st.sampled_from(["g", "lin", "poly", "inv"]), l=st.integers(1, 2), discard=st.integers(0, 50),
-       begin_frac=st.floats(0, 1), mode=st.sampled_from([0, 1]))
-def test_evaluation_any_shape(k, n, kind, l, discard, begin_frac, mode):
+       begin_frac=st.floats(0, 1), mode=st.sampled_from([0, 1]), sobol_first=SOBOL_FIRST)
+def test_evaluation_any_shape(k, n, kind, l, discard, begin_frac, mode, sobol_first):
     from varsens_amd import _native
     c = ctx()
     rng = np.random.RandomState(k * 1000 + n)
     lo = rng.rand(k) - 0.5
     hi = lo + 0.5 + rng.rand(k)
     perm = orc.seed1_permutation(n).astype(np.uint32)
-    d = c.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k, discard), mode, lo if mode else None,
-                        hi if mode else None, perm)
     scaling = (lambda x: orc.scale_linear(x, lo, hi)) if mode else None
-    S = orc.build_sample(k, n, scaling, discard=discard)
+    if sobol_first is None:
+        d = c.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k, discard), mode, lo if mode else None,
+                            hi if mode else None, perm)
+        S = orc.build_sample(k, n, scaling, discard=discard)
+    else:       # a Sobol design from any first index: aligned blocks take the one-look-up M_1 path, others the general one
+        dirs = sobol_directions(k)
+        d = c.design_create(_native.GEN_SOBOL, k, n, sobol_first, mode, lo if mode else None, hi if mode else None, perm,
+                            None, dirs)
+        S = orc.build_sample(k, n, scaling, raw=orc.sobol(k, sobol_first, 2 * n, dirs))
     if kind == "inv":
         lo_, params, code = k, None, _native.OBJ_INVERT
         rows_func = lambda X: 1.0 - X
@@ -160,8 +171,8 @@ def fused_both_takes(k, l, mode):
 @settings(**dict(COMMON, max_examples=_SOAK or 160))
 @given(k=FUSED_K, n=st.one_of(st.integers(1, 300), st.sampled_from([63, 64, 65, 127, 128, 129, 1000, 4097])),
        kind=st.sampled_from(["g", "lin", "poly"]), mode=st.sampled_from([0, 1, 2]), begin_frac=st.floats(0, 1),
-       discard=st.integers(0, 40), slot=st.integers(0, 2), l=st.sampled_from([1, 1, 2, 3, 4]))
-def test_fused_both_orders_any_shape(k, n, kind, mode, begin_frac, discard, slot, l):
+       discard=st.integers(0, 40), slot=st.integers(0, 2), l=st.sampled_from([1, 1, 2, 3, 4]), sobol_first=SOBOL_FIRST)
+def test_fused_both_orders_any_shape(k, n, kind, mode, begin_frac, discard, slot, l, sobol_first):
     """vs_eval_reduce_first_second_order == vs_eval + vs_reduce_first_second_order on any window of the design's rows,
     every kernel family (four waves x 4 / 8 columns, four and eight waves x 16; with several outputs four waves x 2 / 4 / 8
     and eight x 8 columns), every scaling, any variance slot, one to four outputs."""
@@ -177,7 +188,10 @@ def test_fused_both_orders_any_shape(k, n, kind, mode, begin_frac, discard, slot
     elif mode == 2:
         lo, hi = np.full(k, 1e-2), 0.5 + 0.5 * rng.rand(k)
     perm = orc.seed1_permutation(n).astype(np.uint32)
-    d = c.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k, discard), mode, lo, hi, perm)
+    if sobol_first is None:
+        d = c.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k, discard), mode, lo, hi, perm)
+    else:
+        d = c.design_create(_native.GEN_SOBOL, k, n, sobol_first, mode, lo, hi, perm, None, sobol_directions(k))
     params = 0.5 + rng.rand(l, k)
     code = {"g": _native.OBJ_G_FUNCTION, "lin": _native.OBJ_LINEAR, "poly": _native.OBJ_POLYNOMIAL}[kind]
     obj = c.objective_create(code, k, l, params)
