@@ -304,7 +304,7 @@ int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* design, const v
  * LINEAR objectives with one output and k <= 128 (every generator and scaling of the design) and with SEVERAL outputs
  * (ABI 6; the reference's two-output known-answer test, varsens/tests/test_g_function.py:77-88): 2 .. 8 outputs and
  * k l <= 32 index rows, k >= 16 and k l <= 64 (2 .. 4 outputs), or 2 or 4 outputs and k l <= 128 (3 outputs: k l <= 112) -- the shapes where
- * the one kernel is measured faster than the two-kernel route --, identity or linear scaling; the generator runs once per
+ * the one kernel is measured faster than the two-kernel route --, every scaling (power: not 33 .. 64 index rows); the generator runs once per
  * design row, every output builds its terms from the same coordinates, index row = column * l + output of ONE tile, so
  * that sens_2[:, o, :, o'] of every pair of outputs comes out of the same pass; separable source objectives with one
  * output and k <= 128 (identity or linear scaling); ISHIGAMI.  Halton indices below 2^32; not a context in strict

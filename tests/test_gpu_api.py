@@ -585,7 +585,7 @@ def test_fused_both_orders_through_api(vs, golden):
     w = vs.Varsens(vs.objectives.Linear(numpy.ones(70)), vs.scale.Identity(), 70, 500, verbose=False)
     assert w.objective._f is None and w.sens_2.shape == (70, 1, 70, 1)
     # several outputs (round 4): one kernel up to 32 index rows (2 .. 8 outputs), up to 64 with k >= 16 and up to 128
-    # with 2 or 4 outputs (3 up to 112 rows); three outputs beyond 112 rows and power scaling take the two-kernel route
+    # with 2 or 4 outputs (3 up to 112 rows), every scaling; three outputs beyond 112 rows take the two-kernel route
     w = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 500, verbose=False)
     assert w.objective._f is None and w.sens_2.shape == (6, 2, 6, 2)
     w2 = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Identity(), 6, 500, verbose=False, fused=False)
@@ -607,7 +607,11 @@ def test_fused_both_orders_through_api(vs, golden):
     w = vs.Varsens(vs.objectives.GFunction([c30, c30[::-1], c30]), vs.scale.Identity(), 30, 500, verbose=False)
     assert w.objective._f is None and w.sens_2.shape == (30, 3, 30, 3)
     w = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Power(1.0, 10.0), 6, 500, verbose=False)
-    assert w.objective._f is not None
+    assert w.objective._f is None        # power scaling (scale.py:62; scale.magnitude reduces to it): one kernel as well
+    w2 = vs.Varsens(vs.objectives.GFunction([model, model[::-1]]), vs.scale.Power(1.0, 10.0), 6, 500, verbose=False, fused=False)
+    assert w2.objective._f is not None
+    for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(w, f), getattr(w2, f), rtol=1e-9, atol=1e-11, err_msg=f)
     # Ishigami (BASELINE configs[2]): its own thread-per-row fused kernel carries the second-order sums too
     i3 = vs.Varsens(vs.objectives.Ishigami(), vs.scale.Linear(-numpy.pi, numpy.pi), 3, 20000, verbose=False)
     assert i3.objective._f is None

@@ -161,11 +161,11 @@ FUSED_K = st.one_of(st.integers(1, 128), st.sampled_from([16, 17, 32, 33, 48, 49
 
 def fused_both_takes(k, l, mode):
     """include/varsens_hip.h, vs_eval_reduce_first_second_order: several outputs of a built-in separable objective --
-    2 .. 8 outputs up to 32 index rows, k >= 16 up to 64, 2 or 4 outputs up to 128 (3 up to 112), no power scaling"""
+    2 .. 8 outputs up to 32 index rows, k >= 16 up to 64 (not with power scaling), 2 or 4 outputs up to 128 (3 up to 112)"""
     if l == 1:
         return k <= 128
     K = k * l
-    return mode != 2 and ((K <= 32 and l <= 8) or (K <= 64 and k >= 16) or (64 < K <= 128 and (l in (2, 4) or (l == 3 and K <= 112))))
+    return ((K <= 32 and l <= 8) or (K <= 64 and k >= 16 and mode != 2) or (64 < K <= 128 and (l in (2, 4) or (l == 3 and K <= 112))))
 
 
 @settings(**dict(COMMON, max_examples=_SOAK or 160))

@@ -425,10 +425,11 @@ def gram_expected_rows(F):
 
 
 @pytest.mark.parametrize("k,l,mode,generator", [(6, 2, 1, None), (20, 3, 1, None), (30, 4, 1, None), (6, 2, 0, "sobol"),
-                                                (40, 2, 1, "sobol"), (5, 3, 2, None), (33, 2, 2, None)])
+                                                (40, 2, 1, "sobol"), (5, 3, 2, None), (33, 2, 2, None), (16, 4, 2, None),
+                                                (32, 4, 2, None), (37, 3, 2, "sobol")])
 def test_fused_both_orders_several_outputs_designs(ctx, k, l, mode, generator):
-    """Linear scaling and the Sobol generator take the several-output kernels too (the general column code); power
-    scaling has no such instance: the engine says so and the two-kernel route serves."""
+    """Linear and power scaling and the Sobol generator take the several-output kernels too (the general column code;
+    power scaling: round 4's last addition -- scale.magnitude of the reference's model studies reduces to it)."""
     from varsens_amd import _native
     from varsens_amd.saltelli import sobol_directions
     n = 2500
@@ -442,15 +443,14 @@ def test_fused_both_orders_several_outputs_designs(ctx, k, l, mode, generator):
     obj = ctx.objective_create(KINDS["g_function"], k, l, P)
     K = k * l
     nacc, ng = _native.acc_len(k, l, 1), _native.gram_len(K)
-    assert ctx.eval_reduce_both_supported(d, obj) == (mode != 2)
+    takes = not (mode == 2 and 32 < k * l <= 64)      # power scaling at 33 .. 64 index rows: measured slower, not routed
+    assert ctx.eval_reduce_both_supported(d, obj) == takes
+    if not takes:
+        return
     f = ctx.alloc(8 * 2 * (k + 1) * n * l)
     ctx.eval(d, obj, 0, n, f)
     acc1, g1 = ctx.alloc(8 * nacc), ctx.alloc(8 * ng)
     ctx.reduce_first_second_order(f, n, k, l, acc1, g1)
-    if mode == 2:
-        with pytest.raises(Exception, match="fused both-orders path covers"):
-            ctx.eval_reduce_first_second_order(d, obj, 0, n, acc1, g1)
-        return
     acc, g = ctx.alloc(8 * nacc), ctx.alloc(8 * ng)
     ctx.eval_reduce_first_second_order(d, obj, 0, n, acc, g)
     per = _native.acc_per_output(k)

@@ -1,5 +1,5 @@
 """Fused evaluate + both orders (vs_eval_reduce_first_second_order) beside vs_eval + vs_reduce_first_second_order:
-median kernel times per call.   K=32 LOG2N=22 KIND=lin [L=4] python3 tools/fused_both.py   (L: outputs)"""
+median kernel times per call.   K=32 LOG2N=22 KIND=lin [L=4] [MODE=2] python3 tools/fused_both.py   (L: outputs; MODE: 0 identity, 1 linear, 2 power)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,9 @@ k, n = int(os.environ.get("K", 32)), 1 << int(os.environ.get("LOG2N", 22))
 kind = os.environ.get("KIND", "lin")
 l = int(os.environ.get("L", 1))
 ctx = _native.Context(0)
-design = ctx.design_create(_native.GEN_HALTON, k, n, 1 + 20 * k, 0, None, None, seed1_permutation(n))
+mode = int(os.environ.get("MODE", 0))      # 0 identity, 1 linear, 2 power scaling
+lo, hi = (None, None) if mode == 0 else (np.full(k, 0.5), np.linspace(1.0, 3.0, k))
+design = ctx.design_create(_native.GEN_HALTON, k, n, 1 + 20 * k, mode, lo, hi, seed1_permutation(n))
 code, params = {"lin": (_native.OBJ_LINEAR, np.arange(1, k + 1, dtype=float)),
                 "g": (_native.OBJ_G_FUNCTION, np.linspace(0, 9, k)),
                 "poly": (_native.OBJ_POLYNOMIAL, 1.0 / (1.0 + np.arange(k) / 8.0))}[kind]

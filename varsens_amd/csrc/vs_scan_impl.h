@@ -209,7 +209,6 @@ static int launch_scan_gram_g(vs_context* ctx, const vs_eval_args& A, unsigned* 
     return VS_OK;
 }
 
-// several outputs: no instance with pow() (power scaling takes vs_eval + vs_reduce_first_second_order)
 template <int KIND, int L, int NBH, int LMAX = 1>
 static int launch_scan_gram_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                                double* first_partials, double* gram_partials, bool plan_only) {
@@ -219,11 +218,7 @@ static int launch_scan_gram_lw(vs_context* ctx, const vs_eval_args& A, unsigned*
     return launch_scan_gram_g<KIND, L, NBH, G, LMAX>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY) VS_GRAM_GENV(1);
     if (halton && A.D.scale_mode == VS_SCALE_LINEAR) VS_GRAM_GENV(2);
-    if constexpr (LMAX == 1) {
-        if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAM_GENV(3);
-    } else {
-        if (A.D.scale_mode == VS_SCALE_POWER) return vs_fail(VS_ERR_ARG, "no fused both-orders kernel for several outputs with power scaling");
-    }
+    if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAM_GENV(3);
     VS_GRAM_GENV(0);
 #undef VS_GRAM_GENV
 }
@@ -286,11 +281,7 @@ static int launch_scan_gramn_nbl(vs_context* ctx, const vs_eval_args& A, unsigne
     return launch_scan_gramn_g<KIND, G, NB, NBL, LMAX>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY) VS_GRAMN_GENV(1);
     if (halton && A.D.scale_mode == VS_SCALE_LINEAR) VS_GRAMN_GENV(2);
-    if constexpr (LMAX == 1) {
-        if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAMN_GENV(3);
-    } else {
-        if (A.D.scale_mode == VS_SCALE_POWER) return vs_fail(VS_ERR_ARG, "no fused both-orders kernel for several outputs with power scaling");
-    }
+    if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAMN_GENV(3);
     VS_GRAMN_GENV(0);
 #undef VS_GRAMN_GENV
 }
