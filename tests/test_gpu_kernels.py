@@ -1074,3 +1074,49 @@ def test_device_halton_against_scipy(ctx):
         got = ctx.download(ctx.halton_fill(k, start, count), (count, k))
         d = np.abs(got - ref) / np.spacing(np.maximum(got, ref))
         assert d.max() <= (2.0 if start < 100000 else 4.0) and np.percentile(d, 99) <= 2.0 and (d == 0).mean() > 0.45
+
+
+# The fused kernels form Halton numerators in three instructions per digit (vs_radical_inverse_pair_horner) where
+# (largest index of the design) * b^(digits - 1) < 2^53 holds for the column -- the host's VS_BASE_HORNER -- and fall
+# back to the digit loop column by column where it does not (general column code), so designs on either side of the
+# condition, and designs with columns on both sides, must give the oracle's bits.  k = 5: base 3 is the first column to
+# lose the flag, when the last index reaches 3^17 (then 17 -> 18 digits, top weight 3^17: 3^17 * 3^17 > 2^53).
+_K53, _N53 = 5, 96
+_LAST_OK = 3 ** 17 - 1
+_DISCARDS_53 = [("every column in the three-instruction form (last index 3^17 - 1)", _LAST_OK - 2 * _N53 + 1 - (1 + 20 * _K53)),
+                ("base 3 back on the digit loop (last index 3^17)", _LAST_OK - 2 * _N53 + 2 - (1 + 20 * _K53)),
+                ("bases 2 and 3 on the digit loop (last index 2^27 + 5)", 2 ** 27 + 5 - 2 * _N53 + 1 - (1 + 20 * _K53)),
+                ("far beyond (last index 3e9)", 3_000_000_000 - 2 * _N53 + 1 - (1 + 20 * _K53))]
+
+
+@pytest.mark.parametrize("label,discard", _DISCARDS_53, ids=[c[0] for c in _DISCARDS_53])
+@pytest.mark.parametrize("scaled", [False, True], ids=["identity", "linear"])
+def test_designs_around_the_exactness_bound_of_the_short_digit_step(ctx, label, discard, scaled):
+    from varsens_amd import _native
+    k, n = _K53, _N53
+    lo, hi = np.linspace(-2.0, 1.0, k), np.linspace(3.0, 9.0, k)
+    if scaled:
+        d = make_design(ctx, k, n, _native.SCALE_LINEAR, lo, hi, discard=discard)
+        S = orc.build_sample(k, n, lambda x: orc.scale_linear(x, lo, hi), discard=discard)
+    else:
+        d = make_design(ctx, k, n, discard=discard)
+        S = orc.build_sample(k, n, discard=discard)
+    for kind, name, params in ((_native.OBJ_G_FUNCTION, "g_function", np.array([0.0, 0.5, 3.0, 9.0, 99.0])),
+                               (_native.OBJ_LINEAR, "linear", np.arange(1.0, k + 1))):
+        f, got = eval_dev(ctx, d, kind, k, 1, params, n)
+        F = orc.evaluate_engine_order(name, params, S[0], S[1])
+        same(got, oracle_blocks(F))                                   # vs_eval: the digit loop in every design
+        obj = ctx.objective_create(kind, k, 1, params)
+        assert ctx.eval_reduce_supported(d, obj) and ctx.eval_reduce_both_supported(d, obj)
+        nacc, ng = _native.acc_len(k, 1, 1), _native.gram_len(k)
+        acc, acc2, gram = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc), ctx.alloc(8 * ng)
+        ctx.eval_reduce_first_order(d, obj, 0, n, acc)                # fused kernels: the short form where the column allows
+        ctx.eval_reduce_first_second_order(d, obj, 0, n, acc2, gram)
+        ex = orc.exact_accumulators(*orc.evaluate_scan(name, params, S[0], S[1], fused=True))
+        for r in (ctx.download(acc, (nacc,)), ctx.download(acc2, (nacc,))):
+            np.testing.assert_allclose(r[4 + 3:4 + 3 + k], ex["ac"][:, 0], rtol=1e-13)
+            np.testing.assert_allclose(r[4 + 3 + k:4 + 3 + 2 * k], ex["bd"][:, 0], rtol=1e-13)
+        C, D = np.asarray(F[2])[:, :, 0], np.asarray(F[3])[:, :, 0]
+        G = ctx.download(gram, (2, k, k))
+        np.testing.assert_allclose(G[0], (C + D) @ (C + D).T, rtol=1e-12)
+        np.testing.assert_allclose(G[1], (C - D) @ (C - D).T, rtol=1e-12, atol=1e-12 * np.abs(G[0]).max())

@@ -81,3 +81,55 @@ def test_device_sequence_is_the_correctly_rounded_quotient():
                     m += 1
                     j //= b
                 assert want == float(Fraction(num // b ** (ndig - m), b ** m))
+
+
+def horner_numerator(i, b, ndig):
+    """vs_radical_inverse_pair_horner's numerator, operation for operation (every fp64 instruction an exactly
+    rounded one over Fractions): three instructions per digit step, then -(b^2 - 1) P + i top."""
+    inv_b = inv_b_up(b)
+    bd, top = float(b), float(b ** (ndig - 1))
+    j, p = float(i), 0.0
+    for _ in range(ndig - 1):
+        j = float(math.floor(float(Fraction(j) * Fraction(inv_b))))   # v_mul_f64 (rounded), v_floor_f64
+        p = fma(p, bd, j)
+    m = fma(-bd, bd, 1.0)
+    return fma(m, p, float(Fraction(float(i)) * Fraction(top)))
+
+
+def test_horner_form_gives_the_digit_reversed_integer():
+    """sum_t d_t b^(T-t) = j_0 b^T - (b^2 - 1) sum_{t>=1} j_t b^(T-t) with j_t = i // b^t: the numerator the device forms
+    without forming a digit is the exact digit-reversed integer whenever (largest index) * b^(ndig-1) < 2^53 -- the
+    host's condition for VS_BASE_HORNER -- at the edges of that condition and of the digit counts."""
+    rng = np.random.RandomState(2)
+    bases = [int(b) for b in orc.first_primes(1000)]
+    for b in bases[1:14] + bases[30:34] + bases[125:129] + bases[-2:]:
+        for max_index in (5, b - 1, b, b * b, 641 + (1 << 23), 2561 + (1 << 25), 94_900_000, (1 << 28) + 7, (1 << 32) - 1):
+            ndig, v = 0, max_index
+            while v:
+                ndig += 1
+                v //= b
+            ok = max_index * b ** (ndig - 1) < 2 ** 53
+            idx = {1, 2, b - 1, b, b + 1, min(b * b, max_index), max_index, max_index - 1, b ** (ndig - 1), b ** (ndig - 1) - 1}
+            idx.update(int(x) for x in rng.randint(1, max_index + 1, 60))
+            for i in idx:
+                if not 1 <= i <= max_index:
+                    continue
+                num, j = 0, i
+                for _ in range(ndig):
+                    num = num * b + j % b
+                    j //= b
+                got = horner_numerator(i, b, ndig)
+                if ok:
+                    assert got == float(num) and Fraction(got) == num, (i, b, ndig)
+    # the condition is the one that matters: beyond it the product i * top is no longer exact for some index
+    b, max_index = 3, (1 << 32) - 1
+    ndig = 21
+    assert 3 ** 20 <= max_index < 3 ** 21 and max_index * 3 ** 20 >= 2 ** 53
+    wrong = 0
+    for i in range(max_index - 2000, max_index):
+        num, j = 0, i
+        for _ in range(ndig):
+            num = num * b + j % b
+            j //= b
+        wrong += Fraction(horner_numerator(i, b, ndig)) != num
+    assert wrong > 0

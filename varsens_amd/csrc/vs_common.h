@@ -79,7 +79,8 @@ struct vs_design {
     double* raw = nullptr;     // device (2n,k) or null
     uint32_t* dirs = nullptr;  // device (k,32) or null
     uint32_t* sobol_tabs = nullptr;  // device (k,4,256): XOR of the direction integers selected by each byte value
-    uint32_t* bases = nullptr; // device, k x {base, magic, shift, pad}
+    uint32_t* bases = nullptr; // device, k x vs_base (vs_device_gen.h)
+    int halton_horner = 0;     // every column's record carries VS_BASE_HORNER (vs_radical_inverse_pair_horner is exact)
 };
 
 struct vs_objective {

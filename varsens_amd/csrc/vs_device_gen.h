@@ -73,11 +73,14 @@ __device__ __forceinline__ double vs_shift_estimate(const double* a, vs_u64 rows
 
 struct vs_base {
     vs_u32 b;        // prime base
-    vs_u32 ndig;     // digits of the largest index of this design in base b (0: indices reach 2^32)
-    double den;      // b^ndig
-    double inv_den;  // RN(1 / den)
+    vs_u32 ndig;     // digits of the largest index of this design in base b (0: indices reach 2^32); bit 31
+                     // (VS_BASE_HORNER): largest index * b^(ndig-1) < 2^53, the three-instruction digit step is exact
+    double top;      // b^(ndig-1): weight of the first reversed digit; the denominator b^ndig is top * b (exact)
+    double inv_den;  // RN(1 / b^ndig)
     double inv_b;    // RN(1 / b) pushed up two ulps: floor(j * inv_b) == j / b for every j < 2^32
 };
+#define VS_BASE_HORNER 0x80000000u
+#define VS_BASE_DIGITS(B) ((B).ndig & 0x7fffffffu)
 
 // Radical inverse of i in base b: the digit-reversed integer of i divided by
 // b^digits, as ONE correctly rounded fp64 quotient of two exact integers
@@ -94,16 +97,17 @@ __device__ __forceinline__ double vs_radical_inverse(vs_u64 i, const vs_base B) 
         const vs_u32 j = (vs_u32)i;
         if (B.b == 2) return (double)__brev(j) * (1.0 / 4294967296.0);
         const double bd = (double)B.b;
+        const double den = B.top * bd;
         double num = 0.0, jd = (double)j;
-        for (vs_u32 t = 0; t < B.ndig; ++t) {   // see vs_radical_inverse_pair for why floor() is exact
+        for (vs_u32 t = 0; t < VS_BASE_DIGITS(B); ++t) {   // see vs_radical_inverse_pair_digits for why floor() is exact
             const double q = floor(jd * B.inv_b);
             num = fma(num, bd, fma(-q, bd, jd));
             jd = q;
         }
         double q0 = num * B.inv_den;
-        double r0 = fma(-q0, B.den, num);
+        double r0 = fma(-q0, den, num);
         double q1 = fma(r0, B.inv_den, q0);
-        double r1 = fma(-q1, B.den, num);
+        double r1 = fma(-q1, den, num);
         return fma(r1, B.inv_den, q1);
     }
     double num = 0.0, den = 1.0;
@@ -118,24 +122,38 @@ __device__ __forceinline__ double vs_radical_inverse(vs_u64 i, const vs_base B) 
     return num / den;
 }
 
-// Two radical inverses in the same base with interleaved digit loops (two
-// independent dependency chains per step).  Fast path only (B.ndig != 0).
-__device__ __forceinline__ void vs_radical_inverse_pair(vs_u32 i1, vs_u32 i2, const vs_base B,
-                                                         double& x1, double& x2) {
+// The correctly rounded quotients n1 / den, n2 / den of two exact integers below den = b^ndig < 2^53: Markstein's fma
+// sequence on the host-rounded reciprocal (two Newton steps, the last one provably the rounded quotient).
+__device__ __forceinline__ void vs_halton_quotients(double n1, double n2, double den, double inv_den, double& x1, double& x2) {
+    double a0 = n1 * inv_den, b0 = n2 * inv_den;
+    double ra = fma(-a0, den, n1), rb = fma(-b0, den, n2);
+    a0 = fma(ra, inv_den, a0);
+    b0 = fma(rb, inv_den, b0);
+    ra = fma(-a0, den, n1);
+    rb = fma(-b0, den, n2);
+    x1 = fma(ra, inv_den, a0);
+    x2 = fma(rb, inv_den, b0);
+}
+
+// Two radical inverses in the same base with interleaved digit loops (two independent dependency chains per step),
+// indices below 2^32 (B.ndig != 0), one digit at a time: 4 instructions per digit and point.  The form for designs whose
+// indices are too large for vs_radical_inverse_pair_horner.
+__device__ __forceinline__ void vs_radical_inverse_pair_digits(vs_u32 i1, vs_u32 i2, const vs_base B,
+                                                                double& x1, double& x2) {
+    // Digit steps entirely in fp64: with inv_b two ulps
+    // above 1/b, floor(j*inv_b) is the exact quotient for j < 2^32, b < 2^16 -- an exact multiple
+    // can no longer round below its integer, and the inflation (< 2^-17 absolute) is far smaller
+    // than the distance 1/b of any other quotient to the next integer.  The digit j - q*b and the
+    // numerator update are exact fmas on integers below 2^53.
     if (B.b == 2) {
         x1 = (double)__brev(i1) * (1.0 / 4294967296.0);
         x2 = (double)__brev(i2) * (1.0 / 4294967296.0);
         return;
     }
-    // Digit steps entirely in fp64 (4 instructions per digit and point): with inv_b two ulps
-    // above 1/b, floor(j*inv_b) is the exact quotient for j < 2^32, b < 2^16 -- an exact multiple
-    // can no longer round below its integer, and the inflation (< 2^-17 absolute) is far smaller
-    // than the distance 1/b of any other quotient to the next integer.  The digit j - q*b and the
-    // numerator update are exact fmas on integers below 2^53.
     const double bd = (double)B.b;
     double n1 = 0.0, n2 = 0.0;
     double j1 = (double)i1, j2 = (double)i2;
-    vs_u32 t = B.ndig;
+    vs_u32 t = VS_BASE_DIGITS(B);
     for (; t >= 2; t -= 2) {  // two digits per trip: no register rotation between steps
         const double q1 = floor(j1 * B.inv_b);
         const double q2 = floor(j2 * B.inv_b);
@@ -152,14 +170,51 @@ __device__ __forceinline__ void vs_radical_inverse_pair(vs_u32 i1, vs_u32 i2, co
         n1 = fma(n1, bd, fma(-q1, bd, j1));
         n2 = fma(n2, bd, fma(-q2, bd, j2));
     }
-    double a0 = n1 * B.inv_den, b0 = n2 * B.inv_den;
-    double ra = fma(-a0, B.den, n1), rb = fma(-b0, B.den, n2);
-    a0 = fma(ra, B.inv_den, a0);
-    b0 = fma(rb, B.inv_den, b0);
-    ra = fma(-a0, B.den, n1);
-    rb = fma(-b0, B.den, n2);
-    x1 = fma(ra, B.inv_den, a0);
-    x2 = fma(rb, B.inv_den, b0);
+    vs_halton_quotients(n1, n2, B.top * bd, B.inv_den, x1, x2);
+}
+
+// The same two numerators in THREE instructions per digit and point (round 4).  With j_0 = i, j_t = floor(j_{t-1} / b)
+// the digits are d_t = j_t - b j_{t+1}, and the digit-reversed integer over T + 1 = ndig digits telescopes:
+//     sum_t d_t b^(T-t) = j_0 b^T - (b^2 - 1) P,     P = sum_{t=1..T} j_t b^(T-t) = (((j_1) b + j_2) b + ...) + j_T,
+// a Horner sum of the quotients themselves -- no digit is ever formed: per step one product, one floor and one fma, then
+// two instructions per point and two per column (b^2 - 1, b^ndig).  Everything is an integer; the largest is j_0 b^T
+// <= (largest index of the design) * b^(ndig-1), which the host checks to be below 2^53 before it sets VS_BASE_HORNER
+// (every design below 9.49e7 indices in all, i.e. up to n = 47 million rows); so the numerator is the same exact integer
+// as the digit loop's and the quotient the same bits.  Base 2 is a bit reversal in either form.
+__device__ __forceinline__ void vs_radical_inverse_pair_horner(vs_u32 i1, vs_u32 i2, const vs_base B,
+                                                                double& x1, double& x2) {
+    if (B.b == 2) {
+        x1 = (double)__brev(i1) * (1.0 / 4294967296.0);
+        x2 = (double)__brev(i2) * (1.0 / 4294967296.0);
+        return;
+    }
+    const double bd = (double)B.b;
+    const double d1 = (double)i1, d2 = (double)i2;
+    // T = ndig - 1 >= 1 steps (the host gives every column at least two digits).  The first one is peeled -- P starts as
+    // j_1, and i itself stays in its registers for the last line --, the others run one per trip: the quotient is updated
+    // in place, so a trip carries no register copy, and its three scalar loop instructions issue beside the other waves'
+    // vector work (two steps per trip needed a tail for odd T, which the compiler turned into six more instructions and
+    // four selects for every column).
+    double j1 = floor(d1 * B.inv_b), j2 = floor(d2 * B.inv_b);
+    double p1 = j1, p2 = j2;
+    for (vs_u32 t = VS_BASE_DIGITS(B) - 2u; t; --t) {
+        j1 = floor(j1 * B.inv_b);
+        j2 = floor(j2 * B.inv_b);
+        p1 = fma(p1, bd, j1);
+        p2 = fma(p2, bd, j2);
+    }
+    const double m = fma(-bd, bd, 1.0);          // -(b^2 - 1)
+    const double n1 = fma(m, p1, d1 * B.top);    // both terms exact integers below 2^53, and so is their sum
+    const double n2 = fma(m, p2, d2 * B.top);
+    vs_halton_quotients(n1, n2, B.top * bd, B.inv_den, x1, x2);
+}
+
+// whichever form the column's record allows (wave-uniform branch): the general column code, the chain and run-time
+// compiled kernels; the straight-line scan kernels (GENV 1 / 2) are routed to by the host only when every column has
+// VS_BASE_HORNER and call vs_radical_inverse_pair_horner directly
+__device__ __forceinline__ void vs_radical_inverse_pair(vs_u32 i1, vs_u32 i2, const vs_base B, double& x1, double& x2) {
+    if (B.ndig & VS_BASE_HORNER) vs_radical_inverse_pair_horner(i1, i2, B, x1, x2);
+    else vs_radical_inverse_pair_digits(i1, i2, B, x1, x2);
 }
 
 // Sobol point of index i for one coordinate: XOR of the direction integers selected by the set
@@ -200,6 +255,8 @@ __device__ __forceinline__ double vs_sobol_point_tab(vs_u64 i, const vs_u32* __r
 struct vs_design_dev {
     int generator, k, scale_mode;
     int sobol_bits;  // Gray-code bits in use (VS_GEN_SOBOL)
+    int halton_horner;   // VS_GEN_HALTON: every column's record has VS_BASE_HORNER (the straight-line kernels need it)
+    int reserved0;
     vs_u64 n, first_index;
     const double* lower;
     const double* width;    // LINEAR: upper - lower [k]; POWER: ratio [k], then ln ratio as hi [k] and lo [k]

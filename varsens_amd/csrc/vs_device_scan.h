@@ -60,10 +60,23 @@ __device__ __forceinline__ vs_u32 vs_sobol_bits_block(const vs_sobol_block& S, c
     return xh ^ tab[S.b0];
 }
 
+// Which form of the digit step a scan kernel runs.  The fused kernels (no f-values: bound by the vector pipe) take the
+// three-instruction form -- always where the host routed a straight-line kernel (ALL: every column has VS_BASE_HORNER),
+// by the column's flag in the general code.  The kernels that WRITE f-values keep the four-instruction loop: they are
+// bound by their stores, and inside the bench step the k = 32 evaluation is SLOWER with the shorter arithmetic phase
+// (0.40-0.41 ms against 0.365, same box, profiles/r04/ab_halton_forms.txt) although it is faster launched alone.
+template <bool FUSED, bool ALL>
+__device__ __forceinline__ void vs_halton_pair(vs_u32 i1, vs_u32 i2, const vs_base& B, double& x1, double& x2) {
+    if constexpr (!FUSED) vs_radical_inverse_pair_digits(i1, i2, B, x1, x2);
+    else if constexpr (ALL) vs_radical_inverse_pair_horner(i1, i2, B, x1, x2);
+    else vs_radical_inverse_pair(i1, i2, B, x1, x2);
+}
+
+template <bool FUSED>
 __device__ __forceinline__ void vs_unit_pair(const vs_design_dev& D, const vs_base& B, vs_u64 r, vs_u64 src2, int c,
                                              double& x1, double& x2, const vs_sobol_block& SB) {
     if (D.generator == VS_GEN_HALTON) {  // B = D.bases[c], fetched one column ahead by the caller
-        vs_radical_inverse_pair((vs_u32)(D.first_index + r), (vs_u32)(D.first_index + src2), B, x1, x2);
+        vs_halton_pair<FUSED, false>((vs_u32)(D.first_index + r), (vs_u32)(D.first_index + src2), B, x1, x2);
     } else if (D.generator == VS_GEN_SOBOL) {
         // (the scan kernels take Sobol points from vs_scan_block's table look-ups, issued for all columns at once)
         if (SB.fast) x1 = (double)vs_sobol_bits_block(SB, D.sobol_tabs + 1024 * c, D.sobol_bits) * (1.0 / 4294967296.0);
@@ -812,7 +825,7 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
         if (c < k) {
             double x1, x2;
             if (GENV == 1 || GENV == 2) {
-                vs_radical_inverse_pair((vs_u32)(A.D.first_index + r), (vs_u32)(A.D.first_index + A.D.n + src2), C.B, x1, x2);
+                vs_halton_pair<FUSED, true>((vs_u32)(A.D.first_index + r), (vs_u32)(A.D.first_index + A.D.n + src2), C.B, x1, x2);
                 t1 = GENV == 2 ? x1 * C.w + C.lo : x1;   // scale.py:33
                 t2 = GENV == 2 ? x2 * C.w + C.lo : x2;
             } else {
@@ -820,7 +833,7 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
                     x1 = (double)sx1[j] * (1.0 / 4294967296.0);
                     x2 = (double)sx2[j] * (1.0 / 4294967296.0);
                 } else {
-                    vs_unit_pair(A.D, C.B, r, A.D.n + src2, c, x1, x2, sobol_block);
+                    vs_unit_pair<FUSED>(A.D, C.B, r, A.D.n + src2, c, x1, x2, sobol_block);
                 }
                 t1 = vs_apply_scale_compact<!FUSED || GENV == 3>(A.D, x1, c);
                 t2 = vs_apply_scale_compact<!FUSED || GENV == 3>(A.D, x2, c);

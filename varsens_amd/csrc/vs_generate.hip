@@ -26,6 +26,8 @@ static vs_design_dev to_dev(const vs_design* g) {
     D.k = g->d.k;
     D.scale_mode = g->d.scale_mode;
     D.sobol_bits = 32;
+    D.halton_horner = g->halton_horner;
+    D.reserved0 = 0;
     if (g->d.generator == VS_GEN_SOBOL) {
         const uint64_t top = g->d.first_index + 2 * g->d.n;  // Gray code of i < 2^b stays below 2^b
         int b = 1;
@@ -66,7 +68,7 @@ static vs_base make_base(uint32_t b, uint64_t max_index) {
     vs_base B;
     B.b = b;
     B.ndig = 0;
-    B.den = 1.0;
+    B.top = 1.0;
     B.inv_den = 1.0;
     B.inv_b = 0.5;
     if (max_index < (1ull << 32)) {
@@ -76,18 +78,28 @@ static vs_base make_base(uint32_t b, uint64_t max_index) {
             den *= b;  // <= max_index * b < 2^53
         }
         if (B.ndig == 0) { B.ndig = 1; den = b; }
-        B.den = (double)den;
-        B.inv_den = 1.0 / B.den;
+        if (B.ndig == 1) { B.ndig = 2; den *= b; }   // a leading zero digit: same quotient (vs_radical_inverse_pair_horner peels a step)
+        const uint64_t top = den / b;   // b^(ndig-1) <= max_index
+        B.top = (double)top;
+        B.inv_den = 1.0 / (double)den;
+        // the three-instruction digit step (vs_radical_inverse_pair_horner) forms index * top: exact below 2^53
+        if ((unsigned __int128)max_index * top < ((unsigned __int128)1 << 53)) B.ndig |= VS_BASE_HORNER;
     }
     B.inv_b = nextafter(nextafter(1.0 / (double)b, 2.0), 2.0);
     return B;
 }
 
 // max_index: largest sequence index the kernels will ask for
-static int upload_bases(vs_context* ctx, int k, uint64_t max_index, uint32_t** out_dev, uint32_t* largest) {
+static int upload_bases(vs_context* ctx, int k, uint64_t max_index, uint32_t** out_dev, uint32_t* largest,
+                        int* horner = nullptr) {
     std::vector<uint32_t> p = first_primes(k);
     std::vector<vs_base> tab(k);
-    for (int c = 0; c < k; ++c) tab[c] = make_base(p[c], max_index);
+    int all = 1;
+    for (int c = 0; c < k; ++c) {
+        tab[c] = make_base(p[c], max_index);
+        if (!(tab[c].ndig & VS_BASE_HORNER)) all = 0;
+    }
+    if (horner) *horner = all;
     *largest = p[k - 1];
     VS_HIP(hipMalloc(out_dev, sizeof(vs_base) * k));
     VS_HIP(hipMemcpyAsync(*out_dev, tab.data(), sizeof(vs_base) * k, hipMemcpyHostToDevice, ctx->stream));
@@ -284,7 +296,7 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
     }
     if (desc->generator == VS_GEN_HALTON) {
         uint32_t largest = 0;
-        rc = upload_bases(ctx, k, desc->first_index + 2 * n - 1, &g->bases, &largest);
+        rc = upload_bases(ctx, k, desc->first_index + 2 * n - 1, &g->bases, &largest, &g->halton_horner);
         if (rc) return bail(rc);
         if ((long double)(desc->first_index + 2 * n) * largest >= 9007199254740992.0L)
             return bail(vs_fail(VS_ERR_ARG, "Halton index range too large for exact fp64 (index*base >= 2^53)"));

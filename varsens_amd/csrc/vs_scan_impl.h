@@ -125,11 +125,14 @@ static int launch_scan_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io,
     return VS_OK;
 }
 
-// the specialised column code for the common designs: Halton (indices below 2^32: every design the scan
-// kernels accept) with identity or linear scaling; Sobol, raw points and power scaling take the general one
+// the specialised column code for the common designs: Halton with identity or linear scaling and -- in the fused
+// kernels -- every index small enough for the three-instruction digit step (vs_radical_inverse_pair_horner: below 9.49e7
+// indices in all, n up to 47 million rows); larger Halton designs there, Sobol, raw points and power scaling take the
+// general one
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
 static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
-    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0 &&
+    // (the kernels that write f-values run the four-instruction digit loop: any design below 2^32 indices)
+    const bool halton = A.D.generator == VS_GEN_HALTON && (A.D.halton_horner != 0 || !FUSED) && ctx->tune.scan_general == 0 &&
                         (A.kind != VS_OBJ_G_FUNCTION || A.plain_recip != 0);   // else: the column code that can divide
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY)
         return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 1>(ctx, A, P_io, shift_dev, plan_only);
@@ -212,7 +215,7 @@ static int launch_scan_gram_g(vs_context* ctx, const vs_eval_args& A, unsigned* 
 template <int KIND, int L, int NBH, int LMAX = 1>
 static int launch_scan_gram_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                                double* first_partials, double* gram_partials, bool plan_only) {
-    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0 &&
+    const bool halton = A.D.generator == VS_GEN_HALTON && A.D.halton_horner != 0 && ctx->tune.scan_general == 0 &&
                         (A.kind != VS_OBJ_G_FUNCTION || A.plain_recip != 0);   // else: the column code that can divide
 #define VS_GRAM_GENV(G) \
     return launch_scan_gram_g<KIND, L, NBH, G, LMAX>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
@@ -275,7 +278,7 @@ static int launch_scan_gramn_g(vs_context* ctx, const vs_eval_args& A, unsigned*
 template <int KIND, int NB, int NBL, int LMAX = 1>
 static int launch_scan_gramn_nbl(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                                  double* first_partials, double* gram_partials, bool plan_only) {
-    const bool halton = A.D.generator == VS_GEN_HALTON && ctx->tune.scan_general == 0 &&
+    const bool halton = A.D.generator == VS_GEN_HALTON && A.D.halton_horner != 0 && ctx->tune.scan_general == 0 &&
                         (A.kind != VS_OBJ_G_FUNCTION || A.plain_recip != 0);   // else: the column code that can divide
 #define VS_GRAMN_GENV(G) \
     return launch_scan_gramn_g<KIND, G, NB, NBL, LMAX>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
