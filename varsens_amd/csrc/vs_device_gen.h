@@ -138,21 +138,21 @@ __device__ __forceinline__ void vs_halton_quotients(double n1, double n2, double
 // Two radical inverses in the same base with interleaved digit loops (two independent dependency chains per step),
 // indices below 2^32 (B.ndig != 0), one digit at a time: 4 instructions per digit and point.  The form for designs whose
 // indices are too large for vs_radical_inverse_pair_horner.
-__device__ __forceinline__ void vs_radical_inverse_pair_digits(vs_u32 i1, vs_u32 i2, const vs_base B,
-                                                                double& x1, double& x2) {
+__device__ __forceinline__ void vs_radical_inverse_pair_digits(vs_u32 i1, vs_u32 i2, double d1, double d2, const vs_base B,
+                                                                double& x1, double& x2, bool may_be_2 = true) {   // d1, d2 = (double)i1, i2
     // Digit steps entirely in fp64: with inv_b two ulps
     // above 1/b, floor(j*inv_b) is the exact quotient for j < 2^32, b < 2^16 -- an exact multiple
     // can no longer round below its integer, and the inflation (< 2^-17 absolute) is far smaller
     // than the distance 1/b of any other quotient to the next integer.  The digit j - q*b and the
     // numerator update are exact fmas on integers below 2^53.
-    if (B.b == 2) {
+    if (may_be_2 && B.b == 2) {
         x1 = (double)__brev(i1) * (1.0 / 4294967296.0);
         x2 = (double)__brev(i2) * (1.0 / 4294967296.0);
         return;
     }
     const double bd = (double)B.b;
     double n1 = 0.0, n2 = 0.0;
-    double j1 = (double)i1, j2 = (double)i2;
+    double j1 = d1, j2 = d2;
     vs_u32 t = VS_BASE_DIGITS(B);
     for (; t >= 2; t -= 2) {  // two digits per trip: no register rotation between steps
         const double q1 = floor(j1 * B.inv_b);
@@ -181,15 +181,14 @@ __device__ __forceinline__ void vs_radical_inverse_pair_digits(vs_u32 i1, vs_u32
 // <= (largest index of the design) * b^(ndig-1), which the host checks to be below 2^53 before it sets VS_BASE_HORNER
 // (every design below 9.49e7 indices in all, i.e. up to n = 47 million rows); so the numerator is the same exact integer
 // as the digit loop's and the quotient the same bits.  Base 2 is a bit reversal in either form.
-__device__ __forceinline__ void vs_radical_inverse_pair_horner(vs_u32 i1, vs_u32 i2, const vs_base B,
-                                                                double& x1, double& x2) {
-    if (B.b == 2) {
+__device__ __forceinline__ void vs_radical_inverse_pair_horner(vs_u32 i1, vs_u32 i2, double d1, double d2, const vs_base B,
+                                                                double& x1, double& x2, bool may_be_2 = true) {   // d1, d2 = (double)i1, i2
+    if (may_be_2 && B.b == 2) {   // may_be_2: false where the caller knows the column is not the design's first
         x1 = (double)__brev(i1) * (1.0 / 4294967296.0);
         x2 = (double)__brev(i2) * (1.0 / 4294967296.0);
         return;
     }
     const double bd = (double)B.b;
-    const double d1 = (double)i1, d2 = (double)i2;
     // T = ndig - 1 >= 1 steps (the host gives every column at least two digits).  The first one is peeled -- P starts as
     // j_1, and i itself stays in its registers for the last line --, the others run one per trip: the quotient is updated
     // in place, so a trip carries no register copy, and its three scalar loop instructions issue beside the other waves'
@@ -212,9 +211,13 @@ __device__ __forceinline__ void vs_radical_inverse_pair_horner(vs_u32 i1, vs_u32
 // whichever form the column's record allows (wave-uniform branch): the general column code, the chain and run-time
 // compiled kernels; the straight-line scan kernels (GENV 1 / 2) are routed to by the host only when every column has
 // VS_BASE_HORNER and call vs_radical_inverse_pair_horner directly
+__device__ __forceinline__ void vs_radical_inverse_pair(vs_u32 i1, vs_u32 i2, double d1, double d2, const vs_base B,
+                                                        double& x1, double& x2, bool may_be_2 = true) {
+    if (B.ndig & VS_BASE_HORNER) vs_radical_inverse_pair_horner(i1, i2, d1, d2, B, x1, x2, may_be_2);
+    else vs_radical_inverse_pair_digits(i1, i2, d1, d2, B, x1, x2, may_be_2);
+}
 __device__ __forceinline__ void vs_radical_inverse_pair(vs_u32 i1, vs_u32 i2, const vs_base B, double& x1, double& x2) {
-    if (B.ndig & VS_BASE_HORNER) vs_radical_inverse_pair_horner(i1, i2, B, x1, x2);
-    else vs_radical_inverse_pair_digits(i1, i2, B, x1, x2);
+    vs_radical_inverse_pair(i1, i2, (double)i1, (double)i2, B, x1, x2);
 }
 
 // Sobol point of index i for one coordinate: XOR of the direction integers selected by the set

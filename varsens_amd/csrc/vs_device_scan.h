@@ -66,17 +66,19 @@ __device__ __forceinline__ vs_u32 vs_sobol_bits_block(const vs_sobol_block& S, c
 // bound by their stores, and inside the bench step the k = 32 evaluation is SLOWER with the shorter arithmetic phase
 // (0.40-0.41 ms against 0.365, same box, profiles/r04/ab_halton_forms.txt) although it is faster launched alone.
 template <bool FUSED, bool ALL>
-__device__ __forceinline__ void vs_halton_pair(vs_u32 i1, vs_u32 i2, const vs_base& B, double& x1, double& x2) {
-    if constexpr (!FUSED) vs_radical_inverse_pair_digits(i1, i2, B, x1, x2);
-    else if constexpr (ALL) vs_radical_inverse_pair_horner(i1, i2, B, x1, x2);
-    else vs_radical_inverse_pair(i1, i2, B, x1, x2);
+__device__ __forceinline__ void vs_halton_pair(vs_u32 i1, vs_u32 i2, double d1, double d2, const vs_base& B, double& x1, double& x2,
+                                               bool may_be_2) {   // base 2 is column 0: only a wave's first column can be it
+    if constexpr (!FUSED) vs_radical_inverse_pair_digits(i1, i2, d1, d2, B, x1, x2, may_be_2);
+    else if constexpr (ALL) vs_radical_inverse_pair_horner(i1, i2, d1, d2, B, x1, x2, may_be_2);
+    else vs_radical_inverse_pair(i1, i2, d1, d2, B, x1, x2, may_be_2);
 }
 
 template <bool FUSED>
 __device__ __forceinline__ void vs_unit_pair(const vs_design_dev& D, const vs_base& B, vs_u64 r, vs_u64 src2, int c,
                                              double& x1, double& x2, const vs_sobol_block& SB) {
     if (D.generator == VS_GEN_HALTON) {  // B = D.bases[c], fetched one column ahead by the caller
-        vs_halton_pair<FUSED, false>((vs_u32)(D.first_index + r), (vs_u32)(D.first_index + src2), B, x1, x2);
+        const vs_u32 i1 = (vs_u32)(D.first_index + r), i2 = (vs_u32)(D.first_index + src2);
+        vs_halton_pair<FUSED, false>(i1, i2, (double)i1, (double)i2, B, x1, x2, c == 0);
     } else if (D.generator == VS_GEN_SOBOL) {
         // (the scan kernels take Sobol points from vs_scan_block's table look-ups, issued for all columns at once)
         if (SB.fast) x1 = (double)vs_sobol_bits_block(SB, D.sobol_tabs + 1024 * c, D.sobol_bits) * (1.0 / 4294967296.0);
@@ -813,6 +815,10 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
             }
         }
     }
+    // the two Halton indices of the row as integers and as doubles, once for all columns (the straight-line code
+    // converted them again in every column: two of its ~70 vector instructions)
+    const vs_u32 hi1 = (vs_u32)(A.D.first_index + r), hi2 = (vs_u32)(A.D.first_index + A.D.n + src2);
+    const double hd1 = (double)hi1, hd2 = (double)hi2;
     vs_scan_col Cnext;
     const int lk = A.l * k;
     vs_scan_col_load<Term, GENV, MULTI>(Cnext, A.D, params, VS_SCAN_COLUMN(q, 0, W), k, lk);
@@ -825,7 +831,7 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
         if (c < k) {
             double x1, x2;
             if (GENV == 1 || GENV == 2) {
-                vs_halton_pair<FUSED, true>((vs_u32)(A.D.first_index + r), (vs_u32)(A.D.first_index + A.D.n + src2), C.B, x1, x2);
+                vs_halton_pair<FUSED, true>(hi1, hi2, hd1, hd2, C.B, x1, x2, j == 0);   // VS_SCAN_COLUMN(q, j, W) = 0 needs j = 0
                 t1 = GENV == 2 ? x1 * C.w + C.lo : x1;   // scale.py:33
                 t2 = GENV == 2 ? x2 * C.w + C.lo : x2;
             } else {
