@@ -189,14 +189,15 @@ __device__ __forceinline__ void vs_radical_inverse_pair_horner(vs_u32 i1, vs_u32
         return;
     }
     const double bd = (double)B.b;
-    // T = ndig - 1 >= 1 steps (the host gives every column at least two digits).  The first one is peeled -- P starts as
-    // j_1, and i itself stays in its registers for the last line --, the others run one per trip: the quotient is updated
-    // in place, so a trip carries no register copy, and its three scalar loop instructions issue beside the other waves'
-    // vector work (two steps per trip needed a tail for odd T, which the compiler turned into six more instructions and
-    // four selects for every column).
-    double j1 = floor(d1 * B.inv_b), j2 = floor(d2 * B.inv_b);
-    double p1 = j1, p2 = j2;
-    for (vs_u32 t = VS_BASE_DIGITS(B) - 2u; t; --t) {
+    // T = ndig - 1 >= 2 steps (the host gives every column with VS_BASE_HORNER at least three digits).  The first two are
+    // peeled: P starts as j_1 b + j_2 out of fresh registers, i itself stays where it is for the last line, and the loop
+    // over the remaining steps updates its quotient in place -- no register copy anywhere.  One step per trip: its
+    // three scalar loop instructions issue beside the other waves' vector work (two steps per trip needed a tail for
+    // odd T, which the compiler turned into six more instructions and four selects for every column).
+    const double q1 = floor(d1 * B.inv_b), q2 = floor(d2 * B.inv_b);
+    double j1 = floor(q1 * B.inv_b), j2 = floor(q2 * B.inv_b);
+    double p1 = fma(q1, bd, j1), p2 = fma(q2, bd, j2);
+    for (vs_u32 t = VS_BASE_DIGITS(B) - 3u; t; --t) {
         j1 = floor(j1 * B.inv_b);
         j2 = floor(j2 * B.inv_b);
         p1 = fma(p1, bd, j1);

@@ -78,12 +78,12 @@ static vs_base make_base(uint32_t b, uint64_t max_index) {
             den *= b;  // <= max_index * b < 2^53
         }
         if (B.ndig == 0) { B.ndig = 1; den = b; }
-        if (B.ndig == 1) { B.ndig = 2; den *= b; }   // a leading zero digit: same quotient (vs_radical_inverse_pair_horner peels a step)
+        while (B.ndig < 3 && den * b < (1ull << 53)) { ++B.ndig; den *= b; }   // leading zero digits: same quotient (vs_radical_inverse_pair_horner peels two steps)
         const uint64_t top = den / b;   // b^(ndig-1) <= max_index
         B.top = (double)top;
         B.inv_den = 1.0 / (double)den;
         // the three-instruction digit step (vs_radical_inverse_pair_horner) forms index * top: exact below 2^53
-        if ((unsigned __int128)max_index * top < ((unsigned __int128)1 << 53)) B.ndig |= VS_BASE_HORNER;
+        if (B.ndig >= 3 && (unsigned __int128)max_index * top < ((unsigned __int128)1 << 53)) B.ndig |= VS_BASE_HORNER;
     }
     B.inv_b = nextafter(nextafter(1.0 / (double)b, 2.0), 2.0);
     return B;
