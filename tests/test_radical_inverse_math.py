@@ -133,3 +133,50 @@ def test_horner_form_gives_the_digit_reversed_integer():
             j //= b
         wrong += Fraction(horner_numerator(i, b, ndig)) != num
     assert wrong > 0
+
+
+def two_word_reciprocal(den):
+    """the host's (inv_den, inv_lo) of make_base (vs_generate.hip): RN(1/den) and RN of what is left"""
+    hi = 1.0 / float(den)
+    r = fma(-float(den), hi, 1.0)            # exact: the residual of a correctly rounded reciprocal fits a double
+    assert Fraction(r) == 1 - Fraction(den) * Fraction(hi)
+    return hi, r / float(den)
+
+
+def quotient_dd(n, hi, lo):
+    """vs_halton_quotients_dd: one rounded product and one fma"""
+    return fma(float(n), hi, float(Fraction(float(n)) * Fraction(lo)))
+
+
+def test_two_instruction_quotient_is_the_correctly_rounded_one():
+    """x = fma(n, inv_den, RN(n inv_lo)) equals RN(n / den) for every numerator below a denominator b^ndig <= 2^49 (the
+    host's condition for VS_BASE_HORNER): random numerators, the ends of the range, and the numerators CLOSEST to a
+    rounding boundary -- for a boundary m (odd multiple of half an ulp) the integers next to den * m."""
+    rng = np.random.RandomState(3)
+    bases = [int(b) for b in orc.first_primes(1000)]
+    checked = 0
+    for b in bases[1:16] + bases[60:64] + bases[125:129] + bases[-3:]:
+        for ndig in range(3, 40):
+            den = b ** ndig
+            if den > 2 ** 49:
+                break
+            if den < 2 ** 20 and ndig > 3:
+                continue
+            hi, lo = two_word_reciprocal(den)
+            assert lo == float(Fraction(1, den) - Fraction(hi))           # RN(1/den - inv_den)
+            ns = {1, 2, den - 1, den - 2, den // 2, den // 2 + 1, den // 3, (den * 2) // 3}
+            ns.update(int(x) for x in rng.randint(1, min(den, 2 ** 62), 40, dtype=np.int64) % den)
+            # numerators next to rounding boundaries of quotients in [1/2, 1) and [1/4, 1/2): boundary = (2 j + 1) 2^-54, 2^-55
+            for e in (54, 55, 60):
+                for _ in range(12):
+                    j = int(rng.randint(2 ** 51, 2 ** 52, dtype=np.int64))
+                    mid = Fraction(2 * j + 1, 2 ** e)
+                    if e == 54 and not (Fraction(1, 2) <= mid < 1):
+                        continue
+                    t = den * mid
+                    ns.update((int(t), int(t) + 1))
+            for n in ns:
+                if 0 < n < den:
+                    assert quotient_dd(n, hi, lo) == float(Fraction(n, den)), (n, b, ndig)
+                    checked += 1
+    assert checked > 5000

@@ -78,6 +78,7 @@ struct vs_base {
     double top;      // b^(ndig-1): weight of the first reversed digit; the denominator b^ndig is top * b (exact)
     double inv_den;  // RN(1 / b^ndig)
     double inv_b;    // RN(1 / b) pushed up two ulps: floor(j * inv_b) == j / b for every j < 2^32
+    double inv_lo;   // RN(1 / b^ndig - inv_den): the reciprocal's second word (vs_halton_quotients_dd)
 };
 #define VS_BASE_HORNER 0x80000000u
 #define VS_BASE_DIGITS(B) ((B).ndig & 0x7fffffffu)
@@ -135,6 +136,18 @@ __device__ __forceinline__ void vs_halton_quotients(double n1, double n2, double
     x2 = fma(rb, inv_den, b0);
 }
 
+// The same quotients in TWO instructions per point where the denominator is small enough (round 4).  With the
+// reciprocal as a double-double y = inv_den + inv_lo + d, |d| <= u^2 y (u = 2^-53), the fma below rounds
+//     V = n inv_den + RN(n inv_lo),     |V - n/den| <= 2 u^2 (n/den) (1 + 2u),
+// once.  n/den is a ratio of integers with an odd (or power-of-two) denominator b^ndig: it is never a rounding
+// boundary, and its distance to the nearest one is at least ulp(n/den) / (4 den) >= u (n/den) / (4 den).  So for
+// den < 2^53 / 8.1 no boundary lies between V and n/den, and RN(V) = RN(n/den): the host sets VS_BASE_HORNER only for
+// den <= 2^49 (twice that margin).  Tests: tests/test_radical_inverse_math.py restates it over exact rationals.
+__device__ __forceinline__ void vs_halton_quotients_dd(double n1, double n2, double inv_den, double inv_lo, double& x1, double& x2) {
+    x1 = fma(n1, inv_den, n1 * inv_lo);
+    x2 = fma(n2, inv_den, n2 * inv_lo);
+}
+
 // Two radical inverses in the same base with interleaved digit loops (two independent dependency chains per step),
 // indices below 2^32 (B.ndig != 0), one digit at a time: 4 instructions per digit and point.  The form for designs whose
 // indices are too large for vs_radical_inverse_pair_horner.
@@ -177,7 +190,7 @@ __device__ __forceinline__ void vs_radical_inverse_pair_digits(vs_u32 i1, vs_u32
 // the digits are d_t = j_t - b j_{t+1}, and the digit-reversed integer over T + 1 = ndig digits telescopes:
 //     sum_t d_t b^(T-t) = j_0 b^T - (b^2 - 1) P,     P = sum_{t=1..T} j_t b^(T-t) = (((j_1) b + j_2) b + ...) + j_T,
 // a Horner sum of the quotients themselves -- no digit is ever formed: per step one product, one floor and one fma, then
-// two instructions per point and two per column (b^2 - 1, b^ndig).  Everything is an integer; the largest is j_0 b^T
+// two instructions per point and one per column (b^2 - 1).  Everything is an integer; the largest is j_0 b^T
 // <= (largest index of the design) * b^(ndig-1), which the host checks to be below 2^53 before it sets VS_BASE_HORNER
 // (every design below 9.49e7 indices in all, i.e. up to n = 47 million rows); so the numerator is the same exact integer
 // as the digit loop's and the quotient the same bits.  Base 2 is a bit reversal in either form.
@@ -206,7 +219,7 @@ __device__ __forceinline__ void vs_radical_inverse_pair_horner(vs_u32 i1, vs_u32
     const double m = fma(-bd, bd, 1.0);          // -(b^2 - 1)
     const double n1 = fma(m, p1, d1 * B.top);    // both terms exact integers below 2^53, and so is their sum
     const double n2 = fma(m, p2, d2 * B.top);
-    vs_halton_quotients(n1, n2, B.top * bd, B.inv_den, x1, x2);
+    vs_halton_quotients_dd(n1, n2, B.inv_den, B.inv_lo, x1, x2);
 }
 
 // whichever form the column's record allows (wave-uniform branch): the general column code, the chain and run-time

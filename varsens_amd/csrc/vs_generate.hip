@@ -71,6 +71,7 @@ static vs_base make_base(uint32_t b, uint64_t max_index) {
     B.top = 1.0;
     B.inv_den = 1.0;
     B.inv_b = 0.5;
+    B.inv_lo = 0.0;
     if (max_index < (1ull << 32)) {
         uint64_t den = 1;
         for (uint64_t v = max_index; v; v /= b) {
@@ -82,8 +83,13 @@ static vs_base make_base(uint32_t b, uint64_t max_index) {
         const uint64_t top = den / b;   // b^(ndig-1) <= max_index
         B.top = (double)top;
         B.inv_den = 1.0 / (double)den;
+        // second word of the reciprocal: 1 - den * inv_den exactly (long double holds the 53 x 53 bit product of two
+        // doubles only to 64 bits: form it with an fma instead), over den
+        B.inv_lo = fma(-(double)den, B.inv_den, 1.0) / (double)den;
         // the three-instruction digit step (vs_radical_inverse_pair_horner) forms index * top: exact below 2^53
-        if (B.ndig >= 3 && (unsigned __int128)max_index * top < ((unsigned __int128)1 << 53)) B.ndig |= VS_BASE_HORNER;
+        // ... and takes its quotient from the two-word reciprocal: den <= 2^49 (vs_halton_quotients_dd)
+        if (B.ndig >= 3 && (unsigned __int128)max_index * top < ((unsigned __int128)1 << 53) && den <= (1ull << 49))
+            B.ndig |= VS_BASE_HORNER;
     }
     B.inv_b = nextafter(nextafter(1.0 / (double)b, 2.0), 2.0);
     return B;
