@@ -551,6 +551,61 @@ __device__ __forceinline__ void vs_gramn_epilogue(double* __restrict__ lds, int 
     }
 }
 
+// The folds of the W segment totals a wave with segment Q needs: the whole row (left to right), the prefix of the
+// segments before its own -- the value that chain has when it reaches segment Q, the same additions in the same order --
+// and the suffix of those after it (right to left).  One body per Q behind a switch on the wave-uniform q: 2 W + 2 (W - 1
+// - Q) folds and nothing else.  (Until round 4 one body served every wave with `w < q` / `w > q` inside the unrolled
+// loops: the compiler turned those into selects -- at W = 4 22 folds and 28 v_cndmask per block and output, at W = 8
+// 46 and 60.)
+template <int FOLD, int W, int Q>
+__device__ __forceinline__ void vs_fold_segments_q(const double* __restrict__ totl, double& Pa, double& Pb, double& Sa,
+                                                   double& Sb, double& a, double& b) {
+    constexpr int T = VS_EVAL_ROWS;
+    const double ident = FOLD == VS_OBJ_LINEAR ? 0.0 : 1.0;
+    double xa = ident, xb = ident;
+    Pa = ident;
+    Pb = ident;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        if (w == Q) {
+            Pa = xa;
+            Pb = xb;
+        }
+        xa = vs_fold<FOLD>(xa, totl[(0 * W + w) * T]);
+        xb = vs_fold<FOLD>(xb, totl[(1 * W + w) * T]);
+    }
+    a = xa;
+    b = xb;
+    Sa = ident;
+    Sb = ident;
+#pragma unroll
+    for (int w = W - 1; w > Q; --w) {
+        Sa = vs_fold<FOLD>(totl[(0 * W + w) * T], Sa);
+        Sb = vs_fold<FOLD>(totl[(1 * W + w) * T], Sb);
+    }
+}
+
+template <int FOLD, int W>
+__device__ __forceinline__ void vs_fold_segments_of(const double* __restrict__ totl, int q, double& Pa, double& Pb,
+                                                    double& Sa, double& Sb, double& a, double& b) {
+#define VS_FOLD_Q(QQ) vs_fold_segments_q<FOLD, W, (QQ) < W ? (QQ) : 0>(totl, Pa, Pb, Sa, Sb, a, b)
+    if constexpr (W == 1) {
+        VS_FOLD_Q(0);
+    } else {
+        switch (q) {
+            case 0: VS_FOLD_Q(0); break;
+            case 1: VS_FOLD_Q(1); break;
+            case 2: VS_FOLD_Q(2); break;
+            case 3: VS_FOLD_Q(3); break;
+            case 4: VS_FOLD_Q(4); break;
+            case 5: VS_FOLD_Q(5); break;
+            case 6: VS_FOLD_Q(6); break;
+            default: VS_FOLD_Q(7); break;
+        }
+    }
+#undef VS_FOLD_Q
+}
+
 // Everything behind the terms of one output: totals exchange, prefixes, suffix checkpoints, outputs.
 // ta/tb: the wave's 2L terms in registers (TLDS: in its LDS slab `tl` instead); Ta/Tb their totals.
 // NBH > 0 (FUSED): the outputs go into the Gram tile `gt` (tile + lane) instead of the 4L register sums.
@@ -576,24 +631,8 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
     tot[(1 * W + q) * T + lane] = Tb;
     __syncthreads();
     // ---- folds over the other segments: prefix (left to right), suffix (right to left), whole row
-    double Pa = ident, Pb = ident, Sa = ident, Sb = ident, a = ident, b = ident;
-#pragma unroll
-    for (int w = 0; w < W; ++w) {
-        const double ua = tot[(0 * W + w) * T + lane], ub = tot[(1 * W + w) * T + lane];
-        a = vs_fold<FOLD>(a, ua);
-        b = vs_fold<FOLD>(b, ub);
-        if (w < q) {
-            Pa = vs_fold<FOLD>(Pa, ua);
-            Pb = vs_fold<FOLD>(Pb, ub);
-        }
-    }
-#pragma unroll
-    for (int w = W - 1; w > 0; --w) {
-        if (w > q) {
-            Sa = vs_fold<FOLD>(tot[(0 * W + w) * T + lane], Sa);
-            Sb = vs_fold<FOLD>(tot[(1 * W + w) * T + lane], Sb);
-        }
-    }
+    double Pa, Pb, Sa, Sb, a, b;
+    vs_fold_segments_of<FOLD, W>(tot + lane, q, Pa, Pb, Sa, Sb, a, b);
     // ---- checkpoints of the right-to-left suffix chain: ca[m] = fold of the a-terms after sub-block m
     double ca[NSUB], cb[NSUB];
     {

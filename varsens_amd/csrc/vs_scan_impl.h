@@ -79,11 +79,12 @@ struct builtin_term {
 //       0 = any generator and scaling (fused: except power scaling); 3 = fused, power scaling
 // columns per wave whose four sums the fused kernel keeps in LDS instead of registers (vs_scan_body): what the
 // four-waves-per-SIMD shape is short of, so that nothing goes to scratch
-#define VS_SCAN_SUMS_IN_LDS(L, W, FUSED, GENV) ((FUSED) && (L) == 8 && (W) == 4 ? VS_SCAN_SLDS_84(GENV) : 0)
-// (Halton with identity / linear scaling: one column; the general generator paths and the one with pow() behind a
-// call need more room)
+#define VS_SCAN_SUMS_IN_LDS(KIND, L, W, FUSED, GENV) ((FUSED) && (L) == 8 && (W) == 4 ? VS_SCAN_SLDS_84(KIND, GENV) : 0)
+// (Halton with identity / linear scaling: one column -- two for the linear objective, whose kernel was one register
+// short once the folds of the segment totals were compiled per wave: 0.268 ms either way --; the general generator
+// paths and the one with pow() behind a call need more room)
 #ifndef VS_SCAN_SLDS_84
-#define VS_SCAN_SLDS_84(GENV) ((GENV) == 1 || (GENV) == 2 ? 1 : (GENV) == 0 ? 2 : 4)
+#define VS_SCAN_SLDS_84(KIND, GENV) ((GENV) == 1 || (GENV) == 2 ? ((KIND) == VS_OBJ_LINEAR ? 2 : 1) : (GENV) == 0 ? 2 : 4)
 #endif
 
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(VS_EVAL_ROWS* W)
 __attribute__((amdgpu_waves_per_eu(VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI))))
 scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
     extern __shared__ double scan_lds[];  // totals slabs [2 families][W][64] (+ term slabs, + sum slabs), vs_scan_lds
-    vs_scan_body<builtin_term<KIND, GENV == 0 || GENV == 3>, KIND, L, W, FUSED, TLDS, MULTI, GENV, VS_SCAN_SUMS_IN_LDS(L, W, FUSED, GENV)>(
+    vs_scan_body<builtin_term<KIND, GENV == 0 || GENV == 3>, KIND, L, W, FUSED, TLDS, MULTI, GENV, VS_SCAN_SUMS_IN_LDS(KIND, L, W, FUSED, GENV)>(
         A, scan_lds, shift_src, partials);
     // counters of the fold that follows (see reduce_first_kernel).  At the END of the kernel: a global
     // store in front of the row loop would make every load of design constants "possibly clobbered"
@@ -107,7 +108,7 @@ scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t*
 
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
 static int launch_scan_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
-    const size_t lds = sizeof(double) * vs_scan_lds<L, W, TLDS, VS_SCAN_SUMS_IN_LDS(L, W, FUSED, GENV)>::doubles;
+    const size_t lds = sizeof(double) * vs_scan_lds<L, W, TLDS, VS_SCAN_SUMS_IN_LDS(KIND, L, W, FUSED, GENV)>::doubles;
     const void* fn = (const void*)scan_kernel<KIND, L, W, FUSED, TLDS, MULTI, GENV>;
     if (lds > 64 * 1024) VS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
