@@ -76,7 +76,7 @@ extern "C" int vs_context_create(int device, vs_context** out) {
         if (t.eval_waves != 0 && t.eval_waves != 4 && t.eval_waves != 8) t.eval_waves = 0;
         t.eval_mode = (int)knob("VS_EVAL_MODE", t.eval_mode, 0, 2);
         t.fused_wgs_per_cu = (int)knob("VS_FUSED_WGS_PER_CU", t.fused_wgs_per_cu, 0, 8);
-        t.fused_both_wide = (int)knob("VS_FUSED_BOTH_WIDE", t.fused_both_wide, 0, 1);
+        t.fused_both_wide = (int)knob("VS_FUSED_BOTH_WIDE", t.fused_both_wide, 0, 2);
         // shapes are L*100+W; one that is not instantiated makes the launch fail with VS_ERR_ARG naming the knob
         t.fused_variant = (int)knob("VS_FUSED_VARIANT", t.fused_variant, 0, 3216);
         t.scan_shape = (int)knob("VS_SCAN_SHAPE", t.scan_shape, 0, 3216);

@@ -899,10 +899,10 @@ static fused_route fused_both_route(const vs_context* ctx, const vs_design* desi
         // spends its time in the outputs' barriers and walks and loses to vs_eval + vs_reduce_first_second_order
         // (profiles/r04/fused_both_several_outputs_sweep.txt: k=8 l=8 3.25 vs 2.54 ms, k=12 l=3 1.74 vs 1.55; from 16
         // columns on it wins: k=16 l=4 2.37 vs 2.49, k=20 l=3 2.25 vs 2.49, k=32 l=2 2.19 vs 2.46)
-        if (nb == 4 && obj->k < 16) return FUSED_NONE;
+        if (nb == 4 && obj->k < 16 && ctx->tune.fused_both_wide != 2) return FUSED_NONE;
         // power scaling: the four-wave kernel of 33 .. 64 index rows loses there too (k=16 l=4 3.09 vs 2.44 ms, k=32 l=2
         // 3.75 vs 2.78); below and above it wins (k=16 l=2 1.01 vs 1.32, k=32 l=4 5.00 vs 5.52, k=64 l=2 5.35 vs 6.17)
-        if (nb == 4 && design->d.scale_mode == VS_SCALE_POWER) return FUSED_NONE;
+        if (nb == 4 && design->d.scale_mode == VS_SCALE_POWER && ctx->tune.fused_both_wide != 2) return FUSED_NONE;
         return FUSED_SCAN;
     }
     const fused_route r = fused_route_for(ctx, design, obj);
