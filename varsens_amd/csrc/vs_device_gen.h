@@ -98,6 +98,18 @@ __device__ __forceinline__ double vs_radical_inverse(vs_u64 i, const vs_base B) 
         const vs_u32 j = (vs_u32)i;
         if (B.b == 2) return (double)__brev(j) * (1.0 / 4294967296.0);
         const double bd = (double)B.b;
+        if (B.ndig & VS_BASE_HORNER) {   // three instructions per digit, two for the quotient: vs_radical_inverse_pair_horner
+            const double d = (double)j;
+            const double q1 = floor(d * B.inv_b);
+            double jj = floor(q1 * B.inv_b);
+            double p = fma(q1, bd, jj);
+            for (vs_u32 t = VS_BASE_DIGITS(B) - 3u; t; --t) {
+                jj = floor(jj * B.inv_b);
+                p = fma(p, bd, jj);
+            }
+            const double n = fma(fma(-bd, bd, 1.0), p, d * B.top);
+            return fma(n, B.inv_den, n * B.inv_lo);
+        }
         const double den = B.top * bd;
         double num = 0.0, jd = (double)j;
         for (vs_u32 t = 0; t < VS_BASE_DIGITS(B); ++t) {   // see vs_radical_inverse_pair_digits for why floor() is exact
