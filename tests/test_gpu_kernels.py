@@ -24,8 +24,13 @@ def same(a, b):
 
 # ------------------------------------------------------------------ generators
 
+# (the large starts: indices whose numerators the short digit step forms as i * b^(digits-1) close to 2^53 -- 3^17 - 1 is
+# the last index with every column of k = 5 in that form --, indices where some columns are back on the digit loop, the
+# last indices below 2^32; k = 1000: bases up to 7919, denominators up to 2^49 for the two-word quotient)
 @pytest.mark.parametrize("k,start,count", [(1, 1, 1), (7, 1, 513), (40, 801, 5000), (128, 2561, 3000),
-                                           (3, 2 ** 32 - 100, 300)])
+                                           (3, 2 ** 32 - 100, 300), (5, 3 ** 17 - 400, 400), (5, 3 ** 17 - 200, 400),
+                                           (64, 2 ** 25 - 100, 300), (128, 2 ** 26 + 12345, 200), (1000, 60_000_000, 40),
+                                           (16, 2 ** 27 - 50, 100), (32, 9 * 10 ** 8, 200)])
 def test_halton_fill_bit_exact(ctx, k, start, count):
     buf = ctx.halton_fill(k, start, count)
     got = ctx.download(buf, (count, k))
