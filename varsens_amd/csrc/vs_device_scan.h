@@ -63,8 +63,11 @@ __device__ __forceinline__ vs_u32 vs_sobol_bits_block(const vs_sobol_block& S, c
 // Which form of the digit step a scan kernel runs.  The fused kernels (no f-values: bound by the vector pipe) take the
 // three-instruction form -- always where the host routed a straight-line kernel (ALL: every column has VS_BASE_HORNER),
 // by the column's flag in the general code.  The kernels that WRITE f-values keep the four-instruction loop: they are
-// bound by their stores, and inside the bench step the k = 32 evaluation is SLOWER with the shorter arithmetic phase
-// (0.40-0.41 ms against 0.365, same box, profiles/r04/ab_halton_forms.txt) although it is faster launched alone.
+// bound by their stores, and inside a sustained evaluate -> reduce step the evaluation is SLOWER with the shorter
+// arithmetic phase at every k up to 96 (k = 32: 0.40-0.41 ms against 0.365, same box; tools/eval_in_step.py,
+// profiles/r04/ab_halton_forms.txt) although it is faster launched alone -- except the eight waves x 16 columns of
+// 97 .. 128 columns, whose arithmetic and store phases overlap worst (config 5: 9.25 -> 8.50 ms): VS_SCAN_SHORT_DIGITS.
+#define VS_SCAN_SHORT_DIGITS(FUSED, L, W) ((FUSED) || ((L) == 16 && (W) == 8))
 template <bool FUSED, bool ALL>
 __device__ __forceinline__ void vs_halton_pair(vs_u32 i1, vs_u32 i2, double d1, double d2, const vs_base& B, double& x1, double& x2,
                                                bool may_be_2) {   // base 2 is column 0: only a wave's first column can be it
@@ -870,7 +873,7 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
         if (c < k) {
             double x1, x2;
             if (GENV == 1 || GENV == 2) {
-                vs_halton_pair<FUSED, true>(hi1, hi2, hd1, hd2, C.B, x1, x2, j == 0);   // VS_SCAN_COLUMN(q, j, W) = 0 needs j = 0
+                vs_halton_pair<VS_SCAN_SHORT_DIGITS(FUSED, L, W), true>(hi1, hi2, hd1, hd2, C.B, x1, x2, j == 0);   // VS_SCAN_COLUMN(q, j, W) = 0 needs j = 0
                 t1 = GENV == 2 ? x1 * C.w + C.lo : x1;   // scale.py:33
                 t2 = GENV == 2 ? x2 * C.w + C.lo : x2;
             } else {
@@ -878,7 +881,7 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
                     x1 = (double)sx1[j] * (1.0 / 4294967296.0);
                     x2 = (double)sx2[j] * (1.0 / 4294967296.0);
                 } else {
-                    vs_unit_pair<FUSED>(A.D, C.B, r, A.D.n + src2, c, x1, x2, sobol_block);
+                    vs_unit_pair<VS_SCAN_SHORT_DIGITS(FUSED, L, W)>(A.D, C.B, r, A.D.n + src2, c, x1, x2, sobol_block);
                 }
                 t1 = vs_apply_scale_compact<!FUSED || GENV == 3>(A.D, x1, c);
                 t2 = vs_apply_scale_compact<!FUSED || GENV == 3>(A.D, x2, c);

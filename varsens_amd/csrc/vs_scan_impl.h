@@ -132,8 +132,10 @@ static int launch_scan_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io,
 // general one
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
 static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
-    // (the kernels that write f-values run the four-instruction digit loop: any design below 2^32 indices)
-    const bool halton = A.D.generator == VS_GEN_HALTON && (A.D.halton_horner != 0 || !FUSED) && ctx->tune.scan_general == 0 &&
+    // (the kernels that write f-values run the four-instruction digit loop -- but for 97 .. 128 columns --: any design
+    // below 2^32 indices)
+    const bool halton = A.D.generator == VS_GEN_HALTON && (A.D.halton_horner != 0 || !VS_SCAN_SHORT_DIGITS(FUSED, L, W)) &&
+                        ctx->tune.scan_general == 0 &&
                         (A.kind != VS_OBJ_G_FUNCTION || A.plain_recip != 0);   // else: the column code that can divide
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY)
         return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 1>(ctx, A, P_io, shift_dev, plan_only);
