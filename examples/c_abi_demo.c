@@ -39,7 +39,7 @@ int main(void) {
     d.n = n;
     d.first_index = 1 + 20 * K;                       /* ghalton skip of saltelli.py:83 */
     d.scale_mode = VS_SCALE_IDENTITY;
-    d.reserved = 0;
+    d.flags = 0;
     d.lower = d.upper = NULL;
     d.perm = perm;
     d.raw = NULL;

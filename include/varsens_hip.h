@@ -36,7 +36,7 @@ extern "C" {
  * 4: VS_PERM_EMPTY, vs_profile_select.
  * 5: vs_eval_reduce_first_second_order, vs_eval_reduce_both_supported.
  * 6: vs_eval_reduce_first_second_order takes objectives with several outputs; vs_design_desc_validate. */
-#define VS_ABI_VERSION 6
+#define VS_ABI_VERSION 7
 
 typedef enum vs_status {
     VS_OK = 0,
@@ -163,7 +163,7 @@ typedef struct vs_design_desc {
                               un-shuffled second half is first_index + n + r
                               (saltelli.py:83-84,92,95).  Ignored for VS_GEN_RAW. */
     int32_t scale_mode;    /* VS_SCALE_*: scale.py:33 (linear), :62 (power) */
-    int32_t reserved;
+    int32_t flags;         /* VS_DESIGN_*; 0 from callers of ABI <= 6 (the field was `reserved`) */
     const double* lower;   /* host, k entries (LINEAR/POWER) */
     const double* upper;   /* host, k entries (LINEAR/POWER) */
     const uint32_t* perm;  /* host: M_2[r] = second_half[perm[r - perm_begin]] for the rows
@@ -180,6 +180,13 @@ typedef struct vs_design_desc {
     uint64_t perm_count;   /* entries in `perm` (0: n; VS_PERM_EMPTY: none) */
 } vs_design_desc;
 #define VS_PERM_EMPTY UINT64_MAX
+/* flags (ABI 7).  VS_DESIGN_SEED1_SHUFFLE: `perm` is NULL and the library supplies the seed-1 shuffle of
+ * numpy.random.seed(1); numpy.random.shuffle(M_2) (saltelli.py:100-101) itself, for the rows [perm_begin, perm_begin +
+ * perm_count) (perm_count = 0: all n rows; VS_PERM_EMPTY: none) -- vs_seed1_permutation on the host, once per n and
+ * process, and ONE device copy per (n, slice) kept in the context for every later design that asks for it (a
+ * Varsens(objective, scaling, k, n) call per model of a study uploads the 4 n bytes once, not once per call: k = 32,
+ * n = 2^22: 2.1 -> 1.0 ms per call).  Copies no design uses any more are dropped when more than four are held. */
+#define VS_DESIGN_SEED1_SHUFFLE 1
 
 /* Host helper (no GPU involved): out[r] = index of the row that numpy.random.seed(1);
  * numpy.random.shuffle(M_2) (saltelli.py:100-101) moves to position r -- MT19937 init_genrand(1),

@@ -324,3 +324,18 @@ def test_descriptor_checks_through_the_binding(native):
     d.k = 0
     assert lib.vs_design_desc_validate(C.byref(d), None) == -1
     assert b"out of range" in lib.vs_last_error()
+    # ABI 7: the library's own seed-1 shuffle (VS_DESIGN_SEED1_SHUFFLE) -- nothing read from the host, slice checked,
+    # a perm pointer beside the flag and unknown flags refused
+    d.k, d.flags = 4, native.DESIGN_SEED1_SHUFFLE
+    assert lib.vs_design_desc_validate(C.byref(d), C.byref(entries)) == 0 and entries.value == 0
+    d.perm_begin, d.perm_count = 10, 40
+    assert lib.vs_design_desc_validate(C.byref(d), C.byref(entries)) == 0 and entries.value == 0
+    d.perm_count = 41
+    assert lib.vs_design_desc_validate(C.byref(d), None) == -1 and b"exceeds n" in lib.vs_last_error()
+    d.perm_begin, d.perm_count = 50, native.PERM_EMPTY
+    assert lib.vs_design_desc_validate(C.byref(d), None) == 0
+    keep = np.zeros(50, np.uint32)
+    d.perm_begin, d.perm_count, d.perm = 0, 0, keep.ctypes.data
+    assert lib.vs_design_desc_validate(C.byref(d), None) == -1 and b"perm must be NULL" in lib.vs_last_error()
+    d.perm, d.flags = None, 6
+    assert lib.vs_design_desc_validate(C.byref(d), None) == -1 and b"unknown design flags" in lib.vs_last_error()

@@ -1125,3 +1125,44 @@ def test_designs_around_the_exactness_bound_of_the_short_digit_step(ctx, label, 
         G = ctx.download(gram, (2, k, k))
         np.testing.assert_allclose(G[0], (C + D) @ (C + D).T, rtol=1e-12)
         np.testing.assert_allclose(G[1], (C - D) @ (C - D).T, rtol=1e-12, atol=1e-12 * np.abs(G[0]).max())
+
+
+def test_library_supplied_seed1_shuffle_and_its_cache(ctx):
+    """VS_DESIGN_SEED1_SHUFFLE (ABI 7): the design made from the library's own shuffle evaluates to the bits of the one
+    made from the uploaded permutation -- whole and as a rank's slice, an empty slice included --; the device copy is
+    shared by later designs of the same (n, slice) and outlives the designs that used it; more (n, slice) pairs than the
+    cache holds, alive at once and released in any order, stay correct."""
+    from varsens_amd import _native
+    k = 5
+    params = np.array([0.0, 0.5, 3.0, 9.0, 99.0])
+
+    def blocks(design, n, begin, count):
+        _, got = eval_dev(ctx, design, _native.OBJ_G_FUNCTION, k, 1, params, n, begin=begin, count=count)
+        return got
+
+    alive = []
+    for n in (64, 1000, 1001, 4097, 70000, 333):        # six sizes: more than the four copies kept unreferenced
+        perm = orc.seed1_permutation(n).astype(np.uint32)
+        want = blocks(ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 0, None, None, perm), n, 0, n)
+        d1 = ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 0, None, None, None, seed1_shuffle=(0, n))
+        same(blocks(d1, n, 0, n), want)
+        d2 = ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 0, None, None, None, seed1_shuffle=(0, n))
+        d1.free()                                        # the shared copy stays for d2
+        same(blocks(d2, n, 0, n), want)
+        b, c = n // 3, n // 2                            # a rank's slice: only its rows evaluate
+        ds = ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 0, None, None, None, seed1_shuffle=(b, c))
+        same(blocks(ds, n, b, c), want[:, b:b + c])
+        with pytest.raises(_native.VarsensHipError, match="shuffle slice"):
+            blocks(ds, n, 0, n)
+        de = ctx.design_create(_native.GEN_HALTON, k, n, orc.halton_skip(k), 0, None, None, None, seed1_shuffle=(n, 0))
+        de.free()
+        alive += [(d2, n, want), (ds, n, want[:, b:b + c], b, c)]
+    for item in alive[::2] + alive[1::2]:                # every design still evaluates, then goes, in mixed order
+        if len(item) == 3:
+            same(blocks(item[0], item[1], 0, item[1]), item[2])
+        else:
+            same(blocks(item[0], item[1], item[3], item[4]), item[2])
+        item[0].free()
+    with pytest.raises(_native.VarsensHipError, match="exclude each other"):
+        ctx.design_create(_native.GEN_HALTON, k, 64, orc.halton_skip(k), 0, None, None,
+                          orc.seed1_permutation(64).astype(np.uint32), seed1_shuffle=(0, 64))

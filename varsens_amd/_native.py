@@ -12,11 +12,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARSENS_HIP_LIB") or os.path.join(_HERE, "libvarsens_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 COMM_ID_BYTES = 128
 
 GEN_HALTON, GEN_SOBOL, GEN_RAW = 0, 1, 2
 PERM_EMPTY = (1 << 64) - 1   # VS_PERM_EMPTY: vs_design_desc.perm_count of a rank without rows
+DESIGN_SEED1_SHUFFLE = 1      # vs_design_desc.flags: the library supplies (and caches) the seed-1 shuffle itself
 SCALE_IDENTITY, SCALE_LINEAR, SCALE_POWER = 0, 1, 2
 OBJ_G_FUNCTION, OBJ_ISHIGAMI, OBJ_LINEAR, OBJ_POLYNOMIAL, OBJ_INVERT, OBJ_SOURCE = 1, 2, 3, 4, 5, 6
 REDUCE_NAN_TRIM = 1
@@ -77,7 +78,7 @@ class ProfileRecord(C.Structure):
 
 class DesignDesc(C.Structure):
     _fields_ = [("generator", C.c_int32), ("k", C.c_int32), ("n", C.c_uint64), ("first_index", C.c_uint64),
-                ("scale_mode", C.c_int32), ("reserved", C.c_int32),
+                ("scale_mode", C.c_int32), ("flags", C.c_int32),
                 ("lower", C.c_void_p), ("upper", C.c_void_p), ("perm", C.c_void_p), ("raw", C.c_void_p),
                 ("sobol_directions", C.c_void_p), ("perm_begin", C.c_uint64), ("perm_count", C.c_uint64)]
 
@@ -381,9 +382,11 @@ class Context(object):
 
     # -- design / objective handles
     def design_create(self, generator, k, n, first_index=0, scale_mode=SCALE_IDENTITY, lower=None, upper=None,
-                      perm=None, raw=None, sobol_directions=None, perm_begin=0):
+                      perm=None, raw=None, sobol_directions=None, perm_begin=0, seed1_shuffle=None):
         """``perm``: the whole seed-1 permutation (n entries), or -- with ``perm_begin`` -- the entries of a
-        rank's own rows [perm_begin, perm_begin + len(perm)) only."""
+        rank's own rows [perm_begin, perm_begin + len(perm)) only.  ``seed1_shuffle=(begin, count)`` instead of
+        ``perm``: the library supplies the seed-1 shuffle of those rows itself and keeps its device copy in the
+        context (VS_DESIGN_SEED1_SHUFFLE)."""
         keep = []
 
         def ptr(a, dtype, shape=None):
@@ -410,6 +413,14 @@ class Context(object):
             if count == 0:      # an empty shard: 0 would mean "all n rows" to the C ABI
                 desc.perm, count = ptr(np.zeros(1, np.uint32), np.uint32), PERM_EMPTY
             desc.perm_begin, desc.perm_count = int(perm_begin), int(count)
+        if seed1_shuffle is not None:
+            if perm is not None:
+                raise VarsensHipError("seed1_shuffle and perm exclude each other")
+            begin, count = int(seed1_shuffle[0]), int(seed1_shuffle[1])
+            if begin < 0 or count < 0 or begin + count > n:
+                raise VarsensHipError("seed1_shuffle=(begin, count) must lie inside the n rows")
+            desc.flags = DESIGN_SEED1_SHUFFLE
+            desc.perm_begin, desc.perm_count = begin, (count if count else PERM_EMPTY)
         desc.raw = ptr(raw, np.float64, (2 * n, k))
         desc.sobol_directions = ptr(sobol_directions, np.uint32, (k, 32))
         h = C.c_void_p()

@@ -128,6 +128,8 @@ extern "C" int vs_context_destroy(vs_context* ctx) {
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->counters) hipFree(ctx->counters);
     if (ctx->counters_host) hipHostFree(ctx->counters_host);
+    for (auto& e : ctx->perm_cache)
+        if (e.dev) hipFree(e.dev);
     hipStreamDestroy(ctx->streams[0]);
     hipStreamDestroy(ctx->streams[1]);
     delete ctx;

@@ -66,6 +66,16 @@ struct vs_context {
     std::vector<vs_prof_slot> prof;
     std::vector<vs_prof_slot> prof_pool;
     size_t prof_capacity = 0;
+    // device copies of the seed-1 shuffle (VS_DESIGN_SEED1_SHUFFLE): one per (n, slice), shared by the designs that
+    // asked for it (refs), dropped least-recently-used once unreferenced and more than four are held
+    struct perm_entry {
+        uint64_t n, begin, count;
+        uint32_t* dev;
+        int refs;
+        uint64_t stamp;
+    };
+    std::vector<perm_entry> perm_cache;
+    uint64_t perm_stamp = 0;
     // RCCL
     void* comm = nullptr;
     int comm_ranks = 0;
@@ -77,6 +87,7 @@ struct vs_design {
     double* lower = nullptr;   // device, k (POWER: lower; LINEAR: lower)
     double* width = nullptr;   // device, k (LINEAR: upper-lower; POWER: upper/lower)
     uint32_t* perm = nullptr;  // device, n or null
+    bool perm_shared = false;  // perm belongs to ctx->perm_cache (VS_DESIGN_SEED1_SHUFFLE): released, not freed
     double* raw = nullptr;     // device (2n,k) or null
     uint32_t* dirs = nullptr;  // device (k,32) or null
     uint32_t* sobol_tabs = nullptr;  // device (k,4,256): XOR of the direction integers selected by each byte value

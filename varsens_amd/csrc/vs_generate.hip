@@ -14,6 +14,9 @@
 // operation.
 #include <cmath>
 
+#include <memory>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "vs_common.h"
@@ -209,12 +212,69 @@ extern "C" int vs_design_destroy(vs_context* ctx, vs_design* g) {
     }
     if (g->lower) hipFree(g->lower);
     if (g->width) hipFree(g->width);
-    if (g->perm) hipFree(g->perm);
+    if (g->perm && g->perm_shared) {
+        if (ctx)
+            for (auto& e : ctx->perm_cache)
+                if (e.dev == g->perm && e.refs > 0) { --e.refs; break; }
+    } else if (g->perm) {
+        hipFree(g->perm);
+    }
     if (g->raw) hipFree(g->raw);
     if (g->dirs) hipFree(g->dirs);
     if (g->sobol_tabs) hipFree(g->sobol_tabs);
     if (g->bases) hipFree(g->bases);
     delete g;
+    return VS_OK;
+}
+
+// VS_DESIGN_SEED1_SHUFFLE: the device copy of rows [begin, begin + count) of the seed-1 shuffle of n rows, from the
+// context's cache or made now (host: vs_seed1_permutation once per n and process, the last two n kept).
+static int seed1_shuffle_on_device(vs_context* ctx, uint64_t n, uint64_t begin, uint64_t count, uint32_t** out) {
+    for (auto& e : ctx->perm_cache)
+        if (e.n == n && e.begin == begin && e.count == count) {
+            ++e.refs;
+            e.stamp = ++ctx->perm_stamp;
+            *out = e.dev;
+            return VS_OK;
+        }
+    static std::mutex host_lock;
+    static std::vector<std::pair<uint64_t, std::shared_ptr<std::vector<uint32_t>>>> host_perms;
+    std::shared_ptr<std::vector<uint32_t>> perm;
+    {
+        std::lock_guard<std::mutex> hold(host_lock);
+        for (auto& h : host_perms)
+            if (h.first == n) perm = h.second;
+        if (!perm) {
+            perm = std::make_shared<std::vector<uint32_t>>(n);
+            const int rc = vs_seed1_permutation(perm->data(), n);
+            if (rc) return rc;
+            if (host_perms.size() >= 2) host_perms.erase(host_perms.begin());
+            host_perms.emplace_back(n, perm);
+        }
+    }
+    // room: drop unreferenced copies, least recently used first, beyond four
+    while (ctx->perm_cache.size() >= 4) {
+        int victim = -1;
+        for (size_t i = 0; i < ctx->perm_cache.size(); ++i)
+            if (ctx->perm_cache[i].refs == 0 && (victim < 0 || ctx->perm_cache[i].stamp < ctx->perm_cache[victim].stamp))
+                victim = (int)i;
+        if (victim < 0) break;   // all in use: the cache grows with the designs alive
+        hipStreamSynchronize(ctx->streams[0]);
+        hipStreamSynchronize(ctx->streams[1]);
+        hipFree(ctx->perm_cache[victim].dev);
+        ctx->perm_cache.erase(ctx->perm_cache.begin() + victim);
+    }
+    uint32_t* dev = nullptr;
+    VS_HIP(hipMalloc(&dev, sizeof(uint32_t) * (count ? count : 1)));
+    if (count) {
+        const hipError_t e = hipMemcpy(dev, perm->data() + begin, sizeof(uint32_t) * count, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            hipFree(dev);
+            return vs_fail(VS_ERR_HIP, "upload of the seed-1 shuffle failed: %s", hipGetErrorString(e));
+        }
+    }
+    ctx->perm_cache.push_back({n, begin, count, dev, 1, ++ctx->perm_stamp});
+    *out = dev;
     return VS_OK;
 }
 
@@ -270,7 +330,13 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
         VS_TRY(hipMemcpyAsync(g->width, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, ctx->stream));
         VS_TRY(hipStreamSynchronize(ctx->stream));
     }
-    if (desc->perm) {
+    if (desc->flags & VS_DESIGN_SEED1_SHUFFLE) {
+        const uint64_t count = desc->perm_count == VS_PERM_EMPTY ? 0 : desc->perm_count ? desc->perm_count : n;
+        rc = seed1_shuffle_on_device(ctx, n, desc->perm_begin, count, &g->perm);
+        if (rc) return bail(rc);
+        g->perm_shared = true;
+        g->d.perm_count = count;
+    } else if (desc->perm) {
         VS_TRY(hipMalloc(&g->perm, sizeof(uint32_t) * (perm_count ? perm_count : 1)));
         VS_TRY(hipMemcpyAsync(g->perm, desc->perm, sizeof(uint32_t) * perm_count, hipMemcpyHostToDevice, ctx->stream));
         g->d.perm_count = perm_count;

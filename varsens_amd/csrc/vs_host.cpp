@@ -138,6 +138,15 @@ extern "C" int vs_design_desc_validate(const vs_design_desc* desc, uint64_t* per
         VS_REQUIRE(desc->first_index <= (1ull << 32) && desc->first_index + 2 * n <= (1ull << 32),
                    "Sobol indices must stay below 2^32");
     }
+    VS_REQUIRE((desc->flags & ~VS_DESIGN_SEED1_SHUFFLE) == 0, "unknown design flags 0x%x", (unsigned)desc->flags);
+    if (desc->flags & VS_DESIGN_SEED1_SHUFFLE) {   // the library's own seed-1 shuffle: nothing is read from the host
+        VS_REQUIRE(!desc->perm, "VS_DESIGN_SEED1_SHUFFLE: perm must be NULL (the library supplies the shuffle)");
+        const uint64_t c = desc->perm_count == VS_PERM_EMPTY ? 0 : desc->perm_count ? desc->perm_count : n;
+        VS_REQUIRE(desc->perm_begin <= n && c <= n - desc->perm_begin, "perm slice [%llu,+%llu) exceeds n=%llu",
+                   (unsigned long long)desc->perm_begin, (unsigned long long)c, (unsigned long long)n);
+        if (perm_entries) *perm_entries = 0;
+        return VS_OK;
+    }
     // the shuffle may be given for a slice of rows only (a rank's shard): perm_count entries from row perm_begin
     const uint64_t count = !desc->perm ? 0
                            : desc->perm_count == VS_PERM_EMPTY ? 0   // a rank without rows: nothing is read

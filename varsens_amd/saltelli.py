@@ -137,11 +137,10 @@ class Sample(object):
             self.scaling = _scale.Identity()
 
         if self.verbose: print("Eliminating correlations")
-        perm = seed1_permutation(n)
-        perm_begin = 0
-        if self._shard is not None:
-            perm_begin, count = _shard_rows(n, self._shard)
-            perm = perm[perm_begin:perm_begin + count]
+        # the seed-1 shuffle of M_2 (saltelli.py:100-101): the engine supplies it itself and keeps the device copy per
+        # (n, slice) in the context -- a study that calls Varsens(objective, scaling, k, n) once per model uploads the
+        # 4 n bytes once (VS_DESIGN_SEED1_SHUFFLE)
+        shuffle = _shard_rows(n, self._shard) if self._shard is not None else (0, n)
 
         if generator == 'halton':
             gen, first = _native.GEN_HALTON, 1 + 20 * k + int(discard)   # saltelli.py:83: skip 20k + discard
@@ -152,10 +151,11 @@ class Sample(object):
         if isinstance(self.scaling, _scale.DeviceScale):
             mode, lo, hi = self.scaling.device_spec(k)
             if unit is None:
-                self._design = self._ctx.design_create(gen, k, n, first, mode, lo, hi, perm, None, dirs, perm_begin)
+                self._design = self._ctx.design_create(gen, k, n, first, mode, lo, hi, None, None, dirs,
+                                                       seed1_shuffle=shuffle)
             else:
-                self._design = self._ctx.design_create(_native.GEN_RAW, k, n, 0, mode, lo, hi, perm, unit, None,
-                                                       perm_begin)
+                self._design = self._ctx.design_create(_native.GEN_RAW, k, n, 0, mode, lo, hi, None, unit, None,
+                                                       seed1_shuffle=shuffle)
         else:
             # opaque callable: its own Python code has to see the two (n,k) halves (saltelli.py:92,95)
             if unit is None:
@@ -172,7 +172,8 @@ class Sample(object):
             if m1.shape != (n, k) or m2.shape != (n, k):
                 raise Exception("scaling must map an (n,k) block to an (n,k) block")
             self._design = self._ctx.design_create(_native.GEN_RAW, k, n, 0, _native.SCALE_IDENTITY, None, None,
-                                                   perm, numpy.concatenate([m1, m2], axis=0), None, perm_begin)
+                                                   None, numpy.concatenate([m1, m2], axis=0), None,
+                                                   seed1_shuffle=shuffle)
         if self.verbose: print("...Sample Created.")
 
     # -- materialisation on demand --------------------------------------------------------
