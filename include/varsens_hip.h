@@ -35,7 +35,8 @@ extern "C" {
  * 3: the second-order sums are S S^T and T T^T (VS_GRAM_LEN doubles) instead of D C^T, D D^T, C C^T.
  * 4: VS_PERM_EMPTY, vs_profile_select.
  * 5: vs_eval_reduce_first_second_order, vs_eval_reduce_both_supported.
- * 6: vs_eval_reduce_first_second_order takes objectives with several outputs; vs_design_desc_validate. */
+ * 6: vs_eval_reduce_first_second_order takes objectives with several outputs; vs_design_desc_validate.
+ * 7: vs_design_desc.flags (was `reserved`, 0): VS_DESIGN_SEED1_SHUFFLE. */
 #define VS_ABI_VERSION 7
 
 typedef enum vs_status {
