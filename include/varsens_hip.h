@@ -186,7 +186,8 @@ typedef struct vs_design_desc {
  * perm_count) (perm_count = 0: all n rows; VS_PERM_EMPTY: none) -- vs_seed1_permutation on the host, once per n and
  * process, and ONE device copy per (n, slice) kept in the context for every later design that asks for it (a
  * Varsens(objective, scaling, k, n) call per model of a study uploads the 4 n bytes once, not once per call: k = 32,
- * n = 2^22: 2.1 -> 1.0 ms per call).  Copies no design uses any more are dropped when more than four are held. */
+ * n = 2^22: 2.1 -> 0.7 ms per call).  Copies no design uses any more are dropped, least recently used first, when more
+ * than four (or 1 GiB of them) are held. */
 #define VS_DESIGN_SEED1_SHUFFLE 1
 
 /* Host helper (no GPU involved): out[r] = index of the row that numpy.random.seed(1);

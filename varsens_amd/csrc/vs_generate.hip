@@ -248,12 +248,18 @@ static int seed1_shuffle_on_device(vs_context* ctx, uint64_t n, uint64_t begin, 
             perm = std::make_shared<std::vector<uint32_t>>(n);
             const int rc = vs_seed1_permutation(perm->data(), n);
             if (rc) return rc;
-            if (host_perms.size() >= 2) host_perms.erase(host_perms.begin());
-            host_perms.emplace_back(n, perm);
+            if (n <= (1ull << 25)) {   // kept for the next context / slice: up to two, 128 MiB each at most
+                if (host_perms.size() >= 2) host_perms.erase(host_perms.begin());
+                host_perms.emplace_back(n, perm);
+            }
         }
     }
-    // room: drop unreferenced copies, least recently used first, beyond four
-    while (ctx->perm_cache.size() >= 4) {
+    // room: drop unreferenced copies, least recently used first, beyond four entries or 1 GiB of them
+    for (;;) {
+        uint64_t idle_bytes = 0;
+        for (auto& e : ctx->perm_cache)
+            if (e.refs == 0) idle_bytes += 4 * e.count;
+        if (ctx->perm_cache.size() < 4 && idle_bytes + 4 * count <= (1ull << 30)) break;
         int victim = -1;
         for (size_t i = 0; i < ctx->perm_cache.size(); ++i)
             if (ctx->perm_cache[i].refs == 0 && (victim < 0 || ctx->perm_cache[i].stamp < ctx->perm_cache[victim].stamp))
