@@ -132,7 +132,7 @@ static int launch_scan_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io,
 // general one
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
 static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
-    // (the kernels that write f-values run the four-instruction digit loop -- but for 97 .. 128 columns --: any design
+    // (the kernels that write f-values run the four-instruction digit loop -- but from 97 columns on --: any design
     // below 2^32 indices)
     const bool halton = A.D.generator == VS_GEN_HALTON && (A.D.halton_horner != 0 || !VS_SCAN_SHORT_DIGITS(FUSED, L, W)) &&
                         ctx->tune.scan_general == 0 &&
