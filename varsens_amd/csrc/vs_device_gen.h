@@ -73,8 +73,10 @@ __device__ __forceinline__ double vs_shift_estimate(const double* a, vs_u64 rows
 
 struct vs_base {
     vs_u32 b;        // prime base
-    vs_u32 ndig;     // digits of the largest index of this design in base b (0: indices reach 2^32); bit 31
-                     // (VS_BASE_HORNER): largest index * b^(ndig-1) < 2^53, the three-instruction digit step is exact
+    vs_u32 ndig;     // digits of the largest index of this design in base b, padded to three (0: indices reach 2^32);
+                     // bit 31 (VS_BASE_HORNER, set by make_base): at least three digits, largest index * b^(ndig-1)
+                     // < 2^53 -- the three-instruction digit step is exact -- and b^ndig <= 2^49 -- the two-word
+                     // reciprocal gives the correctly rounded quotient
     double top;      // b^(ndig-1): weight of the first reversed digit; the denominator b^ndig is top * b (exact)
     double inv_den;  // RN(1 / b^ndig)
     double inv_b;    // RN(1 / b) pushed up two ulps: floor(j * inv_b) == j / b for every j < 2^32
