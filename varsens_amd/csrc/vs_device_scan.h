@@ -68,7 +68,11 @@ __device__ __forceinline__ vs_u32 vs_sobol_bits_block(const vs_sobol_block& S, c
 // profiles/r04/ab_halton_forms.txt) although it is faster launched alone -- except the eight waves x 16 columns of
 // 97 .. 128 columns and x 32 of 129 .. 256, whose arithmetic and store phases overlap worst (config 5: 9.25 -> 8.50 ms;
 // k = 200, n = 2^20: 0.82 -> 0.67): VS_SCAN_SHORT_DIGITS.
+#ifdef VS_HALTON_DIGITS   // A/B build (tools/ab_halton_forms.sh): the four-instruction loop and Markstein's quotient everywhere
+#define VS_SCAN_SHORT_DIGITS(FUSED, L, W) false
+#else
 #define VS_SCAN_SHORT_DIGITS(FUSED, L, W) ((FUSED) || ((L) >= 16 && (W) == 8))
+#endif
 template <bool FUSED, bool ALL>
 __device__ __forceinline__ void vs_halton_pair(vs_u32 i1, vs_u32 i2, double d1, double d2, const vs_base& B, double& x1, double& x2,
                                                bool may_be_2) {   // base 2 is column 0: only a wave's first column can be it
