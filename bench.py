@@ -531,7 +531,7 @@ def main():
                 "max_abs_diff_sens_2_vs_two_kernel_path": s2_diff if api_fused else None,
                 "note": "Varsens(objective, scaling, k, n) with its default second_order=True (sens, sens_t, sens_2, "
                         "sens_2n per pass): the evaluation and both reductions in one kernel where the engine has one "
-                        "(built-in separable objective, one output, k <= 32), else vs_eval + "
+                        "(built-in separable objective with k*l <= 128 index rows, Ishigami, separable source objectives), else vs_eval + "
                         "vs_reduce_first_second_order; then vs_finish_first_order + vs_finish_second_order.  The "
                         "headline `value` is the first-order pass north_star names"}
         line["both_orders_one_call"] = {
