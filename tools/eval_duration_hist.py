@@ -18,3 +18,7 @@ h, e = np.histogram(d, bins=12)
 for c, a, b in zip(h, e[:-1], e[1:]):
     print("  %7.1f .. %7.1f us  %4d %s" % (a, b, c, "#" * int(60 * c / max(1, h.max()))))
 print("in launch order (us, every 8th):", " ".join("%.0f" % x for x in d[::8][:60]))
+# by position in a rotation of R buffers (R=3: bench.py's f-value buffers): does one of them cost more?
+R = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+for m in range(R):
+    print("  launches %d mod %d: mean %.1f us  median %.1f  (%d)" % (m, R, d[m::R].mean(), np.median(d[m::R]), len(d[m::R])))
