@@ -658,14 +658,14 @@ class Varsens(object):
 
         nacc = _native.acc_len(k, l, world)
         acc, gram, whole = self._result_buffers(nacc, k * l)
+        release = None
         if fused and obj._rows > 0:
             # evaluate and reduce in one kernel: the 2n(k+1) values never reach HBM
             if self._second_order:
                 ctx.eval_reduce_first_second_order(design, handle, obj._row_begin, obj._rows, acc, gram, rank, world)
             else:
                 ctx.eval_reduce_first_order(design, handle, obj._row_begin, obj._rows, acc, rank, world)
-            ctx.sync()
-            handle.free()
+            release = handle        # freed behind the download of the results, which waits for the kernel
         else:
             if fused:
                 handle.free()   # a rank without rows: the empty record of the reduction kernels
@@ -675,36 +675,50 @@ class Varsens(object):
             else:
                 ctx.reduce_first_order(obj._values(), obj._rows, k, l, acc, flags, rank, world)
         self._finish(acc, nacc, gram, world, whole)
+        if release is not None:
+            release.free()
 
     def _result_buffers(self, nacc, K):
-        """The accumulator record and (second order) the 2 K^2 sums S S^T, T T^T as two windows of ONE device
-        buffer: a rank's whole contribution crosses the GPUs in a single all-reduce."""
-        total = nacc + (_native.gram_len(K) if self._second_order else 0)
-        whole = self._ctx.alloc(8 * total)
-        acc = _native.DeviceView(whole, 0, 8 * nacc)
-        gram = _native.DeviceView(whole, 8 * nacc, 8 * _native.gram_len(K)) if self._second_order else None
+        """ONE device buffer per analysis: [S S^T, T T^T sums (second order) | accumulator record | finished results].
+        The first two windows are a rank's whole contribution -- one all-reduce over `_reduce_doubles(nacc, K)` doubles
+        from the buffer's start --, the last two come back to the host in one download (`_finish`)."""
+        k, l = int(self.k), int(self.objective._l)
+        ng = _native.gram_len(K) if self._second_order else 0
+        nacc_even = nacc + (nacc & 1)       # the finished results start on a 16-byte boundary
+        nout = _native.first_order_len(k, l) + (2 * K * K if self._second_order else 0)
+        whole = self._ctx.alloc(8 * (ng + nacc_even + nout))
+        gram = _native.DeviceView(whole, 0, 8 * ng) if self._second_order else None
+        acc = _native.DeviceView(whole, 8 * ng, 8 * nacc)
         return acc, gram, whole
+
+    def _reduce_doubles(self, nacc, K):
+        return nacc + (_native.gram_len(K) if self._second_order else 0)
 
     def _finish(self, acc, nacc, gram, slots, whole):
         """Exchange, finishing kernels and the result attributes; `slots` = variance slots in the record."""
         ctx, obj = self._ctx, self.objective
         k, n, l = int(self.k), int(self.n), int(obj._l)
         world = self._comm.world if self._comm is not None else 1
-        if world > 1:
-            self._comm.allreduce(whole, whole.nbytes // 8)      # ONE all-reduce: record + Gram sums
-        # the finished results of both orders in ONE device buffer [first order | sens_2 | sens_2n]: one allocation and
-        # one download per analysis (a call at k = 6, n = 1024 is 0.2 ms of wall time, most of it these round trips)
-        nf = _native.first_order_len(k, l)
         K = k * l
-        out = ctx.alloc(8 * (nf + (2 * K * K if self._second_order else 0)))
-        first = _native.DeviceView(out, 0, 8 * nf)
+        if world > 1:
+            self._comm.allreduce(whole, self._reduce_doubles(nacc, K))      # ONE all-reduce: Gram sums + record
+        # the finished results of both orders behind the record in the same buffer [first order | sens_2 | sens_2n]:
+        # one allocation and ONE download per analysis (a call at k = 6, n = 1024 is 0.12 ms of wall time, most of it
+        # such round trips)
+        nf = _native.first_order_len(k, l)
+        ng = _native.gram_len(K) if self._second_order else 0
+        nacc_even = nacc + (nacc & 1)
+        at = 8 * (ng + nacc_even)
+        first = _native.DeviceView(whole, at, 8 * nf)
         ctx.finish_first_order(acc, n, k, l, first, slots)
         if self._second_order:
-            s2 = _native.DeviceView(out, 8 * nf, 8 * K * K)
-            s2n = _native.DeviceView(out, 8 * (nf + K * K), 8 * K * K)
+            s2 = _native.DeviceView(whole, at + 8 * nf, 8 * K * K)
+            s2n = _native.DeviceView(whole, at + 8 * (nf + K * K), 8 * K * K)
             ctx.finish_second_order(gram, first, n, k, l, s2, s2n)
-        host = ctx.download(out, (out.nbytes // 8,))
-        self.accumulators = ctx.download(acc, (nacc,))
+        tail = _native.DeviceView(whole, 8 * ng, whole.nbytes - 8 * ng)
+        both = ctx.download(tail, (tail.nbytes // 8,))           # (waits for everything launched before it)
+        self.accumulators = both[:nacc].copy()
+        host = both[nacc_even:]
         r = host[:nf].reshape(2 + 4 * k, l)
         self.E_2 = r[0].copy()
         self.var_y = r[1].copy()
@@ -716,7 +730,6 @@ class Varsens(object):
             self.sens_2 = host[nf:nf + K * K].reshape(k, l, k, l).copy()
             self.sens_2n = host[nf + K * K:].reshape(k, l, k, l).copy()
         whole.free()
-        out.free()
 
     def _compute_streamed(self, rows_per_pass):
         """The same estimators with the f-values streamed through one HBM buffer in row ranges:
@@ -750,7 +763,7 @@ class Varsens(object):
                 ctx.reduce_first_second_order(f, count, k, l, acc, gram, 0, rank * passes + c, slots)
             else:
                 ctx.reduce_first_order(f, count, k, l, acc, 0, rank * passes + c, slots)
-            ctx.accumulate(total_buf, pass_buf, total_buf.nbytes // 8)
+            ctx.accumulate(total_buf, pass_buf, self._reduce_doubles(nacc, K))
         ctx.sync()
         handle.free()
         f.free()
