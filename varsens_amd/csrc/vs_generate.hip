@@ -14,6 +14,7 @@
 // operation.
 #include <cmath>
 
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <utility>
@@ -245,7 +246,11 @@ static int seed1_shuffle_on_device(vs_context* ctx, uint64_t n, uint64_t begin, 
         for (auto& h : host_perms)
             if (h.first == n) perm = h.second;
         if (!perm) {
-            perm = std::make_shared<std::vector<uint32_t>>(n);
+            try {
+                perm = std::make_shared<std::vector<uint32_t>>(n);
+            } catch (const std::exception&) {   // no C++ exception crosses the C ABI
+                return vs_fail(VS_ERR_ARG, "no host memory for the seed-1 shuffle of n=%llu rows", (unsigned long long)n);
+            }
             const int rc = vs_seed1_permutation(perm->data(), n);
             if (rc) return rc;
             if (n <= (1ull << 25)) {   // kept for the next context / slice: up to two, 128 MiB each at most
