@@ -36,8 +36,13 @@ extern "C" {
  * 4: VS_PERM_EMPTY, vs_profile_select.
  * 5: vs_eval_reduce_first_second_order, vs_eval_reduce_both_supported.
  * 6: vs_eval_reduce_first_second_order takes objectives with several outputs; vs_design_desc_validate.
- * 7: vs_design_desc.flags (was `reserved`, 0): VS_DESIGN_SEED1_SHUFFLE. */
-#define VS_ABI_VERSION 7
+ * 7: vs_design_desc.flags (was `reserved`, 0): VS_DESIGN_SEED1_SHUFFLE.  The field is VALIDATED from here on: a caller
+ *    written against ABI <= 6 must have zeroed it (the header said "reserved, 0"); unknown bits are VS_ERR_ARG.
+ * 8: vs_upload_values / vs_download_values / vs_sample_rows[_begin/_wait]: objective values and sample rows cross the
+ *    host boundary in the reference's layouts, converted on the device; VS_ERR_NOMEM; every entry point runs under a
+ *    guard that turns C++ exceptions into status codes; a design is released through the context that made it and
+ *    vs_context_destroy refuses (VS_ERR_STATE) while designs of the context are alive. */
+#define VS_ABI_VERSION 8
 
 typedef enum vs_status {
     VS_OK = 0,
@@ -46,7 +51,8 @@ typedef enum vs_status {
     VS_ERR_NODEVICE = -3, /* no usable GPU */
     VS_ERR_COMM = -4,     /* RCCL failure */
     VS_ERR_STATE = -5,    /* call sequence error (e.g. comm not initialised) */
-    VS_ERR_COMPILE = -6   /* hiprtc compilation of a user objective failed */
+    VS_ERR_COMPILE = -6,  /* hiprtc compilation of a user objective failed */
+    VS_ERR_NOMEM = -7     /* host memory exhausted (std::bad_alloc inside the library) */
 } vs_status;
 
 typedef struct vs_context vs_context;     /* one GPU + one stream */
@@ -126,7 +132,8 @@ enum {
     VS_KERNEL_SECOND_ORDER = 9,
     VS_KERNEL_SECOND_FOLD = 10,
     VS_KERNEL_FUSED = 11,
-    VS_KERNEL_ALLREDUCE = 12    /* the RCCL all-reduce of vs_comm_allreduce (events around the collective) */
+    VS_KERNEL_ALLREDUCE = 12,   /* the RCCL all-reduce of vs_comm_allreduce (events around the collective) */
+    VS_KERNEL_VALUES = 13       /* layout conversion of objective values on their way in or out (vs_upload_values ...) */
 };
 
 int vs_profile_begin(vs_context* ctx, int capacity);
@@ -202,8 +209,24 @@ int vs_seed1_permutation(uint32_t* out, uint64_t n);
  * desc->perm that will be read.  VS_OK or VS_ERR_ARG with vs_last_error(). */
 int vs_design_desc_validate(const vs_design_desc* desc, uint64_t* perm_entries);
 
+/* Ownership: a design belongs to the context that created it -- its tables live on that GPU and, with
+ * VS_DESIGN_SEED1_SHUFFLE, it holds a share of that context's shuffle cache.  vs_design_destroy releases it through
+ * that context whatever `ctx` is passed (NULL included); vs_context_destroy returns VS_ERR_STATE while designs of the
+ * context are alive.  Destroy designs (and objectives) before their context. */
 int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_design** out);
 int vs_design_destroy(vs_context* ctx, vs_design* design);
+
+/* ---------------------------------- sample rows for a model that runs on the host (call stack (b), saltelli.py:308-355)
+ * The reference hands sample.M_1[i], sample.M_2[i], sample.N_j[i][j], sample.N_nj[i][j] to the objective one row at a
+ * time.  vs_sample_rows writes rows [row_begin, row_begin+row_count) of Sample.flat() (saltelli.py:127-160) straight
+ * into caller memory: the rows are produced piece by piece on the device and leave through a pinned ring, the kernel of
+ * piece i+1 running under the copy of piece i.  The asynchronous pair lets a host loop evaluate chunk i while chunk i+1
+ * is produced and copied: vs_sample_rows_begin enqueues kernel and copy of a chunk into one of two library-owned pinned
+ * slots and returns at once; vs_sample_rows_wait blocks until that slot is filled and returns a pointer to its
+ * row_count x k doubles, valid until the next vs_sample_rows_begin on the same slot. */
+int vs_sample_rows(vs_context* ctx, const vs_design* design, uint64_t row_begin, uint64_t row_count, double* host_rows);
+int vs_sample_rows_begin(vs_context* ctx, const vs_design* design, uint64_t row_begin, uint64_t row_count, int slot);
+int vs_sample_rows_wait(vs_context* ctx, int slot, const double** host_rows);
 
 /* Rows [row_begin, row_begin+row_count) of Sample.flat() (saltelli.py:127-160):
  * global row order [M_1; M_2; N_j[0..k); N_nj[0..k)], 2n(k+1) rows of k values,
@@ -257,13 +280,30 @@ int vs_objective_create_separable(vs_context* ctx, int k, const char* term_body,
  *     f_dev[(o*(2k+2) + block)*rows + r],  block order [fM_1, fM_2, fN_j[0..k), fN_nj[0..k)]
  * i.e. the reference's (2(k+1)*rows, l) array transposed to (l, 2(k+1)*rows).  For l = 1 the two
  * coincide.  Every block of every output is one contiguous stream, so all kernels run at the
- * l = 1 speed for any l.  Host code holding reference-order values transposes before vs_upload.
+ * l = 1 speed for any l.  Host code holding reference-order values hands them to vs_upload_values (below), which
+ * converts on the device.
  *
  * vs_eval replaces the four evaluation loops of Objective.__init__ (saltelli.py:329-355)
  * for design rows [row_begin, row_begin+row_count) (a shard of r in [0,n)) and writes
  * 2(k+1)*row_count*l doubles in that layout. */
 int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,
             uint64_t row_begin, uint64_t row_count, double* f_dev);
+
+/* ------------------------------------------ a7: objective values from / to the host (Objective.load, Objective.flat)
+ * vs_upload_values replaces the slicing, `/ scaling` and NaN scan of Objective.load (saltelli.py:449-486) for values a
+ * user computed elsewhere (call stack (c): Objective(k, n, objective_vals=v); (d): files).  host_vals is the reference's
+ * flat array, (2 n (k+1), l) row-major in block order [fM_1; fM_2; fN_j[0..k); fN_nj[0..k)] for the GLOBAL n; rows
+ * [row_begin, row_begin+rows) of every block (a rank's shard; 0, n for all) go to f_dev in the planar layout above
+ * (2 (k+1) rows l doubles).  `divide`: NULL, or 1 or l divisors -- value / divide[0] or value / divide[output], a true
+ * division (the reference's x / scaling).  *nan_rows (may be NULL): how many of the shard's rows hold a NaN in output 0
+ * of any block -- the rows Objective.load deletes (saltelli.py:474-486) and VS_REDUCE_NAN_TRIM leaves out --, counted
+ * on the device.  The host never transposes, divides or scans: pieces of the array go through a pinned ring, the copy
+ * engine and a tile-transposing kernel (one output without divisor: the copy engine writes the destination itself).
+ * Synchronous: host_vals is not read after the call returns.
+ * vs_download_values is the inverse, Objective.flat() of the shard (saltelli.py:357-391): (2 (k+1) rows, l) row-major. */
+int vs_upload_values(vs_context* ctx, const double* host_vals, uint64_t n, int k, int l, uint64_t row_begin,
+                     uint64_t rows, const double* divide, int ndivide, double* f_dev, uint64_t* nan_rows);
+int vs_download_values(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l, double* host_vals);
 
 /* ------------------------------ a7-a11: the estimators (Varsens.compute_varsens)
  * Accumulator record produced per GPU and summed across GPUs.  All doubles.

@@ -7,7 +7,12 @@
 //     is a report), n on both sides of the 2048-swap batches;
 //   * vs_design_desc_validate (varsens/saltelli.py:62-108): well-formed descriptors, every refusal, a rank's slice of
 //     the shuffle in a buffer of exactly perm_count entries, VS_PERM_EMPTY with a one-entry buffer that must not be
-//     read beyond, perm_count = 0 (= n entries).
+//     read beyond, perm_count = 0 (= n entries);
+//   * "no C++ exception crosses the boundary" (include/varsens_hip.h): the global `operator new` is replaced below by
+//     one that throws std::bad_alloc on the i-th allocation from now; the helpers of csrc/vs_host.h that allocate (the
+//     process-wide cache of seed-1 shuffles, the Sobol byte tables) are run with i = 0, 1, 2, ... until they succeed:
+//     every failing run must come back as VS_ERR_NOMEM with a message -- not std::terminate --, leak nothing
+//     (LeakSanitizer at exit) and leave the helper usable.
 #include <cinttypes>
 #include <cstdint>
 #include <cstdio>
@@ -15,7 +20,31 @@
 #include <cstring>
 #include <vector>
 
+#include <new>
+
 #include "varsens_hip.h"
+#include "vs_host.h"
+
+// ---- an allocator that fails on demand ------------------------------------------------------------------------------
+static long g_fail_in = -1;   // < 0: never; 0: the next allocation throws; i: the i-th from now
+static long g_allocations = 0;
+static void* counted_alloc(std::size_t n) {
+    ++g_allocations;
+    if (g_fail_in == 0) {
+        g_fail_in = -1;
+        throw std::bad_alloc();
+    }
+    if (g_fail_in > 0) --g_fail_in;
+    void* p = std::malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void* operator new(std::size_t n) { return counted_alloc(n); }
+void* operator new[](std::size_t n) { return counted_alloc(n); }
+void operator delete(void* p) noexcept { std::free(p); }
+void operator delete[](void* p) noexcept { std::free(p); }
+void operator delete(void* p, std::size_t) noexcept { std::free(p); }
+void operator delete[](void* p, std::size_t) noexcept { std::free(p); }
 
 static int failures = 0;
 #define CHECK(cond)                                                      \
@@ -158,6 +187,73 @@ int main() {
     std::free(whole);
     std::free(slice);
     std::free(none);
+
+    // ---- allocation failures come back as status codes
+    {
+        // the entry points that allocate nothing do not care
+        g_fail_in = 0;
+        uint32_t small[16];
+        CHECK(vs_seed1_permutation(small, 16) == VS_OK);
+        vs_design_desc e;
+        std::memset(&e, 0, sizeof(e));
+        e.generator = VS_GEN_HALTON;
+        e.k = 3;
+        e.n = 10;
+        CHECK(vs_design_desc_validate(&e, nullptr) == VS_OK);
+        CHECK(g_fail_in == 0);   // (still armed: nothing was allocated)
+        g_fail_in = -1;
+
+        // the cache of seed-1 shuffles: fail the i-th allocation until the call gets through
+        const uint64_t m = 5000;
+        int refused = 0;
+        std::shared_ptr<const std::vector<uint32_t>> got;
+        for (long i = 0; i < 64; ++i) {
+            g_fail_in = i;
+            const int rc = vs_seed1_host_cached(m, &got);
+            g_fail_in = -1;
+            if (rc == VS_OK) break;
+            CHECK(rc == VS_ERR_NOMEM);
+            CHECK(std::strstr(vs_last_error(), "out of host memory") != nullptr);
+            CHECK(!got);
+            ++refused;
+        }
+        CHECK(refused >= 1);   // (it does allocate: the first runs must have been refused)
+        CHECK(got && got->size() == m);
+        std::vector<uint32_t> direct(m);
+        CHECK(vs_seed1_permutation(direct.data(), m) == VS_OK);
+        CHECK(got && std::memcmp(got->data(), direct.data(), sizeof(uint32_t) * m) == 0);
+        std::shared_ptr<const std::vector<uint32_t>> again;
+        const long before = g_allocations;
+        CHECK(vs_seed1_host_cached(m, &again) == VS_OK && again.get() == got.get());   // from the cache ...
+        CHECK(g_allocations == before);                                                 // ... without allocating
+        std::printf("seed-1 cache: %d allocation failures refused with VS_ERR_NOMEM\n", refused);
+        // three more sizes push the first ones out of the two-entry cache (the evicted vectors are freed: LeakSanitizer)
+        for (uint64_t extra : {7001ull, 7002ull, 7003ull}) {
+            std::shared_ptr<const std::vector<uint32_t>> x;
+            CHECK(vs_seed1_host_cached(extra, &x) == VS_OK && x && x->size() == extra);
+        }
+        CHECK(vs_seed1_host_cached(0, &again) == VS_ERR_ARG);
+        CHECK(vs_seed1_host_cached(m, nullptr) == VS_ERR_ARG);
+
+        // the Sobol byte tables
+        const int kk = 3;
+        std::vector<uint32_t> dd(32 * kk);
+        for (size_t i = 0; i < dd.size(); ++i) dd[i] = 0x80000000u >> (i % 32);
+        std::vector<uint32_t> tabs;
+        refused = 0;
+        for (long i = 0; i < 64; ++i) {
+            g_fail_in = i;
+            const int rc = vs_sobol_byte_tables(kk, dd.data(), &tabs);
+            g_fail_in = -1;
+            if (rc == VS_OK) break;
+            CHECK(rc == VS_ERR_NOMEM);
+            ++refused;
+        }
+        CHECK(refused >= 1 && tabs.size() == (size_t)kk * 1024);
+        CHECK(tabs[0] == 0 && tabs[1] == 0x80000000u && tabs[3] == 0xc0000000u && tabs[256 + 1] == 0x00800000u);
+        CHECK(vs_sobol_byte_tables(0, dd.data(), &tabs) == VS_ERR_ARG);
+        std::printf("sobol tables: %d allocation failures refused with VS_ERR_NOMEM\n", refused);
+    }
     std::printf("%s\n", failures ? "host checks FAILED" : "host checks ok");
     return failures ? 1 : 0;
 }

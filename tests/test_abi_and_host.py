@@ -297,6 +297,10 @@ def test_host_entry_points_under_sanitizers():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "host checks ok" in p.stdout and "FAILED" not in p.stdout
     assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-4000:]
+    # "no C++ exception crosses the boundary": the driver replaces `operator new` by one that throws on the i-th
+    # allocation; the helpers that allocate came back with VS_ERR_NOMEM every time, nothing leaked, nothing terminated
+    assert re.search(r"seed-1 cache: [1-9]\d* allocation failures refused with VS_ERR_NOMEM", p.stdout), p.stdout[-2000:]
+    assert re.search(r"sobol tables: [1-9]\d* allocation failures refused with VS_ERR_NOMEM", p.stdout)
 
     def fnv(a):
         h = 1469598103934665603
@@ -311,6 +315,41 @@ def test_host_entry_points_under_sanitizers():
     assert set(seen) >= {0, 1, 2, 5, 13, 1024, 2048, 2049, 100003}
     for n in (0, 1, 2, 3, 5, 13, 1024, 2047, 2048, 2049, 2050, 4097, 100003):
         assert seen[n] == fnv(orc.seed1_permutation(n)), n
+
+
+def test_every_entry_point_is_guarded():
+    """include/varsens_hip.h: "no C++ exception crosses the boundary".  Every `extern "C"` function of the library that
+    returns a status opens with VS_GUARD_BEGIN and closes with VS_GUARD_END (csrc/vs_guard.h: std::bad_alloc ->
+    VS_ERR_NOMEM, anything else -> VS_ERR_STATE); the two that cannot fail (vs_abi_version, vs_last_error) are one-line
+    returns.  The sources are the evidence here -- the device entry points cannot run without a GPU; the host-only ones
+    run under a failing `operator new` in test_host_entry_points_under_sanitizers."""
+    csrc = os.path.join(ROOT, "varsens_amd", "csrc")
+    declared = set(header_symbols())
+    defined = {}
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".cpp")):
+            continue
+        lines = open(os.path.join(csrc, name)).read().split("\n")
+        for i, line in enumerate(lines):
+            m = re.match(r'extern "C" (?:const char\*|int) (vs_\w+)\(', line)
+            if not m:
+                continue
+            j = i
+            while not lines[j].rstrip().endswith(("{", "}")):
+                j += 1
+            if lines[j].rstrip().endswith("}"):      # one-liner
+                defined[m.group(1)] = "trivial" if re.search(r"\{ return [A-Za-z_]+; \}$", lines[j]) else "unguarded"
+                continue
+            end = j + 1
+            while lines[end] != "}":
+                end += 1
+            body = [b.strip() for b in lines[j + 1:end] if b.strip()]
+            defined[m.group(1)] = "guarded" if body[0] == "VS_GUARD_BEGIN" and body[-1] == "VS_GUARD_END" else "unguarded"
+    assert set(defined) == declared, sorted(set(defined) ^ declared)
+    assert sorted(n for n, how in defined.items() if how == "trivial") == ["vs_abi_version", "vs_last_error"]
+    assert not [n for n, how in defined.items() if how == "unguarded"]
+    guard = open(os.path.join(csrc, "vs_guard.h")).read()
+    assert "catch (const std::bad_alloc&)" in guard and "VS_ERR_NOMEM" in guard and "catch (...)" in guard
 
 
 def test_descriptor_checks_through_the_binding(native):

@@ -464,8 +464,8 @@ def test_sample_attributes_are_materialised_once(vs, monkeypatch):
     tests/test_sample.py:44-54): every attribute costs one launch and one download, however often it is read."""
     s = vs.Sample(5, 13, vs.scale.Identity(), verbose=False)
     calls = []
-    real = s._ctx.sample_flat
-    monkeypatch.setattr(s._ctx, "sample_flat", lambda *a: (calls.append(a[1:3]), real(*a))[1])
+    real = s._ctx.sample_rows
+    monkeypatch.setattr(s._ctx, "sample_rows", lambda *a: (calls.append(a[1:3]), real(*a))[1])
     want = orc.build_sample(5, 13)
     for i in range(13):
         numpy.testing.assert_array_equal(s.M_1[i], want[0][i])

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VARSENS_HIP_LIB") or os.path.join(_HERE, "libvarsens_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 COMM_ID_BYTES = 128
 
 GEN_HALTON, GEN_SOBOL, GEN_RAW = 0, 1, 2
@@ -26,6 +26,7 @@ ORDER_FAST, ORDER_STRICT = 0, 1
 KERNEL_NAMES = {
     1: "halton_fill", 2: "sobol_fill", 3: "sample_flat", 4: "eval", 5: "reduce_first",
     6: "fold", 7: "finish", 8: "nan_mask", 9: "second_order", 10: "second_fold", 11: "fused", 12: "allreduce",
+    13: "values",
 }
 
 ACC_HEADER = 4
@@ -112,6 +113,12 @@ SIGNATURES = {
     "vs_design_create": (C.c_int, [C.c_void_p, C.POINTER(DesignDesc), C.POINTER(C.c_void_p)]),
     "vs_design_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vs_sample_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "vs_sample_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "vs_sample_rows_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]),
+    "vs_sample_rows_wait": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "vs_upload_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                   C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "vs_download_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]),
     "vs_objective_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_void_p)]),
     "vs_objective_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -256,11 +263,18 @@ class Context(object):
         _check(self.lib.vs_context_create(int(device), C.byref(h)))
         self.handle = h
         self.device = int(device)
-        self._designs = []
+        self._handles = []      # weak references to the designs / objectives made through this context
 
     # -- plumbing
     def close(self):
+        """Destroys the context; designs and objectives made through it are released first (a design belongs to the
+        context that made it, and vs_context_destroy refuses while any is alive)."""
         if self.handle:
+            for ref in list(self._handles):
+                h = ref()
+                if h is not None:
+                    h.free()
+            self._handles = []
             self.lib.vs_context_destroy(self.handle)
             self.handle = None
 
@@ -336,6 +350,60 @@ class Context(object):
         _check(self.lib.vs_download(self.handle, out.ctypes.data_as(C.c_void_p), buf.at(byte_offset), out.nbytes))
         return out
 
+    def upload_values(self, values, n, k, row_begin, rows, f_buf, divide=None):
+        """Objective.load on the device (vs_upload_values): `values` is the reference's flat (2n(k+1), l) array; rows
+        [row_begin, row_begin + rows) of every block land in `f_buf` in the planar layout, divided by `divide` (None, a
+        scalar or l divisors).  Returns the number of shard rows Objective.load would delete (NaN in output 0)."""
+        v = np.asarray(values)
+        if v.dtype != np.float64 or not v.flags.c_contiguous:
+            v = np.ascontiguousarray(v, dtype=np.float64)
+        if v.ndim == 1:
+            v = v.reshape(-1, 1)
+        l = v.shape[1]
+        if v.shape[0] != 2 * n * (k + 1):
+            raise VarsensHipError("values must have 2n(k+1) = %d rows, got %d" % (2 * n * (k + 1), v.shape[0]))
+        if 8 * 2 * (k + 1) * rows * l > f_buf.nbytes:
+            raise VarsensHipError("values exceed the device buffer")
+        dptr, nd = None, 0
+        if divide is not None:
+            d = np.ascontiguousarray(np.asarray(divide, dtype=np.float64).ravel())
+            if d.size not in (1, l):
+                raise VarsensHipError("divide must be a scalar or hold one divisor per output")
+            dptr, nd = d.ctypes.data_as(C.c_void_p), int(d.size)
+        lost = C.c_uint64(0)
+        _check(self.lib.vs_upload_values(self.handle, v.ctypes.data_as(C.c_void_p), int(n), int(k), int(l),
+                                         int(row_begin), int(rows), dptr, nd, C.c_void_p(f_buf.ptr), C.byref(lost)))
+        return int(lost.value)
+
+    def download_values(self, f_buf, rows, k, l):
+        """Objective.flat() of the shard (vs_download_values): (2(k+1) rows, l) in the reference's order."""
+        if 8 * 2 * (k + 1) * rows * l > f_buf.nbytes:
+            raise VarsensHipError("download exceeds the device buffer")
+        out = np.empty((2 * (k + 1) * int(rows), int(l)), dtype=np.float64)
+        _check(self.lib.vs_download_values(self.handle, C.c_void_p(f_buf.ptr), int(rows), int(k), int(l),
+                                           out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def sample_rows(self, design, row_begin, row_count, k):
+        """Rows of Sample.flat() straight into a host array (vs_sample_rows)."""
+        out = np.empty((int(row_count), int(k)), dtype=np.float64)
+        _check(self.lib.vs_sample_rows(self.handle, design.h, int(row_begin), int(row_count),
+                                       out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def sample_rows_begin(self, design, row_begin, row_count, slot):
+        _check(self.lib.vs_sample_rows_begin(self.handle, design.h, int(row_begin), int(row_count), int(slot)))
+
+    def sample_rows_wait(self, slot, row_count, k):
+        """The rows begun on `slot` as a READ-ONLY view of the library's pinned memory -- valid until the next
+        sample_rows_begin on the same slot."""
+        p = C.c_void_p()
+        _check(self.lib.vs_sample_rows_wait(self.handle, int(slot), C.byref(p)))
+        buf = (C.c_double * (int(row_count) * int(k))).from_address(p.value)
+        view = np.frombuffer(buf, dtype=np.float64).reshape(int(row_count), int(k))
+        view.setflags(write=False)
+        return view
+
     def memset(self, buf, byte=0):
         _check(self.lib.vs_memset(self.handle, C.c_void_p(buf.ptr), int(byte), buf.nbytes))
 
@@ -381,6 +449,13 @@ class Context(object):
         return buf
 
     # -- design / objective handles
+    def _track(self, handle):
+        import weakref
+        if len(self._handles) > 256:    # drop the references whose handles are gone
+            self._handles = [r for r in self._handles if r() is not None and r().h]
+        self._handles.append(weakref.ref(handle))
+        return handle
+
     def design_create(self, generator, k, n, first_index=0, scale_mode=SCALE_IDENTITY, lower=None, upper=None,
                       perm=None, raw=None, sobol_directions=None, perm_begin=0, seed1_shuffle=None):
         """``perm``: the whole seed-1 permutation (n entries), or -- with ``perm_begin`` -- the entries of a
@@ -425,7 +500,7 @@ class Context(object):
         desc.sobol_directions = ptr(sobol_directions, np.uint32, (k, 32))
         h = C.c_void_p()
         _check(self.lib.vs_design_create(self.handle, C.byref(desc), C.byref(h)))
-        return Handle(self, h, self.lib.vs_design_destroy)
+        return self._track(Handle(self, h, self.lib.vs_design_destroy))
 
     def objective_create(self, kind, k, l, params=None):
         if params is None or len(params) == 0:
@@ -435,7 +510,7 @@ class Context(object):
             n = arr.size
         h = C.c_void_p()
         _check(self.lib.vs_objective_create(self.handle, int(kind), int(k), int(l), p, n, C.byref(h)))
-        return Handle(self, h, self.lib.vs_objective_destroy)
+        return self._track(Handle(self, h, self.lib.vs_objective_destroy))
 
     def objective_create_source(self, k, l, body, params=None):
         if params is None or len(params) == 0:
@@ -446,7 +521,7 @@ class Context(object):
         h = C.c_void_p()
         _check(self.lib.vs_objective_create_source(self.handle, int(k), int(l), body.encode("utf-8"), p, n,
                                                    C.byref(h)))
-        return Handle(self, h, self.lib.vs_objective_destroy)
+        return self._track(Handle(self, h, self.lib.vs_objective_destroy))
 
     def objective_create_separable(self, k, term_body, fold_sum, params=None):
         if params is None or len(params) == 0:
@@ -457,7 +532,7 @@ class Context(object):
         h = C.c_void_p()
         _check(self.lib.vs_objective_create_separable(self.handle, int(k), term_body.encode("utf-8"),
                                                       1 if fold_sum else 0, p, n, C.byref(h)))
-        return Handle(self, h, self.lib.vs_objective_destroy)
+        return self._track(Handle(self, h, self.lib.vs_objective_destroy))
 
     # -- compute
     def sample_flat(self, design, row_begin, row_count, out_buf):

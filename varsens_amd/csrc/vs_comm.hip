@@ -49,6 +49,7 @@ int load_rccl() {
 static_assert(VS_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
 
 extern "C" int vs_comm_unique_id(void* id_out) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(id_out, "id_out is null");
     int rc = load_rccl();
     if (rc) return rc;
@@ -56,9 +57,11 @@ extern "C" int vs_comm_unique_id(void* id_out) {
     VS_NCCL(g_rccl.GetUniqueId(&id));
     memcpy(id_out, &id, sizeof(id));
     return VS_OK;
+    VS_GUARD_END
 }
 
 extern "C" int vs_comm_init(vs_context* ctx, const void* id, int nranks, int rank) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && id, "null argument");
     VS_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d not in [0,%d)", rank, nranks);
     if (ctx->comm) return vs_fail(VS_ERR_STATE, "communicator already initialised");
@@ -73,17 +76,21 @@ extern "C" int vs_comm_init(vs_context* ctx, const void* id, int nranks, int ran
     ctx->comm_ranks = nranks;
     ctx->comm_rank = rank;
     return VS_OK;
+    VS_GUARD_END
 }
 
 extern "C" int vs_comm_allreduce(vs_context* ctx, double* buf_dev, size_t count) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && buf_dev, "null argument");
     if (!ctx->comm) return vs_fail(VS_ERR_STATE, "vs_comm_init has not been called on this context");
     vs_launch_scope scope(ctx, VS_KERNEL_ALLREDUCE);
     VS_NCCL(g_rccl.AllReduce(buf_dev, buf_dev, count, ncclFloat64, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
     return VS_OK;
+    VS_GUARD_END
 }
 
 extern "C" int vs_comm_destroy(vs_context* ctx) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx, "ctx is null");
     if (!ctx->comm) return VS_OK;
     hipStreamSynchronize(ctx->stream);
@@ -93,4 +100,5 @@ extern "C" int vs_comm_destroy(vs_context* ctx) {
     ctx->comm_rank = -1;
     if (r != ncclSuccess) return vs_fail(VS_ERR_COMM, "ncclCommDestroy failed: %s", g_rccl.GetErrorString(r));
     return VS_OK;
+    VS_GUARD_END
 }

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "varsens_hip.h"
+#include "vs_guard.h"
 
 struct vs_prof_slot {
     int kernel_id;
@@ -34,6 +35,7 @@ struct vs_tuning {
     int reduce_both = 1;         // VS_REDUCE_BOTH=0: never take the combined first+second-order kernel
     int fused_both_wide = 1;     // VS_FUSED_BOTH_WIDE=0: no fused evaluate + both-orders kernel beyond 32 columns; 2 (with
                                  // VS_TUNING=1, tools/fused_multi_sweep.sh): also the several-output shapes measured slower
+    int copy_threads = 4;        // VS_COPY_THREADS: host threads that feed / drain the pinned ring of vs_values.hip
     long profile_mask = -1;      // VS_PROFILE_MASK: bracket only these kernel ids with events
 };
 
@@ -80,9 +82,23 @@ struct vs_context {
     void* comm = nullptr;
     int comm_ranks = 0;
     int comm_rank = -1;
+    // pinned ring, device staging and copy threads of the calls that move objective values and sample rows across
+    // the host boundary (vs_values.hip); made on first use
+    struct vs_staging* staging = nullptr;
+    // designs made by this context that are still alive (vs_design_destroy takes them off): vs_context_destroy refuses
+    // while there are any -- their tables and their shares of the shuffle cache would dangle
+    int live_designs = 0;
+
+    vs_context() = default;
+    vs_context(const vs_context&) = delete;
+    vs_context& operator=(const vs_context&) = delete;
+    // releases whatever was created, in whatever state a failed vs_context_create left the object (vs_api.hip)
+    ~vs_context();
 };
+void vs_staging_release(vs_context* ctx);   // vs_values.hip
 
 struct vs_design {
+    vs_context* owner = nullptr;  // the context that made it: its tables live on that GPU, a shared shuffle in its cache
     vs_design_desc d;          // host copy (pointers below replace the host ones)
     double* lower = nullptr;   // device, k (POWER: lower; LINEAR: lower)
     double* width = nullptr;   // device, k (LINEAR: upper-lower; POWER: upper/lower)
@@ -133,19 +149,12 @@ int vs_rtc_gram_plan(vs_context* ctx, const vs_objective* o, uint64_t rows, unsi
 int vs_rtc_launch_gram(vs_context* ctx, const vs_objective* o, const void* eval_args, size_t eval_args_bytes,
                        unsigned P, const double* shift_dev, double* first_partials, double* gram_partials);
 
-int vs_fail(int code, const char* fmt, ...);
-
 #define VS_HIP(call)                                                                        \
     do {                                                                                    \
         hipError_t e__ = (call);                                                            \
         if (e__ != hipSuccess)                                                              \
             return vs_fail(VS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
                            __FILE__, __LINE__);                                             \
-    } while (0)
-
-#define VS_REQUIRE(cond, ...)                        \
-    do {                                             \
-        if (!(cond)) return vs_fail(VS_ERR_ARG, __VA_ARGS__); \
     } while (0)
 
 // Brackets a launch with profiling events when enabled.

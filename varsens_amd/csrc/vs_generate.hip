@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "vs_common.h"
+#include "vs_host.h"
 
 #include "vs_device_gen.h"
 
@@ -153,6 +154,7 @@ static unsigned grid_for(uint64_t total, unsigned block, unsigned cap) {
 }
 
 extern "C" int vs_halton_fill(vs_context* ctx, int k, uint64_t start, uint64_t count, double* out_dev) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx, "ctx is null");
     VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && k <= 65536, "k=%d out of range", k);
@@ -176,10 +178,12 @@ extern "C" int vs_halton_fill(vs_context* ctx, int k, uint64_t start, uint64_t c
     VS_HIP(hipStreamSynchronize(ctx->stream));
     VS_HIP(hipFree(bases));
     return VS_OK;
+    VS_GUARD_END
 }
 
 extern "C" int vs_sobol_fill(vs_context* ctx, int k, const uint32_t* directions, uint64_t start,
                              uint64_t count, double* out_dev) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && directions, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1, "k=%d out of range", k);
@@ -199,23 +203,30 @@ extern "C" int vs_sobol_fill(vs_context* ctx, int k, const uint32_t* directions,
     VS_HIP(hipStreamSynchronize(ctx->stream));
     VS_HIP(hipFree(dirs));
     return VS_OK;
+    VS_GUARD_END
 }
 
 // ---------------------------------------------------------------------------
 // design objects
 // ---------------------------------------------------------------------------
 
+// A design belongs to the context that made it (vs_design::owner): its tables live on that GPU and, with
+// VS_DESIGN_SEED1_SHUFFLE, it holds a share of that context's shuffle cache.  It is released through its owner whatever
+// `ctx` the caller passes (NULL included); vs_context_destroy refuses while designs of the context are alive.
 extern "C" int vs_design_destroy(vs_context* ctx, vs_design* g) {
+    VS_GUARD_BEGIN
     if (!g) return VS_OK;
-    if (ctx) {  // kernels on either stream may still read the tables
-        hipStreamSynchronize(ctx->streams[0]);
-        hipStreamSynchronize(ctx->streams[1]);
+    vs_context* owner = g->owner ? g->owner : ctx;
+    if (owner) {  // kernels on either stream may still read the tables
+        hipSetDevice(owner->device);
+        hipStreamSynchronize(owner->streams[0]);
+        hipStreamSynchronize(owner->streams[1]);
     }
     if (g->lower) hipFree(g->lower);
     if (g->width) hipFree(g->width);
     if (g->perm && g->perm_shared) {
-        if (ctx)
-            for (auto& e : ctx->perm_cache)
+        if (owner)
+            for (auto& e : owner->perm_cache)
                 if (e.dev == g->perm && e.refs > 0) { --e.refs; break; }
     } else if (g->perm) {
         hipFree(g->perm);
@@ -224,12 +235,15 @@ extern "C" int vs_design_destroy(vs_context* ctx, vs_design* g) {
     if (g->dirs) hipFree(g->dirs);
     if (g->sobol_tabs) hipFree(g->sobol_tabs);
     if (g->bases) hipFree(g->bases);
+    if (g->owner && g->owner->live_designs > 0) --g->owner->live_designs;
     delete g;
     return VS_OK;
+    VS_GUARD_END
 }
 
 // VS_DESIGN_SEED1_SHUFFLE: the device copy of rows [begin, begin + count) of the seed-1 shuffle of n rows, from the
-// context's cache or made now (host: vs_seed1_permutation once per n and process, the last two n kept).
+// context's cache or made now (host: vs_seed1_host_cached, once per n and process).  A rank without rows
+// (count = 0) gets a one-entry buffer and no host permutation is computed for it.
 static int seed1_shuffle_on_device(vs_context* ctx, uint64_t n, uint64_t begin, uint64_t count, uint32_t** out) {
     for (auto& e : ctx->perm_cache)
         if (e.n == n && e.begin == begin && e.count == count) {
@@ -238,26 +252,10 @@ static int seed1_shuffle_on_device(vs_context* ctx, uint64_t n, uint64_t begin, 
             *out = e.dev;
             return VS_OK;
         }
-    static std::mutex host_lock;
-    static std::vector<std::pair<uint64_t, std::shared_ptr<std::vector<uint32_t>>>> host_perms;
-    std::shared_ptr<std::vector<uint32_t>> perm;
-    {
-        std::lock_guard<std::mutex> hold(host_lock);
-        for (auto& h : host_perms)
-            if (h.first == n) perm = h.second;
-        if (!perm) {
-            try {
-                perm = std::make_shared<std::vector<uint32_t>>(n);
-            } catch (const std::exception&) {   // no C++ exception crosses the C ABI
-                return vs_fail(VS_ERR_ARG, "no host memory for the seed-1 shuffle of n=%llu rows", (unsigned long long)n);
-            }
-            const int rc = vs_seed1_permutation(perm->data(), n);
-            if (rc) return rc;
-            if (n <= (1ull << 25)) {   // kept for the next context / slice: up to two, 128 MiB each at most
-                if (host_perms.size() >= 2) host_perms.erase(host_perms.begin());
-                host_perms.emplace_back(n, perm);
-            }
-        }
+    std::shared_ptr<const std::vector<uint32_t>> perm;
+    if (count) {
+        const int rc = vs_seed1_host_cached(n, &perm);
+        if (rc) return rc;
     }
     // room: drop unreferenced copies, least recently used first, beyond four entries or 1 GiB of them
     for (;;) {
@@ -275,6 +273,7 @@ static int seed1_shuffle_on_device(vs_context* ctx, uint64_t n, uint64_t begin, 
         hipFree(ctx->perm_cache[victim].dev);
         ctx->perm_cache.erase(ctx->perm_cache.begin() + victim);
     }
+    ctx->perm_cache.reserve(ctx->perm_cache.size() + 1);   // before the device allocation: nothing to undo if it throws
     uint32_t* dev = nullptr;
     VS_HIP(hipMalloc(&dev, sizeof(uint32_t) * (count ? count : 1)));
     if (count) {
@@ -290,6 +289,7 @@ static int seed1_shuffle_on_device(vs_context* ctx, uint64_t n, uint64_t begin, 
 }
 
 extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_design** out) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && desc && out, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     *out = nullptr;
@@ -304,12 +304,18 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
 
     VS_HIP(hipSetDevice(ctx->device));
     vs_design* g = new vs_design();
+    g->owner = ctx;
+    ++ctx->live_designs;
+    // until the last step is through, the half-built design goes with this scope -- on an error return and on an
+    // exception on its way to the guard alike
+    struct holder {
+        vs_context* ctx;
+        vs_design* g;
+        ~holder() { if (g) vs_design_destroy(ctx, g); }
+    } hold{ctx, g};
     g->d = *desc;
     int rc = VS_OK;
-    auto bail = [&](int code) {
-        vs_design_destroy(ctx, g);
-        return code;
-    };
+    auto bail = [&](int code) { return code; };
 #define VS_TRY(call)                                                                              \
     do {                                                                                          \
         hipError_t e__ = (call);                                                                  \
@@ -365,15 +371,9 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
         VS_TRY(hipMemcpyAsync(g->dirs, desc->sobol_directions, sizeof(uint32_t) * 32 * k,
                               hipMemcpyHostToDevice, ctx->stream));
         // byte tables of the direction integers (vs_sobol_point_tab)
-        std::vector<uint32_t> tabs((size_t)k * 1024);
-        for (int c = 0; c < k; ++c)
-            for (int b = 0; b < 4; ++b)
-                for (int v = 0; v < 256; ++v) {
-                    uint32_t x = 0;
-                    for (int j = 0; j < 8; ++j)
-                        if ((v >> j) & 1) x ^= desc->sobol_directions[(size_t)c * 32 + 8 * b + j];
-                    tabs[((size_t)c * 4 + b) * 256 + v] = x;
-                }
+        std::vector<uint32_t> tabs;
+        rc = vs_sobol_byte_tables(k, desc->sobol_directions, &tabs);
+        if (rc) return bail(rc);
         VS_TRY(hipMalloc(&g->sobol_tabs, sizeof(uint32_t) * tabs.size()));
         VS_TRY(hipMemcpy(g->sobol_tabs, tabs.data(), sizeof(uint32_t) * tabs.size(), hipMemcpyHostToDevice));
     }
@@ -390,8 +390,10 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
     g->d.perm = nullptr;
     g->d.raw = nullptr;
     g->d.sobol_directions = nullptr;
+    hold.g = nullptr;
     *out = g;
     return VS_OK;
+    VS_GUARD_END
 }
 
 // ---------------------------------------------------------------------------
@@ -419,8 +421,22 @@ sample_flat_kernel(vs_design_dev D, uint64_t row_begin, uint64_t total, double* 
     }
 }
 
+// the launch alone, on a given stream: vs_sample_flat below and the host-bound row fetches of vs_values.hip
+int vs_sample_flat_launch(vs_context* ctx, const vs_design* design, uint64_t row_begin, uint64_t row_count,
+                          double* out_dev, hipStream_t stream) {
+    const uint64_t total = row_count * (uint64_t)design->d.k;
+    {
+        vs_launch_scope scope(ctx, VS_KERNEL_SAMPLE_FLAT);
+        hipLaunchKernelGGL(sample_flat_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, stream,
+                           to_dev(design), row_begin, total, out_dev);
+    }
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
 extern "C" int vs_sample_flat(vs_context* ctx, const vs_design* design, uint64_t row_begin,
                               uint64_t row_count, double* out_dev) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && design, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     const uint64_t rows_total = 2 * design->d.n * ((uint64_t)design->d.k + 1);
@@ -432,14 +448,8 @@ extern "C" int vs_sample_flat(vs_context* ctx, const vs_design* design, uint64_t
     VS_REQUIRE(!design->perm || design->d.perm_count == design->d.n,
                "vs_sample_flat needs the whole shuffle (this design holds a slice of %llu rows)",
                (unsigned long long)design->d.perm_count);
-    uint64_t total = row_count * (uint64_t)design->d.k;
-    {
-        vs_launch_scope scope(ctx, VS_KERNEL_SAMPLE_FLAT);
-        hipLaunchKernelGGL(sample_flat_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, ctx->stream,
-                           to_dev(design), row_begin, total, out_dev);
-    }
-    VS_HIP(hipGetLastError());
-    return VS_OK;
+    return vs_sample_flat_launch(ctx, design, row_begin, row_count, out_dev, ctx->stream);
+    VS_GUARD_END
 }
 
 // ---------------------------------------------------------------------------
@@ -447,6 +457,7 @@ extern "C" int vs_sample_flat(vs_context* ctx, const vs_design* design, uint64_t
 // ---------------------------------------------------------------------------
 
 extern "C" int vs_objective_destroy(vs_context* ctx, vs_objective* obj) {
+    VS_GUARD_BEGIN
     if (!obj) return VS_OK;
     if (ctx) {
         hipStreamSynchronize(ctx->streams[0]);
@@ -456,10 +467,26 @@ extern "C" int vs_objective_destroy(vs_context* ctx, vs_objective* obj) {
     vs_rtc_release(obj);
     delete obj;
     return VS_OK;
+    VS_GUARD_END
 }
+
+namespace {
+// a half-built objective goes with the scope that holds it (error returns and exceptions on their way to the guard)
+struct objective_holder {
+    vs_context* ctx;
+    vs_objective* o;
+    ~objective_holder() { if (o) vs_objective_destroy(ctx, o); }
+    vs_objective* release() {
+        vs_objective* p = o;
+        o = nullptr;
+        return p;
+    }
+};
+}  // namespace
 
 extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, const double* params,
                                    size_t nparams, vs_objective** out) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && out, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     *out = nullptr;
@@ -482,6 +509,7 @@ extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, cons
     }
     VS_REQUIRE(nparams == 0 || params, "params is null");
     vs_objective* o = new vs_objective();
+    objective_holder hold{ctx, o};
     o->kind = kind;
     o->k = k;
     o->l = l;
@@ -514,23 +542,24 @@ extern "C" int vs_objective_create(vs_context* ctx, int kind, int k, int l, cons
         if (hipMalloc(&o->params, sizeof(double) * host.size()) != hipSuccess ||
             hipMemcpyAsync(o->params, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, ctx->stream) !=
                 hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            vs_objective_destroy(ctx, o);
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
             return vs_fail(VS_ERR_HIP, "uploading objective parameters failed");
-        }
     }
-    *out = o;
+    *out = hold.release();
     return VS_OK;
+    VS_GUARD_END
 }
 
 extern "C" int vs_objective_create_source(vs_context* ctx, int k, int l, const char* body, const double* params,
                                           size_t nparams, vs_objective** out) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && out && body, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     *out = nullptr;
     VS_REQUIRE(k >= 1 && l >= 1 && l <= 1024, "k and l must be positive (l <= 1024)");
     VS_REQUIRE(nparams == 0 || params, "params is null");
     vs_objective* o = new vs_objective();
+    objective_holder hold{ctx, o};
     o->kind = VS_OBJ_SOURCE;
     o->k = k;
     o->l = l;
@@ -539,22 +568,19 @@ extern "C" int vs_objective_create_source(vs_context* ctx, int k, int l, const c
         if (hipMalloc(&o->params, sizeof(double) * nparams) != hipSuccess ||
             hipMemcpyAsync(o->params, params, sizeof(double) * nparams, hipMemcpyHostToDevice, ctx->stream) !=
                 hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            vs_objective_destroy(ctx, o);
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
             return vs_fail(VS_ERR_HIP, "uploading objective parameters failed");
-        }
     }
     int rc = vs_rtc_build(ctx, o, body, 0);
-    if (rc) {
-        vs_objective_destroy(ctx, o);
-        return rc;
-    }
-    *out = o;
+    if (rc) return rc;
+    *out = hold.release();
     return VS_OK;
+    VS_GUARD_END
 }
 
 extern "C" int vs_objective_create_separable(vs_context* ctx, int k, const char* term_body, int fold,
                                              const double* params, size_t nparams, vs_objective** out) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && out && term_body, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     *out = nullptr;
@@ -562,6 +588,7 @@ extern "C" int vs_objective_create_separable(vs_context* ctx, int k, const char*
     VS_REQUIRE(fold == VS_FOLD_PRODUCT || fold == VS_FOLD_SUM, "fold must be VS_FOLD_PRODUCT or VS_FOLD_SUM");
     VS_REQUIRE(nparams == 0 || params, "params is null");
     vs_objective* o = new vs_objective();
+    objective_holder hold{ctx, o};
     o->kind = VS_OBJ_SOURCE;
     o->k = k;
     o->l = 1;
@@ -570,18 +597,14 @@ extern "C" int vs_objective_create_separable(vs_context* ctx, int k, const char*
         if (hipMalloc(&o->params, sizeof(double) * nparams) != hipSuccess ||
             hipMemcpyAsync(o->params, params, sizeof(double) * nparams, hipMemcpyHostToDevice, ctx->stream) !=
                 hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            vs_objective_destroy(ctx, o);
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
             return vs_fail(VS_ERR_HIP, "uploading objective parameters failed");
-        }
     }
     int rc = vs_rtc_build(ctx, o, term_body, fold == VS_FOLD_SUM ? 2 : 1);
-    if (rc) {
-        vs_objective_destroy(ctx, o);
-        return rc;
-    }
-    *out = o;
+    if (rc) return rc;
+    *out = hold.release();
     return VS_OK;
+    VS_GUARD_END
 }
 
 // ---------------------------------------------------------------------------
@@ -885,15 +908,18 @@ static fused_route fused_route_for(const vs_context* ctx, const vs_design* desig
 
 extern "C" int vs_eval_reduce_supported(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                                         int* supported) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && design && obj && supported, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     *supported = (obj->k == design->d.k && fused_route_for(ctx, design, obj) != FUSED_NONE) ? 1 : 0;
     return VS_OK;
+    VS_GUARD_END
 }
 
 extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                                           uint64_t row_begin, uint64_t row_count, int rank, int max_ranks,
                                           double* acc_dev) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && design && obj && acc_dev, "null argument");
     VS_REQUIRE(obj->k == design->d.k, "objective has k=%d, design has k=%d", obj->k, design->d.k);
     VS_REQUIRE(row_begin <= design->d.n && row_count <= design->d.n - row_begin, "rows exceed n");
@@ -940,6 +966,7 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
     }
     if (rc) return rc;
     return vs_fold_partials(ctx, P, k, l, row_count, shift_buf, (int)shift_stride, nullptr, rank, max_ranks, acc_dev);
+    VS_GUARD_END
 }
 
 // vs_scan_gram.hip
@@ -992,14 +1019,17 @@ static fused_route fused_both_route(const vs_context* ctx, const vs_design* desi
 
 extern "C" int vs_eval_reduce_both_supported(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                                              int* supported) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && design && obj && supported, "null argument");
     *supported = fused_both_route(ctx, design, obj) != FUSED_NONE ? 1 : 0;
     return VS_OK;
+    VS_GUARD_END
 }
 
 extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                                                  uint64_t row_begin, uint64_t row_count, int rank, int max_ranks,
                                                  double* acc_dev, double* gram_dev) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && design && obj && acc_dev && gram_dev, "null argument");
     VS_REQUIRE(obj->k == design->d.k, "objective has k=%d, design has k=%d", obj->k, design->d.k);
     VS_REQUIRE(row_begin <= design->d.n && row_count <= design->d.n - row_begin, "rows exceed n");
@@ -1011,7 +1041,7 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     if (route == FUSED_NONE)
         return vs_fail(VS_ERR_ARG, "the fused both-orders path covers ISHIGAMI, G_FUNCTION / POLYNOMIAL / LINEAR with k l <= 128 "
                                    "(several outputs: 2 .. 8 up to 32 index rows, k >= 16 beyond, 2 .. 4 outputs beyond 64 rows -- 3 only up to 112 --, "
-                                   "no power scaling) and separable "
+                                   "power scaling everywhere but at 33 .. 64 index rows of several outputs) and separable "
                                    "source objectives with one output and k <= 128 (Halton indices below 2^32, scan evaluation "
                                    "order); use vs_eval + vs_reduce_first_second_order (vs_eval_reduce_both_supported tells)");
     const int k = obj->k, l = obj->l, K = k * l;
@@ -1065,10 +1095,12 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     rc = vs_fold_partials(ctx, P, k, l, row_count, shift_buf, (int)shift_stride, nullptr, rank, max_ranks, acc_dev);
     if (rc) return rc;
     return vs_gram_fold_st(ctx, gram_partials, P, K, SB, gram_dev);
+    VS_GUARD_END
 }
 
 extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,
                        uint64_t row_begin, uint64_t row_count, double* f_dev) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && design && obj, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(obj->k == design->d.k, "objective has k=%d, design has k=%d", obj->k, design->d.k);
@@ -1118,4 +1150,5 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
         }
     }
     return vs_fail(VS_ERR_ARG, "unknown objective kind %d", obj->kind);
+    VS_GUARD_END
 }

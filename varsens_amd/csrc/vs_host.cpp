@@ -5,19 +5,19 @@
 //   * the error store behind vs_last_error();
 //   * vs_seed1_permutation: numpy.random.seed(1); numpy.random.shuffle(M_2) (varsens/saltelli.py:100-101);
 //   * vs_design_desc_validate: every check vs_design_create makes on a descriptor before it touches the GPU
-//     (varsens/saltelli.py:62-108: k, n, generator, scaling bounds, the shuffle slice of a rank).
+//     (varsens/saltelli.py:62-108: k, n, generator, scaling bounds, the shuffle slice of a rank);
+//   * the helpers of vs_host.h that allocate on the host (the process-wide cache of seed-1 shuffles, the Sobol byte
+//     tables): the sanitizer driver runs them with an `operator new` that fails on demand and expects status codes.
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <utility>
 
 #include "varsens_hip.h"
-
-int vs_fail(int code, const char* fmt, ...);
-#define VS_REQUIRE(cond, ...)                        \
-    do {                                             \
-        if (!(cond)) return vs_fail(VS_ERR_ARG, __VA_ARGS__); \
-    } while (0)
+#include "vs_guard.h"
+#include "vs_host.h"
 
 static thread_local char g_err[8192] = "";
 
@@ -77,6 +77,7 @@ struct mt19937 {
 }  // namespace
 
 extern "C" int vs_seed1_permutation(uint32_t* out, uint64_t n) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(out || n == 0, "out is null");
     VS_REQUIRE(n <= 0xffffffffull, "n=%llu out of range", (unsigned long long)n);
     if (n < 2) {
@@ -114,6 +115,7 @@ extern "C" int vs_seed1_permutation(uint32_t* out, uint64_t n) {
         }
     }
     return VS_OK;
+    VS_GUARD_END
 }
 
 
@@ -121,6 +123,7 @@ extern "C" int vs_seed1_permutation(uint32_t* out, uint64_t n) {
 // *perm_entries (may be null): how many entries of desc->perm the engine will read -- 0 without a shuffle or for an
 // empty slice (VS_PERM_EMPTY), n for perm_count = 0, else perm_count.
 extern "C" int vs_design_desc_validate(const vs_design_desc* desc, uint64_t* perm_entries) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(desc, "null descriptor");
     const int k = desc->k;
     const uint64_t n = desc->n;
@@ -161,4 +164,49 @@ extern "C" int vs_design_desc_validate(const vs_design_desc* desc, uint64_t* per
     }
     if (perm_entries) *perm_entries = count;
     return VS_OK;
+    VS_GUARD_END
+}
+
+
+// ---- host helpers that allocate (vs_host.h) ---------------------------------------------------
+
+int vs_seed1_host_cached(uint64_t n, std::shared_ptr<const std::vector<uint32_t>>* out) {
+    VS_GUARD_BEGIN
+    VS_REQUIRE(out, "out is null");
+    VS_REQUIRE(n >= 1 && n <= 0xffffffffull, "n=%llu out of range", (unsigned long long)n);
+    static std::mutex lock;
+    static std::vector<std::pair<uint64_t, std::shared_ptr<const std::vector<uint32_t>>>> kept;
+    std::lock_guard<std::mutex> hold(lock);
+    for (auto& h : kept)
+        if (h.first == n) {
+            *out = h.second;
+            return VS_OK;
+        }
+    auto perm = std::make_shared<std::vector<uint32_t>>(n);   // 4 n bytes; std::bad_alloc -> VS_ERR_NOMEM (guard)
+    const int rc = vs_seed1_permutation(perm->data(), n);
+    if (rc) return rc;
+    if (n <= (1ull << 25)) {   // kept for the next context / slice: up to two, 128 MiB each at most
+        kept.reserve(3);
+        if (kept.size() >= 2) kept.erase(kept.begin());
+        kept.emplace_back(n, perm);
+    }
+    *out = std::move(perm);
+    return VS_OK;
+    VS_GUARD_END
+}
+
+int vs_sobol_byte_tables(int k, const uint32_t* directions, std::vector<uint32_t>* tabs) {
+    VS_GUARD_BEGIN
+    VS_REQUIRE(k >= 1 && directions && tabs, "bad argument");
+    tabs->assign((size_t)k * 1024, 0u);
+    for (int c = 0; c < k; ++c)
+        for (int b = 0; b < 4; ++b)
+            for (int v = 0; v < 256; ++v) {
+                uint32_t x = 0;
+                for (int j = 0; j < 8; ++j)
+                    if ((v >> j) & 1) x ^= directions[(size_t)c * 32 + 8 * b + j];
+                (*tabs)[((size_t)c * 4 + b) * 256 + v] = x;
+            }
+    return VS_OK;
+    VS_GUARD_END
 }

@@ -495,6 +495,7 @@ static int launch_reduce(vs_context* ctx, const vs_reduce_args& A, dim3 grid, si
 
 extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                                      int flags, int rank, int max_ranks, double* acc_dev) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && acc_dev, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && l >= 1, "k and l must be positive");
@@ -590,6 +591,7 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
         VS_HIP(hipGetLastError());
     }
     return VS_OK;
+    VS_GUARD_END
 }
 
 // Fold `P` workgroup records sitting in ctx->partials ([P][l][VS_PLEN(k)]) into this rank's
@@ -634,6 +636,7 @@ int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, c
 
 extern "C" int vs_finish_first_order(vs_context* ctx, const double* acc_dev, uint64_t n, int k, int l,
                                      int max_ranks, double* out_dev) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && acc_dev && out_dev, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && l >= 1 && max_ranks >= 1 && n >= 2, "bad dimensions");
@@ -644,4 +647,5 @@ extern "C" int vs_finish_first_order(vs_context* ctx, const double* acc_dev, uin
     }
     VS_HIP(hipGetLastError());
     return VS_OK;
+    VS_GUARD_END
 }

@@ -1723,12 +1723,15 @@ int vs_gram_fold_st(vs_context* ctx, const double* partials, uint32_t P, int K, 
 
 extern "C" int vs_reduce_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                                       int flags, double* gram_dev) {
+    VS_GUARD_BEGIN
     return second_order_impl(ctx, f_dev, rows, k, l, flags, gram_dev, false, 0, 1, nullptr);
+    VS_GUARD_END
 }
 
 extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l,
                                             int flags, int rank, int max_ranks, double* acc_dev,
                                             double* gram_dev) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && acc_dev && gram_dev, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && l >= 1, "k and l must be positive");
@@ -1845,10 +1848,12 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     }
     VS_HIP(hipGetLastError());
     return VS_OK;
+    VS_GUARD_END
 }
 
 extern "C" int vs_finish_second_order(vs_context* ctx, const double* gram_dev, const double* first_dev,
                                       uint64_t n, int k, int l, double* sens2_dev, double* sens2n_dev) {
+    VS_GUARD_BEGIN
     VS_REQUIRE(ctx && gram_dev && first_dev && sens2_dev && sens2n_dev, "null argument");
     VS_HIP(hipSetDevice(ctx->device));
     VS_REQUIRE(k >= 1 && l >= 1 && n >= 2, "bad dimensions");
@@ -1860,4 +1865,5 @@ extern "C" int vs_finish_second_order(vs_context* ctx, const double* gram_dev, c
     }
     VS_HIP(hipGetLastError());
     return VS_OK;
+    VS_GUARD_END
 }

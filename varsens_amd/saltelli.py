@@ -33,8 +33,9 @@ _default_ctx = {}
 
 # largest array an attribute such as Sample.N_j may materialise on the host
 HOST_MATERIALISE_LIMIT = int(os.environ.get("VARSENS_HOST_LIMIT_BYTES", 8 << 30))
-# rows handed to an opaque Python objective per chunk
+# rows handed to an opaque Python objective per chunk: row-by-row callables / numpy-vectorised ones
 _HOST_CHUNK_ROWS = 1 << 16
+_HOST_CHUNK_ROWS_VECTORIZED = 1 << 18
 
 
 def default_context(device=None):
@@ -185,11 +186,29 @@ class Sample(object):
                             (count, self.k, HOST_MATERIALISE_LIMIT))
         if 'flat' in self._host:
             return self._host['flat'][begin:begin + count]
-        buf = self._ctx.alloc(8 * count * self.k)
-        self._ctx.sample_flat(self._design, begin, count, buf)
-        out = self._ctx.download(buf, (count, self.k))
-        buf.free()
-        return out
+        # produced piece by piece on the device and copied out through the library's pinned ring, the kernel of one
+        # piece under the copy of the one before (vs_sample_rows): no allocation, launch, copy and free per request
+        return self._ctx.sample_rows(self._design, begin, count, self.k)
+
+    def _row_chunks(self, spans):
+        """The rows of `spans` = [(begin, count), ...] one span at a time, span i+1 being produced and copied while
+        the caller works on span i (vs_sample_rows_begin / _wait: two pinned slots).  Yields read-only views of the
+        library's memory, each valid until the next one is asked for."""
+        if 'flat' in self._host:
+            for begin, count in spans:
+                yield self._host['flat'][begin:begin + count]
+            return
+        for begin, count in spans:
+            if count * self.k * 8 > HOST_MATERIALISE_LIMIT:
+                raise Exception("refusing to materialise %d x %d sample rows on the host (VARSENS_HOST_LIMIT_BYTES)" %
+                                (count, self.k))
+        ctx, design, k = self._ctx, self._design, self.k
+        if spans:
+            ctx.sample_rows_begin(design, spans[0][0], spans[0][1], 0)
+        for i, (begin, count) in enumerate(spans):
+            if i + 1 < len(spans):
+                ctx.sample_rows_begin(design, spans[i + 1][0], spans[i + 1][1], (i + 1) & 1)
+            yield ctx.sample_rows_wait(i & 1, count, k)
 
     def _attribute(self, name, begin, count, shape):
         """One launch and one download per attribute, however often it is read: the reference's own idiom is
@@ -311,6 +330,7 @@ class Objective(object):
         self._f = None          # device buffer, planar: [l][2k+2][rows] (include/varsens_hip.h)
         self._l = None
         self._nan_trim = False  # only values that come through load() are trimmed (saltelli.py:474-495)
+        self._nan_rows = 0      # rows of this shard load() found a NaN in (counted on the device)
         self._host_cache = None
         self._params = None
         self._order = None      # device objectives: the context's evaluation order at construction
@@ -377,8 +397,10 @@ class Objective(object):
         handle.free()
 
     def _evaluate_on_host(self):
-        """An opaque Python objective: rows come from the GPU in chunks, the calls happen
-        here one row at a time as in varsens/saltelli.py:329-355, the values go back to HBM."""
+        """An opaque Python objective: the sample rows come from the GPU chunk by chunk -- chunk i+1 is generated and
+        copied into pinned memory while the model runs on chunk i --, the calls happen here one row at a time as in
+        varsens/saltelli.py:329-355 (or once per chunk with ``vectorized=True``), and the values go back to HBM in the
+        reference's own order: the device transposes them into its layout (vs_upload_values)."""
         k, n = int(self.k), int(self.n)
         func = self.objective_func
         first = self.sample._rows(self._row_begin, 1)
@@ -393,21 +415,28 @@ class Objective(object):
                 l = 1
         self._l = l
         rows = self._rows
-        vals = numpy.zeros((2 * k + 2, rows, l))
+        vals = numpy.empty((2 * k + 2, rows, l))
         total, step = (2 * k + 2) * rows, 0
         report = max(1, int(0.01 * total))
+        chunk = _HOST_CHUNK_ROWS_VECTORIZED if self._vectorized else _HOST_CHUNK_ROWS
+        spans, where = [], []
         for block in range(2 * k + 2):
-            for c0 in range(0, rows, _HOST_CHUNK_ROWS):
-                c1 = min(rows, c0 + _HOST_CHUNK_ROWS)
-                pts = self.sample._rows(block * n + self._row_begin + c0, c1 - c0)
-                if self._vectorized:   # extension: one call per block of rows (numpy-vectorised models)
-                    vals[block, c0:c1] = numpy.asarray(func(pts), dtype=numpy.float64).reshape(c1 - c0, l)
-                    continue
-                for i in range(c1 - c0):
-                    vals[block, c0 + i] = func(pts[i])
-                    step += 1
-                    if self.verbose and step % report == 0: print(str(int(round(100. * step / total))) + "%")
-        self._f = self._ctx.upload(_native.to_planar(vals))
+            for c0 in range(0, rows, chunk):
+                c1 = min(rows, c0 + chunk)
+                spans.append((block * n + self._row_begin + c0, c1 - c0))
+                where.append((block, c0, c1))
+        for (block, c0, c1), pts in zip(where, self.sample._row_chunks(spans)):
+            if self._vectorized:   # extension: one call per block of rows (numpy-vectorised models); `pts` is a
+                # read-only view that lives for the duration of the call
+                vals[block, c0:c1] = numpy.asarray(func(pts), dtype=numpy.float64).reshape(c1 - c0, l)
+                continue
+            pts = numpy.array(pts)    # the rows are the model's to keep, as the reference's sample.M_1[i] are
+            for i in range(c1 - c0):
+                vals[block, c0 + i] = func(pts[i])
+                step += 1
+                if self.verbose and step % report == 0: print(str(int(round(100. * step / total))) + "%")
+        self._f = self._ctx.alloc(8 * 2 * (k + 1) * rows * l)
+        self._ctx.upload_values(vals.reshape(-1, l), rows, k, 0, rows, self._f)
 
     # -- access ---------------------------------------------------------------------------
     def _blocks(self):
@@ -416,8 +445,9 @@ class Objective(object):
             k = int(self.k)
             if 8 * (2 * k + 2) * self._rows * self._l > HOST_MATERIALISE_LIMIT:
                 raise Exception("refusing to copy the objective values to the host (VARSENS_HOST_LIMIT_BYTES)")
-            v = _native.from_planar(self._ctx.download(self._values(), (self._l, 2 * k + 2, self._rows)))
-            if self._nan_trim:
+            # the device turns its planes back into the reference's order on the way out (vs_download_values)
+            v = self._ctx.download_values(self._values(), self._rows, k, self._l).reshape(2 * k + 2, self._rows, self._l)
+            if self._nan_trim and self._nan_rows:              # (the device counted them when the values came in)
                 drop = numpy.isnan(v[:, :, 0]).any(axis=0)     # first output only (saltelli.py:482)
                 v = v[:, ~drop]
             self._host_cache = v
@@ -478,17 +508,23 @@ class Objective(object):
                             (2 * n * (1 + k)))
         if x.ndim == 1:
             x = x[:, numpy.newaxis]
-        if scaling != 1.0:
-            x = x / scaling                                   # saltelli.py:451-468
         self._l = x.shape[1]
-        blocks = x.reshape(2 * k + 2, n, self._l)
-        if (self._row_begin, self._rows) != (0, n):
-            blocks = blocks[:, self._row_begin:self._row_begin + self._rows]
-        self._f = self._ctx.upload(_native.to_planar(blocks))
+        # `x / scaling` (saltelli.py:451-468) happens on the device while the values are laid out: a scalar or one
+        # divisor per output; anything else numpy can broadcast is divided here, as the reference does
+        divide = None
+        if not (numpy.isscalar(scaling) and scaling == 1.0):
+            d = numpy.asarray(scaling, dtype=numpy.float64)
+            if d.size == 1 or (d.size == self._l and d.shape in ((self._l,), (1, self._l))):
+                divide = d.ravel()
+            else:
+                x = x / scaling
+        # slicing into fM_1 .. fN_nj, the shard's rows, the transposition into the device layout and the NaN scan of
+        # saltelli.py:474-486 are one call: the array goes through a pinned ring in pieces, a kernel lays each piece out
+        self._f = self._ctx.alloc(8 * 2 * (k + 1) * self._rows * self._l)
+        lost = self._ctx.upload_values(x, n, k, self._row_begin, self._rows, self._f, divide)
         self._nan_trim = True
+        self._nan_rows = lost
         self._host_cache = None
-        first = blocks[:, :, 0]
-        lost = int(numpy.isnan(first).any(axis=0).sum())
         if lost > 0:
             print("WARNING: %d of %d objectives were NaN, %f%% loss" %
                   (lost, 2 * n * (1 + k), 100.0 * lost / (2 * n * (1 + k))))
