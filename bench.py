@@ -278,6 +278,24 @@ def spawn_ranks(world, argv=None, script=None):
     return worst if worst >= 0 else 128 - worst
 
 
+def job_slice(log2n, world, rank, strong):
+    """(global n, first row, rows) of rank `rank` in a job of `world` GPUs: weak scaling keeps 2^log2n draws PER GPU
+    (global n = world * 2^log2n, rank r owns rows [r * 2^log2n, (r + 1) * 2^log2n)), strong scaling splits 2^log2n draws
+    IN TOTAL (dist.shard_rows).  The one place the slice arithmetic lives: a real rank and its one-GPU rehearsal
+    (--rehearse-rank r --of N) call it with the same arguments."""
+    from varsens_amd import dist
+    if strong:
+        n = 1 << log2n
+        begin, rows = dist.shard_rows(n, world, rank)
+    else:
+        if not (0 <= rank < world):
+            raise Exception("rank %d not in [0,%d)" % (rank, world))
+        rows = 1 << log2n
+        n = rows * world
+        begin = rank * rows
+    return n, begin, rows
+
+
 def averages(recs):
     per = {}
     for name, ms in recs:
@@ -303,10 +321,19 @@ def main():
                     help="host = rehearsal of the multi-rank flow without RCCL (records cross the host over gloo)")
     ap.add_argument("--shared-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses GPU 0")
+    ap.add_argument("--rehearse-rank", type=int, default=None, metavar="R",
+                    help="with --of N, on ONE GPU: the step loop of rank R of an N-GPU job -- the design of the global n, "
+                         "this rank's row slice and shuffle slice, N variance slots in the record, no exchange; prints "
+                         "that rank's step and stage times (tools/rehearse_weak_scaling.py predicts the weak-scaling "
+                         "efficiency from ranks 0, 3 and 7 of 8)")
+    ap.add_argument("--of", type=int, default=8, metavar="N", help="job size rehearsed by --rehearse-rank")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launch rehearsal without a GPU: start the ranks, run the host collectives, print who came")
     args = ap.parse_args()
 
+    rehearse = args.rehearse_rank is not None
+    if rehearse and (args.gpus != 1 or not (0 <= args.rehearse_rank < args.of)):
+        raise SystemExit("--rehearse-rank R --of N runs on one GPU (--gpus 1) with 0 <= R < N")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))    # before anything that could initialise a GPU in this process
 
@@ -348,13 +375,9 @@ def main():
                     "HOST FALLBACK over the %s rendezvous (RCCL init failed on at least one rank)" % group.backend)
 
     k = args.k
-    if args.strong:
-        n = 1 << args.log2n             # global draws, fixed
-        begin, rows = dist.shard_rows(n, world, rank)
-    else:
-        rows = 1 << args.log2n          # per GPU (weak scaling)
-        n = rows * world                # global draws
-        begin = rank * rows
+    # slots / vrank: the job this process is a rank OF -- itself, or the N-GPU job a one-GPU rehearsal stands in for
+    slots, vrank = (args.of, args.rehearse_rank) if rehearse else (world, rank)
+    n, begin, rows = job_slice(args.log2n, slots, vrank, args.strong)
     l = 1
     N_local = 2 * (k + 1) * rows
     N_total = 2 * (k + 1) * n
@@ -365,7 +388,7 @@ def main():
                                perm_begin=begin)
     objective = ctx.objective_create(_native.OBJ_LINEAR, k, l, np.arange(1, k + 1, dtype=float))
     fbuf = [ctx.alloc(8 * N_local) for _ in range(F_BUFFERS)]
-    nacc = _native.acc_len(k, l, world)
+    nacc = _native.acc_len(k, l, slots)
     accs = [ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)]
     outs = [ctx.alloc(8 * _native.first_order_len(k, l)) for _ in range(2)]
     counter = [0]
@@ -377,7 +400,7 @@ def main():
         ctx.stream_wait_event(1, 2 + b)
         ctx.stream_select(1)
         comm.allreduce(accs[b], nacc)
-        ctx.finish_first_order(accs[b], n, k, l, outs[b], world)
+        ctx.finish_first_order(accs[b], n, k, l, outs[b], slots)
         ctx.event_record(b, 1)
         ctx.stream_select(0)
         return outs[b]
@@ -390,7 +413,7 @@ def main():
         ctx.stream_select(0)
         ctx.eval(design, objective, begin, rows, fbuf[i % F_BUFFERS])
         ctx.stream_wait_event(0, b)             # pass i-2 is done with record b
-        ctx.reduce_first_order(fbuf[(i - 1) % F_BUFFERS], rows, k, l, accs[b], 0, rank, world)
+        ctx.reduce_first_order(fbuf[(i - 1) % F_BUFFERS], rows, k, l, accs[b], 0, vrank, slots)
         return finish_on_aux(b)
 
     def step_single_buffer():
@@ -400,7 +423,7 @@ def main():
         ctx.stream_select(0)
         ctx.eval(design, objective, begin, rows, fbuf[0])
         ctx.stream_wait_event(0, b)
-        ctx.reduce_first_order(fbuf[0], rows, k, l, accs[b], 0, rank, world)
+        ctx.reduce_first_order(fbuf[0], rows, k, l, accs[b], 0, vrank, slots)
         return finish_on_aux(b)
 
     def fused_step():
@@ -409,7 +432,7 @@ def main():
         counter[0] += 1
         ctx.stream_select(0)
         ctx.stream_wait_event(0, b)
-        ctx.eval_reduce_first_order(design, objective, begin, rows, accs[b], rank, world)
+        ctx.eval_reduce_first_order(design, objective, begin, rows, accs[b], vrank, slots)
         return finish_on_aux(b)
 
     def timed(fn, steps, warmup, profile=False, only=None):
@@ -434,7 +457,7 @@ def main():
     # through the all-reduce of the timed steps (RCCL, or the host exchange of a rehearsal) AND, as it was before the
     # exchange, through the rendezvous to be summed on the host in rank order.  `ranks_in_record` is the record's
     # own rank counter (every rank writes 1.0): it must come out as n_gpus.
-    ctx.reduce_first_order(fbuf[F_BUFFERS - 1], rows, k, l, accs[0], 0, rank, world)
+    ctx.reduce_first_order(fbuf[F_BUFFERS - 1], rows, k, l, accs[0], 0, vrank, slots)
     ctx.sync()
     record_before = ctx.download(accs[0], (nacc,))
     comm.allreduce(accs[0], nacc)
@@ -465,10 +488,30 @@ def main():
     if ctx.eval_reduce_supported(design, objective):
         t_fused, recs_fused, fout = timed(fused_step, args.steps, args.warmup, profile=True)
         fres = ctx.download(fout, (2 + 4 * k, l))
-        fused = {"value": N_total / (t_fused / args.steps) / 1e9, "unit": "GSamples/s",
+        fused = {"value": (N_local if rehearse else N_total) / (t_fused / args.steps) / 1e9, "unit": "GSamples/s",
                  "ms_per_step": 1e3 * t_fused / args.steps, "kernel_ms": averages(recs_fused).get("fused"),
                  "max_abs_diff_sens_vs_two_kernel_path": float(np.max(np.abs(
                      fres[2 + 2 * k:2 + 3 * k] - result[2 + 2 * k:2 + 3 * k])))}
+    if rehearse:
+        # One rank of an N-GPU job, alone on its GPU: what that rank's step costs apart from the exchange (a 1 KB
+        # all-reduce on the auxiliary stream beside the next evaluation).  The global design is N times as long, so
+        # every Halton column carries the digits of its largest index (vs_base.ndig) and M_2's shuffled rows come from
+        # the whole second half: the evaluation's arithmetic grows with N although the rows per GPU do not.
+        print(json.dumps({
+            "rehearsal": {"rank": vrank, "of": slots, "scaling": "strong" if args.strong else "weak",
+                          "n_global": n, "first_row": begin, "rows": rows,
+                          "note": "one process, one GPU: design of the global n, this rank's rows and shuffle slice, "
+                                  "%d variance slots, no exchange" % slots},
+            "metric": "step of one rank: evaluate batch i, reduce batch i-1 (k=%d, 2^%d rows per GPU)" % (k, args.log2n),
+            "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps, "warmup": args.warmup,
+            "gsamples_per_s_this_rank": N_local / (elapsed / args.steps) / 1e9,
+            "stages_ms": avg, "ms_per_step_all_bracketed": 1e3 * elapsed_all / args.steps,
+            "fused_path": fused, "single_buffer_ms_per_step": 1e3 * t_single / args.steps,
+            "dtype": "f64", "data": "synthetic"}), flush=True)
+        comm.close()
+        ctx.close()
+        group.close()
+        return
     # second order (sens_2 / sens_2n Gram sums on the fp64 matrix cores), on its own: a few launches
     gram = ctx.alloc(8 * _native.gram_len(k))
     so_steps = max(3, min(args.steps, 20))
@@ -476,7 +519,7 @@ def main():
     avg_so = averages(recs_so)
     # both orders in one call (what Varsens(...) runs by default after the evaluation): one pass over the f-values
     acc_bo = ctx.alloc(8 * nacc)
-    t_bo, recs_bo, _ = timed(lambda: ctx.reduce_first_second_order(fbuf[0], rows, k, l, acc_bo, gram, 0, rank, world),
+    t_bo, recs_bo, _ = timed(lambda: ctx.reduce_first_second_order(fbuf[0], rows, k, l, acc_bo, gram, 0, vrank, slots),
                              so_steps, 2, profile=True)
     avg_bo = averages(recs_bo)
 
@@ -490,16 +533,16 @@ def main():
         counter[0] += 1
         ctx.stream_select(0)
         ctx.eval(design, objective, begin, rows, fbuf[i % F_BUFFERS])
-        ctx.reduce_first_second_order(fbuf[(i - 1) % F_BUFFERS], rows, k, l, acc_bo, gram, 0, rank, world)
-        ctx.finish_first_order(acc_bo, n, k, l, first_bo, world)
+        ctx.reduce_first_second_order(fbuf[(i - 1) % F_BUFFERS], rows, k, l, acc_bo, gram, 0, vrank, slots)
+        ctx.finish_first_order(acc_bo, n, k, l, first_bo, slots)
         ctx.finish_second_order(gram, first_bo, n, k, l, s2, s2n)
         return first_bo
 
     def api_fused_step():
         """k <= 32, one output, built-in separable objective: evaluation and both reductions in ONE kernel"""
         ctx.stream_select(0)
-        ctx.eval_reduce_first_second_order(design, objective, begin, rows, acc_bo, gram, rank, world)
-        ctx.finish_first_order(acc_bo, n, k, l, first_bo, world)
+        ctx.eval_reduce_first_second_order(design, objective, begin, rows, acc_bo, gram, vrank, slots)
+        ctx.finish_first_order(acc_bo, n, k, l, first_bo, slots)
         ctx.finish_second_order(gram, first_bo, n, k, l, s2, s2n)
         return first_bo
 

@@ -117,6 +117,24 @@ def test_seed1_permutation_matches_reference(golden):
     assert np.array_equal(np.random.get_state()[1], state), "the global numpy RNG must be left alone"
 
 
+def test_opt_in_numpy_reseed_reproduces_the_references_side_effect():
+    """varsens/saltelli.py:100-101 reseeds numpy's GLOBAL generator and shuffles the (n, k) array M_2 with it; code
+    that draws from numpy.random afterwards sees a definite stream.  Sample(..., reseed_numpy=True) /
+    VARSENS_RESEED_NUMPY=1 leave the generator in exactly that state (the default leaves it alone)."""
+    from varsens_amd.saltelli import reseed_numpy_like_the_reference
+    saved = np.random.get_state()
+    try:
+        for n, k in ((1, 3), (2, 1), (13, 5), (1024, 6), (5000, 2)):
+            np.random.seed(1)                       # what the reference does ...
+            np.random.shuffle(np.zeros((n, k)))
+            want = np.random.random(4)              # ... and what its caller then draws
+            np.random.seed(12345)
+            reseed_numpy_like_the_reference(n)
+            assert np.array_equal(np.random.random(4), want), (n, k)
+    finally:
+        np.random.set_state(saved)
+
+
 def test_native_permutation_is_numpys_legacy_shuffle(native):
     """vs_seed1_permutation (C restatement of MT19937 + legacy shuffle) == numpy RandomState(1).shuffle."""
     import time

@@ -69,3 +69,47 @@ def test_failed_rank_gives_no_result_line_and_the_worst_status(tmp_path):
     assert p.returncode == 3
     assert p.stdout.strip() == "", "a failed run must not put a result line on stdout"
     assert "[0, 0, 3]" in p.stderr
+
+
+def test_job_slice_is_what_a_rank_and_its_rehearsal_share():
+    """bench.job_slice: the slice arithmetic of a rank of an N-GPU job -- used by the real rank and by its one-GPU
+    rehearsal (`--rehearse-rank r --of N`, tools/rehearse_weak_scaling.py).  Weak scaling: 2^log2n rows per GPU, global
+    n = N * 2^log2n, rank r owns [r 2^log2n, (r+1) 2^log2n); strong: dist.shard_rows of 2^log2n rows in total.  Either
+    way the slices tile [0, n) in rank order, and the shuffle entries a rank uploads are those of its own rows."""
+    import sys as _sys
+    _sys.path.insert(0, ROOT)
+    import bench
+    from varsens_amd import dist
+    from oracle import saltelli_oracle as orc
+    for strong in (False, True):
+        for world in (1, 2, 3, 8):
+            for log2n in (4, 10):
+                at, total = 0, None
+                for rank in range(world):
+                    n, begin, rows = bench.job_slice(log2n, world, rank, strong)
+                    total = n if total is None else total
+                    assert n == total == ((1 << log2n) if strong else world << log2n)
+                    assert begin == at and rows >= 0
+                    if strong:
+                        assert (begin, rows) == dist.shard_rows(n, world, rank)
+                    else:
+                        assert rows == 1 << log2n
+                    at += rows
+                assert at == total
+    # the rehearsal of rank 7 of 8 reads the shuffle entries of rows [7 * 16, 8 * 16) of the 128-row design
+    n, begin, rows = bench.job_slice(4, 8, 7, False)
+    assert (n, begin, rows) == (128, 112, 16)
+    perm = orc.seed1_permutation(n)
+    assert sorted(perm) == list(range(n)) and len(perm[begin:begin + rows]) == 16
+    import pytest
+    with pytest.raises(Exception, match="not in"):
+        bench.job_slice(4, 8, 8, False)
+
+
+def test_rehearsal_arguments_are_checked():
+    p = subprocess.run([sys.executable, BENCH, "--rehearse-rank", "8", "--of", "8"], env=clean_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and "0 <= R < N" in p.stderr
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse-rank", "0", "--of", "8"], env=clean_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and "one GPU" in p.stderr

@@ -980,3 +980,46 @@ def test_sobol_large_design_uses_every_byte_table(vs):
     top = int(perm.argmax())                   # the row of M_2 that holds the largest sequence index of all
     assert numpy.array_equal(s._rows(n + top, 1)[0], orc.sobol(k, 4096 + 2 * n - 1, 1, d)[0])
     assert 4096 + 2 * n - 1 >= 1 << 24
+
+
+def test_sobol_file_round_trip_equals_the_in_memory_design(vs, tmp_path):
+    """f3, the buildable part (quantlib/sobolGen.cpp:52-63; consumer varsens/saltelli.py:43-46, 224-227):
+    `examples/sobol_gen.py dimensions samples` writes the CSV the reference's QuantLib tool writes -- 2n points after
+    the 4096 skip, comma separated --, and the file goes through Sample(k, n, scaling, loadFile=..., delimiter=',') ->
+    Objective -> Varsens.  Everything equals the in-memory generator='sobol' run bit for bit.  (The integers are
+    Joe-Kuo, not Levitan-Lemieux: the header of the file says so; value parity with QuantLib stays unpinned.)"""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    k, n = 6, 1024
+    path = tmp_path / "sobol.csv"
+    with open(path, "w") as fh:
+        p = subprocess.run([sys.executable, os.path.join(root, "examples", "sobol_gen.py"), str(k), str(2 * n)],
+                           stdout=fh, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    text = open(path).read().splitlines()
+    assert text[0].startswith("# Sobol points 4096 .. %d" % (4096 + 2 * n - 1)) and "Joe-Kuo" in text[0]
+    rows = [t for t in text if not t.startswith("#")]
+    assert len(rows) == 2 * n and all(len(r.split(",")) == k for r in rows)
+    scaling = vs.scale.Linear([-1.0] * k, [3.0] * k)
+    from_file = vs.Sample(k, n, scaling, verbose=False, loadFile=str(path), delimiter=",")
+    in_memory = vs.Sample(k, n, scaling, verbose=False, generator="sobol")
+    assert numpy.array_equal(from_file.flat(), in_memory.flat())
+    # scipy's unscrambled Sobol sequence: the pin of the device generator (oracle/saltelli_oracle.py)
+    from scipy.stats import qmc
+    eng = qmc.Sobol(d=k, scramble=False, bits=32)
+    eng.fast_forward(4096)
+    unit = eng.random(2 * n)
+    assert numpy.array_equal(from_file.M_1, orc.scale_linear(unit[:n], -1.0, 3.0))
+    obj = vs.objectives.GFunction(model)
+    a = vs.Varsens(vs.Objective(k, n, from_file, obj, verbose=False), verbose=False)
+    b = vs.Varsens(vs.Objective(k, n, in_memory, obj, verbose=False), verbose=False)
+    assert numpy.array_equal(a.objective.flat(), b.objective.flat())
+    for name in ("E_2", "var_y", "U_j", "U_nj", "sens", "sens_t", "sens_2", "sens_2n"):
+        assert numpy.array_equal(getattr(a, name), getattr(b, name)), name
+    # the reference's own formatting (six significant digits, no header) is a file numpy reads just the same
+    p = subprocess.run([sys.executable, os.path.join(root, "examples", "sobol_gen.py"), str(k), "8", "64", "--precision", "6",
+                        "--no-header"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0 and len(p.stdout.splitlines()) == 8
+    numpy.testing.assert_allclose(numpy.loadtxt(p.stdout.splitlines(), delimiter=","), unit[:8], rtol=1e-5, atol=1e-6)

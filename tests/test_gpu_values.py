@@ -225,3 +225,22 @@ def test_context_close_releases_its_designs(vs):
     assert t._design.h
     c.close()
     assert c.handle is None and t._design.h is None
+
+
+def test_sample_can_leave_numpy_seeded_as_the_reference_does(vs):
+    """varsens/saltelli.py:100: numpy.random.seed(1) + the shuffle of M_2 are a visible side effect on numpy's global
+    generator; opt-in here (reseed_numpy=True or VARSENS_RESEED_NUMPY=1), the default leaves the generator alone."""
+    k, n = 4, 500
+    saved = numpy.random.get_state()
+    try:
+        numpy.random.seed(1)
+        numpy.random.shuffle(numpy.zeros((n, k)))
+        want = numpy.random.random(3)
+        numpy.random.seed(777)
+        before = numpy.random.get_state()[1].copy()
+        vs.Sample(k, n, vs.scale.Identity(), verbose=False)
+        assert numpy.array_equal(numpy.random.get_state()[1], before)
+        vs.Sample(k, n, vs.scale.Identity(), verbose=False, reseed_numpy=True)
+        assert numpy.array_equal(numpy.random.random(3), want)
+    finally:
+        numpy.random.set_state(saved)

@@ -69,6 +69,17 @@ def seed1_permutation(n):
     return order
 
 
+def reseed_numpy_like_the_reference(n):
+    """The reference's visible side effect (varsens/saltelli.py:100-101): ``numpy.random.seed(1)`` followed by
+    ``numpy.random.shuffle(M_2)`` leaves numpy's GLOBAL generator in the state "seeded with 1, then n - 1 Fisher-Yates
+    draws".  The engine takes its permutation from its own MT19937 (vs_seed1_permutation) and by default leaves numpy's
+    generator alone; a caller whose later code draws from ``numpy.random`` and must see the reference's numbers asks for
+    this (``Sample(..., reseed_numpy=True)`` or ``VARSENS_RESEED_NUMPY=1``).  The draws depend on the row count only --
+    shuffling n bytes consumes what shuffling the (n, k) array does."""
+    numpy.random.seed(1)
+    numpy.random.shuffle(numpy.empty(int(n), dtype=numpy.uint8))
+
+
 def sobol_directions(k):
     table = numpy.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data",
                                     "sobol_joe_kuo_1024x32.npy"))
@@ -91,7 +102,9 @@ class Sample(object):
 
     Parameters are those of the reference (varsens/saltelli.py:62):
     ``Sample(k, n, scaling=None, discard=0, verbose=True, raw=None, **loadArgs)``
-    plus keyword-only extras: ``generator`` ('halton' default, 'sobol'),
+    plus keyword-only extras: ``generator`` ('halton' default, 'sobol'), ``reseed_numpy`` (default: the environment's
+    ``VARSENS_RESEED_NUMPY`` = 1, else False: leave numpy's global generator as the reference leaves it, seeded with 1
+    and advanced by the shuffle -- see ``reseed_numpy_like_the_reference``),
     ``context`` (a _native.Context), ``shard=(row_begin, row_count)`` (a rank of a multi-GPU job
     evaluates only these draws: only their entries of the seed-1 shuffle are uploaded, and the
     materialising attributes M_1 .. flat() are not available).
@@ -103,6 +116,7 @@ class Sample(object):
 
     def __init__(self, k, n, scaling=None, discard=0, verbose=True, raw=None, **loadArgs):
         generator = loadArgs.pop('generator', 'halton')
+        reseed = loadArgs.pop('reseed_numpy', os.environ.get("VARSENS_RESEED_NUMPY", "0") == "1")
         self._ctx = loadArgs.pop('context', None) or default_context()
         # a rank of a multi-GPU job: only the shuffle entries of its own rows go to its GPU
         self._shard = loadArgs.pop('shard', None)
@@ -138,6 +152,8 @@ class Sample(object):
             self.scaling = _scale.Identity()
 
         if self.verbose: print("Eliminating correlations")
+        if reseed:
+            reseed_numpy_like_the_reference(n)
         # the seed-1 shuffle of M_2 (saltelli.py:100-101): the engine supplies it itself and keeps the device copy per
         # (n, slice) in the context -- a study that calls Varsens(objective, scaling, k, n) once per model uploads the
         # 4 n bytes once (VS_DESIGN_SEED1_SHUFFLE)
