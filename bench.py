@@ -36,27 +36,43 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # data-sheet fp64 matrix rate (the guide lists no fp64 figure); tools/mfma_f64_peak.hip measures 77.6
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04", "bench_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05", "bench_pmc.json")
 F_BUFFERS = 3
 
 
-def pmc_kernel(prefix, k, log2n):
-    """Counters per launch from the committed rocprofv3 PMC passes (collected on this exact workload), or None."""
-    if (k, log2n) != (32, 22) or not os.path.isfile(PMC_SUMMARY):
-        return None
+def pmc_summary(k, log2n):
+    """(kernels, source) -- the per-launch counters of the committed rocprofv3 PMC passes (tools/pmc_run.py, collected
+    on this exact workload by tools/collect_profiles.sh), or (None, why not).  The file is stamped with the build id of
+    the library it was measured on; it prices THIS run's kernels only when that is the id of the library this run
+    loads (vs_build_id(): sha256 prefix over sources and flags, varsens_amd/build.py) -- a stale file never does."""
+    rel = os.path.relpath(PMC_SUMMARY, ROOT)
+    if (k, log2n) != (32, 22):
+        return None, "none: the committed counter passes are of k=32, n=2^22"
+    if not os.path.isfile(PMC_SUMMARY):
+        return None, "none: %s is missing" % rel
     try:
-        for name, c in json.load(open(PMC_SUMMARY))["kernels"].items():
-            if name.startswith(prefix):
-                return c
-    except Exception:
-        return None
+        from varsens_amd import _native
+        summary = json.load(open(PMC_SUMMARY))
+        stamp, mine = summary.get("library_build_id"), _native.build_id()
+        if stamp != mine:
+            return None, ("none: %s was collected on library build %s, this run loads build %s -- re-run "
+                          "tools/collect_profiles.sh" % (rel, stamp, mine))
+        return summary["kernels"], "%s (separate rocprofv3 --pmc passes, tools/pmc_run.py; library build %s = this run's)" % (rel, mine)
+    except Exception as exc:
+        return None, "none: %s unreadable (%s)" % (rel, exc)
+
+
+def pmc_kernel(kernels, prefix):
+    for name, c in (kernels or {}).items():
+        if name.startswith(prefix):
+            return c
     return None
 
 
-def pmc_traffic(prefix, k, log2n):
+def pmc_traffic(kernels, prefix):
     """HBM bytes per launch: FETCH_SIZE doubled per the gfx950 wide-load correction, plus WRITE_SIZE (both KB)
     (tools/pmc_run.py writes per-launch averages under the counters' own names)."""
-    c = pmc_kernel(prefix, k, log2n)
+    c = pmc_kernel(kernels, prefix)
     if not c or "FETCH_SIZE" not in c:
         return None
     return (2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0
@@ -581,7 +597,8 @@ def main():
         achieved = 8.0 * N_local / t_red / 1e9
         t_eval = avg["eval"] * 1e-3
         eval_gbs = 8.0 * N_local / t_eval / 1e9
-        eval_pmc = pmc_kernel("void scan_kernel<3, 8, 4, false", k, args.log2n) or {}   # linear objective, evaluation
+        pmc, pmc_source = pmc_summary(k, args.log2n)
+        eval_pmc = pmc_kernel(pmc, "void scan_kernel<3, 8, 4, false") or {}   # linear objective, evaluation
         # issued MFMA work of the second-order kernels: 16x16 tiles of S S^T and T T^T (S = C + D, T = C - D: two
         # symmetric K x K products); up to 32 index rows per half both live in one 2K-row tile whose
         # S x T tiles are skipped
@@ -639,8 +656,8 @@ def main():
             "roofline": {"kernel": "reduce_first_kernel (sens/sens_t streaming reduction)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("void reduce_first_kernel", k, args.log2n),
-                         "traffic_source": "profiles/r04/bench_pmc.json (separate rocprofv3 --pmc passes, tools/pmc_run.py)",
+                         "traffic": pmc_traffic(pmc, "void reduce_first_kernel"),
+                         "traffic_source": pmc_source,
                          "algorithmic_bytes_per_launch": 8 * N_local,
                          "avg_launch_ms": avg["reduce_first"],
                          "input_last_written": "one step earlier (3 rotating buffers): not an Infinity-Cache number"},
@@ -661,8 +678,8 @@ def main():
                           "v_mfma_f64_16x16x4_f64)",
                 "bound": "hbm", "achieved": 16.0 * k * l * rows / (so_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": 16.0 * k * l * rows / (so_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("void gram_diag_wide_kernel", k, args.log2n)
-                           or pmc_traffic("void gram_diag_wave_kernel", k, args.log2n),
+                "traffic": pmc_traffic(pmc, "void gram_diag_wide_kernel")
+                           or pmc_traffic(pmc, "void gram_diag_wave_kernel"),
                 "algorithmic_bytes_per_launch": 16 * k * l * rows,
                 "avg_launch_ms": so_ms, "mfma_tiles_16x16": tiles, "mfma_flops_per_launch": mfma_flops,
                 "mfma_tflops": mfma_flops / (so_ms * 1e-3) / 1e12, "mfma_peak_tflops": FP64_MFMA_PEAK_TFLOPS,

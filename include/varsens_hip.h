@@ -62,6 +62,10 @@ typedef struct vs_objective vs_objective; /* an objective function resident on t
 /* ------------------------------------------------------------------ basics */
 
 int vs_abi_version(void);
+/* Identity of the sources and compiler flags this library was built from (16 hex digits; "unknown" for a build that
+ * did not go through varsens_amd/build.py).  Measurement tooling stamps its counter summaries with it; bench.py quotes
+ * a committed `roofline.traffic` only when the stamp is this library's. */
+const char* vs_build_id(void);
 const char* vs_last_error(void);
 int vs_device_count(int* count);
 

@@ -37,6 +37,15 @@ def test_library_exports_every_declared_symbol(native):
     assert lib.vs_abi_version() == native.ABI_VERSION
 
 
+def test_library_says_what_it_was_built_from(native):
+    """vs_build_id() = varsens_amd.build.source_id(): sha256 prefix over flags + sources.  bench.py quotes the committed
+    counter traffic only when the summary carries this id (tools/pmc_run.py stamps it)."""
+    from varsens_amd import build as b
+    assert re.fullmatch(r"[0-9a-f]{16}", native.build_id())
+    assert native.build_id() == b.source_id()
+    assert b.source_id(extra_cflags=["-DVS_SOMETHING"]) != b.source_id(extra_cflags=[])
+
+
 def test_no_host_fallback(native):
     """Without a GPU the engine refuses to create a context (and says why); with one it works."""
     if native.device_count() == 0:
@@ -189,7 +198,9 @@ def test_bench_cpu_baseline_leg():
     assert so["blas_threads"] >= 1 and so["cores"] == so["blas_threads"] and so["gsamples_per_s"] > 0
     assert so["compute_varsens_with_second_order_s"] >= so["tensordot_leg_s"] >= 0
     assert R["sens_2"].shape == (k, 1, k, 1) and cpu["host_cores_available"] == 8
-    assert bench.pmc_traffic("void reduce_first_kernel", 32, 22) is None or bench.pmc_traffic("void reduce_first_kernel", 32, 22) > 2.2e9
+    kernels, source = bench.pmc_summary(32, 22)    # the committed counter passes, if they are of this build
+    traffic = bench.pmc_traffic(kernels, "void reduce_first_kernel")
+    assert (kernels is None and source.startswith("none:") and traffic is None) or traffic > 2.2e9
 
 
 def test_header_is_plain_c_and_a_c_program_links(native, tmp_path):
@@ -364,7 +375,7 @@ def test_every_entry_point_is_guarded():
             body = [b.strip() for b in lines[j + 1:end] if b.strip()]
             defined[m.group(1)] = "guarded" if body[0] == "VS_GUARD_BEGIN" and body[-1] == "VS_GUARD_END" else "unguarded"
     assert set(defined) == declared, sorted(set(defined) ^ declared)
-    assert sorted(n for n, how in defined.items() if how == "trivial") == ["vs_abi_version", "vs_last_error"]
+    assert sorted(n for n, how in defined.items() if how == "trivial") == ["vs_abi_version", "vs_build_id", "vs_last_error"]
     assert not [n for n, how in defined.items() if how == "unguarded"]
     guard = open(os.path.join(csrc, "vs_guard.h")).read()
     assert "catch (const std::bad_alloc&)" in guard and "VS_ERR_NOMEM" in guard and "catch (...)" in guard

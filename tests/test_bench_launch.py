@@ -113,3 +113,29 @@ def test_rehearsal_arguments_are_checked():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse-rank", "0", "--of", "8"], env=clean_env(),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert p.returncode != 0 and "one GPU" in p.stderr
+
+
+def test_committed_counter_traffic_prices_only_the_library_it_was_measured_on(tmp_path, monkeypatch):
+    """bench.py's `roofline.traffic` comes from the committed PMC passes (profiles/rNN/bench_pmc.json).  The file is
+    stamped with the build id of the library it was collected on (tools/pmc_run.py); a run that loads another build
+    gets `traffic: null` and the reason, never a stale number."""
+    import sys as _sys
+    _sys.path.insert(0, ROOT)
+    import bench
+    from varsens_amd import _native
+    kernels = {"void reduce_first_kernel<2, 4, false>(vs_reduce_args)": {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 24.0}}
+    path = tmp_path / "bench_pmc.json"
+    monkeypatch.setattr(bench, "PMC_SUMMARY", str(path))
+    got, why = bench.pmc_summary(32, 22)
+    assert got is None and "missing" in why
+    path.write_text(json.dumps({"library_build_id": "0123456789abcdef", "kernels": kernels}))
+    got, why = bench.pmc_summary(32, 22)
+    assert got is None and "0123456789abcdef" in why and _native.build_id() in why
+    assert bench.pmc_traffic(got, "void reduce_first_kernel") is None
+    path.write_text(json.dumps({"kernels": kernels}))                       # a summary from before the stamp existed
+    assert bench.pmc_summary(32, 22)[0] is None
+    path.write_text(json.dumps({"library_build_id": _native.build_id(), "kernels": kernels}))
+    got, why = bench.pmc_summary(32, 22)
+    assert got == kernels and _native.build_id() in why
+    assert bench.pmc_traffic(got, "void reduce_first_kernel") == (2 * 1000.0 + 24.0) * 1024.0
+    assert bench.pmc_summary(16, 22)[0] is None                              # counters of another workload

@@ -126,7 +126,9 @@ def main():
              "rocprof_sgpr_count": "rocprofv3's SGPR_Count column", "lds_bytes": "bytes per workgroup",
              "scratch_bytes": "bytes per lane", "FETCH_SIZE, WRITE_SIZE": "KB", "hbm_bytes": "bytes per launch",
              "SQ_*": "per launch, summed over the chip (see the docstring of tools/pmc_run.py)"}
-    json.dump({"command": cmd, "units": units, "env": {k: os.environ[k] for k in ("K", "LOG2N") if k in os.environ},
+    sys.path.insert(0, root)
+    from varsens_amd import build as vs_build   # (pure Python: this process still never touches the GPU)
+    json.dump({"command": cmd, "units": units, "library_build_id": vs_build.source_id(), "env": {k: os.environ[k] for k in ("K", "LOG2N") if k in os.environ},
                "failed_groups": failed, "kernels": pmc}, open(os.path.join(out, name + ".json"), "w"), indent=1)
     shutil.rmtree(work, ignore_errors=True)
     print("pmc_run %s: %d kernels, failed groups: %s" % (name, len(pmc), failed or "none"), flush=True)

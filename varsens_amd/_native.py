@@ -88,6 +88,7 @@ class DesignDesc(C.Structure):
 SIGNATURES = {
     "vs_abi_version": (C.c_int, []),
     "vs_last_error": (C.c_char_p, []),
+    "vs_build_id": (C.c_char_p, []),
     "vs_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "vs_context_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "vs_context_destroy": (C.c_int, [C.c_void_p]),
@@ -189,6 +190,11 @@ def load_library(path=None):
 def _check(rc):
     if rc != 0:
         raise VarsensHipError("%s (status %d)" % (load_library().vs_last_error().decode("utf-8", "replace"), rc))
+
+
+def build_id():
+    """vs_build_id() of the loaded library: what it was built from (varsens_amd.build.source_id)."""
+    return load_library().vs_build_id().decode()
 
 
 def seed1_permutation(n):

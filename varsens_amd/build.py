@@ -31,6 +31,24 @@ def _hipcc():
     raise RuntimeError("hipcc not found; libvarsens_hip.so cannot be built")
 
 
+def source_id(extra_cflags=None):
+    """Identity of what the library is built FROM: sha256 over the compiler flags and every source the build reads
+    (csrc/* but the generated .inc files, include/*.h), first 16 hex digits.  It is compiled into the library
+    (vs_build_id()) and stamped into the counter summaries tools/pmc_run.py writes, so that bench.py can tell whether a
+    committed `roofline.traffic` figure was measured on the kernels it is about to price -- and say `traffic: null`
+    when it was not.  Independent of the compiler's output being reproducible."""
+    import hashlib
+    h = hashlib.sha256()
+    flags = list(FLAGS) + (os.environ.get("VS_EXTRA_CFLAGS", "").split() if extra_cflags is None else list(extra_cflags))
+    h.update(" ".join(flags).encode())
+    files = [f for f in glob.glob(os.path.join(CSRC, "*")) if not f.endswith(".inc")] + \
+        glob.glob(os.path.join(ROOT, "include", "*.h"))
+    for f in sorted(files, key=os.path.basename):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.isfile(OUT):
         return True
@@ -77,11 +95,14 @@ def build(force=False, verbose=True):
         hipcc = _hipcc()
         # VS_EXTRA_CFLAGS: diagnostic builds of the tools/ scripts (e.g. -DVS_SCAN_STAMPS); never set by the product
         cflags = [f for f in FLAGS if f != "-shared"] + os.environ.get("VS_EXTRA_CFLAGS", "").split()
+        build_id = source_id()
 
         def compile_one(src):
             obj = os.path.join(objdir, src.replace(".hip", ".o").replace(".cpp", ".o"))
             if force or _deps_newer(obj):
                 cmd = [hipcc] + cflags + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
+                if src == "vs_host.cpp":    # vs_build_id()
+                    cmd.insert(1, '-DVS_BUILD_ID="%s"' % build_id)
                 if verbose:
                     print(" ".join(cmd), flush=True)
                 subprocess.check_call(cmd)

@@ -29,7 +29,11 @@ int vs_fail(int code, const char* fmt, ...) {
     return code;
 }
 
+#ifndef VS_BUILD_ID
+#define VS_BUILD_ID "unknown"   // set by varsens_amd/build.py: sha256 prefix of the sources and flags (source_id())
+#endif
 extern "C" int vs_abi_version(void) { return VS_ABI_VERSION; }
+extern "C" const char* vs_build_id(void) { return VS_BUILD_ID; }
 extern "C" const char* vs_last_error(void) { return g_err; }
 
 // ---- the seed-1 row shuffle ---------------------------------------------------------------
