@@ -54,14 +54,20 @@ def g_truth(a):
     return 1.0 / (3.0 * (np.asarray(a) + 1.0) ** 2)
 
 
-def profile_row(k, n, b, rng):
+def profile_row(k, n, b, rng, second_order=False):
+    """`second_order`: run the reference's own call -- Varsens(...) always computes sens_2 / sens_2n too
+    (varsens/saltelli.py:612-622, called from varsens/profile/parameters.py:63) -- instead of the first order alone;
+    the error metric is the same (it reads `sens` only), the work is not: at k = 192 every model then goes through the
+    evaluation kernel and the Gram kernels for 192 index rows per half."""
     s = vs.Sample(k, n, vs.scale.Identity(), verbose=False)
     errs = []
     for _ in range(b):
         a = rng.uniform(0.0, 99.0, size=k)
-        v = vs.Varsens(vs.objectives.GFunction(a), sample=s, verbose=False, second_order=False)
+        v = vs.Varsens(vs.objectives.GFunction(a), sample=s, verbose=False, second_order=second_order)
         estimate = v.sens[:, 0] * v.var_y[0]
         errs.append(float(np.sum((g_truth(a) - estimate) ** 2)))
+        if second_order:
+            assert v.sens_2.shape == (k, 1, k, 1) and np.isfinite(v.sens_2).all()
     errs = np.array(errs)
     mu, sd = errs.mean(), errs.std()
     half = 0.0
@@ -78,24 +84,28 @@ def model_error(k, a, sample):
     return float(np.sum((g_truth(a) - estimate) ** 2)), estimate
 
 
-def run_dim(k, b, nmax, seed, out=None):
+def run_dim(k, b, nmax, seed, out=None, second_order=False):
+    import time
     rng = np.random.RandomState(seed)
     pub = published(k)
-    lines = ["# k=%d b=%d seed=%d; device: n, mean, sd, lci, uci, max, median, median/k | published "
-             "(varsens/profile/error-profile-dim%d.csv): mean, sd, max | 1/n^2" % (k, b, seed, k)]
+    lines = ["# k=%d b=%d seed=%d%s; device: n, mean, sd, lci, uci, max, median, median/k | published "
+             "(varsens/profile/error-profile-dim%d.csv): mean, sd, max | 1/n^2 | wall ms per model"
+             % (k, b, seed, " second_order=True (the reference's default call)" if second_order else "", k)]
     n = 5
     while n <= nmax:
-        row = profile_row(k, n, b, rng)
+        t0 = time.perf_counter()
+        row = profile_row(k, n, b, rng, second_order)
+        per_model_ms = 1e3 * (time.perf_counter() - t0) / b
         line = "%d,%.6e,%.6e,%.6e,%.6e,%.6e,%.6e,%.6e" % row
         if n in pub:
             line += " | %.6e,%.6e,%.6e" % (pub[n][0], pub[n][1], pub[n][4])
-        line += " | %.6e" % (1.0 / n ** 2)
+        line += " | %.6e | %.3f" % (1.0 / n ** 2, per_model_ms)
         lines.append(line)
         print(line, flush=True)
         n *= 2
     if out:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "accuracy_profile_k%d_b%d.csv" % (k, b)), "w") as fh:
+        with open(os.path.join(out, "accuracy_profile_k%d_b%d%s.csv" % (k, b, "_second_order" if second_order else "")), "w") as fh:
             fh.write("\n".join(lines) + "\n")
 
 
@@ -106,12 +116,16 @@ def main():
     ap.add_argument("--nmax", type=int, default=20480)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--all", action="store_true", help="the five published dimensionalities 6, 24, 48, 96, 192")
+    ap.add_argument("--dims", default=None, help="comma-separated dimensionalities, e.g. 192")
+    ap.add_argument("--second-order", action="store_true",
+                    help="the reference's default call: sens_2 / sens_2n computed for every model as well")
     ap.add_argument("--out", default=None, help="directory for accuracy_profile_k<k>_b<b>.csv")
     args = ap.parse_args()
-    for k in ((6, 24, 48, 96, 192) if args.all else (args.k,)):
-        print("# k=%d b=%d  columns: n, mean, sd, lci, uci, max, median, median/k | published mean, sd, max | 1/n^2" %
-              (k, args.b))
-        run_dim(k, args.b, args.nmax, args.seed, args.out)
+    dims = [int(x) for x in args.dims.split(",")] if args.dims else ((6, 24, 48, 96, 192) if args.all else (args.k,))
+    for k in dims:
+        print("# k=%d b=%d  columns: n, mean, sd, lci, uci, max, median, median/k | published mean, sd, max | 1/n^2 "
+              "| wall ms per model" % (k, args.b))
+        run_dim(k, args.b, args.nmax, args.seed, args.out, args.second_order)
 
 
 if __name__ == "__main__":

@@ -274,7 +274,7 @@ def test_varsens_takes_the_stream_plan_from_the_largest_shard():
 # reloaded in front of each fetch), each with the most it may have -- so that a regression shows.  Every other kernel of the
 # library -- the north-star reduction, every scan / fused kernel, the Gram kernels of all BASELINE configurations --
 # must have none (DESIGN said "no spills" where the code objects said 11 .. 67).
-SPILL_ALLOWED = {"gram_macro_kernel": 4, "gram_macro_st_kernel": 10}
+SPILL_ALLOWED = {"gram_macro_st_kernel": 10}    # the masked / odd-row fallback of 65 .. 128 index rows
 
 
 def test_hot_kernels_do_not_spill():

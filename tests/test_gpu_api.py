@@ -459,6 +459,58 @@ def test_sharded_run_with_a_host_callable(vs):
     assert part.sample._shard == (10, 10)
 
 
+@pytest.mark.parametrize("second_order", [True, False])
+def test_the_exchange_covers_a_prefix_of_the_result_buffer(vs, second_order):
+    """one device buffer per analysis holds [Gram sums | record | finished results]; `comm.allreduce(buffer,
+    count)` is asked to sum the FIRST `count` doubles only -- the window behind them is where the finishing kernels put
+    their results.  A communicator that honours `count` (here: the host exchange's way -- download count doubles, add a
+    second rank's copy of them, upload count doubles) leaves that window alone, and the analysis of two identical
+    half-jobs equals the one-rank analysis of the doubled sums."""
+    from varsens_amd import _native
+    k, n, l = 6, 512, 1
+    seen = {}
+
+    class TwoIdenticalRanks(object):
+        world, rank = 2, 0
+
+        def __init__(self, ctx):
+            self.ctx = ctx
+
+        def allreduce(self, buf, count):
+            nacc = _native.acc_len(k, l, 2)
+            want = nacc + (_native.gram_len(k * l) if second_order else 0)
+            assert count == want and 8 * count < buf.nbytes        # a prefix, not the whole buffer
+            seen["count"], seen["nbytes"] = count, buf.nbytes
+            self.ctx.sync()
+            tail_before = self.ctx.download(buf, ((buf.nbytes - 8 * count) // 8,), byte_offset=8 * count)
+            mine = self.ctx.download(buf, (count,))
+            other = mine.copy()
+            # the other rank: the same sums, its own variance slot (slot 1) instead of slot 0
+            slots = (_native.gram_len(k * l) if second_order else 0) + _native.ACC_HEADER + l * _native.acc_per_output(k)
+            sl = _native.acc_slot(l)
+            other[slots + sl:slots + 2 * sl] = mine[slots:slots + sl]
+            other[slots:slots + sl] = 0.0
+            self.ctx.upload_into(buf, mine + other)
+            tail_after = self.ctx.download(buf, (len(tail_before),), byte_offset=8 * count)
+            assert numpy.array_equal(tail_before.view(numpy.uint64), tail_after.view(numpy.uint64))
+
+        def max(self, value):
+            return value
+
+    from varsens_amd.saltelli import default_context
+    ctx = default_context()
+    obj = vs.objectives.GFunction(model)
+    half = vs.Varsens(obj, vs.scale.Identity(), k, n, verbose=False, second_order=second_order,
+                      comm=TwoIdenticalRanks(ctx), fused=False)
+    assert seen["count"] > 0
+    one = vs.Varsens(obj, vs.scale.Identity(), k, n, verbose=False, second_order=second_order, fused=False)
+    # twice the sums over the same divisors: U_j doubles, E_2 doubles; var_y pools two identical samples
+    numpy.testing.assert_allclose(half.U_j, 2.0 * one.U_j, rtol=1e-13)
+    numpy.testing.assert_allclose(half.E_2, 2.0 * one.E_2, rtol=1e-13)
+    numpy.testing.assert_allclose(half.var_y, one.var_y * (2 * n - 1) * 2 / (4 * n - 1), rtol=1e-12)
+    assert half.accumulators[2] == 2.0
+
+
 def test_sample_attributes_are_materialised_once(vs, monkeypatch):
     """The reference's idiom is `sample.M_1[i]` inside a loop (varsens/saltelli.py:335-355,
     tests/test_sample.py:44-54): every attribute costs one launch and one download, however often it is read."""

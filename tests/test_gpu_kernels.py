@@ -114,6 +114,28 @@ def test_power_scaling_within_two_ulp_of_numpy(ctx):
     assert ulp.mean() < 0.5
 
 
+def test_power_scaling_overflow_is_inf_like_pow(ctx):
+    """raw points at or above 1 with a ratio near DBL_MAX overflow exp(x ln r); the result must be pow's inf
+    (0 for the underflow), not the NaN of fma(inf, e, inf)."""
+    from varsens_amd import _native
+    k, n = 3, 4
+    lo = np.array([1.0, 2.0, 1e-3])
+    hi = np.array([1.7e308, 1e308, 1e300])
+    raw = np.array([[1.0, 1.5, 30.0], [0.999, 2.0, 1.25], [1.0000000001, 1.0, 0.5], [-1.5, -40.0, 1.0],
+                    [0.0, 0.25, 1.0], [1.0, 1.0, 1.0], [3.0, 0.5, 2.0], [0.5, 0.75, -2.0]])
+    d = make_design(ctx, k, n, _native.SCALE_POWER, lo, hi, raw=raw, perm=False)
+    buf = ctx.alloc(8 * 2 * n * k)
+    ctx.sample_flat(d, 0, 2 * n, buf)
+    got = ctx.download(buf, (2 * n, k))
+    with np.errstate(all="ignore"):
+        want = lo * (hi / lo) ** raw
+    assert not np.isnan(got).any()
+    assert np.array_equal(np.isinf(got), np.isinf(want)) and np.isinf(want).sum() >= 5
+    fin = np.isfinite(want) & (want != 0)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-13)
+    assert np.array_equal(got[want == 0], want[want == 0])
+
+
 # ------------------------------------------------------------------ fused evaluation
 
 def eval_dev(ctx, design, kind, k, l, params, n, begin=0, count=None):

@@ -321,7 +321,9 @@ __device__ __forceinline__ double vs_power_scale(double lower, double ratio, dou
         const double y = p * lhi;
         const double e = fma(p, lhi, -y) + p * llo;
         const double r = exp(y);
-        return lower * fma(r, e, r);
+        // exp overflowed (raw points at or above 1 with a huge ratio): fma(inf, e, inf) is NaN for e <= 0 where
+        // pow(ratio, p) is inf -- the correction only applies to a finite r
+        return lower * (r - r == 0.0 ? fma(r, e, r) : r);
     }
     return lower * pow(ratio, p);
 }

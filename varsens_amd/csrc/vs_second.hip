@@ -654,14 +654,23 @@ __device__ __forceinline__ void gram_macro_body(const vs_gram_args& A, const int
     // of chunks): sample pair p goes into the padding of tile row p (16 of 20 doubles per row are index-row
     // data): a at [16,17], b at [18,19]
     const bool abth = first && tid < (WIDE ? 32 : 16);
-    const double* abp = A.f + (tid >= (WIDE ? 16 : 8) ? rows : 0) + 2 * (WIDE ? tid & 15 : tid & 7);
+    // the a / b address and sample offset are rebuilt at every fetch (by the 16 or 32 threads that stage a and b: part
+    // of wave 0) from an opaque copy of the thread index instead of living in three registers across the MFMA loop:
+    // at the kernel's 128 registers they were the three dwords the allocator sent through scratch
+    auto ab_lane = [&]() {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
     vs_d2 rawab = (vs_d2){0.0, 0.0};
     double pa = 0.0, pb = 0.0;
     auto fetch = [&](uint64_t c) {   // WIDE: c is the first chunk of a pair
         const uint64_t s0 = c * VS2_WCHUNK;
         const bool whole = WIDE ? s0 + 2 * VS2_WCHUNK <= rows : c < nfull;
         if (FIRST && abth) {
-            const uint64_t sm = s0 + 2 * (WIDE ? tid & 15 : tid & 7);
+            const int t = ab_lane();
+            const uint64_t sm = s0 + 2 * (WIDE ? t & 15 : t & 7);
+            const double* abp = A.f + (t >= (WIDE ? 16 : 8) ? rows : 0) + 2 * (WIDE ? t & 15 : t & 7);
             if (whole && ALIGNED) {
                 rawab = __builtin_nontemporal_load((const vs_d2*)(abp + s0));
             } else {
@@ -719,8 +728,9 @@ __device__ __forceinline__ void gram_macro_body(const vs_gram_args& A, const int
             }
         }
         if (FIRST && abth) {
-            if (WIDE) *(vs_d2*)(tiles + b * BUF + (tid & 7) * VS2_WPITCH + 16 + 2 * (tid >> 4)) = rawab;
-            else *(vs_d2*)(tiles + b * BUF + (tid & 7) * VS2_WPITCH + 16 + 2 * (tid >> 3)) = rawab;
+            const int t = ab_lane();   // (as in fetch: the tile address is not kept across the loop either)
+            if (WIDE) *(vs_d2*)(tiles + b * BUF + (t & 7) * VS2_WPITCH + 16 + 2 * (t >> 4)) = rawab;
+            else *(vs_d2*)(tiles + b * BUF + (t & 7) * VS2_WPITCH + 16 + 2 * (t >> 3)) = rawab;
         }
     };
 
@@ -753,6 +763,9 @@ __device__ __forceinline__ void gram_macro_body(const vs_gram_args& A, const int
                 pb = fma(ab[2], fa[h][0], pb);
                 pa = fma(ab[1], fa[h][1], pa);
                 pb = fma(ab[3], fa[h][1], pb);
+                // one a / b quadruple alive at a time, and none beside the B fragments of the tiles below (the kernel
+                // sits at its 128 registers: unpinned, three dwords went through scratch)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -1432,8 +1445,7 @@ gram_convert_kernel(const double* __restrict__ cd, int K, double* __restrict__ g
 // (MASKED, ALIGNED, FIRST, WIDE) instances of the [C; D] macro kernel the launches can pick
 #define VS2_MACRO_INSTANCES(X) \
     X(false, false, false, false) X(false, true, false, false) X(true, false, false, false) X(true, true, false, false) \
-    X(false, false, true, false) X(false, true, true, false) X(false, true, false, true) X(true, true, false, true) \
-    X(false, true, true, true)
+    X(false, false, true, false) X(false, true, true, false) X(false, true, false, true) X(true, true, false, true) X(false, true, true, true)
 // (MASKED, ALIGNED, WIDE) instances of the S/T macro kernel
 #define VS2_ST_INSTANCES(X) \
     X(false, false, false) X(false, true, false) X(false, true, true) X(true, false, false) X(true, true, false) X(true, true, true)

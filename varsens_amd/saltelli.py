@@ -577,6 +577,12 @@ class Varsens(object):
     ``world``, ``rank`` and ``allreduce(buffer, count)`` -- see varsens_amd.dist),
     ``context``.
 
+    The contract of ``comm.allreduce(buffer, count)``: sum the FIRST ``count`` doubles of the device buffer over the
+    ranks, in place, on the context's current stream.  ``count`` is smaller than the buffer: an analysis keeps
+    ``[Gram sums | accumulator record | finished results]`` in one allocation, the exchange covers the first two
+    windows (``_reduce_doubles``) and the finishing kernels write the third afterwards -- a communicator must not touch
+    what lies behind ``count`` (tests/test_gpu_api.py::test_the_exchange_covers_a_prefix_of_the_result_buffer).
+
         >>> import varsens_amd as varsens                                  # doctest: +SKIP
         >>> v = varsens.Varsens(varsens.objectives.GFunction([0, .5, 3, 9, 99, 99]),
         ...                     varsens.scale.Identity(), 6, 1024, verbose=False)  # doctest: +SKIP
