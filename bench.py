@@ -710,9 +710,8 @@ def main():
                     "second-order kernel's operand fragments (k <= 64); the separate passes take reduce_first + second_order"}
         if world == 1 and not args.no_cpu_baseline:
             n_small = min(rows, 1 << 22)   # the whole pass at the default size: 2.2 GB over PCIe, ~2 s of numpy
-            blocks = np.empty((2 * k + 2, n_small, l))
-            for b in range(2 * k + 2):
-                blocks[b] = ctx.download(fbuf[0], (n_small, l), byte_offset=8 * b * rows * l)
+            # (the device turns its row-blocked layout back into the reference's flat order: vs_download_values)
+            blocks = ctx.download_values(fbuf[0], rows, k, l).reshape(2 * k + 2, rows, l)[:, :n_small]
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
             cpu, _ = cpu_baseline(k, blocks, n_small, cores)
             line["cpu_baseline"] = cpu

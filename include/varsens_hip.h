@@ -38,11 +38,14 @@ extern "C" {
  * 6: vs_eval_reduce_first_second_order takes objectives with several outputs; vs_design_desc_validate.
  * 7: vs_design_desc.flags (was `reserved`, 0): VS_DESIGN_SEED1_SHUFFLE.  The field is VALIDATED from here on: a caller
  *    written against ABI <= 6 must have zeroed it (the header said "reserved, 0"); unknown bits are VS_ERR_ARG.
- * 8: vs_upload_values / vs_download_values / vs_sample_rows[_begin/_wait]: objective values and sample rows cross the
- *    host boundary in the reference's layouts, converted on the device; VS_ERR_NOMEM; every entry point runs under a
+ * 8: the f-values on the device are ROW-BLOCKED (see "F-VALUE LAYOUT"; shards of up to 4096 rows: unchanged);
+ *    vs_device_info.f_shift; vs_upload_values / vs_download_values / vs_sample_rows[_begin/_wait]: objective values and
+ *    sample rows cross the host boundary in the reference's layouts, converted on the device; vs_build_id;
+ *    VS_ERR_NOMEM; every entry point runs under a
  *    guard that turns C++ exceptions into status codes; a design is released through the context that made it and
  *    vs_context_destroy refuses (VS_ERR_STATE) while designs of the context are alive. */
 #define VS_ABI_VERSION 8
+#define VS_F_SHIFT 12   /* default log2 of the rows per row block of the f-value layout */
 
 typedef enum vs_status {
     VS_OK = 0,
@@ -77,6 +80,8 @@ typedef struct vs_device_info {
     int32_t lds_bytes_per_cu;
     int32_t clock_mhz;
     uint64_t hbm_bytes;
+    int32_t f_shift;      /* ABI 8: log2 of the rows per row block of this context's f-value layout (VS_F_SHIFT) */
+    int32_t reserved;
 } vs_device_info;
 
 int vs_context_create(int device, vs_context** out);
@@ -279,13 +284,21 @@ enum { VS_FOLD_PRODUCT = 0, VS_FOLD_SUM = 1 };
 int vs_objective_create_separable(vs_context* ctx, int k, const char* term_body, int fold,
                                   const double* params, size_t nparams, vs_objective** out);
 
-/* F-VALUE LAYOUT on the device ("planar"): one plane per output o, each plane the
- * shard's Objective.flat() order (saltelli.py:357-391) for that output:
- *     f_dev[(o*(2k+2) + block)*rows + r],  block order [fM_1, fM_2, fN_j[0..k), fN_nj[0..k)]
- * i.e. the reference's (2(k+1)*rows, l) array transposed to (l, 2(k+1)*rows).  For l = 1 the two
- * coincide.  Every block of every output is one contiguous stream, so all kernels run at the
- * l = 1 speed for any l.  Host code holding reference-order values hands them to vs_upload_values (below), which
- * converts on the device.
+/* F-VALUE LAYOUT on the device: ROW-BLOCKED planes (ABI 8; ABI <= 7 was planar, the special case of one row block).
+ * The 2(k+1) * rows * l values of a shard -- the reference's fM_1, fM_2, fN_j, fN_nj of its rows, Objective.flat()
+ * (saltelli.py:357-391) transposed to one PLANE per (output o, block b), plane p = o (2k+2) + b, block order
+ * [fM_1, fM_2, fN_j[0..k), fN_nj[0..k)] -- are stored row block by row block: rows [R 2^s, (R+1) 2^s) form row block R
+ * (s = VS_F_SHIFT = 12: 4096 rows; vs_device_info.f_shift says what a context uses), and inside a row block the
+ * planes follow each other, each holding the row block's rows contiguously:
+ *     f_dev[(R << s) * P + p * pitch_R + (r - (R << s))],   R = r >> s,  P = l (2k+2),  pitch_R = min(2^s, rows - (R << s))
+ * The last row block is packed at its own row count: exactly P * rows doubles in all.  A shard of at most 2^s rows is one
+ * row block -- plane after plane, f_dev[p * rows + r], the layout of ABI <= 7; for l = 1 that is Objective.flat() itself.
+ * Why: a workgroup that produces or consumes a tile of rows touches every plane of those rows.  Plane-major storage puts
+ * them `rows` doubles apart (k = 128, n = 2^24: 258 streams 128 MiB apart, a TLB entry and a DRAM page each); row-blocked
+ * they lie within P * 32 KiB -- the evaluation of that shape stores at 6.1 instead of 4.1 TB/s.  Every block of every
+ * output is still a set of contiguous runs, so all kernels run at the l = 1 speed for any l.
+ * Host code never needs the formula: vs_upload_values / vs_download_values (below) convert between the reference's
+ * (2(k+1) rows, l) arrays and this layout on the device.
  *
  * vs_eval replaces the four evaluation loops of Objective.__init__ (saltelli.py:329-355)
  * for design rows [row_begin, row_begin+row_count) (a shard of r in [0,n)) and writes

@@ -64,7 +64,12 @@ def spot(ctx, f, k, rows_total, l, rows):
     for b in range(2 * k + 2):
         for i, r in enumerate(rows):
             for o in range(l):
-                out[b, i, o] = ctx.download(f, (1,), byte_offset=8 * ((o * (2 * k + 2) + b) * rows_total + int(r)))[0]
+                # row-blocked f-values (include/varsens_hip.h): row block R of 2^s rows, then plane o (2k+2) + b
+                step = 1 << ctx.f_shift
+                first = (int(r) // step) * step
+                pitch = min(step, rows_total - first)
+                at = first * l * (2 * k + 2) + (o * (2 * k + 2) + b) * pitch + (int(r) - first)
+                out[b, i, o] = ctx.download(f, (1,), byte_offset=8 * at)[0]
     return out
 
 
@@ -121,7 +126,7 @@ def test_config2_against_the_reference_run(ctx, golden, capsys):
         f = device_eval(ctx, k, n, _native.OBJ_G_FUNCTION, a)
     finally:
         ctx.set_eval_order("fast")
-    blocks = _native.from_planar(ctx.download(f, (1, 2 * k + 2, n)))          # [2k+2][n][1], flat order
+    blocks = ctx.download_blocks(f, k, 1, n)          # [2k+2][n][1], flat order
     assert hashlib.sha256(np.ascontiguousarray(blocks.reshape(-1, 1)).tobytes()).hexdigest() == str(g["fvals_sha"])
     assert np.array_equal(blocks[0][:8], g["fM_1_head"]) and np.array_equal(blocks[2:2 + k, :4], g["fN_j_head"])
     rec, fin = first_order(ctx, f, n, n, k)
@@ -157,7 +162,7 @@ def test_config2_against_the_reference_run(ctx, golden, capsys):
     np.testing.assert_allclose(ctx.download(s2n, (k, 1, k, 1)), g["sens_2n"], rtol=1e-9, atol=1e-12)
     # the default (fast) evaluation order: f-values within 1 ulp-level of the reference's, same indices
     f2 = device_eval(ctx, k, n, _native.OBJ_G_FUNCTION, a)
-    fast = _native.from_planar(ctx.download(f2, (1, 2 * k + 2, n)))
+    fast = ctx.download_blocks(f2, k, 1, n)
     assert np.max(np.abs(fast - blocks) / np.abs(blocks)) <= 1e-15
     rec2, fin2 = first_order(ctx, f2, n, n, k)
     np.testing.assert_allclose(fin2[:2 + 2 * k], fin[:2 + 2 * k], rtol=1e-13)
@@ -258,8 +263,8 @@ def test_reduction_power_of_two_scaling_is_exact(ctx):
     rng = np.random.RandomState(8)
     k, rows = 16, 1 << 18
     blocks = rng.randn(2 * k + 2, rows, 1)
-    r1, f1 = first_order(ctx, ctx.upload(_native.to_planar(blocks)), rows, rows, k)
-    r2, f2 = first_order(ctx, ctx.upload(_native.to_planar(2.0 * blocks)), rows, rows, k)
+    r1, f1 = first_order(ctx, ctx.upload_blocks(blocks), rows, rows, k)
+    r2, f2 = first_order(ctx, ctx.upload_blocks(2.0 * blocks), rows, rows, k)
     per = _native.acc_per_output(k)
     body1, body2 = r1[4:4 + per], r2[4:4 + per]
     assert np.array_equal(body2[0], 4.0 * body1[0]) and np.array_equal(body2[3:], 4.0 * body1[3:])

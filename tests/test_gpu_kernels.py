@@ -143,8 +143,7 @@ def eval_dev(ctx, design, kind, k, l, params, n, begin=0, count=None):
     obj = ctx.objective_create(kind, k, l, params)
     f = ctx.alloc(8 * 2 * (k + 1) * count * l)
     ctx.eval(design, obj, begin, count, f)
-    from varsens_amd._native import from_planar
-    return f, from_planar(ctx.download(f, (l, 2 * k + 2, count)))
+    return f, ctx.download_blocks(f, k, l, count)
 
 
 def oracle_blocks(F):
@@ -377,7 +376,7 @@ def reduce_dev(ctx, blocks, n, flags=0, rank=0, world=1):
     from varsens_amd import _native
     nb, rows, l = blocks.shape
     k = (nb - 2) // 2
-    f = ctx.upload(_native.to_planar(blocks))
+    f = ctx.upload_blocks(blocks)
     acc = ctx.alloc(8 * _native.acc_len(k, l, world))
     ctx.reduce_first_order(f, rows, k, l, acc, flags, rank, world)
     out = ctx.alloc(8 * _native.first_order_len(k, l))
@@ -507,7 +506,7 @@ def test_reduce_shards_merge_like_one_pass(ctx):
     world = 2
     recs = []
     for rank, (b, e) in enumerate([(0, 4000), (4000, rows)]):
-        f = ctx.upload(_native.to_planar(blocks[:, b:e]))
+        f = ctx.upload_blocks(blocks[:, b:e])
         acc = ctx.alloc(8 * _native.acc_len(k, l, world))
         ctx.reduce_first_order(f, e - b, k, l, acc, 0, rank, world)
         recs.append(ctx.download(acc, (_native.acc_len(k, l, world),)))
@@ -552,8 +551,7 @@ def test_rccl_single_rank_allreduce(ctx):
 def test_second_order_gram(ctx, k, rows, l):
     rng = np.random.RandomState(k * 7 + rows + l)
     blocks = 1.0 + rng.randn(2 * k + 2, rows, l)
-    from varsens_amd._native import to_planar
-    f = ctx.upload(to_planar(blocks))
+    f = ctx.upload_blocks(blocks)
     K = k * l
     gram = ctx.alloc(8 * 2 * K * K)
     ctx.reduce_second_order(f, rows, k, l, gram)
@@ -589,7 +587,7 @@ def test_first_and_second_order_in_one_pass(ctx, k, rows, l):
     from varsens_amd import _native
     rng = np.random.RandomState(k * 13 + rows + l)
     blocks = 3.0 + rng.randn(2 * k + 2, rows, l)
-    f = ctx.upload(_native.to_planar(blocks))
+    f = ctx.upload_blocks(blocks)
     K = k * l
     nacc = _native.acc_len(k, l, 1)
     acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
@@ -616,12 +614,11 @@ def test_wide_staging_agrees_with_the_chunk_kernels(ctx, k, rows, monkeypatch):
     from varsens_amd import _native
     rng = np.random.RandomState(k + rows)
     blocks = 2.0 + rng.randn(2 * k + 2, rows, 1)
-    host = _native.to_planar(blocks)
     nacc = _native.acc_len(k, 1, 1)
     narrow = tuned_context(monkeypatch, VS_GRAM_WIDE=0)
     out = []
     for c in (ctx, narrow):
-        f = c.upload(host)
+        f = c.upload_blocks(blocks)
         acc, g1, g2 = c.alloc(8 * nacc), c.alloc(8 * 2 * k * k), c.alloc(8 * 2 * k * k)
         c.reduce_second_order(f, rows, k, 1, g1)
         c.reduce_first_second_order(f, rows, k, 1, acc, g2)
@@ -642,7 +639,7 @@ def test_one_pass_with_nan_trim_takes_the_separate_kernels(ctx):
     blocks = 1.0 + rng.rand(2 * k + 2, rows, 1)
     blocks[3, 17, 0] = np.nan
     blocks[0, 900, 0] = np.nan
-    f = ctx.upload(_native.to_planar(blocks))
+    f = ctx.upload_blocks(blocks)
     nacc = _native.acc_len(k, 1, 1)
     acc1, acc2 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
     g1, g2 = ctx.alloc(8 * 2 * k * k), ctx.alloc(8 * 2 * k * k)
@@ -664,7 +661,7 @@ def test_second_order_nan_trim(ctx, k, rows):
     blocks = 1.0 + rng.rand(2 * k + 2, rows, 1)
     bad = rng.choice(rows, 11, replace=False)
     blocks[rng.randint(0, 2 * k + 2, 11), bad, 0] = np.nan
-    f = ctx.upload(_native.to_planar(blocks))
+    f = ctx.upload_blocks(blocks)
     gram = ctx.alloc(8 * 2 * k * k)
     ctx.reduce_second_order(f, rows, k, 1, gram, flags=_native.REDUCE_NAN_TRIM)
     G = ctx.download(gram, (2, k, k))
@@ -686,7 +683,7 @@ def test_second_order_nan_only_in_fM(ctx, block, k, rows, l):
     blocks = 1.0 + rng.rand(2 * k + 2, rows, l)
     r_bad = rows // 3
     blocks[block, r_bad, 0] = np.nan
-    f = ctx.upload(_native.to_planar(blocks))
+    f = ctx.upload_blocks(blocks)
     K = k * l
     gram = ctx.alloc(8 * 2 * K * K)
     ctx.reduce_second_order(f, rows, k, l, gram, flags=_native.REDUCE_NAN_TRIM)
@@ -716,7 +713,7 @@ def test_two_stream_pipeline_matches_serial(ctx):
     k, rows = 8, 40000
     data = [1.0 + rng.rand(2 * k + 2, rows, 1) for _ in range(4)]
     serial = [reduce_dev(ctx, d, rows)[1] for d in data]
-    bufs = [ctx.upload(_native.to_planar(d)) for d in data]
+    bufs = [ctx.upload_blocks(d) for d in data]
     accs = [ctx.alloc(8 * _native.acc_len(k, 1, 1)) for _ in range(2)]
     outs = [ctx.alloc(8 * _native.first_order_len(k, 1)) for _ in range(4)]
     for i, f in enumerate(bufs):
@@ -856,7 +853,7 @@ def test_fused_both_orders_matches_two_kernel_path(ctx, kind, k, n, mode):
     np.testing.assert_allclose(G2, G1, rtol=1e-12, atol=1e-13 * scale)
     assert np.array_equal(G2[0], G2[0].T) and np.array_equal(G2[1], G2[1].T)
     # and straight against the f-values: S S^T, T T^T in numpy
-    F = ctx.download(f, (2 * k + 2, n))
+    F = ctx.download_blocks(f, k, 1, n)[:, :, 0]
     S, T = F[2:2 + k] + F[2 + k:], F[2:2 + k] - F[2 + k:]
     np.testing.assert_allclose(G2[0], S @ S.T, rtol=1e-12, atol=1e-12 * scale)
     np.testing.assert_allclose(G2[1], T @ T.T, rtol=1e-12, atol=1e-12 * scale)
@@ -884,7 +881,7 @@ def test_fused_both_orders_ishigami(ctx, n):
     np.testing.assert_allclose(r2[4:4 + per], r1[4:4 + per], rtol=1e-12, atol=1e-12 * np.abs(r1[4:4 + per]).max())
     np.testing.assert_allclose(G2, G1, rtol=1e-12, atol=1e-12 * np.abs(G1).max())
     assert np.array_equal(G2[0], G2[0].T) and np.array_equal(G2[1], G2[1].T)
-    F = ctx.download(f, (8, n))
+    F = ctx.download_blocks(f, 3, 1, n)[:, :, 0]
     S, T = F[2:5] + F[5:8], F[2:5] - F[5:8]
     np.testing.assert_allclose(G2[0], S @ S.T, rtol=1e-12, atol=1e-12 * np.abs(G1).max())
     np.testing.assert_allclose(G2[1], T @ T.T, rtol=1e-12, atol=1e-12 * np.abs(G1).max())
@@ -975,7 +972,7 @@ def test_reduce_very_wide_k(ctx):
     from varsens_amd import _native
     k2, rows2 = 200, 150
     b2 = rng.randn(2 * k2 + 2, rows2, 1)
-    f = ctx.upload(_native.to_planar(b2))
+    f = ctx.upload_blocks(b2)
     gram = ctx.alloc(8 * 2 * k2 * k2)
     ctx.reduce_second_order(f, rows2, k2, 1, gram)
     G = ctx.download(gram, (2, k2, k2))

@@ -41,7 +41,7 @@ def test_reduction_any_shape(k, rows, l, seed, offset):
     c = ctx()
     rng = np.random.RandomState(seed)
     blocks = offset + rng.randn(2 * k + 2, rows, l)
-    f = c.upload(_native.to_planar(blocks))
+    f = c.upload_blocks(blocks)
     nacc = _native.acc_len(k, l, 1)
     acc = c.alloc(8 * nacc)
     c.reduce_first_order(f, rows, k, l, acc)
@@ -91,7 +91,7 @@ def test_both_orders_any_shape(k, rows, seed, trim):
         blocks[rng.randint(0, 2 * k + 2, 3), bad, 0] = np.nan
         keep[bad] = False
         flags = _native.REDUCE_NAN_TRIM
-    f = c.upload(_native.to_planar(blocks))
+    f = c.upload_blocks(blocks)
     nacc = _native.acc_len(k, 1, 1)
     acc1, acc2 = c.alloc(8 * nacc), c.alloc(8 * nacc)
     g1, g2 = c.alloc(8 * 2 * k * k), c.alloc(8 * 2 * k * k)
@@ -151,7 +151,7 @@ def test_evaluation_any_shape(k, n, kind, l, discard, begin_frac, mode, sobol_fi
     obj = c.objective_create(code, k, lo_, params)
     f = c.alloc(8 * 2 * (k + 1) * count * lo_)
     c.eval(d, obj, begin, count, f)
-    got = _native.from_planar(c.download(f, (lo_, 2 * k + 2, count)))
+    got = c.download_blocks(f, k, lo_, count)
     assert np.array_equal(got, want[:, begin:begin + count])
     f.free(); obj.free(); d.free()
 

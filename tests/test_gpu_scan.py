@@ -71,12 +71,11 @@ def design(ctx, k, n, mode=0, lo=None, hi=None, raw=None, generator=None, dirs=N
 
 
 def device_blocks(ctx, d, kind, k, l, P, n, begin=0, count=None):
-    from varsens_amd._native import from_planar
     count = n if count is None else count
     obj = ctx.objective_create(KINDS[kind], k, l, P)
     f = ctx.alloc(8 * 2 * (k + 1) * count * l)
     ctx.eval(d, obj, begin, count, f)
-    return f, obj, from_planar(ctx.download(f, (l, 2 * k + 2, count)))
+    return f, obj, ctx.download_blocks(f, k, l, count)
 
 
 def blocks_of(F):

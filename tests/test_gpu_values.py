@@ -34,10 +34,12 @@ def _values(k, n, l, seed, nans=()):
     return v
 
 
-def _planar(vals, k, n, l, begin, rows):
-    """what the device buffer must hold: [l][2k+2][rows] of the shard (include/varsens_hip.h), by numpy"""
+def _device(ctx, vals, k, n, l, begin, rows):
+    """what the device buffer must hold: the shard's values in the row-blocked layout (include/varsens_hip.h), laid out
+    by numpy on the host"""
+    from varsens_amd import _native
     blocks = vals.reshape(2 * k + 2, n, l)[:, begin:begin + rows]
-    return numpy.ascontiguousarray(blocks.transpose(2, 0, 1))
+    return _native.to_device_layout(blocks, ctx.f_shift)
 
 
 # (k, n, l, shard): one output (the copy engine writes the destination), a few, more than a tile of 32, row counts off
@@ -54,8 +56,8 @@ def test_upload_values_lays_out_what_numpy_would(vs, ctx, k, n, l, shard):
     f = ctx.alloc(8 * 2 * (k + 1) * rows * l)
     lost = ctx.upload_values(vals, n, k, begin, rows, f)
     assert lost == 0
-    got = ctx.download(f, (l, 2 * k + 2, rows))
-    assert numpy.array_equal(_bits(got), _bits(_planar(vals, k, n, l, begin, rows)))
+    got = ctx.download(f, (l * (2 * k + 2) * rows,))
+    assert numpy.array_equal(_bits(got), _bits(_device(ctx, vals, k, n, l, begin, rows)))
     # and back: Objective.flat() of the shard, the reference's order
     back = ctx.download_values(f, rows, k, l)
     want = vals.reshape(2 * k + 2, n, l)[:, begin:begin + rows].reshape(-1, l)
@@ -71,8 +73,8 @@ def test_upload_values_divides_like_numpy(vs, ctx, l, divide):
     vals = _values(k, n, l, seed=l)
     f = ctx.alloc(8 * 2 * (k + 1) * n * l)
     ctx.upload_values(vals, n, k, 0, n, f, divide)
-    got = ctx.download(f, (l, 2 * k + 2, n))
-    assert numpy.array_equal(_bits(got), _bits(_planar(vals / divide, k, n, l, 0, n)))
+    got = ctx.download(f, (l * (2 * k + 2) * n,))
+    assert numpy.array_equal(_bits(got), _bits(_device(ctx, vals / divide, k, n, l, 0, n)))
     f.free()
 
 

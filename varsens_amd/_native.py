@@ -53,14 +53,35 @@ def first_order_len(k, l):
     return (2 + 4 * k) * l
 
 
-def to_planar(blocks):
-    """[2k+2][rows][l] (the reference's flat order, reshaped) -> the device layout [l][2k+2][rows]."""
-    return np.ascontiguousarray(np.asarray(blocks, dtype=np.float64).transpose(2, 0, 1))
+F_SHIFT = 12     # default log2 of the rows per row block of the f-value layout (VS_F_SHIFT, include/varsens_hip.h)
 
 
-def from_planar(planes):
-    """Device layout [l][2k+2][rows] -> [2k+2][rows][l]."""
-    return np.ascontiguousarray(np.asarray(planes).transpose(1, 2, 0))
+def to_device_layout(blocks, f_shift=F_SHIFT):
+    """[2k+2][rows][l] (the reference's flat order, reshaped) -> the device's row-blocked f-values as one flat array
+    (include/varsens_hip.h, "F-VALUE LAYOUT"): row blocks of 2^f_shift rows; inside a row block plane after plane, plane
+    p = output * (2k+2) + block.  numpy on the host: the independent statement of the layout the tests hold the device's
+    own conversion kernels (vs_upload_values / vs_download_values) and every reading kernel against."""
+    b = np.asarray(blocks, dtype=np.float64)
+    nb, rows, l = b.shape
+    planes = np.ascontiguousarray(b.transpose(2, 0, 1)).reshape(l * nb, rows)
+    step = 1 << f_shift
+    if rows <= step:
+        return planes.reshape(-1)
+    return np.concatenate([planes[:, r0:r0 + step].reshape(-1) for r0 in range(0, rows, step)])
+
+
+def from_device_layout(flat, k, l, rows, f_shift=F_SHIFT):
+    """The inverse: the device's flat f-values -> [2k+2][rows][l]."""
+    flat = np.asarray(flat).reshape(-1)
+    nb = 2 * k + 2
+    step = 1 << f_shift
+    planes = np.empty((l * nb, rows), dtype=flat.dtype)
+    at = 0
+    for r0 in range(0, rows, step):
+        w = min(step, rows - r0)
+        planes[:, r0:r0 + w] = flat[at:at + l * nb * w].reshape(l * nb, w)
+        at += l * nb * w
+    return np.ascontiguousarray(planes.reshape(l, nb, rows).transpose(1, 2, 0))
 
 
 class VarsensHipError(RuntimeError):
@@ -70,7 +91,7 @@ class VarsensHipError(RuntimeError):
 class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64), ("compute_units", C.c_int32),
                 ("wavefront_size", C.c_int32), ("lds_bytes_per_cu", C.c_int32), ("clock_mhz", C.c_int32),
-                ("hbm_bytes", C.c_uint64)]
+                ("hbm_bytes", C.c_uint64), ("f_shift", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ProfileRecord(C.Structure):
@@ -295,7 +316,7 @@ class Context(object):
         _check(self.lib.vs_context_info(self.handle, C.byref(d)))
         return dict(name=d.name.decode(), arch=d.arch.decode(), compute_units=d.compute_units,
                     wavefront_size=d.wavefront_size, lds_bytes_per_cu=d.lds_bytes_per_cu,
-                    clock_mhz=d.clock_mhz, hbm_bytes=d.hbm_bytes)
+                    clock_mhz=d.clock_mhz, hbm_bytes=d.hbm_bytes, f_shift=d.f_shift)
 
     def sync(self):
         _check(self.lib.vs_sync(self.handle))
@@ -355,6 +376,22 @@ class Context(object):
             raise VarsensHipError("download exceeds the device buffer")
         _check(self.lib.vs_download(self.handle, out.ctypes.data_as(C.c_void_p), buf.at(byte_offset), out.nbytes))
         return out
+
+    @property
+    def f_shift(self):
+        """log2 of the rows per row block of this context's f-value layout"""
+        if getattr(self, "_f_shift", None) is None:
+            self._f_shift = int(self.info()["f_shift"])
+        return self._f_shift
+
+    def upload_blocks(self, blocks):
+        """[2k+2][rows][l] host values -> a device buffer in the device layout, laid out by numpy on the host (test and
+        tool helper: the product path is upload_values, which converts on the device)."""
+        return self.upload(to_device_layout(blocks, self.f_shift))
+
+    def download_blocks(self, f_buf, k, l, rows):
+        """The device buffer's f-values as [2k+2][rows][l], un-laid by numpy on the host (test and tool helper)."""
+        return from_device_layout(self.download(f_buf, (2 * (k + 1) * rows * l,)), k, l, rows, self.f_shift)
 
     def upload_values(self, values, n, k, row_begin, rows, f_buf, divide=None):
         """Objective.load on the device (vs_upload_values): `values` is the reference's flat (2n(k+1), l) array; rows

@@ -107,6 +107,7 @@ extern "C" int vs_context_create(int device, vs_context** out) {
         t.gram_st = (int)knob("VS_GRAM_ST", t.gram_st, 0, 1);
         t.reduce_both = (int)knob("VS_REDUCE_BOTH", t.reduce_both, 0, 1);
         t.copy_threads = (int)knob("VS_COPY_THREADS", t.copy_threads, 1, 16);
+        t.f_shift = (int)knob("VS_F_SHIFT", t.f_shift, VS_F_SHIFT_MIN, 40);
         t.profile_mask = knob("VS_PROFILE_MASK", t.profile_mask, -1, 0x7fffffffL);
         static bool told = false;
         if (ignored && !told) {
@@ -148,6 +149,7 @@ extern "C" int vs_context_info(vs_context* ctx, vs_device_info* out) {
     out->lds_bytes_per_cu = (int32_t)ctx->prop.maxSharedMemoryPerMultiProcessor;
     out->clock_mhz = ctx->prop.clockRate / 1000;
     out->hbm_bytes = ctx->prop.totalGlobalMem;
+    out->f_shift = ctx->tune.f_shift;
     return VS_OK;
     VS_GUARD_END
 }

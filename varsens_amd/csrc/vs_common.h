@@ -12,6 +12,14 @@
 #include "varsens_hip.h"
 #include "vs_guard.h"
 
+// f-value layout (vs_device_gen.h: vs_f_tile): default and smallest log2 of the rows per row block
+#ifndef VS_F_SHIFT
+#define VS_F_SHIFT 12
+#endif
+#ifndef VS_F_SHIFT_MIN
+#define VS_F_SHIFT_MIN 11
+#endif
+
 struct vs_prof_slot {
     int kernel_id;
     hipEvent_t start, stop;
@@ -35,6 +43,8 @@ struct vs_tuning {
     int reduce_both = 1;         // VS_REDUCE_BOTH=0: never take the combined first+second-order kernel
     int fused_both_wide = 1;     // VS_FUSED_BOTH_WIDE=0: no fused evaluate + both-orders kernel beyond 32 columns; 2 (with
                                  // VS_TUNING=1, tools/fused_multi_sweep.sh): also the several-output shapes measured slower
+    int f_shift = VS_F_SHIFT;    // VS_F_SHIFT: log2 of the rows per row block of the f-value layout (vs_f_tile): 11 .. 40; >= log2(rows)
+                                 // is the planar layout of ABI <= 7 (tests run the kernels at 11 to cross row blocks at small n)
     int copy_threads = 4;        // VS_COPY_THREADS: host threads that feed / drain the pinned ring of vs_values.hip
     long profile_mask = -1;      // VS_PROFILE_MASK: bracket only these kernel ids with events
 };

@@ -345,11 +345,50 @@ __device__ __forceinline__ double vs_m2(const vs_design_dev& D, vs_u64 r, int c)
 }
 
 
+// ---------------------------------------------------------------------------
+// The f-value layout on the device: ROW-BLOCKED (include/varsens_hip.h).  The shard's `rows` draws are cut into row
+// blocks of 2^sh rows (VS_F_SHIFT = 12: 4096); inside a row block the `planes` = l (2k+2) planes -- plane p =
+// output * (2k+2) + block, block order [fM_1, fM_2, fN_j[0..k), fN_nj[0..k)] -- follow each other, each holding the
+// row block's rows contiguously:
+//     f[(R << sh) * planes + p * pitch_R + (r - (R << sh))],   R = r >> sh,   pitch_R = min(2^sh, rows - (R << sh))
+// (the last row block is packed at its own row count, so the array has exactly planes * rows doubles; a shard of up to
+// 2^sh rows is one row block: plane after plane, the planar layout of ABI <= 7).  Why: a workgroup that produces or
+// consumes a tile of rows touches ALL planes of those rows; plane-major (planar) storage puts them `rows` doubles
+// apart -- 258 address streams 128 MiB apart at k = 128, n = 2^24, one TLB entry and one DRAM page each -- where the
+// row-blocked form keeps them within planes * 32 KiB: the k = 128, n = 2^24 evaluation stores at 6.1 instead of
+// 4.1 TB/s (profiles/r05/eval_blocked_layout.txt).  Every kernel works on row tiles that lie inside one row block
+// (tile sizes are powers of two <= 2048 <= 2^sh, tiles aligned to their size): per tile one (base, pitch) pair,
+// wave-uniform, and the address of (plane p, i-th row of the tile) is f + base + p * pitch + i.
+// ---------------------------------------------------------------------------
+#ifndef VS_F_SHIFT
+#define VS_F_SHIFT 12          // default log2 of the rows per row block
+#endif
+#ifndef VS_F_SHIFT_MIN
+#define VS_F_SHIFT_MIN 11      // the widest row tile of any kernel is 2048 rows (reduce_first_kernel)
+#endif
+struct vs_ftile {
+    vs_u64 base;    // doubles from f to (plane 0, row r0)
+    vs_u64 pitch;   // doubles between consecutive planes of one row
+};
+__host__ __device__ __forceinline__ vs_ftile vs_f_tile(vs_u64 rows, vs_u64 planes, int sh, vs_u64 r0) {
+    const vs_u64 first = (r0 >> sh) << sh;            // first row of r0's row block
+    const vs_u64 left = rows - first, full = (vs_u64)1 << sh;
+    vs_ftile t;
+    t.pitch = left < full ? left : full;
+    t.base = first * planes + (r0 - first);
+    return t;
+}
+// one element (plane p, row r): for the kernels that own a row, not a tile
+__host__ __device__ __forceinline__ vs_u64 vs_f_index(vs_u64 rows, vs_u64 planes, int sh, vs_u64 p, vs_u64 r) {
+    const vs_ftile t = vs_f_tile(rows, planes, sh, r);
+    return t.base + p * t.pitch;
+}
+
 struct vs_eval_args {
     vs_design_dev D;
     int kind, l;
     int plain_recip;   // host side only -- G_FUNCTION: every 1 + a has a Markstein-safe reciprocal (else: general column code)
-    int reserved;
+    int f_shift;       // log2 of the rows per row block of the f-value layout (vs_f_tile)
     const double* params;
     vs_u64 row_begin, rows;
     double* f;

@@ -625,7 +625,7 @@ template <int FOLD, int L, int W, bool FUSED, bool TLDS, int NBH = 0, int SLDS =
 __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L], const double (&tb)[TLDS ? 1 : L],
                                                const double* __restrict__ tl, double Ta, double Tb,
                                                double* __restrict__ tot, int q, int lane, double* __restrict__ f,
-                                               vs_u64 rows, int k, bool valid, double shift, vs_scan_acc<L, W>& acc,
+                                               vs_u64 rows /* evaluation: the pitch between the planes at f */, int k, bool valid, double shift, vs_scan_acc<L, W>& acc,
                                                double* __restrict__ gt = nullptr, double* __restrict__ sl = nullptr,
                                                int rmul = 1, int radd = 0, int abrow = 0, double* __restrict__ heads = nullptr) {
     constexpr int T = VS_EVAL_ROWS;
@@ -811,7 +811,11 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     const vs_u64 r = A.row_begin + (valid ? lr : rows - 1);  // clamp: loads stay in range, stores are guarded
     const double ident = FOLD == VS_OBJ_LINEAR ? 0.0 : 1.0;
     const vs_u64 src2 = vs_perm_at(A.D, r);  // row of the un-shuffled second half behind M_2[r]
-    double* f = FUSED ? nullptr : fplane + rb * T;   // wave-uniform: the block's first row in plane 0
+    // wave-uniform: the block's first row in plane 0 of the row-blocked layout (vs_f_tile; a 64-row block lies inside
+    // one row block), and the pitch between the planes of these rows; `fplane` is the start of the f-values
+    const vs_ftile ft = vs_f_tile(rows, (2 * (vs_u64)k + 2) * (vs_u64)A.l, A.f_shift, rb * T);
+    const vs_u64 fpitch = ft.pitch;
+    double* f = FUSED ? nullptr : fplane + ft.base + (MULTI ? 0 : (vs_u64)blockIdx.y * (2 * (vs_u64)k + 2)) * fpitch;
 #ifdef VS_SCAN_STAMPS   // diagnostic build (tools/scan_stamps.py): shader-clock stamps of every 512th block, behind the f-values
     // (all stores at the end: a global store in front of the column loop would keep the design constants out of the
     // scalar cache)
@@ -921,7 +925,7 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
 #ifdef VS_SCAN_STAMPS
         asm("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(stamp1) : "v"(Ta), "v"(Tb));
 #endif
-        vs_scan_finish<FOLD, L, W, FUSED, TLDS, NBH, SLDS>(ta, tb, tl, Ta, Tb, tot, q, lane, f, rows, k, valid, shift, acc,
+        vs_scan_finish<FOLD, L, W, FUSED, TLDS, NBH, SLDS>(ta, tb, tl, Ta, Tb, tot, q, lane, f, fpitch, k, valid, shift, acc,
                                                            gt, sl);
 #ifdef VS_SCAN_STAMPS
         if constexpr (!FUSED) {
@@ -938,7 +942,7 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     } else if constexpr (NBH > 0) {
         vs_scan_gram_outputs<0, Term, FOLD, L, W, NBH, LMAX>(A, params, q, lane, tot, rows, k, lk, valid, ta, tb, shifts, acc, gt);
     } else {
-        const vs_u64 plane = (2 * (vs_u64)k + 2) * rows;
+        const vs_u64 plane = (2 * (vs_u64)k + 2) * fpitch;   // output o's planes of these rows
         for (int o = 0; o < A.l; ++o) {
             int qo = q;
             asm("" : "+s"(qo) : "s"(o));  // as above: keep q-derived addresses inside the loop over outputs
@@ -958,7 +962,7 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
                 Tb = vs_fold<FOLD>(Tb, ub[j]);
             }
             vs_scan_finish<FOLD, L, W, FUSED, false>(ua, ub, tl, Ta, Tb, tot + (o & 1) * (2 * W * T), qo, lane,
-                                                     f + (vs_u64)o * plane, rows, k, valid, shift, acc);
+                                                     f + (vs_u64)o * plane, fpitch, k, valid, shift, acc);
         }
     }
 }
@@ -994,7 +998,7 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index, provably uniform
     const int o = MULTI ? 0 : blockIdx.y;   // MULTI: all outputs inside the block walk
     const double* params = A.params + (size_t)o * k;
-    double* fplane = FUSED ? nullptr : A.f + (vs_u64)o * (2 * (vs_u64)k + 2) * A.rows;
+    double* fplane = FUSED ? nullptr : A.f;   // (vs_scan_block places the 64-row block and the output's planes)
     const double shift = FUSED ? shift_src[(size_t)o * (2 * (size_t)k + 2)] : 0.0;  // f_o(M_1[row]) of a one-row evaluation
     double* tl = lds + vs_scan_lds<L, W, TLDS, SLDS>::totals + (size_t)q * (2 * L * T) + lane;
     double* sl = lds + vs_scan_lds<L, W, TLDS, SLDS>::totals + vs_scan_lds<L, W, TLDS, SLDS>::terms +

@@ -658,12 +658,15 @@ eval_kernel(vs_eval_args A, double* scratch, int tiles) {
     const uint64_t r = A.row_begin + (valid ? lr : rows - 1);  // clamp: loads stay in range, stores are guarded
     double* X1 = lds + lane;                  // X1[c*T]
     double* X2 = lds + (size_t)k * T + lane;  // X2[c*T]
-    // planar f-values: f[((o*(2k+2) + block)*rows + row]; plane/block bases are wave-uniform
-    double* f = A.f + rb * T + lane;
-    const uint64_t plane = (2 * (uint64_t)k + 2) * rows;
+    // row-blocked f-values (vs_f_tile): the 64 rows lie in one row block; plane (o, block) of these rows is
+    // fpitch doubles behind the plane before it; bases are wave-uniform
+    const vs_ftile ft = vs_f_tile(rows, (2 * (uint64_t)k + 2) * (uint64_t)l, A.f_shift, rb * T);
+    const uint64_t fpitch = ft.pitch;
+    double* f = A.f + ft.base + lane;
+    const uint64_t plane = (2 * (uint64_t)k + 2) * fpitch;
 #define VS_OUT(block, o, v)                                               \
     do {                                                                  \
-        if (valid) VS_STORE(f + ((uint64_t)(o) * plane + (uint64_t)(block) * rows), (v)); \
+        if (valid) VS_STORE(f + ((uint64_t)(o) * plane + (uint64_t)(block) * fpitch), (v)); \
     } while (0)
 
     // ---- phase 1: coordinates (for a single-output separable objective: terms)
@@ -937,7 +940,7 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
     A.D = to_dev(design);
     A.kind = obj->kind;
     A.plain_recip = obj->recip_ok ? 1 : 0;
-    A.reserved = 0;
+    A.f_shift = ctx->tune.f_shift;
     A.l = l;
     A.params = obj->params;
     A.row_begin = row_begin;
@@ -1052,7 +1055,7 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     A.D = to_dev(design);
     A.kind = obj->kind;
     A.plain_recip = obj->recip_ok ? 1 : 0;
-    A.reserved = 0;
+    A.f_shift = ctx->tune.f_shift;
     A.l = l;
     A.params = obj->params;
     A.row_begin = row_begin;
@@ -1117,7 +1120,7 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
     A.D = to_dev(design);
     A.kind = obj->kind;
     A.plain_recip = obj->recip_ok ? 1 : 0;
-    A.reserved = 0;
+    A.f_shift = ctx->tune.f_shift;
     A.l = obj->l;
     A.params = obj->params;
     A.row_begin = row_begin;

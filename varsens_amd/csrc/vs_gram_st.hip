@@ -97,15 +97,14 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
     constexpr int PIECES = ST_ROWS / 2, RSTEP = 512 / PIECES;
     static_assert(4 * RSTEP == NROWS, "four row blocks per half");
     const int lrow = tid / PIECES, piece = tid % PIECES;
-    const uint64_t jstep = (uint64_t)RSTEP * rows, dstep = (uint64_t)K * rows;
-    uint64_t poff[ONE ? 1 : 8];   // several outputs: first double of the plane of load j (dead rows: row 0, never loaded)
+    uint32_t poff[ONE ? 1 : 8];   // several outputs: the plane of load j (dead rows: row 0, never loaded)
     if (!ONE) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int u = lrow + RSTEP * (j & 3);
             const int mm = u < K ? u : 0;
             const int jj = mm / A.l, o = mm - jj * A.l;
-            poff[ONE ? 0 : j] = ((uint64_t)o * (2 * (uint64_t)A.k + 2) + (j >= 4 ? 2 + A.k : 2) + (uint64_t)jj) * rows;
+            poff[ONE ? 0 : j] = (uint32_t)(o * (2 * A.k + 2) + (j >= 4 ? 2 + A.k : 2) + jj);
         }
     }
     // LDS write address of the stash: tiles + (piece >> 3) * SUB + lrow * VS2_WPITCH + 2 * (piece & 7) (+ RSTEP j rows:
@@ -157,16 +156,20 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
         asm volatile("" : "+v"(lr));   // not loop-invariant as far as the compiler can tell
         // rows is even and a thread's two sample rows start at an even index: both are inside or both outside
         const bool in_rows = s0 + 2 * piece < rows;
+        // row-blocked f-values (vs_second.h): the stage's 32 / 64 sample rows lie in one row block; fb = plane 0 at the
+        // stage's first row, fp = doubles between the planes of these rows
+        VS2_FTILE(s0);
+        const uint64_t jstep = (uint64_t)RSTEP * fp, dstep = (uint64_t)K * fp;   // one output: planes u -> u + RSTEP, c_u -> d_u
         if (FIRST && abth) {
-            const double* qab = A.f + (lr ? rows : 0) + s0 + 2 * piece;
+            const double* qab = fb + (lr ? fp : 0) + 2 * piece;
             rawab[set] = in_rows ? __builtin_nontemporal_load((const vs_d2*)qab) : (vs_d2){0.0, 0.0};
         }
-        const double* q0 = A.f + (uint64_t)(2 + lr) * rows + 2 * piece + s0;   // c_u, u = lr; plane of c_u is 2 + u, of d_u 2 + K + u
+        const double* q0 = fb + (uint64_t)(2 + lr) * fp + 2 * piece;   // c_u, u = lr; plane of c_u is 2 + u, of d_u 2 + K + u
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int jb = j & 3;
             const bool in = (FULLK || lr + RSTEP * jb < K) && in_rows;   // rows past K are zeros in the tile
-            const double* q = ONE ? q0 + jb * jstep + (j >= 4 ? dstep : 0) : A.f + poff[ONE ? 0 : j] + 2 * piece + s0;
+            const double* q = ONE ? q0 + jb * jstep + (j >= 4 ? dstep : 0) : fb + (uint64_t)poff[ONE ? 0 : j] * fp + 2 * piece;
             raw[set][j] = in ? __builtin_nontemporal_load((const vs_d2*)q) : (vs_d2){0.0, 0.0};
         }
     };

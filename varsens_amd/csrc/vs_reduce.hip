@@ -46,6 +46,7 @@ struct vs_reduce_args {
     double* partials;   // [tile_wgs][l][VS_PLEN(k)]
     const uint8_t* keep;      // MASKED: 1 = row kept
     const uint32_t* counters; // MASKED: early exit + shift row
+    int f_shift;        // log2 of the rows per row block of the f-value layout (vs_f_tile)
 };
 
 template <int VEC>
@@ -102,12 +103,16 @@ reduce_first_kernel(vs_reduce_args A) {
     __syncthreads();
 
     const uint64_t rows = A.rows;
-    constexpr uint64_t estride = 1;  // planar layout: consecutive rows are consecutive doubles
-    const double* fo = A.f + (uint64_t)o * (2 * (uint64_t)k + 2) * rows;  // plane of output o
-    // common shift of the variance sums: a leading-sample mean of fM_1 (un-masked pass), or the first
-    // kept a-value (masked pass: the leading values may hold the NaNs)
+    // row-blocked f-values (vs_f_tile): a tile of this kernel (at most 2048 rows, aligned) lies inside one row block, so
+    // per tile there is ONE wave-uniform (base, pitch); plane (o, block) of the tile's rows starts at
+    // f + base + (o (2k+2) + block) pitch, rows consecutive behind it
+    const uint64_t planes = (uint64_t)l * (2 * (uint64_t)k + 2), oplane = (uint64_t)o * (2 * (uint64_t)k + 2);
+    // common shift of the variance sums: a leading-sample mean of fM_1 (un-masked pass: the first min(rows, 1024) rows
+    // of plane (o, 0) are contiguous in the first row block), or the first kept a-value (masked pass: the leading
+    // values may hold the NaNs)
     const uint64_t shift_row = MASKED ? (uint64_t)A.counters[CNT_FIRST_KEPT] : 0;
-    const double shift = MASKED ? ((shift_row < rows) ? fo[shift_row * estride] : 0.0) : vs_shift_estimate(fo, rows);
+    const double shift = MASKED ? ((shift_row < rows) ? A.f[vs_f_index(rows, planes, A.f_shift, oplane, shift_row)] : 0.0)
+                                : vs_shift_estimate(A.f + vs_f_index(rows, planes, A.f_shift, oplane, 0), rows);
 
     constexpr uint64_t TILE = (uint64_t)VS_WG * NV * VEC;
     const uint64_t ntiles = (rows + TILE - 1) / TILE;
@@ -117,6 +122,9 @@ reduce_first_kernel(vs_reduce_args A) {
     for (uint64_t t = wg; t < ntiles; t += A.tile_wgs) {
         const uint64_t tile = t;
         const uint64_t base = tile * TILE + (uint64_t)tid * VEC;
+        const vs_ftile ft = vs_f_tile(rows, planes, A.f_shift, tile * TILE);
+        const double* fo = A.f + ft.base + oplane * ft.pitch;   // plane (o, 0), first row of the tile
+        const uint64_t fpitch = ft.pitch;
         bool ok[NV];
         double keepf[NV][VEC];
 #pragma unroll
@@ -131,11 +139,10 @@ reduce_first_kernel(vs_reduce_args A) {
             }
         }
         auto load_block = [&](vs_vec<VEC>* dst, uint64_t block) {
-            const double* p = fo + block * rows * estride;
+            const double* p = fo + block * fpitch + (uint64_t)tid * VEC;   // wave-uniform plane base + this thread's rows
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const uint64_t r = base + (uint64_t)v * VS_WG * VEC;
-                if (ok[v]) dst[v].load(p + r * estride);
+                if (ok[v]) dst[v].load(p + (uint64_t)v * VS_WG * VEC);
                 else {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) dst[v].v[e] = 0.0;
@@ -245,16 +252,18 @@ reduce_first_kernel(vs_reduce_args A) {
 // 2k+2 blocks holds a NaN at r in output column 0
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-nan_mask_kernel(const double* __restrict__ f, uint64_t rows, int k, int l, uint8_t* __restrict__ keep,
+nan_mask_kernel(const double* __restrict__ f, uint64_t rows, int k, int l, int f_shift, uint8_t* __restrict__ keep,
                 uint32_t* counters) {
     if (counters[CNT_NANFLAG] == 0) return;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint32_t kept = 0;
     uint32_t first = 0xffffffffu;
+    const uint64_t planes = (uint64_t)l * (2 * (uint64_t)k + 2);
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
         bool bad = false;
+        const vs_ftile ft = vs_f_tile(rows, planes, f_shift, r);   // row r's own (base, pitch): consecutive rows coalesce
         for (int b = 0; b < 2 * k + 2; ++b) {
-            double x = f[(uint64_t)b * rows + r];  // plane of output 0 (saltelli.py:482)
+            double x = f[ft.base + (uint64_t)b * ft.pitch];  // planes of output 0 (saltelli.py:482)
             bad |= (x != x);
         }
         keep[r] = bad ? 0 : 1;
@@ -290,6 +299,7 @@ struct vs_fold_args {
     uint32_t* counters;
     int masked;
     double* seg_sums;   // grid.y > 1: [grid.y][l*plen] sums of the segments of P (two-stage fold)
+    int f_shift;        // f-value layout (vs_f_tile), for the shift values read from f
 };
 
 #define VS_FOLD_THREADS 1024
@@ -411,10 +421,11 @@ fold_first_kernel(vs_fold_args A, double* folded /* [l*plen] scratch */) {
     for (int o = 0; o < l; ++o) {  // every thread walks the outputs: vs_shift_estimate is a wave-wide call
         double mean = 0.0, m2 = 0.0;
         if (kept > 0) {
-            const double* a_block = A.f ? A.f + (uint64_t)o * (2 * (uint64_t)k + 2) * A.rows : nullptr;
+            // plane (o, fM_1) of the row-blocked f-values: its first min(rows, 1024) rows are contiguous (vs_f_tile)
+            const uint64_t planes = (uint64_t)l * (2 * (uint64_t)k + 2), oplane = (uint64_t)o * (2 * (uint64_t)k + 2);
             const double shift = A.shift_values ? A.shift_values[(size_t)o * A.shift_stride]
-                                 : (A.masked ? (shift_row < A.rows ? a_block[shift_row] : 0.0)
-                                             : vs_shift_estimate(a_block, A.rows));
+                                 : (A.masked ? (shift_row < A.rows ? A.f[vs_f_index(A.rows, planes, A.f_shift, oplane, shift_row)] : 0.0)
+                                             : vs_shift_estimate(A.f + vs_f_index(A.rows, planes, A.f_shift, oplane, 0), A.rows));
             const double s1 = ld(o * plen + VS_P_S1), s2 = ld(o * plen + VS_P_S2);
             mean = shift + s1 / cnt;
             m2 = s2 - s1 * (s1 / cnt);
@@ -505,7 +516,9 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     const size_t plen = VS_PLEN(k);
     const size_t width = (size_t)l * plen;
     const bool fast = (rows % 2 == 0) && (((uintptr_t)f_dev & 15) == 0);
-    const int nv = fast ? ctx->tune.reduce_nv : 8;
+    int nv = fast ? ctx->tune.reduce_nv : 8;
+    // a tile (256 threads x nv loads x 1 or 2 rows) must lie inside one row block of the f-value layout
+    while ((uint64_t)VS_WG * nv * (fast ? 2 : 1) > (1ull << ctx->tune.f_shift) && nv > 2) nv >>= 1;
     const uint64_t tile = (uint64_t)VS_WG * nv * (fast ? 2 : 1);
     uint64_t ntiles = (rows + tile - 1) / tile;
     if (ntiles < 1) ntiles = 1;
@@ -531,6 +544,7 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     A.partials = ctx->partials;
     A.keep = nullptr;
     A.counters = ctx->counters;
+    A.f_shift = ctx->tune.f_shift;
     const dim3 grid(tile_wgs * l, jblocks);
     const size_t lds = sizeof(double) * VS_WAVES * (VS_P_HEAD + 4 * (size_t)jchunk);
 
@@ -548,6 +562,7 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
     F.max_ranks = max_ranks;
     F.counters = ctx->counters;
     F.seg_sums = nullptr;   // at most one record per CU: single-stage fold
+    F.f_shift = ctx->tune.f_shift;
     const unsigned fold_blocks = (unsigned)((width + VS_FOLD_COLS - 1) / VS_FOLD_COLS);
 
     for (int pass = 0; pass < 2; ++pass) {
@@ -560,7 +575,7 @@ extern "C" int vs_reduce_first_order(vs_context* ctx, const double* f_dev, uint6
             {
                 vs_launch_scope scope(ctx, VS_KERNEL_NAN_MASK);
                 hipLaunchKernelGGL(nan_mask_kernel, dim3((unsigned)((rows + 255) / 256 < 4096 ? (rows + 255) / 256 : 4096)),
-                                   dim3(256), 0, ctx->stream, f_dev, rows, k, l, ctx->keep, ctx->counters);
+                                   dim3(256), 0, ctx->stream, f_dev, rows, k, l, ctx->tune.f_shift, ctx->keep, ctx->counters);
             }
             VS_HIP(hipGetLastError());
         }
@@ -617,6 +632,7 @@ int vs_fold_partials(vs_context* ctx, uint32_t P, int k, int l, uint64_t rows, c
     F.max_ranks = max_ranks;
     F.counters = ctx->counters;
     F.masked = 0;
+    F.f_shift = ctx->tune.f_shift;
     const uint32_t nseg = vs_fold_segments(P);
     F.seg_sums = nullptr;
     if (nseg > 1) {

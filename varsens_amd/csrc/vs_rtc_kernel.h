@@ -25,8 +25,11 @@ extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_use
     const vs_u64 r = A.row_begin + (valid ? lr : rows - 1);
     double* X1 = lds + lane;
     double* X2 = lds + (size_t)k * T + lane;
-    double* f = A.f + rb * T + lane;              // planar f-values: f[((o*(2k+2) + blk)*rows + row]
-    const vs_u64 plane = (2 * (vs_u64)k + 2) * rows;
+    // row-blocked f-values (vs_f_tile): plane (o, blk) of these 64 rows is fpitch doubles behind the one before it
+    const vs_ftile ft = vs_f_tile(rows, (2 * (vs_u64)k + 2) * (vs_u64)l, A.f_shift, rb * T);
+    const vs_u64 fpitch = ft.pitch;
+    double* f = A.f + ft.base + lane;
+    const vs_u64 plane = (2 * (vs_u64)k + 2) * fpitch;
 
     const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
     const vs_u64 src2 = A.D.n + vs_perm_at(A.D, r);
@@ -56,7 +59,7 @@ extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_use
         vs_user_objective(x, k, A.params, out);
         if (valid)
             for (int o = 0; o < VS_USER_L; ++o)
-                VS_STORE(f + ((vs_u64)o * plane + (vs_u64)blk * rows), out[o]);
+                VS_STORE(f + ((vs_u64)o * plane + (vs_u64)blk * fpitch), out[o]);
     }
     if (!VS_USER_SCRATCH) break;
     __syncthreads();

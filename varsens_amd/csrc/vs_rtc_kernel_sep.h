@@ -81,7 +81,10 @@ extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_use
     const vs_u64 r = A.row_begin + (valid ? lr : rows - 1);
     double* F1 = lds + lane;
     double* F2 = lds + (size_t)k * T + lane;
-    double* f = A.f + (vs_u64)blockIdx.x * T + lane;  // planar f-values, one output
+    // row-blocked f-values (vs_f_tile), one output: plane b of these 64 rows at f + b * fpitch
+    const vs_ftile ft = vs_f_tile(rows, 2 * (vs_u64)k + 2, A.f_shift, (vs_u64)blockIdx.x * T);
+    const vs_u64 fpitch = ft.pitch;
+    double* f = A.f + ft.base + lane;
 
     const bool halton_fast = A.D.generator == VS_GEN_HALTON && A.D.bases[0].ndig != 0;
     const vs_u64 src2 = A.D.n + vs_perm_at(A.D, r);
@@ -140,14 +143,14 @@ extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_use
         for (int m = 0; m < VS_CHAINS; ++m) {
             const int i = i0 + q + VS_EVAL_WAVES * m;
             if (i < k && valid) {
-                VS_STORE(f + (vs_u64)(2 + i) * rows, cj[m]);
-                VS_STORE(f + (vs_u64)(2 + k + i) * rows, dj[m]);
+                VS_STORE(f + (vs_u64)(2 + i) * fpitch, cj[m]);
+                VS_STORE(f + (vs_u64)(2 + k + i) * fpitch, dj[m]);
             }
         }
     }
     if (q == 0 && valid) {
         VS_STORE(f, pa);
-        VS_STORE(f + rows, pb);
+        VS_STORE(f + fpitch, pb);
     }
 }
 #endif  // VS_USER_EVAL_SCAN

@@ -41,8 +41,9 @@ ishigami_eval_kernel(vs_eval_args A) {
     for (uint64_t lr = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lr < A.rows; lr += stride) {
         double v[8];
         ishigami_row(A.D, A.row_begin + lr, pa_, pb_, v);
+        const vs_ftile ft = vs_f_tile(A.rows, 8, A.f_shift, lr);   // row-blocked f-values: the row's own (base, pitch)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) VS_STORE(A.f + (uint64_t)b * A.rows + lr, v[b]);
+        for (int b = 0; b < 8; ++b) VS_STORE(A.f + ft.base + (uint64_t)b * ft.pitch, v[b]);
     }
 }
 

@@ -26,7 +26,17 @@ struct vs_gram_args {
     double* first_partials;  // combined pass only: [slab_wgs][VS_PLEN(k)] first-order records
     const uint8_t* keep;
     const uint32_t* counters;
+    int f_shift;         // log2 of the rows per row block of the f-value layout (vs_f_tile, vs_device_gen.h)
 };
+
+// Row-blocked f-values (vs_f_tile): every fetch of the second-order kernels takes a chunk of 16, 32 or 64 consecutive
+// sample rows starting at a multiple of its size -- inside one row block --, so per fetch there is one wave-uniform
+//   fb = f + base   (plane 0, first sample row of the chunk)    fp = pitch (doubles between the planes of these rows)
+// and what the planar layout addressed as  f + plane * rows + s0 + i  is  fb + plane * fp + i.
+#define VS2_FTILE(s0)                                                                                   \
+    const vs_ftile ft__ = vs_f_tile(rows, (uint64_t)A.l * (2 * (uint64_t)A.k + 2), A.f_shift, (s0));    \
+    const double* const fb = A.f + ft__.base;                                                           \
+    const uint64_t fp = ft__.pitch
 
 // vs_gram_st.hip: the S/T kernel for 33 .. 128 index rows per half (one output, even row count, no mask)
 int vs_gram_st_prepare(vs_context* ctx);

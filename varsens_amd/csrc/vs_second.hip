@@ -49,13 +49,13 @@ __device__ __forceinline__ void pair_from_index(int p, int ntile, int& I, int& J
     J = I + 1 + p;
 }
 
-// address of X[m][r]: index row m < K is C (fN_j), m >= K is D (fN_nj)
-__device__ __forceinline__ const double* x_elem(const vs_gram_args& A, int m, uint64_t r) {
+// plane of X[m] in the f-values: index row m < K is C (fN_j), m >= K is D (fN_nj); plane = output (2k+2) + block
+__device__ __forceinline__ uint32_t x_plane(const vs_gram_args& A, int m) {
     const int K = A.K, l = A.l;
     const int mm = m < K ? m : m - K;
     const int j = mm / l, o = mm - j * l;
-    const uint64_t block = (m < K ? 2 : 2 + A.k) + (uint64_t)j;
-    return A.f + ((uint64_t)o * (2 * (uint64_t)A.k + 2) + block) * A.rows + r;  // planar f-values
+    const uint32_t block = (uint32_t)(m < K ? 2 : 2 + A.k) + (uint32_t)j;
+    return (uint32_t)o * (2u * (uint32_t)A.k + 2u) + block;
 }
 
 // First-order record of a wave-private workgroup (FIRST): the 16 (wave, lane group) pairs each hold a share of
@@ -165,14 +165,14 @@ gram_diag_wave_kernel(vs_gram_args A) {
     // index rows of the tile: s_u = c_u + d_u at row u, t_u = c_u - d_u at row K + u (u < K); rows from 2K on are
     // padding, zeroed once.  A lane loads c and d of the SAME u and sample rows, so s and t form in registers.
     const int lrow = lane >> 3, piece = lane & 7;
-    const double* rp[NJ];    // [2j] = c row, [2j + 1] = d row
+    uint32_t pl[NJ];    // planes of the rows this lane loads: [2j] = c row, [2j + 1] = d row
     bool ok[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int u = 8 * j + lrow;
         ok[j] = u < K;
-        rp[2 * j] = x_elem(A, ok[j] ? u : 0, 0) + 2 * piece;
-        rp[2 * j + 1] = x_elem(A, K + (ok[j] ? u : 0), 0) + 2 * piece;
+        pl[2 * j] = x_plane(A, ok[j] ? u : 0);
+        pl[2 * j + 1] = x_plane(A, K + (ok[j] ? u : 0));
     }
     for (int e = 2 * K * VS2_WPITCH + lane; e < 16 * NB * VS2_WPITCH; e += 64) tile[e] = 0.0;
     double* wr = tile + lrow * VS2_WPITCH + 2 * piece;                       // + 8j rows: s; + K rows more: t
@@ -200,8 +200,6 @@ gram_diag_wave_kernel(vs_gram_args A) {
     const uint64_t W = (uint64_t)gridDim.x * 4;
     // first-order state (FIRST only): planes 0 and 1 of the single output are a and b
     const int fq = lane >> 4;
-    const double* ap = A.f + 2 * fq;
-    const double* bp = ap + rows;
     double shift = 0.0;
     if (FIRST) shift = vs_shift_estimate(A.f, rows);  // wave-wide call, same bits in every wave and in the fold
     vs_d2 an[2], bn[2];
@@ -215,22 +213,25 @@ gram_diag_wave_kernel(vs_gram_args A) {
     // one iteration later, so nothing waits on them while the MFMAs of the current chunk run
     auto fetch = [&](uint64_t c) {
         const uint64_t s0 = c * VS2_WCHUNK;
+        VS2_FTILE(s0);
         if (c < nfull) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
+                const double* q = fb + (uint64_t)pl[j] * fp + 2 * piece;
                 if (ALIGNED) {
-                    raw[j] = __builtin_nontemporal_load((const vs_d2*)(rp[j] + s0));
-                } else {  // odd row count: every other planar block starts 8 bytes off a 16-byte boundary
-                    raw[j].x = __builtin_nontemporal_load(rp[j] + s0);
-                    raw[j].y = __builtin_nontemporal_load(rp[j] + s0 + 1);
+                    raw[j] = __builtin_nontemporal_load((const vs_d2*)q);
+                } else {  // odd row count: planes start 8 bytes off a 16-byte boundary
+                    raw[j].x = __builtin_nontemporal_load(q);
+                    raw[j].y = __builtin_nontemporal_load(q + 1);
                 }
             }
         } else {  // the ragged last chunk
             const uint64_t s = s0 + 2 * piece;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                raw[j].x = s < rows ? rp[j][s0] : 0.0;
-                raw[j].y = s + 1 < rows ? rp[j][s0 + 1] : 0.0;
+                const double* q = fb + (uint64_t)pl[j] * fp + 2 * piece;
+                raw[j].x = s < rows ? q[0] : 0.0;
+                raw[j].y = s + 1 < rows ? q[1] : 0.0;
             }
         }
         if (MASKED) {
@@ -242,15 +243,17 @@ gram_diag_wave_kernel(vs_gram_args A) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const uint64_t s = s0 + 8 * h;
+                const double* ap = fb + 2 * fq + 8 * h;   // planes 0 and 1 of the single output: a = fM_1, b = fM_2
+                const double* bp = ap + fp;
                 if (c < nfull && ALIGNED) {
-                    an[h] = __builtin_nontemporal_load((const vs_d2*)(ap + s));
-                    bn[h] = __builtin_nontemporal_load((const vs_d2*)(bp + s));
+                    an[h] = __builtin_nontemporal_load((const vs_d2*)ap);
+                    bn[h] = __builtin_nontemporal_load((const vs_d2*)bp);
                 } else {
                     const uint64_t e = s + 2 * fq;
-                    an[h].x = e < rows ? ap[s] : 0.0;
-                    an[h].y = e + 1 < rows ? ap[s + 1] : 0.0;
-                    bn[h].x = e < rows ? bp[s] : 0.0;
-                    bn[h].y = e + 1 < rows ? bp[s + 1] : 0.0;
+                    an[h].x = e < rows ? ap[0] : 0.0;
+                    an[h].y = e + 1 < rows ? ap[1] : 0.0;
+                    bn[h].x = e < rows ? bp[0] : 0.0;
+                    bn[h].y = e + 1 < rows ? bp[1] : 0.0;
                 }
             }
         }
@@ -407,8 +410,7 @@ gram_diag_wide_kernel(vs_gram_args A) {
     const int mrow = lane >> 4, li = lane & 15;
     // tile rows: s_u = c_u + d_u at row u, t_u = c_u - d_u at row K + u; rows from 2K on are padding, zeroed once.
     // One output: c_u is plane 2 + u, d_u plane 2 + K + u of f; rows u >= K read u = 0 and are not stored.
-    const double* p0 = A.f + (uint64_t)(2 + mrow) * rows + 2 * li;           // c row mrow
-    const uint64_t jstride = 4 * rows, dstride = (uint64_t)K * rows;
+    // (per fetch: p0 = c row mrow of the unit's rows, jstride = four planes on, dstride = K planes on: the d rows)
     for (int e = 2 * K * VS2_XPITCH + lane; e < 16 * NB * VS2_XPITCH; e += 64) tile[e] = 0.0;
     double* wr = tile + mrow * VS2_XPITCH + 2 * li;                          // + 4j rows: s; + K rows more: t
     double* wrt = wr + K * VS2_XPITCH;
@@ -425,7 +427,6 @@ gram_diag_wide_kernel(vs_gram_args A) {
     }
     const double* rd = tile + (lane & 15) * VS2_XPITCH + 2 * (lane >> 4);    // + 16b rows, + 8 per quarter
     // FIRST: lanes 0..15 load a (plane 0), 16..31 b (plane 1), the rest load them again into two spare rows
-    const double* pab = A.f + (uint64_t)(mrow & 1) * rows + 2 * li;
     double* wrab = tile + (16 * NB + mrow) * VS2_XPITCH + 2 * li;
     const double* rdab = tile + 16 * NB * VS2_XPITCH + 2 * (lane >> 4);      // a; b one tile row further
 
@@ -449,27 +450,31 @@ gram_diag_wide_kernel(vs_gram_args A) {
     vs_d2 raw[NJ], rawab = (vs_d2){0.0, 0.0};
     auto fetch = [&](uint64_t u) {
         const uint64_t s0 = u * VS2_XCHUNK;
+        VS2_FTILE(s0);
+        const double* p0 = fb + (uint64_t)(2 + mrow) * fp + 2 * li;           // c row mrow
+        const uint64_t jstride = 4 * fp, dstride = (uint64_t)K * fp;
+        const double* pab = fb + (uint64_t)(mrow & 1) * fp + 2 * li;
         if (u < nfull) {
 #pragma unroll
             for (int j = 0; j < NJ / 2; ++j) {
-                const double* q = (4 * j + mrow < K ? p0 + j * jstride : p0) + s0;
+                const double* q = (4 * j + mrow < K ? p0 + j * jstride : p0);
                 raw[2 * j] = __builtin_nontemporal_load((const vs_d2*)q);
                 raw[2 * j + 1] = __builtin_nontemporal_load((const vs_d2*)(q + dstride));
             }
-            if (FIRST) rawab = __builtin_nontemporal_load((const vs_d2*)(pab + s0));
+            if (FIRST) rawab = __builtin_nontemporal_load((const vs_d2*)pab);
         } else {  // the ragged last unit
             const uint64_t s = s0 + 2 * li;
 #pragma unroll
             for (int j = 0; j < NJ / 2; ++j) {
-                const double* q = (4 * j + mrow < K ? p0 + j * jstride : p0) + s0;
+                const double* q = (4 * j + mrow < K ? p0 + j * jstride : p0);
                 raw[2 * j].x = s < rows ? q[0] : 0.0;
                 raw[2 * j].y = s + 1 < rows ? q[1] : 0.0;
                 raw[2 * j + 1].x = s < rows ? q[dstride] : 0.0;
                 raw[2 * j + 1].y = s + 1 < rows ? q[dstride + 1] : 0.0;
             }
             if (FIRST) {
-                rawab.x = s < rows ? pab[s0] : 0.0;
-                rawab.y = s + 1 < rows ? pab[s0 + 1] : 0.0;
+                rawab.x = s < rows ? pab[0] : 0.0;
+                rawab.y = s + 1 < rows ? pab[1] : 0.0;
             }
         }
     };
@@ -603,26 +608,25 @@ __device__ __forceinline__ void gram_macro_body(const vs_gram_args& A, const int
     // (WIDE: rows lrow + 32j, j < 4, of MI and of MJ; 16 pieces = 32 sample rows)
     constexpr int NLD = WIDE ? 8 : 4;
     const int lrow = WIDE ? tid >> 4 : tid >> 3, piece = WIDE ? tid & 15 : tid & 7;
-    const double* rp[WIDE ? 2 : 4];
+    uint32_t pl[WIDE ? 1 : 4];   // (not WIDE) planes of the index rows this thread loads
     bool ok[NLD];
     if (WIDE) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) ok[j] = (j < 4 ? MI : MJ) * VS2_MACRO + (j & 3) * 32 + lrow < M && !(diag && j >= 4);
-        rp[0] = rp[1] = A.f + 2 * piece;
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = (j < 2 ? MI : MJ) * VS2_MACRO + (j & 1) * 64 + lrow;
             ok[j] = m < M && !(diag && j >= 2);
-            rp[j] = x_elem(A, ok[j] ? m : 0, 0) + 2 * piece;
+            pl[j] = x_plane(A, ok[j] ? m : 0);
         }
     }
     // WIDE: the address of load j is rebuilt from the index row at every fetch (a handful of integer
     // instructions) instead of living in registers between fetches: index row m is plane 2 + m, rows past 2k
-    // read index row 0 and are zeroed on the way into the tile
-    auto wide_ptr = [&](int j, int lr) {
+    // read index row 0 and are zeroed on the way into the tile; fb, fp: the fetch's chunk (VS2_FTILE)
+    auto wide_ptr = [&](int j, int lr, const double* fb, uint64_t fp) {
         const int m = (j < 4 ? MI : MJ) * VS2_MACRO + (j & 3) * 32 + lr;
-        return rp[0] + (uint64_t)(2 + (m < M ? m : 0)) * rows;
+        return fb + 2 * piece + (uint64_t)(2 + (m < M ? m : 0)) * fp;
     };
     double* wr = tiles + lrow * VS2_WPITCH + 2 * (piece & 7);   // + 64j (WIDE: 32j) rows, + buffer
     // fragments: A = index row 16*wave + (lane&15) of MI's half; B = 16*bj + (lane&15) of MJ's half
@@ -666,16 +670,17 @@ __device__ __forceinline__ void gram_macro_body(const vs_gram_args& A, const int
     double pa = 0.0, pb = 0.0;
     auto fetch = [&](uint64_t c) {   // WIDE: c is the first chunk of a pair
         const uint64_t s0 = c * VS2_WCHUNK;
+        VS2_FTILE(s0);
         const bool whole = WIDE ? s0 + 2 * VS2_WCHUNK <= rows : c < nfull;
         if (FIRST && abth) {
             const int t = ab_lane();
             const uint64_t sm = s0 + 2 * (WIDE ? t & 15 : t & 7);
-            const double* abp = A.f + (t >= (WIDE ? 16 : 8) ? rows : 0) + 2 * (WIDE ? t & 15 : t & 7);
+            const double* abp = fb + (t >= (WIDE ? 16 : 8) ? fp : 0) + 2 * (WIDE ? t & 15 : t & 7);   // plane 0: a, plane 1: b
             if (whole && ALIGNED) {
-                rawab = __builtin_nontemporal_load((const vs_d2*)(abp + s0));
+                rawab = __builtin_nontemporal_load((const vs_d2*)abp);
             } else {
-                rawab.x = sm < rows ? abp[s0] : 0.0;
-                rawab.y = sm + 1 < rows ? abp[s0 + 1] : 0.0;
+                rawab.x = sm < rows ? abp[0] : 0.0;
+                rawab.y = sm + 1 < rows ? abp[1] : 0.0;
             }
         }
         int lr = lrow;
@@ -685,24 +690,25 @@ __device__ __forceinline__ void gram_macro_body(const vs_gram_args& A, const int
             for (int j = 0; j < NLD; ++j) {
                 if (WIDE) {
                     if (diag && j >= 4) continue;
-                    raw[j] = __builtin_nontemporal_load((const vs_d2*)(wide_ptr(j, lr) + s0));
+                    raw[j] = __builtin_nontemporal_load((const vs_d2*)wide_ptr(j, lr, fb, fp));
                     continue;
                 }
                 if (!ok[j]) continue;
+                const double* q = fb + (uint64_t)pl[WIDE ? 0 : j] * fp + 2 * piece;
                 if (ALIGNED) {
-                    raw[j] = __builtin_nontemporal_load((const vs_d2*)(rp[j] + s0));
+                    raw[j] = __builtin_nontemporal_load((const vs_d2*)q);
                 } else {
-                    raw[j].x = __builtin_nontemporal_load(rp[j] + s0);
-                    raw[j].y = __builtin_nontemporal_load(rp[j] + s0 + 1);
+                    raw[j].x = __builtin_nontemporal_load(q);
+                    raw[j].y = __builtin_nontemporal_load(q + 1);
                 }
             }
         } else {
             const uint64_t sm = s0 + 2 * piece;
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
-                const double* q = WIDE ? wide_ptr(j, lr) : rp[j];
-                raw[j].x = (ok[j] && sm < rows) ? q[s0] : 0.0;
-                raw[j].y = (ok[j] && sm + 1 < rows) ? q[s0 + 1] : 0.0;
+                const double* q = WIDE ? wide_ptr(j, lr, fb, fp) : fb + (uint64_t)pl[WIDE ? 0 : j] * fp + 2 * piece;
+                raw[j].x = (ok[j] && sm < rows) ? q[0] : 0.0;
+                raw[j].y = (ok[j] && sm + 1 < rows) ? q[1] : 0.0;
             }
         }
         if (MASKED) {
@@ -871,21 +877,19 @@ gram_macro_st_kernel(vs_gram_args A) {
     constexpr int NLD = WIDE ? 8 : 4, NU = NLD / 2;
     const int lrow = WIDE ? tid >> 4 : tid >> 3, piece = WIDE ? tid & 15 : tid & 7;
     constexpr int USTEP = WIDE ? 32 : 64;   // u_j = lrow + USTEP j
-    const double* rp[WIDE ? 1 : NLD];
-    if (WIDE) {
-        rp[0] = A.f + 2 * piece;
-    } else {
+    uint32_t pl[WIDE ? 1 : NLD];   // (not WIDE) planes of the rows this thread loads
+    if (!WIDE) {
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             const int u = lrow + USTEP * j;
-            rp[j] = x_elem(A, u < K ? u : 0, 0) + 2 * piece;
-            rp[NU + j] = x_elem(A, K + (u < K ? u : 0), 0) + 2 * piece;
+            pl[j] = x_plane(A, u < K ? u : 0);
+            pl[NU + j] = x_plane(A, K + (u < K ? u : 0));
         }
     }
-    // WIDE (one output): c_u is plane 2 + u, d_u plane 2 + K + u; the address is rebuilt at every fetch
-    auto wide_ptr = [&](int j, int lr) {
+    // WIDE (one output): c_u is plane 2 + u, d_u plane 2 + K + u; the address is rebuilt at every fetch (fb, fp: VS2_FTILE)
+    auto wide_ptr = [&](int j, int lr, const double* fb, uint64_t fp) {
         const int u = lr + USTEP * (j % NU);
-        return rp[0] + (uint64_t)(2 + (j >= NU ? K : 0) + (u < K ? u : 0)) * rows;
+        return fb + 2 * piece + (uint64_t)(2 + (j >= NU ? K : 0) + (u < K ? u : 0)) * fp;
     };
     double* wr = tiles + lrow * VS2_WPITCH + 2 * (piece & 7);   // + USTEP j rows: s; + 128 rows: t; + buffer
     // fragments
@@ -915,6 +919,7 @@ gram_macro_st_kernel(vs_gram_args A) {
     bool k0 = true, k1 = true;
     auto fetch = [&](uint64_t c) {   // WIDE: c is the first chunk of a pair
         const uint64_t s0 = c * VS2_WCHUNK;
+        VS2_FTILE(s0);
         const bool whole = WIDE ? s0 + 2 * VS2_WCHUNK <= rows : c < nfull;
         int lr = lrow;
         if (WIDE) asm volatile("" : "+v"(lr));   // not loop-invariant as far as the compiler can tell
@@ -922,12 +927,12 @@ gram_macro_st_kernel(vs_gram_args A) {
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 if (lr + USTEP * (j % NU) >= K) continue;   // rows past K are zeros in the tile: nothing to load
-                const double* q = WIDE ? wide_ptr(j, lr) : rp[WIDE ? 0 : j];
+                const double* q = WIDE ? wide_ptr(j, lr, fb, fp) : fb + (uint64_t)pl[WIDE ? 0 : j] * fp + 2 * piece;
                 if (ALIGNED) {
-                    raw[j] = __builtin_nontemporal_load((const vs_d2*)(q + s0));
+                    raw[j] = __builtin_nontemporal_load((const vs_d2*)q);
                 } else {
-                    raw[j].x = __builtin_nontemporal_load(q + s0);
-                    raw[j].y = __builtin_nontemporal_load(q + s0 + 1);
+                    raw[j].x = __builtin_nontemporal_load(q);
+                    raw[j].y = __builtin_nontemporal_load(q + 1);
                 }
             }
         } else {
@@ -935,9 +940,9 @@ gram_macro_st_kernel(vs_gram_args A) {
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 const bool in = lr + USTEP * (j % NU) < K;
-                const double* q = WIDE ? wide_ptr(j, lr) : rp[WIDE ? 0 : j];
-                raw[j].x = (in && sm < rows) ? q[s0] : 0.0;
-                raw[j].y = (in && sm + 1 < rows) ? q[s0 + 1] : 0.0;
+                const double* q = WIDE ? wide_ptr(j, lr, fb, fp) : fb + (uint64_t)pl[WIDE ? 0 : j] * fp + 2 * piece;
+                raw[j].x = (in && sm < rows) ? q[0] : 0.0;
+                raw[j].y = (in && sm + 1 < rows) ? q[1] : 0.0;
             }
         }
         if (MASKED) {
@@ -1051,18 +1056,17 @@ gram_half_st_kernel(vs_gram_args A) {
 
     // staging: thread t holds sample rows 2(t&15), 2(t&15)+1 of the 32 of c_u and d_u, u = (t>>4) + 32j, j < 2
     const int lrow = tid >> 4, piece = tid & 15;
-    const double* base = A.f + 2 * piece;
-    const double* rp[ONE ? 1 : 4];
+    uint32_t pl[ONE ? 1 : 4];   // (several outputs) planes of the rows this thread loads
     if (!ONE) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int u = lrow + 32 * (j & 1);
-            rp[j] = x_elem(A, (j >= 2 ? K : 0) + (u < K ? u : 0), 0) + 2 * piece;
+            pl[j] = x_plane(A, (j >= 2 ? K : 0) + (u < K ? u : 0));
         }
     }
-    auto ptr = [&](int j, int lr) {   // j < 2: c rows, else d rows
+    auto ptr = [&](int j, int lr, const double* fb, uint64_t fp) {   // j < 2: c rows, else d rows; fb, fp: VS2_FTILE of the fetch
         const int u = lr + 32 * (j & 1);
-        return ONE ? base + (uint64_t)(2 + (j >= 2 ? K : 0) + (u < K ? u : 0)) * rows : rp[ONE ? 0 : j];
+        return fb + 2 * piece + (uint64_t)(ONE ? (uint32_t)(2 + (j >= 2 ? K : 0) + (u < K ? u : 0)) : pl[ONE ? 0 : j]) * fp;
     };
     double* wr = tiles + ((piece >> 3) * VS2_MACRO + lrow) * VS2_WPITCH + 2 * (piece & 7);   // + 32j rows: s; + 64: t
     const double* rdS = tiles + (grp * VS2_MACRO + (lane & 15)) * VS2_WPITCH + 2 * (lane >> 4);   // + 16 blk rows
@@ -1082,6 +1086,7 @@ gram_half_st_kernel(vs_gram_args A) {
     bool k0 = true, k1 = true;
     auto fetch = [&](uint64_t pr) {
         const uint64_t s0 = pr * 2 * VS2_WCHUNK;
+        VS2_FTILE(s0);
         const bool whole = s0 + 2 * VS2_WCHUNK <= rows;
         const uint64_t sm = s0 + 2 * piece;
         int lr = lrow;
@@ -1089,7 +1094,7 @@ gram_half_st_kernel(vs_gram_args A) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool in = lr + 32 * (j & 1) < K;   // rows past K are zeros in the tile: nothing to load
-            const double* q = ptr(j, lr) + s0;
+            const double* q = ptr(j, lr, fb, fp);
             if (whole) {
                 if (in) raw[j] = __builtin_nontemporal_load((const vs_d2*)q);
             } else {
@@ -1178,7 +1183,7 @@ gram_half_st_kernel(vs_gram_args A) {
 // dot-product part), appended to the macro kernel's records.
 #define VS2_HEAD_THREADS 1024
 __global__ void __launch_bounds__(VS2_HEAD_THREADS)
-first_head_kernel(const double* __restrict__ f, uint64_t rows, int k, double* __restrict__ records) {
+first_head_kernel(const double* __restrict__ f, uint64_t rows, int k, int f_shift, double* __restrict__ records) {
     __shared__ double wsum[VS2_HEAD_THREADS / 64][5];
     const double shift = vs_shift_estimate(f, rows);   // wave-wide call; every wave and the fold get the same bits
     double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1193,15 +1198,21 @@ first_head_kernel(const double* __restrict__ f, uint64_t rows, int k, double* __
     };
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // row-blocked f-values (vs_f_tile), one output: a = fM_1 is plane 0, b = fM_2 plane 1 of the row's row block
+    const uint64_t planes = 2 * (uint64_t)k + 2;
     if (rows % 2 == 0 && ((uintptr_t)f & 15) == 0) {   // 16-byte loads: two rows per thread and trip
         for (uint64_t r = 2 * t0; r < rows; r += 2 * stride) {
-            const vs_d2 a = __builtin_nontemporal_load((const vs_d2*)(f + r));
-            const vs_d2 b = __builtin_nontemporal_load((const vs_d2*)(f + rows + r));
+            const vs_ftile ft = vs_f_tile(rows, planes, f_shift, r);
+            const vs_d2 a = __builtin_nontemporal_load((const vs_d2*)(f + ft.base));
+            const vs_d2 b = __builtin_nontemporal_load((const vs_d2*)(f + ft.base + ft.pitch));
             add(a.x, b.x);
             add(a.y, b.y);
         }
     } else {
-        for (uint64_t r = t0; r < rows; r += stride) add(__builtin_nontemporal_load(f + r), __builtin_nontemporal_load(f + rows + r));
+        for (uint64_t r = t0; r < rows; r += stride) {
+            const vs_ftile ft = vs_f_tile(rows, planes, f_shift, r);
+            add(__builtin_nontemporal_load(f + ft.base), __builtin_nontemporal_load(f + ft.base + ft.pitch));
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1225,26 +1236,29 @@ first_head_kernel(const double* __restrict__ f, uint64_t rows, int k, double* __
 // (saltelli.py:474-492); a NaN in blocks 2..2k+1 poisons a Gram total and gram_fold_kernel raises the
 // flag, a NaN in block 0 or 1 is caught here.  2/(2k+2) of the data: cheap beside the Gram pass.
 __global__ void __launch_bounds__(256)
-nan_probe_kernel(const double* __restrict__ f, uint64_t count, uint32_t* counters) {
+nan_probe_kernel(const double* __restrict__ f, uint64_t rows, uint64_t planes, int f_shift, uint32_t* counters) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     bool bad = false;
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
-        const double x = f[e];
-        bad |= (x != x);
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+        const vs_ftile ft = vs_f_tile(rows, planes, f_shift, r);   // the row's planes 0 and 1
+        const double x = f[ft.base], y = f[ft.base + ft.pitch];
+        bad |= (x != x) | (y != y);
     }
     if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(&counters[CNT_NANFLAG], 1u);
 }
 
 // keep mask for the second-order pass (same rule as the first-order one)
 __global__ void __launch_bounds__(256)
-nan_mask2_kernel(const double* __restrict__ f, uint64_t rows, int k, int l, uint8_t* __restrict__ keep,
+nan_mask2_kernel(const double* __restrict__ f, uint64_t rows, int k, int l, int f_shift, uint8_t* __restrict__ keep,
                  const uint32_t* counters) {
     if (counters[CNT_NANFLAG] == 0) return;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t planes = (uint64_t)l * (2 * (uint64_t)k + 2);
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
         bool bad = false;
+        const vs_ftile ft = vs_f_tile(rows, planes, f_shift, r);
         for (int b = 0; b < 2 * k + 2; ++b) {
-            double x = f[(uint64_t)b * rows + r];  // plane of output 0
+            double x = f[ft.base + (uint64_t)b * ft.pitch];  // planes of output 0
             bad |= (x != x);
         }
         keep[r] = bad ? 0 : 1;
@@ -1445,7 +1459,7 @@ gram_convert_kernel(const double* __restrict__ cd, int K, double* __restrict__ g
 // (MASKED, ALIGNED, FIRST, WIDE) instances of the [C; D] macro kernel the launches can pick
 #define VS2_MACRO_INSTANCES(X) \
     X(false, false, false, false) X(false, true, false, false) X(true, false, false, false) X(true, true, false, false) \
-    X(false, false, true, false) X(false, true, true, false) X(false, true, false, true) X(true, true, false, true) X(false, true, true, true)
+    X(false, false, true, false) X(false, true, true, false) X(false, true, false, true) X(true, true, false, true)
 // (MASKED, ALIGNED, WIDE) instances of the S/T macro kernel
 #define VS2_ST_INSTANCES(X) \
     X(false, false, false) X(false, true, false) X(false, true, true) X(true, false, false) X(true, true, false) X(true, true, true)
@@ -1556,6 +1570,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
 
     vs_gram_args A;
     A.f = f_dev;
+    A.f_shift = ctx->tune.f_shift;
     A.rows = rows;
     A.k = k;
     A.l = l;
@@ -1586,11 +1601,10 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     if (rc) return rc;
     VS_REQUIRE(!(with_first && macro_st) || st128, "no one-pass kernel for this shape");
     if ((flags & VS_REDUCE_NAN_TRIM) && rows > 0) {
-        const uint64_t count = 2 * rows;  // blocks 0 and 1 of output 0 are contiguous
-        const uint64_t want_blocks = (count + 255) / 256;
+        const uint64_t want_blocks = (rows + 255) / 256;   // a thread per row: blocks 0 and 1 of output 0
         vs_launch_scope scope(ctx, VS_KERNEL_NAN_MASK);
         hipLaunchKernelGGL(nan_probe_kernel, dim3((unsigned)(want_blocks < 2048 ? want_blocks : 2048)), dim3(256), 0,
-                           ctx->stream, f_dev, count, ctx->counters);
+                           ctx->stream, f_dev, rows, (uint64_t)l * (2 * (uint64_t)k + 2), ctx->tune.f_shift, ctx->counters);
         VS_HIP(hipGetLastError());
     }
     for (int pass = 0; pass < 2; ++pass) {
@@ -1602,7 +1616,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
             A.keep = ctx->keep;
             vs_launch_scope scope(ctx, VS_KERNEL_NAN_MASK);
             hipLaunchKernelGGL(nan_mask2_kernel, dim3((unsigned)((rows + 255) / 256 < 4096 ? (rows + 255) / 256 : 4096)),
-                               dim3(256), 0, ctx->stream, f_dev, rows, k, l, ctx->keep, (const uint32_t*)ctx->counters);
+                               dim3(256), 0, ctx->stream, f_dev, rows, k, l, ctx->tune.f_shift, ctx->keep, (const uint32_t*)ctx->counters);
         }
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
@@ -1634,8 +1648,13 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
             } else if (macro) {
                 const dim3 grid(slab_wgs, npairs);
                 bool launched = false;
+                // With the first-order sums on board the kernel takes the 16-sample-row fetch: the WIDE instance of that
+                // body sat at the kernel's 128 registers with three dwords in scratch (rounds 2-4), and the row-blocked
+                // layout's per-fetch base and pitch pushed a whole staging quadruple out.  Beyond 128 index rows the
+                // kernel is matrix-pipe-bound (busy 0.71 at k = 197, profiles/r05), not fetch-bound: same time.
+                const bool mwide_now = mwide && !with_first;
 #define VS2_LAUNCH_MACRO(MK, AL, FI, WI)                                                                        \
-                if (!launched && masked == MK && aligned == AL && with_first == FI && mwide == WI) {            \
+                if (!launched && masked == MK && aligned == AL && with_first == FI && mwide_now == WI) {        \
                     hipLaunchKernelGGL((gram_macro_kernel<MK, AL, FI, WI>), grid, dim3(512), lds_m, ctx->stream, A); \
                     launched = true;                                                                            \
                 }
@@ -1678,7 +1697,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
         if (with_first && !masked) {
             {
                 vs_launch_scope scope(ctx, VS_KERNEL_REDUCE_FIRST);
-                hipLaunchKernelGGL(first_head_kernel, dim3(P_head), dim3(VS2_HEAD_THREADS), 0, ctx->stream, f_dev, rows, k,
+                hipLaunchKernelGGL(first_head_kernel, dim3(P_head), dim3(VS2_HEAD_THREADS), 0, ctx->stream, f_dev, rows, k, ctx->tune.f_shift,
                                    ctx->partials + (size_t)P_diag * plen);
             }
             VS_HIP(hipGetLastError());
@@ -1797,6 +1816,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     VS_HIP(hipMemsetAsync(gram_dev, 0, sizeof(double) * VS_GRAM_LEN(K), ctx->stream));
     vs_gram_args A;
     A.f = f_dev;
+    A.f_shift = ctx->tune.f_shift;
     A.rows = rows;
     A.k = k;
     A.l = 1;
@@ -1836,7 +1856,7 @@ extern "C" int vs_reduce_first_second_order(vs_context* ctx, const double* f_dev
     VS_HIP(hipGetLastError());
     if (P_head) {
         vs_launch_scope scope(ctx, VS_KERNEL_REDUCE_FIRST);
-        hipLaunchKernelGGL(first_head_kernel, dim3(P_head), dim3(VS2_HEAD_THREADS), 0, ctx->stream, f_dev, rows, k,
+        hipLaunchKernelGGL(first_head_kernel, dim3(P_head), dim3(VS2_HEAD_THREADS), 0, ctx->stream, f_dev, rows, k, ctx->tune.f_shift,
                            ctx->partials + (size_t)P * plen);
         VS_HIP(hipGetLastError());
     }

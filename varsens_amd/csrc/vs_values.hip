@@ -191,18 +191,34 @@ static hipStream_t other_stream(vs_context* ctx) {
 // ---------------------------------------------------------------------------------------------
 // conversion kernels
 // ---------------------------------------------------------------------------------------------
-// The reference's order: value (i, o) at src[i * l + o], i = flat row within the piece.  The device's: plane o at
-// dst[o * plane_stride + i].  A workgroup turns tiles of VS_TR flat rows x VS_TC outputs through LDS: both the global
-// reads (runs of min(l, VS_TC) doubles per row, rows adjacent in memory) and the writes (runs of VS_TR rows per
-// output) are contiguous.  `divide` (null, 1 or l entries): Objective.load's `x / scaling` (saltelli.py:451-468), a
-// true division -- the quotient's bits are numpy's.
+// The reference's order: value (i, o) at src[i * l + o], i = flat row of the shard = block * rows + row.  The device's:
+// row-blocked planes (vs_f_tile, vs_device_gen.h): element (plane o (2k+2) + block, row).  A workgroup turns tiles of
+// VS_TR flat rows x VS_TC outputs through LDS: the global reads (runs of min(l, VS_TC) doubles per row, rows adjacent in
+// memory) and the writes (runs of consecutive rows of one plane, up to the end of a block or row block) are contiguous.
+// `divide` (null, 1 or l entries): Objective.load's `x / scaling` (saltelli.py:451-468), a true division -- the
+// quotient's bits are numpy's.
 #define VS_TR 128
 #define VS_TC 32
 
+struct vs_values_shape {
+    uint64_t rows;     // rows of the shard
+    uint64_t planes;   // l (2k+2)
+    int blocks;        // 2k+2
+    int l;
+    int f_shift;
+};
+
+// doubles from f to the value of output o at flat row i of the shard
+__device__ __forceinline__ uint64_t values_at(const vs_values_shape& S, uint64_t i, int o) {
+    const uint64_t b = i / S.rows, r = i - b * S.rows;
+    return vs_f_index(S.rows, S.planes, S.f_shift, (uint64_t)o * S.blocks + b, r);
+}
+
 __global__ void __launch_bounds__(256)
-values_in_kernel(const double* __restrict__ src, double* __restrict__ dst, uint64_t cnt, int l, uint64_t plane_stride,
-                 const double* __restrict__ divide, int ndivide) {
+values_in_kernel(const double* __restrict__ src, double* __restrict__ f, vs_values_shape S, uint64_t i_first, uint64_t cnt,
+                 const double* __restrict__ divide, int ndivide, double divisor) {
     __shared__ double tile[VS_TC][VS_TR + 1];
+    const int l = S.l;
     const uint64_t row_tiles = (cnt + VS_TR - 1) / VS_TR;
     const int col_tiles = (l + VS_TC - 1) / VS_TC;
     const uint64_t tiles = row_tiles * (uint64_t)col_tiles;
@@ -220,23 +236,18 @@ values_in_kernel(const double* __restrict__ src, double* __restrict__ dst, uint6
             const int c = e / tr, r = e - c * tr;
             double v = tile[c][r];
             if (divide) v = v / divide[ndivide == 1 ? 0 : o0 + c];
-            dst[(uint64_t)(o0 + c) * plane_stride + i0 + r] = v;
+            else if (ndivide) v = v / divisor;    // one output: the divisor is a kernel argument
+            f[values_at(S, i_first + i0 + r, o0 + c)] = v;
         }
         __syncthreads();
     }
 }
 
-// one output: nothing to transpose, only the division
+// device layout -> the reference's order (Objective.flat, saltelli.py:357-391)
 __global__ void __launch_bounds__(256)
-values_divide_kernel(const double* __restrict__ src, double* __restrict__ dst, uint64_t cnt, double divisor) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (uint64_t)gridDim.x * 256)
-        dst[i] = __builtin_nontemporal_load(src + i) / divisor;
-}
-
-// planes -> the reference's order (Objective.flat, saltelli.py:357-391)
-__global__ void __launch_bounds__(256)
-values_out_kernel(const double* __restrict__ src, double* __restrict__ dst, uint64_t cnt, int l, uint64_t plane_stride) {
+values_out_kernel(const double* __restrict__ f, double* __restrict__ dst, vs_values_shape S, uint64_t i_first, uint64_t cnt) {
     __shared__ double tile[VS_TC][VS_TR + 1];
+    const int l = S.l;
     const uint64_t row_tiles = (cnt + VS_TR - 1) / VS_TR;
     const int col_tiles = (l + VS_TC - 1) / VS_TC;
     const uint64_t tiles = row_tiles * (uint64_t)col_tiles;
@@ -247,7 +258,7 @@ values_out_kernel(const double* __restrict__ src, double* __restrict__ dst, uint
         const int tr = (int)min((uint64_t)VS_TR, cnt - i0);
         for (int e = threadIdx.x; e < tr * tc; e += 256) {
             const int c = e / tr, r = e - c * tr;
-            tile[c][r] = src[(uint64_t)(o0 + c) * plane_stride + i0 + r];
+            tile[c][r] = f[values_at(S, i_first + i0 + r, o0 + c)];
         }
         __syncthreads();
         for (int e = threadIdx.x; e < tr * tc; e += 256) {
@@ -260,12 +271,13 @@ values_out_kernel(const double* __restrict__ src, double* __restrict__ dst, uint
 
 // rows of the shard that Objective.load deletes (saltelli.py:474-486): a NaN in output 0 of any of the 2k+2 blocks
 __global__ void __launch_bounds__(256)
-nan_rows_kernel(const double* __restrict__ f, uint64_t rows, int k, unsigned long long* __restrict__ count) {
+nan_rows_kernel(const double* __restrict__ f, vs_values_shape S, unsigned long long* __restrict__ count) {
     unsigned int bad_rows = 0;
-    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * 256) {
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < S.rows; r += (uint64_t)gridDim.x * 256) {
         bool bad = false;
-        for (int b = 0; b < 2 * k + 2; ++b) {
-            const double x = f[(uint64_t)b * rows + r];
+        const vs_ftile ft = vs_f_tile(S.rows, S.planes, S.f_shift, r);
+        for (int b = 0; b < S.blocks; ++b) {
+            const double x = f[ft.base + (uint64_t)b * ft.pitch];
             bad |= (x != x);
         }
         bad_rows += bad ? 1u : 0u;
@@ -332,7 +344,7 @@ extern "C" int vs_upload_values(vs_context* ctx, const double* host_vals, uint64
     VS_HIP(hipEventRecord(S->entry, ks));        // whatever still uses f_dev on the kernel stream comes first
     VS_HIP(hipStreamWaitEvent(cs, S->entry, 0));
     double* divide_dev = nullptr;
-    if (divide && l > 1) {   // per-output divisors for the transposing kernel (one output: a kernel argument)
+    if (divide && l > 1) {   // per-output divisors for the layout kernel (one output: a kernel argument)
         VS_HIP(hipMalloc((void**)&divide_dev, sizeof(double) * ndivide));
         const hipError_t e = hipMemcpy(divide_dev, divide, sizeof(double) * ndivide, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -340,8 +352,14 @@ extern "C" int vs_upload_values(vs_context* ctx, const double* host_vals, uint64
             return vs_fail(VS_ERR_HIP, "upload of the divisors failed: %s", hipGetErrorString(e));
         }
     }
-    const bool direct = l == 1 && !divide;       // flat order == plane order: the copy engine writes the destination
-    const uint64_t plane_stride = (2 * (uint64_t)k + 2) * rows;
+    // one output, no divisor, ONE row block: flat order == device order, the copy engine writes the destination itself
+    const bool direct = l == 1 && !divide && rows <= (1ull << ctx->tune.f_shift);
+    vs_values_shape shape;
+    shape.rows = rows;
+    shape.planes = (uint64_t)l * (2 * (uint64_t)k + 2);
+    shape.blocks = 2 * k + 2;
+    shape.l = l;
+    shape.f_shift = ctx->tune.f_shift;
     bool used[VS_RING_SLOTS] = {};
     auto body = [&]() -> int {
         for (size_t p = 0; p < pieces.size(); ++p) {
@@ -362,13 +380,9 @@ extern "C" int vs_upload_values(vs_context* ctx, const double* host_vals, uint64
                 VS_HIP(hipStreamWaitEvent(ks, S->dma_done[s], 0));
                 {
                     vs_launch_scope scope(ctx, VS_KERNEL_VALUES);
-                    if (l == 1)
-                        hipLaunchKernelGGL(values_divide_kernel, dim3(blocks_for(P.cnt, 1024, 2048)), dim3(256), 0, ks,
-                                           (const double*)stage, f_dev + P.i0, P.cnt, divide[0]);
-                    else
-                        hipLaunchKernelGGL(values_in_kernel, dim3(blocks_for(P.cnt, VS_TR, 4096)), dim3(256), 0, ks,
-                                           (const double*)stage, f_dev + P.i0, P.cnt, l, plane_stride,
-                                           (const double*)divide_dev, ndivide);
+                    hipLaunchKernelGGL(values_in_kernel, dim3(blocks_for(P.cnt, VS_TR, 4096)), dim3(256), 0, ks,
+                                       (const double*)stage, f_dev, shape, P.i0, P.cnt, (const double*)divide_dev,
+                                       divide ? ndivide : 0, divide ? divide[0] : 1.0);
                 }
                 VS_HIP(hipGetLastError());
                 VS_HIP(hipEventRecord(S->kernel_done[s], ks));
@@ -385,7 +399,7 @@ extern "C" int vs_upload_values(vs_context* ctx, const double* host_vals, uint64
             {
                 vs_launch_scope scope(ctx, VS_KERNEL_NAN_MASK);
                 hipLaunchKernelGGL(nan_rows_kernel, dim3(blocks_for(rows, 256, 4096)), dim3(256), 0, ks,
-                                   (const double*)f_dev, rows, k, S->count_dev);
+                                   (const double*)f_dev, shape, S->count_dev);
             }
             VS_HIP(hipGetLastError());
             VS_HIP(hipMemcpyAsync(S->count_host, S->count_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, ks));
@@ -470,16 +484,23 @@ extern "C" int vs_download_values(vs_context* ctx, const double* f_dev, uint64_t
     const uint64_t total = (2 * (uint64_t)k + 2) * rows;
     const uint64_t per = std::max<uint64_t>(1, VS_RING_SLOT_BYTES / (8 * (uint64_t)l));
     const size_t npieces = (size_t)((total + per - 1) / per);
+    vs_values_shape shape;
+    shape.rows = rows;
+    shape.planes = (uint64_t)l * (2 * (uint64_t)k + 2);
+    shape.blocks = 2 * k + 2;
+    shape.l = l;
+    shape.f_shift = ctx->tune.f_shift;
+    const bool direct = l == 1 && rows <= (1ull << ctx->tune.f_shift);   // one row block: device order == flat order
     const std::function<out_piece(size_t)> describe = [&](size_t p) {
         const uint64_t i0 = p * per, cnt = std::min(per, total - i0);
-        return out_piece{l == 1 ? (const char*)(f_dev + i0) : nullptr, (size_t)(8 * cnt * l), (size_t)(8 * i0 * l)};
+        return out_piece{direct ? (const char*)(f_dev + i0) : nullptr, (size_t)(8 * cnt * l), (size_t)(8 * i0 * l)};
     };
     rc = drain_to_host(ctx, S, npieces, (char*)host_vals, describe, [&](size_t p, char* stage, hipStream_t ks) -> int {
         const uint64_t i0 = p * per, cnt = std::min(per, total - i0);
         {
             vs_launch_scope scope(ctx, VS_KERNEL_VALUES);
-            hipLaunchKernelGGL(values_out_kernel, dim3(blocks_for(cnt, VS_TR, 4096)), dim3(256), 0, ks, f_dev + i0,
-                               (double*)stage, cnt, l, total);
+            hipLaunchKernelGGL(values_out_kernel, dim3(blocks_for(cnt, VS_TR, 4096)), dim3(256), 0, ks, f_dev,
+                               (double*)stage, shape, i0, cnt);
         }
         VS_HIP(hipGetLastError());
         return VS_OK;
