@@ -27,12 +27,22 @@ K=128 LOG2N=24 KIND=poly python3 $R/tools/pmc_run.py fused_both_k128_n24 --kerne
 K=32 L=4 LOG2N=22 KIND=lin python3 $R/tools/pmc_run.py fused_both_k32_l4 --kernels scan_gram --groups issue,lds -- python3 $R/tools/fused_both.py
 K=16 L=2 LOG2N=22 KIND=poly python3 $R/tools/pmc_run.py fused_both_k16_l2 --kernels scan_gram --groups issue,lds -- python3 $R/tools/fused_both.py
 python3 $R/tools/pmc_run.py fused_first_k32 --kernels scan_kernel --groups issue,lds,mem -- python3 $R/tools/eval_one.py 32 22 fused lin
-for n in gram_k128_n24 gram_k64_n22 gram_k32_n22 eval_k128_n24 fused_both_k32 fused_both_k128_n24 fused_both_k32_l4 fused_both_k16_l2 fused_first_k32; do cp $R/gpurun_out/pmc/$n.json $R/gpurun_out/pmc/${n}_kernel_stats.csv $OUT/; done
+# round 5: second order beyond 128 index rows at the reference's study shape (k = 197, n = 2^20)
+N=1048576 python3 $R/tools/pmc_run.py gram_k197_n2pow20 --kernels gram_,first_head,reduce_first,scan_kernel -- python3 $R/tools/gram_k197.py
+for n in gram_k128_n24 gram_k64_n22 gram_k32_n22 eval_k128_n24 fused_both_k32 fused_both_k128_n24 fused_both_k32_l4 fused_both_k16_l2 fused_first_k32 gram_k197_n2pow20; do cp $R/gpurun_out/pmc/$n.json $R/gpurun_out/pmc/${n}_kernel_stats.csv $OUT/; done
 echo "kernel pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python3 $R/tools/config5.py > $OUT/config5.log 2>&1
 cp $(find $OUT/stats5 -name '*kernel_stats.csv' | head -1) $OUT/config5_kernel_stats.csv
 rm -rf $OUT/stats $OUT/stats5
 echo "config5 done"
+# round 5: the routes with an opaque model (whole API calls by the wall clock), the row-block size of the f-value layout,
+# and the one-GPU rehearsal of ranks 0, 3, 7 of an 8-GPU weak-scaling job
+python3 $R/tools/host_routes.py 32 20 1 32 20 3 > $OUT/host_routes.txt 2>&1
+bash $R/tools/fshift_sweep.sh > $OUT/fshift_sweep.txt 2>&1
+python3 $R/tools/rehearse_weak_scaling.py --out $OUT/rehearsal > $OUT/rehearsal.log 2>&1
+N=20480 python3 $R/tools/gram_k197.py > $OUT/gram_k197_n20480.txt 2>&1
+python3 $R/tools/gram_k197.py > $OUT/gram_k197_n2pow20.txt 2>&1
+echo "round-5 extras done"
 cat $OUT/bench_n1.json
 cat $OUT/bench_kernel_stats.csv
 cat $OUT/config5.log
