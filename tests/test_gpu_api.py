@@ -1075,3 +1075,30 @@ def test_sobol_file_round_trip_equals_the_in_memory_design(vs, tmp_path):
                         "--no-header"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 0 and len(p.stdout.splitlines()) == 8
     numpy.testing.assert_allclose(numpy.loadtxt(p.stdout.splitlines(), delimiter=","), unit[:8], rtol=1e-5, atol=1e-6)
+
+
+def test_the_binding_shown_in_integration_md_runs(vs, golden):
+    """INTEGRATION.md section 2 shows the ctypes stub a maintainer of the reference would add (varsens/_hip.py):
+    the stub's `first_order` is executed here as it is printed, against the reference's own run of pre-computed values
+    (golden G12, three outputs) and a NaN-trim case (G6)."""
+    import os
+    import re
+    from varsens_amd import _native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# varsens/_hip\.py.*?)```", text, re.S).group(1)
+    block = block.replace('C.CDLL("libvarsens_hip.so")', "C.CDLL(%r)" % _native.LIB_PATH)
+    ns = {}
+    exec(compile(block, "INTEGRATION.md:_hip.py", "exec"), ns)
+    g = golden("g12_vals_k7_n50_l3")
+    k, n = int(g["k"]), int(g["n"])
+    r = ns["first_order"](g["vals"], k, n)
+    numpy.testing.assert_allclose(r[0], g["E_2"], rtol=1e-13)
+    numpy.testing.assert_allclose(r[1], g["var_y"], rtol=1e-13)
+    numpy.testing.assert_allclose(r[2 + 2 * k:2 + 3 * k], g["sens"], rtol=1e-9, atol=1e-12)
+    numpy.testing.assert_allclose(r[2 + 3 * k:2 + 4 * k], g["sens_t"], rtol=1e-9, atol=1e-12)
+    g6 = golden("g6_nantrim_k5_n64_l2")
+    r = ns["first_order"](g6["vals"], 5, 64)
+    numpy.testing.assert_allclose(r[0][0], g6["E_2"][0], rtol=1e-13)
+    numpy.testing.assert_allclose(r[2 + 10:2 + 15, 0], g6["sens"][:, 0], rtol=1e-10, atol=1e-13)
+    ns["lib"].vs_context_destroy(ns["ctx"])
