@@ -77,6 +77,34 @@ def _deps_newer(target):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(tag, extra_cflags, verbose=False):
+    """A/B tooling (tools/ab_*.sh): the library built with extra compiler flags into build_variants/libvarsens_hip_<tag>.so
+    (objects under build/obj_<tag>); load it with VARSENS_HIP_LIB.  Never used by the product."""
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(ROOT, "build", "obj_" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.join(ROOT, "build_variants"), exist_ok=True)
+    out = os.path.join(ROOT, "build_variants", "libvarsens_hip_%s.so" % tag)
+    embed_sources()
+    hipcc = _hipcc()
+    cflags = [f for f in FLAGS if f != "-shared"] + list(extra_cflags)
+    bid = source_id(extra_cflags=extra_cflags)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o").replace(".cpp", ".o"))
+        cmd = [hipcc] + cflags + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
+        if src == "vs_host.cpp":
+            cmd.insert(1, '-DVS_BUILD_ID="%s"' % bid)
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-L/opt/rocm/lib", "-lhiprtc"])
+    return out
+
+
 def build(force=False, verbose=True):
     """One object per source (compiled side by side), then one link.  The library is written to a
     temporary name and renamed into place under a file lock, so that the ranks of a multi-process
@@ -142,7 +170,10 @@ def build_asan_host(verbose=True):
 
 
 if __name__ == "__main__":
-    if "--asan-host" in sys.argv:
+    if "--variant" in sys.argv:     # python -m varsens_amd.build --variant TAG -DFLAG ...
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    elif "--asan-host" in sys.argv:
         print(build_asan_host())
     else:
         build(force="--force" in sys.argv)

@@ -67,11 +67,18 @@ __device__ __forceinline__ vs_u32 vs_sobol_bits_block(const vs_sobol_block& S, c
 // arithmetic phase at every k up to 96 (k = 32: 0.40-0.41 ms against 0.365, same box; tools/eval_in_step.py,
 // profiles/r04/ab_halton_forms.txt) although it is faster launched alone -- except the eight waves x 16 columns of
 // 97 .. 128 columns and x 32 of 129 .. 256, whose arithmetic and store phases overlap worst (config 5: 9.25 -> 8.50 ms;
-// k = 200, n = 2^20: 0.82 -> 0.67): VS_SCAN_SHORT_DIGITS.
+// k = 200, n = 2^20: 0.82 -> 0.67) -- and, asked again in round 5 in the row-blocked layout (tools/ab_short_digits.sh,
+// profiles/r05/ab_short_digits.txt), the one-wave kernels of up to 16 columns, which have no barrier to meet at
+// (k = 16, n = 2^22 inside the step: 0.2075 -> 0.1775 ms; k = 32 +2 %, k = 48 +14 %, k = 64 +-0, k = 96 +4 %: unchanged there):
+// VS_SCAN_SHORT_DIGITS.
 #ifdef VS_HALTON_DIGITS   // A/B build (tools/ab_halton_forms.sh): the four-instruction loop and Markstein's quotient everywhere
 #define VS_SCAN_SHORT_DIGITS(FUSED, L, W) false
 #else
-#define VS_SCAN_SHORT_DIGITS(FUSED, L, W) ((FUSED) || ((L) >= 16 && (W) == 8))
+#ifdef VS_SCAN_SHORT_ALL   // A/B build: the short digit form in every evaluation kernel too
+#define VS_SCAN_SHORT_DIGITS(FUSED, L, W) true
+#else
+#define VS_SCAN_SHORT_DIGITS(FUSED, L, W) ((FUSED) || ((L) >= 16 && (W) == 8) || (W) == 1)
+#endif
 #endif
 template <bool FUSED, bool ALL>
 __device__ __forceinline__ void vs_halton_pair(vs_u32 i1, vs_u32 i2, double d1, double d2, const vs_base& B, double& x1, double& x2,

@@ -282,6 +282,33 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
     };
 #define ST_PIN() __builtin_amdgcn_sched_barrier(0)
 
+#ifdef VS_ST_GLDS_TIMING
+    // TIMING EXPERIMENT (profiles/r05/gram_k64_glds_bound.txt; WRONG RESULTS): the stage's operands go
+    // straight from global memory into LDS (global_load_lds_dwordx4: no vector registers, no ds_write) -- 64 wave-wide
+    // pieces of 1 KiB, lane-linear, one after the other in the stage's buffer; nothing forms s and t, the fragment reads
+    // and MFMAs are the product's.  What a kernel built around LDS-DMA could gain at most on the operand path.
+    auto glds_stage = [&](uint64_t st, int b) {
+        const uint64_t s0 = st * ST_ROWS;
+        int lr = lrow;
+        asm volatile("" : "+v"(lr));
+        VS2_FTILE(s0);
+        const uint64_t jstep = (uint64_t)RSTEP * fp, dstep = (uint64_t)K * fp;
+        const double* q0 = fb + (uint64_t)(2 + lr) * fp + 2 * piece;
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        typedef const __attribute__((address_space(1))) void* glb_ptr;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int jb = j & 3;
+            // rows past K and past the shard's last row read row 0 of the stage instead (always inside the buffer)
+            const bool in = (FULLK || lr + RSTEP * jb < K) && s0 + 2 * piece < rows;
+            const double* q = in ? q0 + jb * jstep + (j >= 4 ? dstep : 0) : fb;
+            __builtin_amdgcn_global_load_lds((glb_ptr)q, (lds_ptr)(tiles + b * STAGE + (j * 8 + wv) * 128), 16, 0, 0);
+        }
+    };
+    if (mine > 0) glds_stage(stage_of(0), 0);
+    __syncthreads();
+#else
     // stage s travels in register set s % DEPTH
     if (mine > 0) {
         fetch(stage_of(0), 0);
@@ -289,6 +316,7 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
         if (mine > 1) fetch(stage_of(1), 0);
     }
     __syncthreads();
+#endif
     // groups 0 .. NG-1 of a stage: sub-tile g / NGS of the wave's two, slots GS (g % NGS) ..; group g lives in F[g & 1]
     frags F[2];
     if (mine > 0) load_group(0, 0, F[0]);
@@ -313,8 +341,12 @@ __device__ __forceinline__ void st_body(const vs_gram_args& A, double* tiles, co
             // the next stage goes into the other buffer (everybody left it at the last barrier) while both waves
             // of the SIMD have MFMAs queued; its registers are then free for the fetch after it, which has the
             // rest of this iteration to land (positions measured: stash after group 0, fetch after group 1)
+#ifdef VS_ST_GLDS_TIMING
+            if (g == 0 && i + 1 < mine) glds_stage(stage_of(i + 1), b ^ 1);
+#else
             if (g == 0 && i + 1 < mine) stash(b ^ 1, 0);
             if (g == 1 && i + 2 < mine) fetch(stage_of(i + 2), 0);
+#endif
         }
     };
     for (uint64_t i = 0; i < mine; ++i) stage_iter(i, (int)(i & 1));
