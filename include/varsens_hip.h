@@ -38,14 +38,14 @@ extern "C" {
  * 6: vs_eval_reduce_first_second_order takes objectives with several outputs; vs_design_desc_validate.
  * 7: vs_design_desc.flags (was `reserved`, 0): VS_DESIGN_SEED1_SHUFFLE.  The field is VALIDATED from here on: a caller
  *    written against ABI <= 6 must have zeroed it (the header said "reserved, 0"); unknown bits are VS_ERR_ARG.
- * 8: the f-values on the device are ROW-BLOCKED (see "F-VALUE LAYOUT"; shards of up to 4096 rows: unchanged);
+ * 8: the f-values on the device are ROW-BLOCKED (see "F-VALUE LAYOUT"; shards of up to 2048 rows: unchanged);
  *    vs_device_info.f_shift; vs_upload_values / vs_download_values / vs_sample_rows[_begin/_wait]: objective values and
  *    sample rows cross the host boundary in the reference's layouts, converted on the device; vs_build_id;
  *    VS_ERR_NOMEM; every entry point runs under a
  *    guard that turns C++ exceptions into status codes; a design is released through the context that made it and
  *    vs_context_destroy refuses (VS_ERR_STATE) while designs of the context are alive. */
 #define VS_ABI_VERSION 8
-#define VS_F_SHIFT 12   /* default log2 of the rows per row block of the f-value layout */
+#define VS_F_SHIFT 11   /* default log2 of the rows per row block of the f-value layout */
 
 typedef enum vs_status {
     VS_OK = 0,
@@ -288,14 +288,14 @@ int vs_objective_create_separable(vs_context* ctx, int k, const char* term_body,
  * The 2(k+1) * rows * l values of a shard -- the reference's fM_1, fM_2, fN_j, fN_nj of its rows, Objective.flat()
  * (saltelli.py:357-391) transposed to one PLANE per (output o, block b), plane p = o (2k+2) + b, block order
  * [fM_1, fM_2, fN_j[0..k), fN_nj[0..k)] -- are stored row block by row block: rows [R 2^s, (R+1) 2^s) form row block R
- * (s = VS_F_SHIFT = 12: 4096 rows; vs_device_info.f_shift says what a context uses), and inside a row block the
+ * (s = VS_F_SHIFT = 11: 2048 rows; vs_device_info.f_shift says what a context uses), and inside a row block the
  * planes follow each other, each holding the row block's rows contiguously:
  *     f_dev[(R << s) * P + p * pitch_R + (r - (R << s))],   R = r >> s,  P = l (2k+2),  pitch_R = min(2^s, rows - (R << s))
  * The last row block is packed at its own row count: exactly P * rows doubles in all.  A shard of at most 2^s rows is one
  * row block -- plane after plane, f_dev[p * rows + r], the layout of ABI <= 7; for l = 1 that is Objective.flat() itself.
  * Why: a workgroup that produces or consumes a tile of rows touches every plane of those rows.  Plane-major storage puts
  * them `rows` doubles apart (k = 128, n = 2^24: 258 streams 128 MiB apart, a TLB entry and a DRAM page each); row-blocked
- * they lie within P * 32 KiB -- the evaluation of that shape stores at 6.1 instead of 4.1 TB/s.  Every block of every
+ * they lie within P * 16 KiB -- the evaluation of that shape stores at 5.6-5.9 instead of 4.1 TB/s.  Every block of every
  * output is still a set of contiguous runs, so all kernels run at the l = 1 speed for any l.
  * Host code never needs the formula: vs_upload_values / vs_download_values (below) convert between the reference's
  * (2(k+1) rows, l) arrays and this layout on the device.

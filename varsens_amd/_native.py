@@ -53,7 +53,7 @@ def first_order_len(k, l):
     return (2 + 4 * k) * l
 
 
-F_SHIFT = 12     # default log2 of the rows per row block of the f-value layout (VS_F_SHIFT, include/varsens_hip.h)
+F_SHIFT = 11     # default log2 of the rows per row block of the f-value layout (VS_F_SHIFT, include/varsens_hip.h)
 
 
 def to_device_layout(blocks, f_shift=F_SHIFT):

@@ -14,7 +14,7 @@
 
 // f-value layout (vs_device_gen.h: vs_f_tile): default and smallest log2 of the rows per row block
 #ifndef VS_F_SHIFT
-#define VS_F_SHIFT 12
+#define VS_F_SHIFT 11
 #endif
 #ifndef VS_F_SHIFT_MIN
 #define VS_F_SHIFT_MIN 11

@@ -347,7 +347,7 @@ __device__ __forceinline__ double vs_m2(const vs_design_dev& D, vs_u64 r, int c)
 
 // ---------------------------------------------------------------------------
 // The f-value layout on the device: ROW-BLOCKED (include/varsens_hip.h).  The shard's `rows` draws are cut into row
-// blocks of 2^sh rows (VS_F_SHIFT = 12: 4096); inside a row block the `planes` = l (2k+2) planes -- plane p =
+// blocks of 2^sh rows (VS_F_SHIFT = 11: 2048, the widest row tile of any kernel); inside a row block the `planes` = l (2k+2) planes -- plane p =
 // output * (2k+2) + block, block order [fM_1, fM_2, fN_j[0..k), fN_nj[0..k)] -- follow each other, each holding the
 // row block's rows contiguously:
 //     f[(R << sh) * planes + p * pitch_R + (r - (R << sh))],   R = r >> sh,   pitch_R = min(2^sh, rows - (R << sh))
@@ -355,13 +355,13 @@ __device__ __forceinline__ double vs_m2(const vs_design_dev& D, vs_u64 r, int c)
 // 2^sh rows is one row block: plane after plane, the planar layout of ABI <= 7).  Why: a workgroup that produces or
 // consumes a tile of rows touches ALL planes of those rows; plane-major (planar) storage puts them `rows` doubles
 // apart -- 258 address streams 128 MiB apart at k = 128, n = 2^24, one TLB entry and one DRAM page each -- where the
-// row-blocked form keeps them within planes * 32 KiB: the k = 128, n = 2^24 evaluation stores at 6.1 instead of
-// 4.1 TB/s (profiles/r05/eval_blocked_layout.txt).  Every kernel works on row tiles that lie inside one row block
+// row-blocked form keeps them within planes * 16 KiB: the k = 128, n = 2^24 evaluation stores at 5.6-5.9 instead of
+// 4.1 TB/s (profiles/r05/fshift_sweep.txt, eval_blocked_layout.txt).  Every kernel works on row tiles that lie inside one row block
 // (tile sizes are powers of two <= 2048 <= 2^sh, tiles aligned to their size): per tile one (base, pitch) pair,
 // wave-uniform, and the address of (plane p, i-th row of the tile) is f + base + p * pitch + i.
 // ---------------------------------------------------------------------------
 #ifndef VS_F_SHIFT
-#define VS_F_SHIFT 12          // default log2 of the rows per row block
+#define VS_F_SHIFT 11          // default log2 of the rows per row block
 #endif
 #ifndef VS_F_SHIFT_MIN
 #define VS_F_SHIFT_MIN 11      // the widest row tile of any kernel is 2048 rows (reduce_first_kernel)
