@@ -246,3 +246,38 @@ def test_sample_can_leave_numpy_seeded_as_the_reference_does(vs):
         assert numpy.array_equal(numpy.random.random(3), want)
     finally:
         numpy.random.set_state(saved)
+
+
+def test_values_in_and_out_over_random_shapes(vs, ctx):
+    """vs_upload_values / vs_download_values at random (k, n, l, shard, divisor): rows around the row-block size of the
+    layout and around the 128-row tile of the layout kernel, pieces around the 16 MiB ring slot -- always the layout numpy
+    builds, always the reference's order back"""
+    rng = numpy.random.default_rng(2024)
+    step = 1 << ctx.f_shift
+    for trial in range(40):
+        k = int(rng.integers(1, 12))
+        l = int(rng.choice([1, 1, 2, 3, 7, 33]))
+        n = int(rng.choice([1, 2, 127, 128, 129, step - 1, step, step + 1, 2 * step + 5, int(rng.integers(1, 3 * step))]))
+        if rng.random() < 0.5:
+            begin = int(rng.integers(0, n))
+            rows = int(rng.integers(0, n - begin + 1))
+        else:
+            begin, rows = 0, n
+        divide = None if rng.random() < 0.5 else (float(rng.uniform(0.5, 4.0)) if rng.random() < 0.5 or l == 1
+                                                  else rng.uniform(0.5, 4.0, l))
+        vals = rng.standard_normal((2 * n * (k + 1), l))
+        nan_rows = set()
+        for _ in range(int(rng.integers(0, 4))):
+            r = int(rng.integers(0, n))
+            vals[int(rng.integers(0, 2 * k + 2)) * n + r, 0] = numpy.nan
+            nan_rows.add(r)
+        f = ctx.alloc(8 * 2 * (k + 1) * max(rows, 1) * l)
+        lost = ctx.upload_values(vals, n, k, begin, rows, f, divide)
+        assert lost == sum(1 for r in nan_rows if begin <= r < begin + rows), (trial, k, n, l, begin, rows)
+        if rows:
+            want = vals if divide is None else vals / divide
+            got = ctx.download(f, (l * (2 * k + 2) * rows,))
+            assert numpy.array_equal(_bits(got), _bits(_device(ctx, want, k, n, l, begin, rows))), (trial, k, n, l, begin, rows)
+            back = ctx.download_values(f, rows, k, l)
+            assert numpy.array_equal(_bits(back), _bits(want.reshape(2 * k + 2, n, l)[:, begin:begin + rows].reshape(-1, l)))
+        f.free()
