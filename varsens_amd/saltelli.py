@@ -435,6 +435,8 @@ class Objective(object):
         total, step = (2 * k + 2) * rows, 0
         report = max(1, int(0.01 * total))
         chunk = _HOST_CHUNK_ROWS_VECTORIZED if self._vectorized else _HOST_CHUNK_ROWS
+        # (each chunk lives in a pinned slot of the library: at most 64 MiB of rows, whatever k is)
+        chunk = max(64, min(chunk, (64 << 20) // (8 * k)))
         spans, where = [], []
         for block in range(2 * k + 2):
             for c0 in range(0, rows, chunk):
