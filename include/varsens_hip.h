@@ -41,6 +41,7 @@ extern "C" {
  * 8: the f-values on the device are ROW-BLOCKED (see "F-VALUE LAYOUT"; shards of up to 2048 rows: unchanged);
  *    vs_device_info.f_shift; vs_upload_values / vs_download_values / vs_sample_rows[_begin/_wait]: objective values and
  *    sample rows cross the host boundary in the reference's layouts, converted on the device; vs_build_id;
+ *    vs_text_write / vs_text_read (the text wire format, threaded);
  *    VS_ERR_NOMEM; every entry point runs under a
  *    guard that turns C++ exceptions into status codes; a design is released through the context that made it and
  *    vs_context_destroy refuses (VS_ERR_STATE) while designs of the context are alive. */
@@ -321,6 +322,19 @@ int vs_eval(vs_context* ctx, const vs_design* design, const vs_objective* obj,
 int vs_upload_values(vs_context* ctx, const double* host_vals, uint64_t n, int k, int l, uint64_t row_begin,
                      uint64_t rows, const double* divide, int ndivide, double* f_dev, uint64_t* nan_rows);
 int vs_download_values(vs_context* ctx, const double* f_dev, uint64_t rows, int k, int l, double* host_vals);
+
+/* ------------------------------------------------ the text wire format (host only: no GPU, no context)
+ * Sample.export / Objective.export write their arrays with numpy.savetxt (saltelli.py:187,192,407,412): every value as
+ * '%.18e', the values of a row joined by `delimiter` (tab for samples, one space for objectives), one row per line;
+ * Sample.load / Objective.load read them with numpy.loadtxt (:217,439).  These files are how the reference fans a study
+ * out over a cluster (varsens/cluster/accre-job.sh:13).  vs_text_write produces the bytes numpy.savetxt produces, and
+ * vs_text_read the values numpy.loadtxt reads ('#' comments and blank lines skipped; delimiter NULL or "": any run of
+ * blanks), formatted / parsed on several threads (numpy: 0.5 / 0.25 us per value on one core).  vs_text_read with
+ * out = NULL only sizes the file (*rows data lines, *cols numbers in the first of them); with a buffer of `capacity`
+ * doubles it fills rows x cols values row-major and fails (VS_ERR_ARG, the row named) on a line that does not hold
+ * *cols numbers. */
+int vs_text_write(const char* path, const double* values, uint64_t rows, uint64_t cols, const char* delimiter);
+int vs_text_read(const char* path, const char* delimiter, double* out, uint64_t capacity, uint64_t* rows, uint64_t* cols);
 
 /* ------------------------------ a7-a11: the estimators (Varsens.compute_varsens)
  * Accumulator record produced per GPU and summed across GPUs.  All doubles.

@@ -12,13 +12,22 @@
 //     one that throws std::bad_alloc on the i-th allocation from now; the helpers of csrc/vs_host.h that allocate (the
 //     process-wide cache of seed-1 shuffles, the Sobol byte tables) are run with i = 0, 1, 2, ... until they succeed:
 //     every failing run must come back as VS_ERR_NOMEM with a message -- not std::terminate --, leak nothing
-//     (LeakSanitizer at exit) and leave the helper usable.
+//     (LeakSanitizer at exit) and leave the helper usable;
+//   * vs_text_write / vs_text_read (varsens/saltelli.py:187,217,407,439: numpy.savetxt / numpy.loadtxt) in a scratch
+//     directory of their own: the bytes of the special values, a threaded round trip bit for bit into a buffer of
+//     exactly rows x cols doubles, every refusal, and the same failing allocator (on whichever thread it hits).
 #include <cinttypes>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
 #include <vector>
+
+#include <unistd.h>
 
 #include <new>
 
@@ -28,13 +37,17 @@
 // ---- an allocator that fails on demand ------------------------------------------------------------------------------
 static long g_fail_in = -1;   // < 0: never; 0: the next allocation throws; i: the i-th from now
 static long g_allocations = 0;
+static std::mutex g_alloc_lock;   // (vs_text_write / vs_text_read allocate on several threads)
 static void* counted_alloc(std::size_t n) {
-    ++g_allocations;
-    if (g_fail_in == 0) {
-        g_fail_in = -1;
-        throw std::bad_alloc();
+    {
+        std::lock_guard<std::mutex> hold(g_alloc_lock);
+        ++g_allocations;
+        if (g_fail_in == 0) {
+            g_fail_in = -1;
+            throw std::bad_alloc();
+        }
+        if (g_fail_in > 0) --g_fail_in;
     }
-    if (g_fail_in > 0) --g_fail_in;
     void* p = std::malloc(n ? n : 1);
     if (!p) throw std::bad_alloc();
     return p;
@@ -253,6 +266,110 @@ int main() {
         CHECK(tabs[0] == 0 && tabs[1] == 0x80000000u && tabs[3] == 0xc0000000u && tabs[256 + 1] == 0x00800000u);
         CHECK(vs_sobol_byte_tables(0, dd.data(), &tabs) == VS_ERR_ARG);
         std::printf("sobol tables: %d allocation failures refused with VS_ERR_NOMEM\n", refused);
+    }
+    // ---- the text wire format
+    {
+        char dir[] = "/tmp/varsens_text_XXXXXX";
+        CHECK(mkdtemp(dir) != nullptr);
+        const std::string path = std::string(dir) + "/values.txt";
+        const double inf = std::numeric_limits<double>::infinity();
+        const double special[8] = {1.0, -0.0, std::nan(""), -std::nan(""), inf, -inf, 5e-324, -1.7976931348623157e308};
+        CHECK(vs_text_write(path.c_str(), special, 2, 4, "\t") == VS_OK);
+        {
+            std::FILE* fh = std::fopen(path.c_str(), "rb");
+            char text[512] = {0};
+            const size_t got = fh ? std::fread(text, 1, sizeof(text) - 1, fh) : 0;
+            if (fh) std::fclose(fh);
+            const char* expect =
+                "1.000000000000000000e+00\t-0.000000000000000000e+00\tnan\tnan\n"
+                "inf\t-inf\t4.940656458412465442e-324\t-1.797693134862315708e+308\n";
+            CHECK(got == std::strlen(expect) && std::memcmp(text, expect, got) == 0);
+        }
+        uint64_t rows = 99, cols = 99;
+        CHECK(vs_text_read(path.c_str(), "\t", nullptr, 0, &rows, &cols) == VS_OK && rows == 2 && cols == 4);
+        double* back = static_cast<double*>(std::malloc(sizeof(double) * 8));   // exactly rows x cols
+        CHECK(vs_text_read(path.c_str(), "\t", back, 8, &rows, &cols) == VS_OK);
+        CHECK(back[0] == 1.0 && back[1] == 0.0 && std::signbit(back[1]) && back[2] != back[2] && back[3] != back[3]);
+        CHECK(back[4] == inf && back[5] == -inf && back[6] == 5e-324 && back[7] == -1.7976931348623157e308);
+        CHECK(vs_text_read(path.c_str(), nullptr, back, 8, &rows, &cols) == VS_OK && back[6] == 5e-324);   // any blanks
+        CHECK(vs_text_read(path.c_str(), "\t", back, 7, &rows, &cols) == VS_ERR_ARG);                   // buffer too small
+        std::free(back);
+
+        // a file large enough for several threads, round trip bit for bit; a space as the delimiter
+        const uint64_t R = 3001, Cc = 9;
+        std::vector<double> big(R * Cc);
+        uint64_t state = 88172645463325252ull;
+        for (auto& x : big) {
+            state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+            uint64_t bits = state;
+            if (((bits >> 52) & 0x7ff) == 0x7ff) bits &= ~(1ull << 62);   // (no NaN payloads: text cannot carry them)
+            std::memcpy(&x, &bits, 8);
+        }
+        CHECK(vs_text_write(path.c_str(), big.data(), R, Cc, " ") == VS_OK);
+        double* again = static_cast<double*>(std::malloc(sizeof(double) * R * Cc));
+        CHECK(vs_text_read(path.c_str(), " ", again, R * Cc, &rows, &cols) == VS_OK && rows == R && cols == Cc);
+        CHECK(std::memcmp(again, big.data(), sizeof(double) * R * Cc) == 0);
+
+        // allocation failures, on whichever thread they land: a status code, nothing leaked, the call still usable
+        int refused = 0, done = 0;
+        for (long i = 0; i < 400 && !done; ++i) {
+            g_fail_in = i;
+            const int rc = vs_text_write(path.c_str(), big.data(), R, Cc, " ");
+            g_fail_in = -1;
+            if (rc == VS_OK) done = 1;
+            else {
+                CHECK(rc == VS_ERR_NOMEM);
+                ++refused;
+            }
+        }
+        CHECK(done && refused >= 1);
+        std::printf("text write: %d allocation failures refused with VS_ERR_NOMEM\n", refused);
+        refused = done = 0;
+        for (long i = 0; i < 400 && !done; ++i) {
+            g_fail_in = i;
+            const int rc = vs_text_read(path.c_str(), " ", again, R * Cc, &rows, &cols);
+            g_fail_in = -1;
+            if (rc == VS_OK) done = 1;
+            else {
+                CHECK(rc == VS_ERR_NOMEM);
+                ++refused;
+            }
+        }
+        CHECK(done && refused >= 1 && std::memcmp(again, big.data(), sizeof(double) * R * Cc) == 0);
+        std::printf("text read: %d allocation failures refused with VS_ERR_NOMEM\n", refused);
+        std::free(again);
+
+        // comments, blank lines, CRLF, a last line without its newline, '+' signs; then the refusals
+        {
+            std::FILE* fh = std::fopen(path.c_str(), "wb");
+            std::fputs("# header\n1 2 3\n\n   \n4 5 6 # tail\r\n+7 8e0 .9", fh);
+            std::fclose(fh);
+            double v[9];
+            CHECK(vs_text_read(path.c_str(), nullptr, v, 9, &rows, &cols) == VS_OK && rows == 3 && cols == 3);
+            CHECK(v[0] == 1 && v[5] == 6 && v[6] == 7 && v[7] == 8 && v[8] == 0.9);
+            fh = std::fopen(path.c_str(), "wb");
+            std::fputs("1 2 3\n4 5\n", fh);
+            std::fclose(fh);
+            CHECK(vs_text_read(path.c_str(), nullptr, v, 9, &rows, &cols) == VS_ERR_ARG);
+            CHECK(std::strstr(vs_last_error(), "data row 2") != nullptr);
+            fh = std::fopen(path.c_str(), "wb");
+            std::fputs("1 2 3\n4 five 6\n", fh);
+            std::fclose(fh);
+            CHECK(vs_text_read(path.c_str(), nullptr, v, 9, &rows, &cols) == VS_ERR_ARG);
+            fh = std::fopen(path.c_str(), "wb");
+            std::fclose(fh);
+            CHECK(vs_text_read(path.c_str(), nullptr, v, 9, &rows, &cols) == VS_OK && rows == 0 && cols == 0);   // empty
+        }
+        CHECK(vs_text_write(path.c_str(), nullptr, 0, 5, " ") == VS_OK);   // no rows: an empty file
+        CHECK(vs_text_read(path.c_str(), " ", nullptr, 0, &rows, &cols) == VS_OK && rows == 0);
+        CHECK(vs_text_write(path.c_str(), nullptr, 2, 2, " ") == VS_ERR_ARG);
+        CHECK(vs_text_write(nullptr, special, 2, 4, " ") == VS_ERR_ARG);
+        CHECK(vs_text_write(dir, special, 2, 4, " ") == VS_ERR_ARG);        // a directory
+        CHECK(vs_text_read(dir, " ", nullptr, 0, &rows, &cols) == VS_ERR_ARG);
+        CHECK(vs_text_read((path + ".missing").c_str(), " ", nullptr, 0, &rows, &cols) == VS_ERR_ARG);
+        CHECK(vs_text_read(path.c_str(), " ", nullptr, 0, nullptr, &cols) == VS_ERR_ARG);
+        unlink(path.c_str());
+        rmdir(dir);
     }
     std::printf("%s\n", failures ? "host checks FAILED" : "host checks ok");
     return failures ? 1 : 0;

@@ -330,6 +330,8 @@ def test_host_entry_points_under_sanitizers():
     # allocation; the helpers that allocate came back with VS_ERR_NOMEM every time, nothing leaked, nothing terminated
     assert re.search(r"seed-1 cache: [1-9]\d* allocation failures refused with VS_ERR_NOMEM", p.stdout), p.stdout[-2000:]
     assert re.search(r"sobol tables: [1-9]\d* allocation failures refused with VS_ERR_NOMEM", p.stdout)
+    assert re.search(r"text write: [1-9]\d* allocation failures refused with VS_ERR_NOMEM", p.stdout)
+    assert re.search(r"text read: [1-9]\d* allocation failures refused with VS_ERR_NOMEM", p.stdout)
 
     def fnv(a):
         h = 1469598103934665603
@@ -344,6 +346,66 @@ def test_host_entry_points_under_sanitizers():
     assert set(seen) >= {0, 1, 2, 5, 13, 1024, 2048, 2049, 100003}
     for n in (0, 1, 2, 3, 5, 13, 1024, 2047, 2048, 2049, 2050, 4097, 100003):
         assert seen[n] == fnv(orc.seed1_permutation(n)), n
+
+
+def _awkward_values(rows, cols, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((rows, cols)) * 10.0 ** rng.integers(-300, 300, (rows, cols))
+    flat = a.reshape(-1)
+    special = [np.nan, np.inf, -np.inf, -0.0, 0.0, 5e-324, -5e-324, np.finfo(float).max, np.finfo(float).tiny,
+               1.0, -1.0, 0.1, 1e22, 1e23, 9007199254740993.0, 2.2250738585072011e-308]
+    flat[:len(special)] = special[:flat.size]
+    flat[-1] = np.frombuffer(np.uint64(0xfff8000000000001).tobytes(), dtype=np.float64)[0]   # a negative NaN
+    return a
+
+
+@pytest.mark.parametrize("delimiter", ["\t", " ", ","])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (9, 1), (37, 5), (5000, 7)])
+def test_text_files_are_numpys(native, tmp_path, delimiter, shape):
+    """The text wire format of Sample.export / Objective.export (varsens/saltelli.py:187,192,407,412: numpy.savetxt,
+    '%.18e') and of .load (:217,439: numpy.loadtxt): vs_text_write gives numpy.savetxt's bytes, vs_text_read
+    numpy.loadtxt's values -- NaN of either sign, infinities, -0.0, denormals, the extremes and values whose 19th digit
+    needs correct rounding; 5000 x 7 is past the size where the work is split over threads."""
+    a = _awkward_values(*shape, seed=shape[0] * 31 + shape[1])
+    ours, theirs = str(tmp_path / "ours.txt"), str(tmp_path / "numpy.txt")
+    np.savetxt(theirs, a, delimiter=delimiter)
+    native.text_write(ours, a, delimiter)
+    assert open(ours, "rb").read() == open(theirs, "rb").read()
+    want = np.loadtxt(theirs, delimiter=delimiter, ndmin=2)
+    got = native.text_read(theirs, delimiter)
+    assert got.dtype == np.float64 and got.shape == want.shape == shape
+    assert np.array_equal(got, want, equal_nan=True) and np.array_equal(np.signbit(got), np.signbit(want))
+    finite = np.isfinite(a)
+    assert np.array_equal(got[finite], a[finite])          # 19 significant digits round-trip a double
+
+
+def test_text_files_edge_cases(native, tmp_path):
+    """What numpy.loadtxt accepts and refuses, line by line: '#' comments, blank lines, CRLF, a last line without its
+    newline, a leading '+', any run of blanks as the default delimiter, 1-D arrays one value per line; ragged rows,
+    words and missing files are errors that name the file (numpy raises ValueError / FileNotFoundError there)."""
+    VarsensHipError = native.VarsensHipError
+    path = str(tmp_path / "edge.txt")
+    open(path, "w").write("# header\n1 2 3\n\n  \n4\t 5   6 # tail\r\n+7 8e0 .9")
+    assert np.array_equal(native.text_read(path), np.loadtxt(path))
+    v = np.array([1.5, np.nan, -np.inf])
+    native.text_write(path, v)
+    np.savetxt(str(tmp_path / "np.txt"), v)
+    assert open(path, "rb").read() == open(str(tmp_path / "np.txt"), "rb").read()
+    assert native.text_read(path).shape == (3, 1)
+    native.text_write(path, np.empty((0, 4)))
+    assert os.path.getsize(path) == 0 and native.text_read(path).shape == (0, 0)
+    for bad in ("1 2 3\n4 5\n", "1 2 3\n4 5 6 7\n", "1 2 3\n4 five 6\n", "1,2,3\n"):
+        open(path, "w").write(bad)
+        with pytest.raises(VarsensHipError, match="edge.txt"):
+            native.text_read(path, " " if "," not in bad else None)
+        with pytest.raises(ValueError):
+            np.loadtxt(path)
+    with pytest.raises(VarsensHipError, match="cannot open"):
+        native.text_read(str(tmp_path / "missing.txt"))
+    with pytest.raises(VarsensHipError, match="cannot open"):
+        native.text_write(str(tmp_path / "no_such_dir" / "x.txt"), v)
+    with pytest.raises(VarsensHipError):
+        native.text_write(path, np.zeros((2, 2, 2)))
 
 
 def test_every_entry_point_is_guarded():

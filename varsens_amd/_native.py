@@ -138,6 +138,9 @@ SIGNATURES = {
     "vs_sample_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "vs_sample_rows_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]),
     "vs_sample_rows_wait": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "vs_text_write": (C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p]),
+    "vs_text_read": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                               C.POINTER(C.c_uint64)]),
     "vs_upload_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                    C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]),
     "vs_download_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]),
@@ -216,6 +219,31 @@ def _check(rc):
 def build_id():
     """vs_build_id() of the loaded library: what it was built from (varsens_amd.build.source_id)."""
     return load_library().vs_build_id().decode()
+
+
+def text_write(path, array, delimiter=" "):
+    """numpy.savetxt(path, array, delimiter=delimiter) -- the same bytes, formatted on several threads (vs_text_write;
+    host code of the engine, no GPU needed).  1-D arrays are written one value per line, as numpy does."""
+    a = np.ascontiguousarray(array, dtype=np.float64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
+    if a.ndim != 2:
+        raise VarsensHipError("text_write takes a 1-D or 2-D array")
+    _check(load_library().vs_text_write(os.fsencode(path), a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1],
+                                        delimiter.encode("utf-8")))
+
+
+def text_read(path, delimiter=None):
+    """numpy.loadtxt(path, delimiter=delimiter, ndmin=2) -- the same values, parsed on several threads (vs_text_read)."""
+    lib = load_library()
+    rows, cols = C.c_uint64(0), C.c_uint64(0)
+    d = None if not delimiter else delimiter.encode("utf-8")
+    _check(lib.vs_text_read(os.fsencode(path), d, None, 0, C.byref(rows), C.byref(cols)))
+    out = np.empty((rows.value, cols.value), dtype=np.float64)
+    if out.size:
+        _check(lib.vs_text_read(os.fsencode(path), d, out.ctypes.data_as(C.c_void_p), out.size, C.byref(rows),
+                                C.byref(cols)))
+    return out
 
 
 def seed1_permutation(n):

@@ -639,7 +639,6 @@ __device__ __forceinline__ void vs_scan_finish(const double (&ta)[TLDS ? 1 : L],
     constexpr int SUB = L < VS_SCAN_SUB ? L : VS_SCAN_SUB;
     constexpr int NSUB = L / SUB;
     static_assert(L % SUB == 0, "columns per wave must be a multiple of the suffix sub-block");
-    const double ident = FOLD == VS_OBJ_LINEAR ? 0.0 : 1.0;
 #define VS_TA(j) (TLDS ? tl[(size_t)(j) * T] : ta[TLDS ? 0 : (j)])
 #define VS_TB(j) (TLDS ? tl[(size_t)(L + (j)) * T] : tb[TLDS ? 0 : (j)])
     tot[(0 * W + q) * T + lane] = Ta;

@@ -280,7 +280,7 @@ class Sample(object):
             name = "%s%s" % (prefix, postfix) if nFiles == 1 else "%s_%d%s" % (prefix, b + 1, postfix)
             if self.verbose: print("Writing to %s ..." % name)
             rows = self._rows(b * blocksize, min(blocksize, total - b * blocksize))
-            numpy.savetxt(name, rows, delimiter=delimiter)
+            _native.text_write(name, rows, delimiter)       # numpy.savetxt's bytes (saltelli.py:187,192), threaded
 
     def load(self, indir='', loadFile=None, prefix=None, postfix='.txt', nFiles=None, offset=1, delimiter='\t'):
         files = _file_list("sample", indir, loadFile, prefix, postfix, nFiles, offset)
@@ -289,7 +289,7 @@ class Sample(object):
             if not os.path.isfile(name):
                 raise Exception("Cannot find input file " + name)
             if self.verbose: print("Reading " + name + " ...")
-            parts.append(numpy.loadtxt(name, delimiter=delimiter, ndmin=2))
+            parts.append(_native.text_read(name, delimiter))   # numpy.loadtxt's values (saltelli.py:217), threaded
         x = numpy.vstack(parts)
         n, k = self.n, self.k
         if x.shape == (2 * n, k):
@@ -504,7 +504,7 @@ class Objective(object):
         for b in range(nFiles):
             name = "%s%s" % (prefix, postfix) if nFiles == 1 else "%s_%d%s" % (prefix, b + 1, postfix)
             if self.verbose: print("Writing to %s ..." % name)
-            numpy.savetxt(name, f[b * blocksize:(b + 1) * blocksize])
+            _native.text_write(name, f[b * blocksize:(b + 1) * blocksize], " ")   # saltelli.py:407,412
 
     def load(self, obj_vals=[], indir='', loadFile=None, prefix=None, postfix='.txt', nFiles=None, offset=1,
              scaling=1.0):
@@ -518,7 +518,10 @@ class Objective(object):
                 if not os.path.isfile(name):
                     raise Exception("Cannot find input file " + name)
                 if self.verbose: print("Reading " + name + " ...")
-                parts.append(numpy.loadtxt(name))
+                part = _native.text_read(name)              # numpy.loadtxt(name) (saltelli.py:439) ...
+                if 1 in part.shape:
+                    part = part.reshape(-1)                 # ... which hands back 1-D for one column (or one line)
+                parts.append(part)
             # one observable: a list of 1-D arrays; several: 2-D arrays (saltelli.py:443-446)
             x = numpy.hstack(parts) if parts[0].ndim == 1 else numpy.vstack(parts)
         if len(x) != 2 * n * (1 + k):
