@@ -946,6 +946,93 @@ def test_fused_both_orders_coverage(ctx):
     np.testing.assert_allclose(ctx.download(acc, (n8,))[4:4 + 35], ctx.download(acc1, (n8,))[4:4 + 35], rtol=1e-12)
 
 
+def sobol_design(ctx, k, n, first, mode=0, lo=None, hi=None):
+    from varsens_amd import _native
+    from varsens_amd.saltelli import sobol_directions
+    dirs = sobol_directions(k)
+    perm = orc.seed1_permutation(n).astype(np.uint32)
+    return ctx.design_create(_native.GEN_SOBOL, k, n, first, mode, lo, hi, perm, None, dirs), dirs, perm
+
+
+# first sequence index: the QuantLib tool's 4096 skip (quantlib/sobolGen.cpp:50); one where the indices of a 1000-row
+# design cross 2^24 (the seventh and eighth nibble of the Gray code come into use) at a first index that is no multiple
+# of 64; one beyond 2^28
+SOBOL_FIRSTS = [4096, (1 << 24) - 777, (1 << 28) + 5]
+
+
+@pytest.mark.parametrize("first", SOBOL_FIRSTS)
+@pytest.mark.parametrize("k", [4, 16, 24, 32, 48, 64, 96, 128, 200])
+def test_sobol_points_through_the_evaluation_kernels(ctx, k, first):
+    """Round 5: the scan kernels take Sobol points from nibble tables in LDS (vs_sobol_points_lds).  A linear objective
+    with one unit weight per output hands the coordinates themselves back as f-values -- every block of the design (M_1,
+    M_2 behind the seed-1 shuffle, N_j, N_nj: varsens/saltelli.py:100-125) bit for bit the oracle's Gray-code XOR
+    (quantlib/sobolGen.cpp:47-60 is the reference's generator of this sequence), for every kernel shape (columns per wave
+    x waves: k = 4 .. 200), a ragged last block and the three index ranges above."""
+    from varsens_amd import _native
+    n = 1000
+    d, dirs, perm = sobol_design(ctx, k, n, first)
+    cols = sorted(set(int(c) for c in np.linspace(0, k - 1, min(k, 6))))
+    l = len(cols)
+    w = np.zeros((l, k))
+    w[np.arange(l), cols] = 1.0
+    obj = ctx.objective_create(_native.OBJ_LINEAR, k, l, w)
+    f = ctx.alloc(8 * 2 * (k + 1) * n * l)
+    ctx.eval(d, obj, 0, n, f)
+    F = ctx.download_blocks(f, k, l, n)                       # [2k+2][n][l]
+    m1 = orc.sobol(k, first, n, dirs)
+    seq2 = orc.sobol(k, first + n, n, dirs)
+    m2 = seq2[perm.astype(np.int64)]
+    same(F[0], m1[:, cols])
+    same(F[1], m2[:, cols])
+    for j in range(k):
+        nj, nnj = m2[:, cols].copy(), m1[:, cols].copy()
+        if j in cols:
+            o = cols.index(j)
+            nj[:, o], nnj[:, o] = m1[:, j], m2[:, j]
+        same(F[2 + j], nj)                                    # M_2 with column j of M_1 (saltelli.py:112-125)
+        same(F[2 + k + j], nnj)
+
+
+@pytest.mark.parametrize("first", SOBOL_FIRSTS)
+@pytest.mark.parametrize("kind,k,l", [("lin", 4, 1), ("g", 16, 1), ("poly", 24, 1), ("g", 32, 1), ("lin", 48, 1), ("g", 64, 1),
+                                      ("poly", 96, 1), ("g", 128, 1), ("lin", 16, 2), ("g", 20, 3), ("lin", 32, 4)])
+def test_sobol_designs_through_the_fused_kernels(ctx, kind, k, l, first):
+    """The fused kernels (evaluate + reduce, no f-values) on Sobol designs against evaluation + reduction of the same
+    design: record and Gram sums to summation order.  The first-order kernel of every shape (all tables in LDS up to 96
+    columns, two columns at a time beyond), the both-orders kernels of 16 / 32 / 64 / 128 index rows with one output and
+    with several (32 x 4: the instance that has no LDS left and keeps the byte tables in memory)."""
+    from varsens_amd import _native
+    n = 3000
+    rng = np.random.RandomState(k + l)
+    code = {"g": _native.OBJ_G_FUNCTION, "lin": _native.OBJ_LINEAR, "poly": _native.OBJ_POLYNOMIAL}[kind]
+    params = {"g": rng.rand(l, k) * 5, "lin": rng.rand(l, k) + 0.5, "poly": 1.0 / (1.0 + rng.rand(l, k))}[kind]
+    lo, hi = np.linspace(0.0, 0.2, k), np.linspace(0.8, 1.0, k)   # (a product of 128 terms stays of order 1)
+    d, _, _ = sobol_design(ctx, k, n, first, 1, lo, hi)
+    obj = ctx.objective_create(code, k, l, params)
+    nacc, ng = _native.acc_len(k, l, 1), _native.gram_len(k * l)
+    f = ctx.alloc(8 * 2 * (k + 1) * n * l)
+    ctx.eval(d, obj, 0, n, f)
+    acc1, acc2, acc3 = ctx.alloc(8 * nacc), ctx.alloc(8 * nacc), ctx.alloc(8 * nacc)
+    g1, g3 = ctx.alloc(8 * ng), ctx.alloc(8 * ng)
+    ctx.reduce_first_second_order(f, n, k, l, acc1, g1)
+    r1 = ctx.download(acc1, (nacc,))
+    per = _native.acc_per_output(k)
+    sums = slice(4, 4 + per * l)
+    if ctx.eval_reduce_supported(d, obj):
+        ctx.eval_reduce_first_order(d, obj, 0, n, acc2)
+        r2 = ctx.download(acc2, (nacc,))
+        assert r2[0] == n and r2[1] == 0
+        np.testing.assert_allclose(r2[sums], r1[sums], rtol=1e-11)
+    else:
+        assert l > 1 and k * l > 128
+    assert ctx.eval_reduce_both_supported(d, obj)
+    ctx.eval_reduce_first_second_order(d, obj, 0, n, acc3, g3)
+    r3 = ctx.download(acc3, (nacc,))
+    np.testing.assert_allclose(r3[sums], r1[sums], rtol=1e-11)
+    G1, G3 = ctx.download(g1, (2, k * l, k * l)), ctx.download(g3, (2, k * l, k * l))
+    np.testing.assert_allclose(G3, G1, rtol=1e-11, atol=1e-12 * np.abs(G1).max())
+
+
 def test_variance_with_outlier_in_first_value(ctx):
     """The variance shift is a leading-sample mean, not the first value: an extreme first value must not
     cost accuracy (numpy's two-pass variance is the reference, saltelli.py:583)."""

@@ -139,6 +139,39 @@ def test_separable_expression_default_call_is_one_kernel(vs, k, n, fold):
     assert w.objective._f is not None
 
 
+@pytest.mark.parametrize("k,n,fold", [(6, 5000, "prod"), (32, 3001, "sum"), (48, 2000, "prod"), (64, 1500, "sum"),
+                                      (100, 1200, "prod"), (128, 700, "sum"), (200, 300, "sum")])
+def test_separable_expression_on_a_sobol_design(vs, k, n, fold):
+    """The run-time compiled scan kernels take Sobol points from nibble tables passed through LDS (round 5: a KiB per
+    wave added to the launch for a Sobol design): evaluation bit for bit the built-in objective's on the same design,
+    the fused first-order and both-orders kernels against the two-kernel route."""
+    rng = np.random.RandomState(k + n)
+    a = rng.rand(k) * 5.0
+    if fold == "prod":
+        user = vs.objectives.SeparableExpression("return (fabs(4.0 * x - 2.0) + p[c]) / (1.0 + p[c]);", fold="prod", params=a)
+        built = vs.objectives.GFunction(a)
+    else:
+        user = vs.objectives.SeparableExpression("return p[c] * x;", fold="sum", params=a)
+        built = vs.objectives.Linear(a)
+    sc = vs.scale.Linear(0.1, 0.9)
+    s = vs.Sample(k, n, sc, verbose=False, generator='sobol')
+    ou = vs.Objective(k, n, s, user, verbose=False)
+    ob = vs.Objective(k, n, s, built, verbose=False)
+    assert np.array_equal(ou.flat(), ob.flat())
+    t = vs.Varsens(ou, verbose=False)                         # evaluation + reduction
+    if k <= 128:
+        u = vs.Varsens(user, sc, k, n, sample=vs.Sample(k, n, sc, verbose=False, generator='sobol'), verbose=False, fused=True)
+        assert u.objective._f is None                         # one kernel, no f-values
+        for f in ("E_2", "var_y", "U_j", "U_nj"):
+            np.testing.assert_allclose(getattr(u, f), getattr(t, f), rtol=1e-11, err_msg=f)
+        for f in ("sens", "sens_t", "sens_2", "sens_2n"):
+            np.testing.assert_allclose(getattr(u, f), getattr(t, f), rtol=1e-8, atol=1e-10, err_msg=f)
+        w = vs.Varsens(user, sc, k, n, sample=vs.Sample(k, n, sc, verbose=False, generator='sobol'), verbose=False, fused=True,
+                       second_order=False)
+        np.testing.assert_allclose(w.sens, t.sens, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(w.sens_t, t.sens_t, rtol=1e-8, atol=1e-10)
+
+
 def test_expression_compile_error_is_reported(vs):
     from varsens_amd._native import VarsensHipError
     s = vs.Sample(3, 8, vs.scale.Identity(), verbose=False)

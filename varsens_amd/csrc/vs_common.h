@@ -16,6 +16,7 @@
 #ifndef VS_F_SHIFT
 #define VS_F_SHIFT 11
 #endif
+#define VS_LDS_BYTES ((size_t)160 * 1024)   // LDS of a gfx950 CU: the most a workgroup can have
 #ifndef VS_F_SHIFT_MIN
 #define VS_F_SHIFT_MIN 11
 #endif
@@ -116,7 +117,7 @@ struct vs_design {
     bool perm_shared = false;  // perm belongs to ctx->perm_cache (VS_DESIGN_SEED1_SHUFFLE): released, not freed
     double* raw = nullptr;     // device (2n,k) or null
     uint32_t* dirs = nullptr;  // device (k,32) or null
-    uint32_t* sobol_tabs = nullptr;  // device (k,4,256): XOR of the direction integers selected by each byte value
+    uint32_t* sobol_tabs = nullptr;  // device (k,4,256): XOR of the direction integers selected by each byte value; then (k,8,16): by each nibble
     uint32_t* bases = nullptr; // device, k x vs_base (vs_device_gen.h)
     int halton_horner = 0;     // every column's record carries VS_BASE_HORNER (vs_radical_inverse_pair_horner is exact)
 };
@@ -148,16 +149,17 @@ struct vs_objective {
 
 int vs_rtc_build(vs_context* ctx, vs_objective* o, const char* body, int fold);
 void vs_rtc_release(vs_objective* o);
+// (sobol: the launch is for a Sobol design -- the scan-form kernels then get a KiB of LDS per wave for its nibble tables)
 int vs_rtc_launch(vs_context* ctx, const vs_objective* o, const void* eval_args, size_t eval_args_bytes,
-                  unsigned blocks, size_t lds);
+                  unsigned blocks, size_t lds, bool sobol);
 int vs_rtc_launch_fused(vs_context* ctx, const vs_objective* o, const void* eval_args, size_t eval_args_bytes,
-                        unsigned P, const double* shift_dev);
+                        unsigned P, const double* shift_dev, bool sobol);
 // launch shape of the scan kernels for k columns (vs_scan.hip); false: k is outside them
 bool vs_scan_shape(int k, bool fused, int* L, int* W, int* tlds, size_t* lds_bytes);
-int vs_rtc_fused_plan(vs_context* ctx, const vs_objective* o, uint64_t rows, unsigned* P_out);
-int vs_rtc_gram_plan(vs_context* ctx, const vs_objective* o, uint64_t rows, unsigned* P_out);
+int vs_rtc_fused_plan(vs_context* ctx, const vs_objective* o, uint64_t rows, unsigned* P_out, bool sobol);
+int vs_rtc_gram_plan(vs_context* ctx, const vs_objective* o, uint64_t rows, unsigned* P_out, bool sobol);
 int vs_rtc_launch_gram(vs_context* ctx, const vs_objective* o, const void* eval_args, size_t eval_args_bytes,
-                       unsigned P, const double* shift_dev, double* first_partials, double* gram_partials);
+                       unsigned P, const double* shift_dev, double* first_partials, double* gram_partials, bool sobol);
 
 #define VS_HIP(call)                                                                        \
     do {                                                                                    \

@@ -295,7 +295,7 @@ struct vs_design_dev {
     vs_u64 perm_begin;
     const double* raw;
     const vs_u32* dirs;
-    const vs_u32* sobol_tabs;
+    const vs_u32* sobol_tabs;   // byte tables [k][4][256], then nibble tables [k][8][16] (VS_SOBOL_NIB words per column)
     const vs_base* bases;
 };
 

@@ -241,6 +241,79 @@ __device__ __forceinline__ void vs_head_add_lds(double* __restrict__ heads, int 
 // wait.  Interleaved, every wave gets one column of each run of W primes.  The folds run in scan-position order.
 #define VS_SCAN_COLUMN(q, j, W) ((j) * (W) + (q))
 
+// Round 5: the look-ups from LDS.  A 64-lane gather costs the texture path ~54 clocks whatever its addresses, on the one
+// such unit a CU has (see vs_scan_block); the same gather from LDS is a ds_read_b32 -- two clocks of the LDS pipe when
+// the lanes' addresses fall into one 64-byte table: 16 banks, equal addresses broadcast.  So the points come from NIBBLE
+// tables (8 positions x 16 entries x 4 B = 512 B per column; the design keeps them behind its byte tables) in LDS of
+// the wave's own, and a point is the XOR of 6 ds_read_b32 (8 beyond 2^24 indices) whose addresses are the lane's nibbles
+// (one VGPR per position and point, the same for every column) + a compile-time offset.  Two ways (SNIB, vs_scan_block):
+//   2: the tables of all L columns of the wave, staged once per kernel (vs_scan_body) -- the persistent fused kernels, W L
+//      512 B beside their slabs (16 KiB at 32 columns, 48 at 96);
+//   1: ONE KiB per wave, through which the tables pass two columns at a time, every 64-row block: a wave-wide 16-byte
+//      load fetches the pair after next, the pair before it is written over the slot -- LDS operations of a wave complete
+//      in order, so the look-ups of the pair that was there are done, no barrier.  Where whole tables have no room (64
+//      KiB at 128 columns: beside the terms of the fused kernel of 97 .. 128 columns, the tiles of the both-orders
+//      kernels) and in the evaluation kernels, one block per workgroup, where it is the same fetch.
+// All look-ups of a block are issued AHEAD of the column loop, as the gathers were: scalar loads and LDS share a counter,
+// and the column loop waits for its scalar prefetch (all of the counter: scalar loads answer out of order) once per
+// column -- look-ups issued a column ahead inside the loop were drained a few instructions later, their latency in the
+// open eight times per block instead of once (k = 32 fused: 0.337 ms against 0.284).
+#define VS_SOBOL_NIB 128   // words per column
+#ifndef VS_SOBOL_GROUP
+#define VS_SOBOL_GROUP 2   // columns whose look-ups are in flight together (vs_sobol_points_lds)
+#endif
+#define VS_SOBOL_LDS_BYTES(SNIB, L, W) ((size_t)(W) * ((SNIB) == 2 ? (L) : (SNIB) == 1 ? 2 : 0) * VS_SOBOL_NIB * 4)
+
+// the lane's piece of the tables of scan positions j0, j0 + 1 (lanes 0 .. 31: j0, 32 .. 63: j0 + 1)
+template <int W>
+__device__ __forceinline__ uint4 vs_sobol_fetch(const vs_design_dev& D, int q, int lane, int j0) {
+    int c = VS_SCAN_COLUMN(q, j0 + (lane >> 5), W);
+    c = c < D.k ? c : D.k - 1;   // (scan positions beyond k: some column's tables, never used; a branch here is a branch per pair)
+    return *(const uint4*)(D.sobol_tabs + 1024 * (size_t)D.k + (size_t)c * VS_SOBOL_NIB + 4 * (lane & 31));
+}
+__device__ __forceinline__ void vs_sobol_put(vs_u32* __restrict__ slot, int lane, uint4 v) {
+    *(uint4*)(slot + 4 * lane) = v;   // (lane >> 5) * 128 + 4 * (lane & 31)
+    // no instruction: ends the compiler's search for stores that might clobber the design constants loaded further
+    // down (see the zeroing of the sums' slab in vs_scan_body)
+    __builtin_amdgcn_wave_barrier();
+}
+// g: Gray code of the point's index; col: the column's 128 words in LDS; NN: nibble positions read -- 6, or 8 for designs
+// beyond 2^24 indices (a position beyond the design's Gray-code bits holds nibble 0, whose entry is 0: no test inside,
+// a branch around a look-up would put a wait for LDS in front of what follows)
+template <int NN>
+__device__ __forceinline__ vs_u32 vs_sobol_bits_lds(vs_u32 g, const vs_u32* __restrict__ col) {
+    vs_u32 x = 0u;
+#pragma unroll
+    for (int b = 0; b < NN; ++b) x ^= col[16 * b + ((g >> (4 * b)) & 15u)];
+    return x;
+}
+// the bits of the two points (Gray codes g1, g2) of the wave's L columns
+template <int SNIB, int NN, int L, int W>
+__device__ __forceinline__ void vs_sobol_points_lds(const vs_design_dev& D, vs_u32* __restrict__ snib, int q, int lane, vs_u32 g1,
+                                                    vs_u32 g2, vs_u32 (&sx1)[L], vs_u32 (&sx2)[L]) {
+    static_assert(L % 2 == 0, "the Sobol tables pass through LDS two columns at a time");
+    constexpr int GROUP = (L == 8 && W == 4) ? 1 : VS_SOBOL_GROUP;
+    uint4 pre = {0u, 0u, 0u, 0u};
+    if (SNIB == 1) {
+        vs_sobol_put(snib, lane, vs_sobol_fetch<W>(D, q, lane, 0));
+        if (L > 2) pre = vs_sobol_fetch<W>(D, q, lane, 2);
+    }
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        if (SNIB == 1 && j > 0 && j % 2 == 0) {
+            vs_sobol_put(snib, lane, pre);
+            if (j + 2 < L) pre = vs_sobol_fetch<W>(D, q, lane, j + 2);
+        }
+        const vs_u32* col = snib + (SNIB == 1 ? j & 1 : j) * VS_SOBOL_NIB;
+        sx1[j] = vs_sobol_bits_lds<NN>(g1, col);   // (columns beyond k: whatever the slot holds; never used)
+        sx2[j] = vs_sobol_bits_lds<NN>(g2, col);
+        // two columns' look-ups in flight (24 .. 32 registers), not all L: left alone the compiler issues every look-up
+        // of the block before the first XOR, 12 L results in registers (four at a time measured the same: 0.397 ms at
+        // k = 64 either way); one where the kernel is held to 128 registers (four waves x 8 columns)
+        if (j % GROUP == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---- fused evaluate + BOTH orders (NBH > 0; k <= 16 NBH <= 32 columns, one output, four waves) -----------------
 // Instead of storing c_i, d_i the output walk writes s_i = c_i + d_i and t_i = c_i - d_i of the block's 64 rows
 // into an LDS tile [index row][sample row = lane]: s_i at tile row i, t_i at 16 NBH + i (rows i >= k stay zero),
@@ -795,12 +868,16 @@ __device__ __forceinline__ void vs_scan_gram_outputs(const vs_eval_args& A, cons
 // MULTI with NBH > 0 (the fused both-orders kernels, up to LMAX outputs): every output's s, t rows go into the one
 // Gram tile (index row = column * l + output), its a, b into their own two tile rows; `shifts`: LMAX variance shifts.
 template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV, int NBH = 0, int SLDS = 0,
-          int LMAX = 1>
+          int LMAX = 1, int SNIB = 0>
 __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const double* __restrict__ params,
                                               int q, int lane, vs_u64 rb, double* __restrict__ tot,
                                               double* __restrict__ tl, double* __restrict__ fplane, double shift,
                                               vs_scan_acc<L, W>& acc, double* __restrict__ gt = nullptr,
-                                              double* __restrict__ sl = nullptr, double* __restrict__ shifts = nullptr) {
+                                              double* __restrict__ sl = nullptr, double* __restrict__ shifts = nullptr,
+                                              vs_u32* __restrict__ snib = nullptr) {
+    // SNIB: Sobol points come from nibble tables in snib, the wave's own LDS (vs_sobol_points_lds) -- 1: a KiB through
+    // which the tables pass two columns at a time, every block; 2: the tables of all L columns, staged once per kernel
+    // (vs_scan_body) --; 0: from the byte tables in memory
     constexpr int T = VS_EVAL_ROWS;
     // q is loop-invariant in the persistent walk; tied to the block index here, or the optimiser hoists
     // every column's addresses and masks (all derived from q) out of that loop and spills scalars for
@@ -840,34 +917,40 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     // GENV 1 / 2: Halton below 2^32 with identity / linear scaling -- straight-line code per column;
     // GENV 0: any generator and scaling, decided by (wave-uniform) branches per column (fused: no power scaling);
     // GENV 3: as 0, power scaling included also when fused.
-    // Sobol designs (the general column code): a point is the XOR of three or four table entries, i.e. gathers.  The
-    // look-ups of ALL the wave's columns are issued here, ahead of the column loop, which then only converts (taken
-    // column by column between the scheduling barriers below, a wave sat their latency out once per column), and the M_1
-    // point of a block with aligned consecutive indices takes one look-up instead of three (vs_sobol_block).  Measured
-    // (round 4, tools/sobol_vs_halton.py): fused first order k = 32, n = 2^22 0.493 -> 0.448 ms (Halton: 0.378), k = 64,
-    // n = 2^21 0.84 (Halton 0.46), k = 128, n = 2^20 0.883 -> 0.863 (0.443).  What is left is the texture path itself: a
-    // 64-lane dword gather costs it ~54 clocks whatever the addresses (nibble tables -- one cache line per look-up, twice
-    // as many look-ups -- were SLOWER: 0.95 ms at k = 128), and it is one unit per CU where Halton's digit loops run on
-    // four SIMDs.  The other way round -- the M_2 point as a GF(2) product on the vector ALU, three instructions per
-    // Gray-code bit with the direction integers as scalar operands, no look-up -- was tried too and is worse still
-    // (k = 32 fused 0.621 ms, k = 64 1.036, k = 128 1.085): the fused kernels have no vector-ALU slack to take 69 more
-    // instructions per point, the look-ups at least run beside it.  (profiles/r04/sobol_vs_halton.txt)
+    // Sobol designs (the general column code): a point is the XOR of table entries selected by the Gray code of its
+    // index.  The look-ups of ALL the wave's columns are issued here, ahead of the column loop, which then only converts.
+    // SNIB != 0 (round 5, vs_sobol_points_lds): nibble tables in LDS.  SNIB == 0 (the instances with no LDS to spare, the
+    // run-time compiled kernels): byte tables in memory, three or four 64-lane gathers per point -- the M_1 point of a
+    // block with aligned consecutive indices takes one instead of three (vs_sobol_block) -- at ~54 clocks of the CU's one
+    // texture unit each, whatever the addresses: round 4 measured 0.448 ms (k = 32, n = 2^22, fused first order; Halton
+    // 0.378), 0.84 (k = 64, n = 2^21; 0.46), 0.863 (k = 128, n = 2^20; 0.443), nibble tables IN MEMORY slower still (one
+    // cache line per look-up, twice as many look-ups: 0.95 ms at k = 128), and the M_2 point as a GF(2) product on the
+    // vector ALU (three instructions per Gray-code bit, no look-up) worse (0.621 / 1.036 / 1.085): profiles/r04/
+    // sobol_vs_halton.txt.  From LDS: 0.275 / 0.396 / 0.464 ms, less than Halton's points cost the same column code
+    // (0.364 / 0.497 / 0.516): profiles/r05/sobol_lds.txt.
     vs_sobol_block sobol_block = {false, 0u, 0u};
     vs_u32 sx1[L], sx2[L];
     bool sobol = false;
     if constexpr (GENV == 0 || GENV == 3) {
         sobol = A.D.generator == VS_GEN_SOBOL;   // wave-uniform
         if (sobol) {
-            sobol_block = vs_sobol_block_of(A.D, r, lane);
+            if constexpr (SNIB != 0) {
+                const vs_u32 i1 = (vs_u32)(A.D.first_index + r), i2 = (vs_u32)(A.D.first_index + A.D.n + src2);
+                const vs_u32 g1 = i1 ^ (i1 >> 1), g2 = i2 ^ (i2 >> 1);
+                if (A.D.sobol_bits <= 24) vs_sobol_points_lds<SNIB, 6, L, W>(A.D, snib, q, lane, g1, g2, sx1, sx2);   // wave-uniform
+                else vs_sobol_points_lds<SNIB, 8, L, W>(A.D, snib, q, lane, g1, g2, sx1, sx2);
+            } else {
+                sobol_block = vs_sobol_block_of(A.D, r, lane);
 #pragma unroll
-            for (int j = 0; j < L; ++j) {
-                const int c = VS_SCAN_COLUMN(q, j, W);
-                sx1[j] = sx2[j] = 0u;
-                if (c < k) {
-                    const vs_u32* tab = A.D.sobol_tabs + 1024 * c;
-                    sx1[j] = sobol_block.fast ? vs_sobol_bits_block(sobol_block, tab, A.D.sobol_bits)
-                                              : vs_sobol_bits_tab(A.D.first_index + r, tab, A.D.sobol_bits);
-                    sx2[j] = vs_sobol_bits_tab(A.D.first_index + A.D.n + src2, tab, A.D.sobol_bits);
+                for (int j = 0; j < L; ++j) {
+                    const int c = VS_SCAN_COLUMN(q, j, W);
+                    sx1[j] = sx2[j] = 0u;
+                    if (c < k) {
+                        const vs_u32* tab = A.D.sobol_tabs + 1024 * c;
+                        sx1[j] = sobol_block.fast ? vs_sobol_bits_block(sobol_block, tab, A.D.sobol_bits)
+                                                  : vs_sobol_bits_tab(A.D.first_index + r, tab, A.D.sobol_bits);
+                        sx2[j] = vs_sobol_bits_tab(A.D.first_index + A.D.n + src2, tab, A.D.sobol_bits);
+                    }
                 }
             }
         }
@@ -995,7 +1078,8 @@ struct vs_scan_lds {
 // scratch memory once per block, each reload behind `s_waitcnt vmcnt(0)`.  With the sums of its last column (two or
 // four columns for the general generator paths; VS_SCAN_SUMS_IN_LDS, vs_scan_impl.h) in LDS, 2 KiB per wave and
 // column: no scratch, same bits (the same fma chain per lane, whichever memory holds the running value).
-template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI = false, int GENV = 0, int SLDS = 0>
+template <class Term, int FOLD, int L, int W, bool FUSED, bool TLDS, bool MULTI = false, int GENV = 0, int SLDS = 0,
+          int SNIB = 0>
 __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __restrict__ lds,
                                              const double* __restrict__ shift_src, double* __restrict__ partials) {
     constexpr int T = VS_EVAL_ROWS;
@@ -1023,6 +1107,14 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
         // workgroup barrier does behind the totals.
         if (SLDS > 0) __builtin_amdgcn_wave_barrier();
     }
+    // Sobol designs (SNIB): the wave's LDS for the nibble tables (vs_sobol_points_lds), behind the kernel's slabs
+    vs_u32* const snib = (vs_u32*)(lds + vs_scan_lds<L, W, TLDS, SLDS>::doubles) + (size_t)q * ((SNIB == 2 ? L : 2) * VS_SOBOL_NIB);
+    if constexpr (SNIB == 2) {
+        if (A.D.generator == VS_GEN_SOBOL) {   // wave-uniform
+#pragma unroll
+            for (int j0 = 0; j0 < L; j0 += 2) vs_sobol_put(snib + j0 * VS_SOBOL_NIB, lane, vs_sobol_fetch<W>(A.D, q, lane, j0));
+        }
+    }
     const vs_u64 nblocks = (A.rows + T - 1) / T;
     int parity = 0;
     // two totals slabs: a wave may publish the totals of block n+1 while slower waves still read
@@ -1030,9 +1122,9 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
     // (one slab: a second barrier closes the block instead.)
     if (FUSED) {
         for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-            vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, false, GENV, 0, SLDS>(A, params, q, lane, rb,
-                                                                               lds + parity * (2 * W * T), tl, fplane, shift,
-                                                                               acc, nullptr, sl);
+            vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, false, GENV, 0, SLDS, 1, SNIB>(A, params, q, lane, rb,
+                                                                                        lds + parity * (2 * W * T), tl, fplane,
+                                                                                        shift, acc, nullptr, sl, nullptr, snib);
             if (TLDS) __syncthreads();
             else parity ^= 1;
         }
@@ -1040,8 +1132,8 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
         // one block per workgroup: every load of design constants then precedes every store of the
         // kernel, so the compiler may take them through the scalar cache (a persistent walk makes them
         // "possibly clobbered" and turns them into vector loads with a wait per column)
-        vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, MULTI, GENV>(A, params, q, lane, blockIdx.x, lds, tl, fplane, shift,
-                                                                  acc);
+        vs_scan_block<Term, FOLD, L, W, FUSED, TLDS, MULTI, GENV, 0, 0, 1, SNIB>(A, params, q, lane, blockIdx.x, lds, tl, fplane,
+                                                                                 shift, acc, nullptr, nullptr, nullptr, snib);
     }
     if (FUSED) {
         const size_t plen = 5 + 4 * (size_t)k;
@@ -1071,7 +1163,7 @@ __device__ __forceinline__ void vs_scan_body(const vs_eval_args& A, double* __re
 // tile, a_o and b_o into rows of their own behind the index rows; a lane's first-order dot products take the a, b of
 // its index row's output.  LDS: totals [slabs][2][4][64] (one slab; two with several outputs), then the tile
 // [32 NBH + 2 LMAX][68].  Partials: first_partials[blockIdx.x][l][5 + 4k], gram_partials as before (16 NBH >= k l).
-template <class Term, int FOLD, int L, int NBH, int GENV, int LMAX = 1>
+template <class Term, int FOLD, int L, int NBH, int GENV, int LMAX = 1, int SNIB = 0>
 __device__ __forceinline__ void vs_scan_gram_body(const vs_eval_args& A, double* __restrict__ lds,
                                                   const double* __restrict__ shift_src,
                                                   double* __restrict__ first_partials,
@@ -1099,12 +1191,20 @@ __device__ __forceinline__ void vs_scan_gram_body(const vs_eval_args& A, double*
     G.pa = G.pb = 0.0;
     // the wave's index rows: block (q & 1) of its half at NBH = 2, block 0 at NBH = 1
     const int abrow = MULTI ? vs_gram_abrow((NBH == 2 ? 16 * (q & 1) : 0) + (lane & 15), l) : 0;
+    // Sobol designs (SNIB): the wave's LDS for the nibble tables (vs_sobol_points_lds), behind everything else
+    vs_u32* const snib = (vs_u32*)(lds + VS_GT_LDS_DOUBLES(W, NBH, LMAX)) + (size_t)q * ((SNIB == 2 ? L : 2) * VS_SOBOL_NIB);
+    if constexpr (SNIB == 2) {
+        if (A.D.generator == VS_GEN_SOBOL) {   // wave-uniform
+#pragma unroll
+            for (int j0 = 0; j0 < L; j0 += 2) vs_sobol_put(snib + j0 * VS_SOBOL_NIB, lane, vs_sobol_fetch<W>(A.D, q, lane, j0));
+        }
+    }
     __syncthreads();
     const vs_u64 nblocks = (A.rows + T - 1) / T;
     for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-        vs_scan_block<Term, FOLD, L, W, true, false, MULTI, GENV, NBH, 0, LMAX>(A, A.params, q, lane, rb, lds, nullptr,
-                                                                                nullptr, shift0, acc, tile + lane,
-                                                                                nullptr, shifts);
+        vs_scan_block<Term, FOLD, L, W, true, false, MULTI, GENV, NBH, 0, LMAX, SNIB>(A, A.params, q, lane, rb, lds, nullptr,
+                                                                                      nullptr, shift0, acc, tile + lane,
+                                                                                      nullptr, shifts, snib);
         __syncthreads();
         vs_gram_consume<NBH>(tile, q, lane, G, abrow);
     }
@@ -1116,7 +1216,7 @@ __device__ __forceinline__ void vs_scan_gram_body(const vs_eval_args& A, double*
 // Partials: first_partials[blockIdx.x][5 + 4k], gram_partials[blockIdx.x][2][16 NB][16 NB].
 // LMAX > 1: the instance for 2 .. LMAX outputs (see vs_scan_gram_body): NB waves x 8 columns (k <= 8 NB: at least two
 // outputs share the 16 NB index rows), NBL = ceil(k l / 16) live blocks.
-template <class Term, int FOLD, int GENV, int NB, int NBL, int LMAX = 1>
+template <class Term, int FOLD, int GENV, int NB, int NBL, int LMAX = 1, int SNIB = 0>
 __device__ __forceinline__ void vs_scan_gramn_body(const vs_eval_args& A, double* __restrict__ lds,
                                                    const double* __restrict__ shift_src,
                                                    double* __restrict__ first_partials,
@@ -1144,12 +1244,20 @@ __device__ __forceinline__ void vs_scan_gramn_body(const vs_eval_args& A, double
 #pragma unroll
     for (int i = 0; i < NB + 1; ++i) G.acc[i] = (vs_d4){0.0, 0.0, 0.0, 0.0};
     G.pas = G.pbs = G.pat = G.pbt = 0.0;
+    // Sobol designs (SNIB): the wave's LDS for the nibble tables (vs_sobol_points_lds), behind everything else
+    vs_u32* const snib = (vs_u32*)(lds + VS_GT_LDS_DOUBLES(W, NBH, LMAX)) + (size_t)q * ((SNIB == 2 ? L : 2) * VS_SOBOL_NIB);
+    if constexpr (SNIB == 2) {
+        if (A.D.generator == VS_GEN_SOBOL) {   // wave-uniform
+#pragma unroll
+            for (int j0 = 0; j0 < L; j0 += 2) vs_sobol_put(snib + j0 * VS_SOBOL_NIB, lane, vs_sobol_fetch<W>(A.D, q, lane, j0));
+        }
+    }
     __syncthreads();
     const vs_u64 nblocks = (A.rows + T - 1) / T;
     for (vs_u64 rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-        vs_scan_block<Term, FOLD, L, W, true, false, MULTI, GENV, NBH, 0, LMAX>(A, A.params, q, lane, rb, lds, nullptr,
-                                                                                nullptr, shift0, acc, tile + lane,
-                                                                                nullptr, shifts);
+        vs_scan_block<Term, FOLD, L, W, true, false, MULTI, GENV, NBH, 0, LMAX, SNIB>(A, A.params, q, lane, rb, lds, nullptr,
+                                                                                      nullptr, shift0, acc, tile + lane,
+                                                                                      nullptr, shifts, snib);
         __syncthreads();
         vs_gramn_consume<NB, NBL, MULTI>(tile, q, lane, G, abs, abt);
     }

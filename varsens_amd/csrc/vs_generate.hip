@@ -374,6 +374,15 @@ extern "C" int vs_design_create(vs_context* ctx, const vs_design_desc* desc, vs_
         std::vector<uint32_t> tabs;
         rc = vs_sobol_byte_tables(k, desc->sobol_directions, &tabs);
         if (rc) return bail(rc);
+        // ... and nibble tables behind them, [k][8][16]: entry v of nibble position b = the XOR of the direction integers
+        // 4b .. 4b + 3 selected by v -- what the scan kernels keep in LDS (vs_sobol_stage): byte b's entries v and 16 v
+        tabs.resize((size_t)k * 1024 + (size_t)k * 128);
+        for (int c = 0; c < k; ++c)
+            for (int b = 0; b < 4; ++b)
+                for (int v = 0; v < 16; ++v) {
+                    tabs[(size_t)k * 1024 + ((size_t)c * 8 + 2 * b) * 16 + v] = tabs[((size_t)c * 4 + b) * 256 + v];
+                    tabs[(size_t)k * 1024 + ((size_t)c * 8 + 2 * b + 1) * 16 + v] = tabs[((size_t)c * 4 + b) * 256 + 16 * v];
+                }
         VS_TRY(hipMalloc(&g->sobol_tabs, sizeof(uint32_t) * tabs.size()));
         VS_TRY(hipMemcpy(g->sobol_tabs, tabs.data(), sizeof(uint32_t) * tabs.size(), hipMemcpyHostToDevice));
     }
@@ -949,7 +958,7 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
     unsigned P = 1;
     int rc = VS_OK;
     if (route == FUSED_ISHIGAMI) P = vs_fused_ishigami_workgroups(ctx, row_count);
-    else if (route == FUSED_USER) rc = vs_rtc_fused_plan(ctx, obj, row_count, &P);
+    else if (route == FUSED_USER) rc = vs_rtc_fused_plan(ctx, obj, row_count, &P, A.D.generator == VS_GEN_SOBOL);
     else rc = vs_scan_fused_plan(ctx, A, &P);
     if (rc) return rc;
     const size_t plen = VS_PLEN(k), width = (size_t)l * plen;
@@ -964,7 +973,7 @@ extern "C" int vs_eval_reduce_first_order(vs_context* ctx, const vs_design* desi
     switch (route) {
         case FUSED_SCAN: rc = vs_scan_fused(ctx, A, P, shift_buf); break;
         case FUSED_ISHIGAMI: rc = vs_fused_ishigami(ctx, A, P, shift_buf, nullptr); break;
-        case FUSED_USER: rc = vs_rtc_launch_fused(ctx, obj, &A, sizeof(A), P, shift_buf); break;
+        case FUSED_USER: rc = vs_rtc_launch_fused(ctx, obj, &A, sizeof(A), P, shift_buf, A.D.generator == VS_GEN_SOBOL); break;
         default: break;
     }
     if (rc) return rc;
@@ -1064,7 +1073,7 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     unsigned P = 1;
     int rc = VS_OK;
     if (route == FUSED_ISHIGAMI) P = vs_fused_ishigami_workgroups(ctx, row_count);
-    else if (route == FUSED_USER) rc = vs_rtc_gram_plan(ctx, obj, row_count, &P);
+    else if (route == FUSED_USER) rc = vs_rtc_gram_plan(ctx, obj, row_count, &P, A.D.generator == VS_GEN_SOBOL);
     else if (multi) rc = vs_scan_gram_multi_launch(ctx, A, nbh, &P, nullptr, nullptr, nullptr, true);
     else if (wide) rc = nbh == 8 ? vs_scan_gram8_launch(ctx, A, &P, nullptr, nullptr, nullptr, true)
                                  : vs_scan_gram4_launch(ctx, A, &P, nullptr, nullptr, nullptr, true);
@@ -1085,7 +1094,8 @@ extern "C" int vs_eval_reduce_first_second_order(vs_context* ctx, const vs_desig
     if (route == FUSED_ISHIGAMI) {   // its kernel writes 3 x 3 entries of every 16 x 16 block; the fold reads only those
         rc = vs_fused_ishigami(ctx, A, P, shift_buf, gram_partials);
     } else if (route == FUSED_USER) {
-        rc = vs_rtc_launch_gram(ctx, obj, &A, sizeof(A), P, shift_buf, ctx->partials, gram_partials);
+        rc = vs_rtc_launch_gram(ctx, obj, &A, sizeof(A), P, shift_buf, ctx->partials, gram_partials,
+                                A.D.generator == VS_GEN_SOBOL);
     } else if (multi) {
         rc = vs_scan_gram_multi_launch(ctx, A, nbh, &P, shift_buf, ctx->partials, gram_partials, false);
     } else if (wide) {
@@ -1149,7 +1159,7 @@ extern "C" int vs_eval(vs_context* ctx, const vs_design* design, const vs_object
             VS_REQUIRE(blocks <= 0x7fffffffull, "too many rows for one launch");
             VS_REQUIRE(!obj->eval_scan || design_compact(design),
                        "separable source objectives need Halton indices below 2^32 (or a context in strict evaluation order)");
-            return vs_rtc_launch(ctx, obj, &A, sizeof(A), (unsigned)blocks, lds);
+            return vs_rtc_launch(ctx, obj, &A, sizeof(A), (unsigned)blocks, lds, A.D.generator == VS_GEN_SOBOL);
         }
     }
     return vs_fail(VS_ERR_ARG, "unknown objective kind %d", obj->kind);

@@ -24,7 +24,9 @@ struct vs_user_term_t {
 extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_USER_FUSED_W)
 vs_user_fused(vs_eval_args A, const double* shift_src, double* partials, unsigned* counters) {
     extern __shared__ double lds[];
-    vs_scan_body<vs_user_term_t, VS_USER_FOLD_KIND, VS_USER_FUSED_L, VS_USER_FUSED_W, true, VS_USER_FUSED_TLDS>(
+    // (the last argument: Sobol points from nibble tables passed through a KiB of LDS per wave, which the host adds to
+    // the launch for a Sobol design -- vs_sobol_points_lds, vs_device_scan.h)
+    vs_scan_body<vs_user_term_t, VS_USER_FOLD_KIND, VS_USER_FUSED_L, VS_USER_FUSED_W, true, VS_USER_FUSED_TLDS, false, 0, 0, 1>(
         A, lds, shift_src, partials);
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the fold that follows (see scan_kernel)
         counters[0] = 0;
@@ -45,11 +47,11 @@ extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS * VS_USER_GRAM_NBH) __
 vs_user_gram(vs_eval_args A, const double* shift_src, double* first_partials, double* gram_partials, unsigned* counters) {
     extern __shared__ double lds[];
 #if VS_USER_GRAM_NBH <= 2
-    vs_scan_gram_body<vs_user_term_t, VS_USER_FOLD_KIND, VS_USER_GRAM_L, VS_USER_GRAM_NBH, 0>(A, lds, shift_src,
-                                                                                             first_partials, gram_partials);
+    vs_scan_gram_body<vs_user_term_t, VS_USER_FOLD_KIND, VS_USER_GRAM_L, VS_USER_GRAM_NBH, 0, 1, 1>(A, lds, shift_src,
+                                                                                                   first_partials, gram_partials);
 #else   // 33 .. 128 columns: NBH waves x 16 columns, body compiled for VS_USER_GRAM_NBL live 16-row blocks
-    vs_scan_gramn_body<vs_user_term_t, VS_USER_FOLD_KIND, 0, VS_USER_GRAM_NBH, VS_USER_GRAM_NBL>(A, lds, shift_src,
-                                                                                                first_partials, gram_partials);
+    vs_scan_gramn_body<vs_user_term_t, VS_USER_FOLD_KIND, 0, VS_USER_GRAM_NBH, VS_USER_GRAM_NBL, 1, 1>(A, lds, shift_src,
+                                                                                                      first_partials, gram_partials);
 #endif
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the folds that follow (see scan_kernel)
         counters[0] = 0;
@@ -64,8 +66,8 @@ vs_user_gram(vs_eval_args A, const double* shift_src, double* first_partials, do
 #if VS_USER_EVAL_SCAN
 extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_USER_EVAL_W) vs_user_eval(vs_eval_args A, double* scratch) {
     extern __shared__ double lds[];
-    vs_scan_body<vs_user_term_t, VS_USER_FOLD_KIND, VS_USER_EVAL_L, VS_USER_EVAL_W, false, false>(A, lds, nullptr,
-                                                                                                 nullptr);
+    vs_scan_body<vs_user_term_t, VS_USER_FOLD_KIND, VS_USER_EVAL_L, VS_USER_EVAL_W, false, false, false, 0, 0, 1>(A, lds, nullptr,
+                                                                                                                 nullptr);
 }
 #else
 extern "C" __global__ void __launch_bounds__(VS_EVAL_ROWS* VS_EVAL_WAVES) vs_user_eval(vs_eval_args A, double* scratch) {

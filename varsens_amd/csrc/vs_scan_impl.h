@@ -87,12 +87,25 @@ struct builtin_term {
 #define VS_SCAN_SLDS_84(KIND, GENV) ((GENV) == 1 || (GENV) == 2 ? ((KIND) == VS_OBJ_LINEAR ? 2 : 1) : (GENV) == 0 ? 2 : 4)
 #endif
 
+// How a scan kernel comes to its Sobol points (vs_scan_block's SNIB; the general column code only): the persistent fused
+// kernels keep the nibble tables of all their columns in LDS (W L 512 B: 16 KiB at 32 columns, 48 at 96) -- except the
+// one whose terms already fill it (TLDS: 97 .. 128 columns) --, the evaluation kernels, one 64-row block per workgroup,
+// pass them through a KiB per wave either way
+#if defined(VS_SOBOL_BYTE_TABLES)   // A/B build (tools/sobol_lds.sh): round 4's byte tables in memory everywhere
+#define VS_SCAN_SNIB(FUSED, TLDS, GENV) 0
+#elif defined(VS_SCAN_SNIB_ALL1)    // A/B build: the one-KiB slot everywhere
+#define VS_SCAN_SNIB(FUSED, TLDS, GENV) ((GENV) == 0 || (GENV) == 3 ? 1 : 0)
+#else
+#define VS_SCAN_SNIB(FUSED, TLDS, GENV) ((GENV) == 0 || (GENV) == 3 ? ((FUSED) && !(TLDS) ? 2 : 1) : 0)
+#endif
+
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
 __global__ void __launch_bounds__(VS_EVAL_ROWS* W)
 __attribute__((amdgpu_waves_per_eu(VS_SCAN_MIN_WAVES(L, W, FUSED, MULTI))))
 scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t* counters) {
     extern __shared__ double scan_lds[];  // totals slabs [2 families][W][64] (+ term slabs, + sum slabs), vs_scan_lds
-    vs_scan_body<builtin_term<KIND, GENV == 0 || GENV == 3>, KIND, L, W, FUSED, TLDS, MULTI, GENV, VS_SCAN_SUMS_IN_LDS(KIND, L, W, FUSED, GENV)>(
+    vs_scan_body<builtin_term<KIND, GENV == 0 || GENV == 3>, KIND, L, W, FUSED, TLDS, MULTI, GENV, VS_SCAN_SUMS_IN_LDS(KIND, L, W, FUSED, GENV),
+                 VS_SCAN_SNIB(FUSED, TLDS, GENV)>(
         A, scan_lds, shift_src, partials);
     // counters of the fold that follows (see reduce_first_kernel).  At the END of the kernel: a global
     // store in front of the row loop would make every load of design constants "possibly clobbered"
@@ -108,7 +121,12 @@ scan_kernel(vs_eval_args A, const double* shift_src, double* partials, uint32_t*
 
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
 static int launch_scan_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
-    const size_t lds = sizeof(double) * vs_scan_lds<L, W, TLDS, VS_SCAN_SUMS_IN_LDS(KIND, L, W, FUSED, GENV)>::doubles;
+    size_t lds = sizeof(double) * vs_scan_lds<L, W, TLDS, VS_SCAN_SUMS_IN_LDS(KIND, L, W, FUSED, GENV)>::doubles;
+    // Sobol designs: LDS for the nibble tables (vs_sobol_pipe; the general column code of these kernels has no other way
+    // to a Sobol point)
+    if (A.D.generator == VS_GEN_SOBOL) lds += VS_SOBOL_LDS_BYTES(VS_SCAN_SNIB(FUSED, TLDS, GENV), L, W);
+    static_assert(sizeof(double) * vs_scan_lds<L, W, TLDS, VS_SCAN_SUMS_IN_LDS(KIND, L, W, FUSED, GENV)>::doubles +
+                          VS_SOBOL_LDS_BYTES(VS_SCAN_SNIB(FUSED, TLDS, GENV), L, W) <= VS_LDS_BYTES, "no room for the Sobol tables");
     const void* fn = (const void*)scan_kernel<KIND, L, W, FUSED, TLDS, MULTI, GENV>;
     if (lds > 64 * 1024) VS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
@@ -177,12 +195,21 @@ static int launch_scan_kind(vs_context* ctx, const vs_eval_args& A, scan_shape s
 }
 
 // ---- fused evaluate + both orders: four waves x L columns, tile of 16 NBH index rows per half (vs_device_scan.h)
+// Sobol points (vs_scan_block's SNIB; the general column code only): the one-KiB slot per wave -- whole tables beside the
+// tiles would cost resident workgroups (k <= 32: 40 000 B per workgroup, four per CU; + 16 KiB: two) or do not fit (k > 32);
+// the instance of 65 .. 128 index rows with several outputs has not even the slot's 8 KiB left and keeps the byte tables
+#if defined(VS_SOBOL_BYTE_TABLES)
+#define VS_GRAM_SNIB(GENV, NB, LMAX) 0
+#else
+#define VS_GRAM_SNIB(GENV, NB, LMAX) ((GENV) == 0 || (GENV) == 3 ? ((NB) == 8 && (LMAX) > 1 ? 0 : 1) : 0)
+#endif
 template <int KIND, int L, int NBH, int GENV, int LMAX = 1>
 __global__ void __launch_bounds__(VS_EVAL_ROWS * 4) __attribute__((amdgpu_waves_per_eu(4)))
 scan_gram_kernel(vs_eval_args A, const double* shift_src, double* first_partials, double* gram_partials,
                  uint32_t* counters) {
     extern __shared__ double scan_lds[];   // [slabs][2][4][64] totals, then the tile [32 NBH + 2 LMAX][68]
-    vs_scan_gram_body<builtin_term<KIND, GENV == 0 || GENV == 3>, KIND, L, NBH, GENV, LMAX>(A, scan_lds, shift_src, first_partials, gram_partials);
+    vs_scan_gram_body<builtin_term<KIND, GENV == 0 || GENV == 3>, KIND, L, NBH, GENV, LMAX, VS_GRAM_SNIB(GENV, NBH, LMAX)>(
+        A, scan_lds, shift_src, first_partials, gram_partials);
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // counters of the folds that follow, at the END (see scan_kernel)
         counters[0] = 0;
         counters[1] = 0xffffffffu;
@@ -195,8 +222,10 @@ scan_gram_kernel(vs_eval_args A, const double* shift_src, double* first_partials
 template <int KIND, int L, int NBH, int GENV, int LMAX = 1>
 static int launch_scan_gram_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev,
                               double* first_partials, double* gram_partials, bool plan_only) {
-    const size_t lds = sizeof(double) * VS_GT_LDS_DOUBLES(4, NBH, LMAX);
+    size_t lds = sizeof(double) * VS_GT_LDS_DOUBLES(4, NBH, LMAX);
+    if (A.D.generator == VS_GEN_SOBOL) lds += VS_SOBOL_LDS_BYTES(VS_GRAM_SNIB(GENV, NBH, LMAX), L, 4);
     const void* fn = (const void*)scan_gram_kernel<KIND, L, NBH, GENV, LMAX>;
+    if (lds > 64 * 1024) VS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     if (plan_only) {
         // twice the resident set (as the first-order fused kernels; 0.61 vs 0.65 ms at k = 32, n = 2^22) -- but every
@@ -243,7 +272,8 @@ __global__ void __launch_bounds__(VS_EVAL_ROWS * NB) __attribute__((amdgpu_waves
 scan_gramn_kernel(vs_eval_args A, const double* shift_src, double* first_partials, double* gram_partials,
                   uint32_t* counters) {
     extern __shared__ double scan_lds[];   // [slabs][2][NB][64] totals, then the tile [32 NB + 2 LMAX][68]
-    vs_scan_gramn_body<builtin_term<KIND, GENV == 0 || GENV == 3>, KIND, GENV, NB, NBL, LMAX>(A, scan_lds, shift_src, first_partials, gram_partials);
+    vs_scan_gramn_body<builtin_term<KIND, GENV == 0 || GENV == 3>, KIND, GENV, NB, NBL, LMAX, VS_GRAM_SNIB(GENV, NB, LMAX)>(
+        A, scan_lds, shift_src, first_partials, gram_partials);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         counters[0] = 0;
         counters[1] = 0xffffffffu;
@@ -258,8 +288,10 @@ static int launch_scan_gramn_g(vs_context* ctx, const vs_eval_args& A, unsigned*
                                double* first_partials, double* gram_partials, bool plan_only) {
     // one output: NB = 8: 148 544 B, one workgroup per CU; NB = 4: 74 816 B, two.  Several: a second totals slab and
     // 2 (LMAX - 1) more tile rows (NB = 8, LMAX = 4: 160 032 B of the 163 840)
-    const size_t lds = sizeof(double) * VS_GT_LDS_DOUBLES(NB, NB, LMAX);
-    static_assert(sizeof(double) * VS_GT_LDS_DOUBLES(NB, NB, LMAX) <= 160 * 1024, "the tile does not fit the LDS of a CU");
+    size_t lds = sizeof(double) * VS_GT_LDS_DOUBLES(NB, NB, LMAX);
+    static_assert(sizeof(double) * VS_GT_LDS_DOUBLES(NB, NB, LMAX) + VS_SOBOL_LDS_BYTES(VS_GRAM_SNIB(GENV, NB, LMAX), LMAX > 1 ? 8 : 16, NB) <=
+                      VS_LDS_BYTES, "the tile does not fit the LDS of a CU");
+    if (A.D.generator == VS_GEN_SOBOL) lds += VS_SOBOL_LDS_BYTES(VS_GRAM_SNIB(GENV, NB, LMAX), LMAX > 1 ? 8 : 16, NB);
     const void* fn = (const void*)scan_gramn_kernel<KIND, GENV, NB, NBL, LMAX>;
     const uint64_t blocks = (A.rows + VS_EVAL_ROWS - 1) / VS_EVAL_ROWS;
     if (plan_only) {
