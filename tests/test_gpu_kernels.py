@@ -960,15 +960,37 @@ def sobol_design(ctx, k, n, first, mode=0, lo=None, hi=None):
 SOBOL_FIRSTS = [4096, (1 << 24) - 777, (1 << 28) + 5]
 
 
+@pytest.fixture(scope="module")
+def general_ctx():
+    """A context whose scan kernels run the general column code for every design (VS_SCAN_GENERAL=1): Sobol designs
+    with identity / linear scaling otherwise take the instance compiled for them alone."""
+    import os
+    from varsens_amd import _native
+    old = {v: os.environ.get(v) for v in ("VS_TUNING", "VS_SCAN_GENERAL")}
+    os.environ.update(VS_TUNING="1", VS_SCAN_GENERAL="1")
+    try:
+        c = _native.Context(0)
+    finally:
+        for v, x in old.items():
+            if x is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = x
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("general", [False, True])
 @pytest.mark.parametrize("first", SOBOL_FIRSTS)
 @pytest.mark.parametrize("k", [4, 16, 24, 32, 48, 64, 96, 128, 200])
-def test_sobol_points_through_the_evaluation_kernels(ctx, k, first):
+def test_sobol_points_through_the_evaluation_kernels(ctx, general_ctx, k, first, general):
     """Round 5: the scan kernels take Sobol points from nibble tables in LDS (vs_sobol_points_lds).  A linear objective
     with one unit weight per output hands the coordinates themselves back as f-values -- every block of the design (M_1,
     M_2 behind the seed-1 shuffle, N_j, N_nj: varsens/saltelli.py:100-125) bit for bit the oracle's Gray-code XOR
     (quantlib/sobolGen.cpp:47-60 is the reference's generator of this sequence), for every kernel shape (columns per wave
     x waves: k = 4 .. 200), a ragged last block and the three index ranges above."""
     from varsens_amd import _native
+    ctx = general_ctx if general else ctx     # the column code for Sobol alone / the general one
     n = 1000
     d, dirs, perm = sobol_design(ctx, k, n, first)
     cols = sorted(set(int(c) for c in np.linspace(0, k - 1, min(k, 6))))
@@ -993,21 +1015,25 @@ def test_sobol_points_through_the_evaluation_kernels(ctx, k, first):
         same(F[2 + k + j], nnj)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("first", SOBOL_FIRSTS)
 @pytest.mark.parametrize("kind,k,l", [("lin", 4, 1), ("g", 16, 1), ("poly", 24, 1), ("g", 32, 1), ("lin", 48, 1), ("g", 64, 1),
                                       ("poly", 96, 1), ("g", 128, 1), ("lin", 16, 2), ("g", 20, 3), ("lin", 32, 4)])
-def test_sobol_designs_through_the_fused_kernels(ctx, kind, k, l, first):
+def test_sobol_designs_through_the_fused_kernels(ctx, kind, k, l, first, mode):
     """The fused kernels (evaluate + reduce, no f-values) on Sobol designs against evaluation + reduction of the same
     design: record and Gram sums to summation order.  The first-order kernel of every shape (all tables in LDS up to 96
     columns, two columns at a time beyond), the both-orders kernels of 16 / 32 / 64 / 128 index rows with one output and
-    with several (32 x 4: the instance that has no LDS left and keeps the byte tables in memory)."""
+    with several (32 x 4: the instance that has no LDS left and keeps the byte tables in memory).  mode 1: linear scaling
+    (one output: the column code compiled for Sobol alone), 2: power scaling (the general column code)."""
     from varsens_amd import _native
     n = 3000
     rng = np.random.RandomState(k + l)
     code = {"g": _native.OBJ_G_FUNCTION, "lin": _native.OBJ_LINEAR, "poly": _native.OBJ_POLYNOMIAL}[kind]
     params = {"g": rng.rand(l, k) * 5, "lin": rng.rand(l, k) + 0.5, "poly": 1.0 / (1.0 + rng.rand(l, k))}[kind]
     lo, hi = np.linspace(0.0, 0.2, k), np.linspace(0.8, 1.0, k)   # (a product of 128 terms stays of order 1)
-    d, _, _ = sobol_design(ctx, k, n, first, 1, lo, hi)
+    if mode == 2:
+        lo = lo + 0.05
+    d, _, _ = sobol_design(ctx, k, n, first, mode, lo, hi)
     obj = ctx.objective_create(code, k, l, params)
     nacc, ng = _native.acc_len(k, l, 1), _native.gram_len(k * l)
     f = ctx.alloc(8 * 2 * (k + 1) * n * l)
@@ -1025,7 +1051,9 @@ def test_sobol_designs_through_the_fused_kernels(ctx, kind, k, l, first):
         np.testing.assert_allclose(r2[sums], r1[sums], rtol=1e-11)
     else:
         assert l > 1 and k * l > 128
-    assert ctx.eval_reduce_both_supported(d, obj)
+    if not ctx.eval_reduce_both_supported(d, obj):
+        assert mode == 2 and l > 1   # (power scaling with several outputs at 33 .. 64 index rows: two kernels)
+        return
     ctx.eval_reduce_first_second_order(d, obj, 0, n, acc3, g3)
     r3 = ctx.download(acc3, (nacc,))
     np.testing.assert_allclose(r3[sums], r1[sums], rtol=1e-11)

@@ -141,8 +141,8 @@ __device__ __forceinline__ void vs_scan_col_load(vs_scan_col& C, const vs_design
     C.pre = 0.0;
     C.pre2 = 0.0;
     if (c < k) {
-        if (GENV == 1 || GENV == 2 || D.generator == VS_GEN_HALTON) C.B = D.bases[c];
-        if (GENV == 2) {
+        if (GENV == 1 || GENV == 2 || (GENV != 4 && D.generator == VS_GEN_HALTON)) C.B = D.bases[c];
+        if (GENV == 2 || (GENV == 4 && D.scale_mode == VS_SCALE_LINEAR)) {   // (GENV 4, identity scaling: x * 1 + 0)
             C.w = D.width[c];
             C.lo = D.lower[c];
         }
@@ -288,11 +288,10 @@ __device__ __forceinline__ vs_u32 vs_sobol_bits_lds(vs_u32 g, const vs_u32* __re
     return x;
 }
 // the bits of the two points (Gray codes g1, g2) of the wave's L columns
-template <int SNIB, int NN, int L, int W>
+template <int SNIB, int NN, int L, int W, int GROUP>
 __device__ __forceinline__ void vs_sobol_points_lds(const vs_design_dev& D, vs_u32* __restrict__ snib, int q, int lane, vs_u32 g1,
                                                     vs_u32 g2, vs_u32 (&sx1)[L], vs_u32 (&sx2)[L]) {
     static_assert(L % 2 == 0, "the Sobol tables pass through LDS two columns at a time");
-    constexpr int GROUP = (L == 8 && W == 4) ? 1 : VS_SOBOL_GROUP;
     uint4 pre = {0u, 0u, 0u, 0u};
     if (SNIB == 1) {
         vs_sobol_put(snib, lane, vs_sobol_fetch<W>(D, q, lane, 0));
@@ -309,7 +308,7 @@ __device__ __forceinline__ void vs_sobol_points_lds(const vs_design_dev& D, vs_u
         sx2[j] = vs_sobol_bits_lds<NN>(g2, col);
         // two columns' look-ups in flight (24 .. 32 registers), not all L: left alone the compiler issues every look-up
         // of the block before the first XOR, 12 L results in registers (four at a time measured the same: 0.397 ms at
-        // k = 64 either way); one where the kernel is held to 128 registers (four waves x 8 columns)
+        // k = 64 either way); one (GROUP, the caller's choice) where the kernel has no registers to spare
         if (j % GROUP == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -916,7 +915,10 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     // takes hundreds of cycles, and each column's digit loop starts on these values.
     // GENV 1 / 2: Halton below 2^32 with identity / linear scaling -- straight-line code per column;
     // GENV 0: any generator and scaling, decided by (wave-uniform) branches per column (fused: no power scaling);
-    // GENV 3: as 0, power scaling included also when fused.
+    // GENV 3: as 0, power scaling included also when fused;
+    // GENV 4 (round 5): Sobol with identity or linear scaling -- straight-line as 1 / 2, points from LDS (SNIB != 0).  The
+    // general code with the same look-ups spends as long on its branches per column as Halton's digit loops take (k = 64,
+    // n = 2^21, fused first order: 0.396 ms; compiled for Sobol and nothing else 0.299; Halton's own instance 0.32).
     // Sobol designs (the general column code): a point is the XOR of table entries selected by the Gray code of its
     // index.  The look-ups of ALL the wave's columns are issued here, ahead of the column loop, which then only converts.
     // SNIB != 0 (round 5, vs_sobol_points_lds): nibble tables in LDS.  SNIB == 0 (the instances with no LDS to spare, the
@@ -931,14 +933,17 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
     vs_sobol_block sobol_block = {false, 0u, 0u};
     vs_u32 sx1[L], sx2[L];
     bool sobol = false;
-    if constexpr (GENV == 0 || GENV == 3) {
-        sobol = A.D.generator == VS_GEN_SOBOL;   // wave-uniform
+    static_assert(GENV != 4 || SNIB != 0, "the Sobol instance takes its points from LDS");
+    if constexpr (GENV == 0 || GENV == 3 || GENV == 4) {
+        sobol = GENV == 4 || A.D.generator == VS_GEN_SOBOL;   // wave-uniform
         if (sobol) {
             if constexpr (SNIB != 0) {
                 const vs_u32 i1 = (vs_u32)(A.D.first_index + r), i2 = (vs_u32)(A.D.first_index + A.D.n + src2);
                 const vs_u32 g1 = i1 ^ (i1 >> 1), g2 = i2 ^ (i2 >> 1);
-                if (A.D.sobol_bits <= 24) vs_sobol_points_lds<SNIB, 6, L, W>(A.D, snib, q, lane, g1, g2, sx1, sx2);   // wave-uniform
-                else vs_sobol_points_lds<SNIB, 8, L, W>(A.D, snib, q, lane, g1, g2, sx1, sx2);
+                // (one column's look-ups in flight instead of two: the kernel of four waves x 8 columns held to 128 registers)
+                constexpr int GROUP = L == 8 && W == 4 && NBH == 0 ? 1 : VS_SOBOL_GROUP;
+                if (A.D.sobol_bits <= 24) vs_sobol_points_lds<SNIB, 6, L, W, GROUP>(A.D, snib, q, lane, g1, g2, sx1, sx2);   // wave-uniform
+                else vs_sobol_points_lds<SNIB, 8, L, W, GROUP>(A.D, snib, q, lane, g1, g2, sx1, sx2);
             } else {
                 sobol_block = vs_sobol_block_of(A.D, r, lane);
 #pragma unroll
@@ -974,6 +979,9 @@ __device__ __forceinline__ void vs_scan_block(const vs_eval_args& A, const doubl
                 vs_halton_pair<VS_SCAN_SHORT_DIGITS(FUSED, L, W), true>(hi1, hi2, hd1, hd2, C.B, x1, x2, j == 0);   // VS_SCAN_COLUMN(q, j, W) = 0 needs j = 0
                 t1 = GENV == 2 ? x1 * C.w + C.lo : x1;   // scale.py:33
                 t2 = GENV == 2 ? x2 * C.w + C.lo : x2;
+            } else if (GENV == 4) {
+                t1 = (double)sx1[j] * (1.0 / 4294967296.0) * C.w + C.lo;   // scale.py:33, or x * 1 + 0 = x (x >= 0)
+                t2 = (double)sx2[j] * (1.0 / 4294967296.0) * C.w + C.lo;
             } else {
                 if (sobol) {
                     x1 = (double)sx1[j] * (1.0 / 4294967296.0);

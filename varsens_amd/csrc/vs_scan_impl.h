@@ -84,7 +84,7 @@ struct builtin_term {
 // short once the folds of the segment totals were compiled per wave: 0.268 ms either way --; the general generator
 // paths and the one with pow() behind a call need more room)
 #ifndef VS_SCAN_SLDS_84
-#define VS_SCAN_SLDS_84(KIND, GENV) ((GENV) == 1 || (GENV) == 2 ? ((KIND) == VS_OBJ_LINEAR ? 2 : 1) : (GENV) == 0 ? 2 : 4)
+#define VS_SCAN_SLDS_84(KIND, GENV) ((GENV) == 1 || (GENV) == 2 || (GENV) == 4 ? ((KIND) == VS_OBJ_LINEAR ? 2 : 1) : (GENV) == 0 ? 2 : 4)
 #endif
 
 // How a scan kernel comes to its Sobol points (vs_scan_block's SNIB; the general column code only): the persistent fused
@@ -93,10 +93,12 @@ struct builtin_term {
 // pass them through a KiB per wave either way
 #if defined(VS_SOBOL_BYTE_TABLES)   // A/B build (tools/sobol_lds.sh): round 4's byte tables in memory everywhere
 #define VS_SCAN_SNIB(FUSED, TLDS, GENV) 0
+#define VS_SOBOL_INSTANCE 0          // ... and no instance of the column code for Sobol alone
+#define VS_SOBOL_GENV 0
 #elif defined(VS_SCAN_SNIB_ALL1)    // A/B build: the one-KiB slot everywhere
-#define VS_SCAN_SNIB(FUSED, TLDS, GENV) ((GENV) == 0 || (GENV) == 3 ? 1 : 0)
+#define VS_SCAN_SNIB(FUSED, TLDS, GENV) ((GENV) == 0 || (GENV) >= 3 ? 1 : 0)
 #else
-#define VS_SCAN_SNIB(FUSED, TLDS, GENV) ((GENV) == 0 || (GENV) == 3 ? ((FUSED) && !(TLDS) ? 2 : 1) : 0)
+#define VS_SCAN_SNIB(FUSED, TLDS, GENV) ((GENV) == 0 || (GENV) >= 3 ? ((FUSED) && !(TLDS) ? 2 : 1) : 0)
 #endif
 
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI, int GENV>
@@ -148,6 +150,17 @@ static int launch_scan_g(vs_context* ctx, const vs_eval_args& A, unsigned* P_io,
 // kernels -- every index small enough for the three-instruction digit step (vs_radical_inverse_pair_horner: below 9.49e7
 // indices in all, n up to 47 million rows); larger Halton designs there, Sobol, raw points and power scaling take the
 // general one
+// GENV 4, the column code for Sobol designs alone (identity or linear scaling, points from LDS): what takes it
+#ifndef VS_SOBOL_INSTANCE
+#define VS_SOBOL_INSTANCE 1
+#define VS_SOBOL_GENV 4
+#endif
+static inline bool vs_sobol_instance_covers(const vs_context* ctx, const vs_eval_args& A) {
+    return A.D.generator == VS_GEN_SOBOL && ctx->tune.scan_general == 0 &&
+           (A.D.scale_mode == VS_SCALE_IDENTITY || A.D.scale_mode == VS_SCALE_LINEAR) &&
+           (A.kind != VS_OBJ_G_FUNCTION || A.plain_recip != 0);   // else: the column code that can divide
+}
+
 template <int KIND, int L, int W, bool FUSED, bool TLDS, bool MULTI>
 static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io, const double* shift_dev, bool plan_only) {
     // (the kernels that write f-values run the four-instruction digit loop -- but from 97 columns on --: any design
@@ -159,6 +172,8 @@ static int launch_scan_lw(vs_context* ctx, const vs_eval_args& A, unsigned* P_io
         return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 1>(ctx, A, P_io, shift_dev, plan_only);
     if (halton && A.D.scale_mode == VS_SCALE_LINEAR)
         return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 2>(ctx, A, P_io, shift_dev, plan_only);
+    if (VS_SOBOL_INSTANCE && vs_sobol_instance_covers(ctx, A))
+        return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, VS_SOBOL_GENV>(ctx, A, P_io, shift_dev, plan_only);
     if constexpr (FUSED) {   // the fused kernels' general variant carries no pow(): power scaling has its own instance
         if (A.D.scale_mode == VS_SCALE_POWER)
             return launch_scan_g<KIND, L, W, FUSED, TLDS, MULTI, 3>(ctx, A, P_io, shift_dev, plan_only);
@@ -201,7 +216,7 @@ static int launch_scan_kind(vs_context* ctx, const vs_eval_args& A, scan_shape s
 #if defined(VS_SOBOL_BYTE_TABLES)
 #define VS_GRAM_SNIB(GENV, NB, LMAX) 0
 #else
-#define VS_GRAM_SNIB(GENV, NB, LMAX) ((GENV) == 0 || (GENV) == 3 ? ((NB) == 8 && (LMAX) > 1 ? 0 : 1) : 0)
+#define VS_GRAM_SNIB(GENV, NB, LMAX) ((GENV) == 0 || (GENV) >= 3 ? ((NB) == 8 && (LMAX) > 1 ? 0 : 1) : 0)
 #endif
 template <int KIND, int L, int NBH, int GENV, int LMAX = 1>
 __global__ void __launch_bounds__(VS_EVAL_ROWS * 4) __attribute__((amdgpu_waves_per_eu(4)))
@@ -253,6 +268,9 @@ static int launch_scan_gram_lw(vs_context* ctx, const vs_eval_args& A, unsigned*
     return launch_scan_gram_g<KIND, L, NBH, G, LMAX>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY) VS_GRAM_GENV(1);
     if (halton && A.D.scale_mode == VS_SCALE_LINEAR) VS_GRAM_GENV(2);
+    if constexpr (LMAX == 1) {   // (several outputs: the general column code)
+        if (VS_SOBOL_INSTANCE && vs_sobol_instance_covers(ctx, A)) VS_GRAM_GENV(VS_SOBOL_GENV);
+    }
     if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAM_GENV(3);
     VS_GRAM_GENV(0);
 #undef VS_GRAM_GENV
@@ -319,6 +337,11 @@ static int launch_scan_gramn_nbl(vs_context* ctx, const vs_eval_args& A, unsigne
     return launch_scan_gramn_g<KIND, G, NB, NBL, LMAX>(ctx, A, P_io, shift_dev, first_partials, gram_partials, plan_only)
     if (halton && A.D.scale_mode == VS_SCALE_IDENTITY) VS_GRAMN_GENV(1);
     if (halton && A.D.scale_mode == VS_SCALE_LINEAR) VS_GRAMN_GENV(2);
+    // (not the body for eight live blocks, k = 113 .. 128: at its 256 registers already, the 32 that hold a block's
+    // Sobol bits ahead of the column loop make it spill -- the general column code's shorter live ranges do not)
+    if constexpr (LMAX == 1 && !(NB == 8 && NBL == 8)) {
+        if (VS_SOBOL_INSTANCE && vs_sobol_instance_covers(ctx, A)) VS_GRAMN_GENV(VS_SOBOL_GENV);
+    }
     if (A.D.scale_mode == VS_SCALE_POWER) VS_GRAMN_GENV(3);
     VS_GRAMN_GENV(0);
 #undef VS_GRAMN_GENV
