@@ -30,7 +30,10 @@ K=16 L=2 LOG2N=22 KIND=poly python3 $R/tools/pmc_run.py fused_both_k16_l2 --kern
 python3 $R/tools/pmc_run.py fused_first_k32 --kernels scan_kernel --groups issue,lds,mem -- python3 $R/tools/eval_one.py 32 22 fused lin
 # round 5: second order beyond 128 index rows at the reference's study shape (k = 197, n = 2^20)
 N=1048576 python3 $R/tools/pmc_run.py gram_k197_n2pow20 --kernels gram_,first_head,reduce_first,scan_kernel -- python3 $R/tools/gram_k197.py
-for n in gram_k128_n24 gram_k64_n22 gram_k32_n22 eval_k128_n24 fused_both_k32 fused_both_k128_n24 fused_both_k32_l4 fused_both_k16_l2 fused_first_k32 gram_k197_n2pow20; do cp $R/gpurun_out/pmc/$n.json $R/gpurun_out/pmc/${n}_kernel_stats.csv $OUT/; done
+# round 5: a Sobol design through the fused first-order kernel (points from nibble tables in LDS), k = 64 and 128
+python3 $R/tools/pmc_run.py fused_first_k64_sobol --kernels scan_kernel --groups issue,lds -- python3 $R/tools/eval_one.py 64 21 fused lin sobol
+python3 $R/tools/pmc_run.py fused_first_k128_sobol --kernels scan_kernel --groups issue,lds -- python3 $R/tools/eval_one.py 128 20 fused lin sobol
+for n in gram_k128_n24 gram_k64_n22 gram_k32_n22 eval_k128_n24 fused_both_k32 fused_both_k128_n24 fused_both_k32_l4 fused_both_k16_l2 fused_first_k32 gram_k197_n2pow20 fused_first_k64_sobol fused_first_k128_sobol; do cp $R/gpurun_out/pmc/$n.json $R/gpurun_out/pmc/${n}_kernel_stats.csv $OUT/; done
 echo "kernel pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -- python3 $R/tools/config5.py > $OUT/config5.log 2>&1
 cp $(find $OUT/stats5 -name '*kernel_stats.csv' | head -1) $OUT/config5_kernel_stats.csv
@@ -43,6 +46,8 @@ bash $R/tools/fshift_sweep.sh > $OUT/fshift_sweep.txt 2>&1
 python3 $R/tools/rehearse_weak_scaling.py --out $OUT/rehearsal > $OUT/rehearsal.log 2>&1
 N=20480 python3 $R/tools/gram_k197.py > $OUT/gram_k197_n20480.txt 2>&1
 python3 $R/tools/gram_k197.py > $OUT/gram_k197_n2pow20.txt 2>&1
+bash $R/tools/sobol_lds.sh > $OUT/sobol_lds.txt 2>&1
+python3 $R/tools/text_io_rate.py 32 14 > $OUT/text_io_rate.txt 2>&1
 echo "round-5 extras done"
 cat $OUT/bench_n1.json
 cat $OUT/bench_kernel_stats.csv
