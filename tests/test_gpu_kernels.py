@@ -573,6 +573,78 @@ def test_second_order_gram(ctx, k, rows, l):
         assert abs(G[0][i, j] - want) <= 1e-13 * max(1.0, abs(want)) * 10
 
 
+def _ctx_with_gram_dma(value):
+    import os
+    from varsens_amd import _native
+    old = {v: os.environ.get(v) for v in ("VS_TUNING", "VS_GRAM_DMA")}
+    os.environ.update(VS_TUNING="1", VS_GRAM_DMA=value)
+    try:
+        return _native.Context(0)
+    finally:
+        for v, x in old.items():
+            if x is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = x
+
+
+@pytest.fixture(scope="module")
+def ctx_dma_all():
+    """gram_dma_kernel also for 17 .. 32 index rows (VS_GRAM_DMA=2; by default it starts at 33)"""
+    c = _ctx_with_gram_dma("2")
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx_no_dma():
+    """A context that keeps 17 .. 64 index rows per half on gram_diag_wide_kernel / gram_st_kernel (VS_GRAM_DMA=0): the
+    kernels gram_dma_kernel replaced for second order alone."""
+    c = _ctx_with_gram_dma("0")
+    yield c
+    c.close()
+
+
+# gram_dma_kernel (csrc/vs_gram_dma.hip): every count of live blocks and of live rows in the last piece of eight, no
+# whole unit at all, a partial last unit of every even length, many units per wave, a short last row block
+@pytest.mark.parametrize("k,rows", [(33, 2), (33, 16), (33, 18), (34, 4110), (39, 32), (40, 14), (40, 4096), (41, 2050),
+                                    (47, 300), (48, 32), (48, 5000), (49, 30), (50, 2062), (55, 1024), (57, 2064),
+                                    (62, 40), (63, 66), (64, 2), (64, 16), (64, 30000), (64, 131078), (36, 262144),
+                                    (56, 2048 * 5 + 20),
+                                    # 17 .. 32 index rows: sixteen waves per CU on images of 32 rows per half
+                                    (17, 2), (17, 34), (20, 16), (23, 4100), (24, 32), (24, 70000), (25, 30), (31, 2062),
+                                    (32, 2), (32, 16), (32, 48), (32, 65598), (32, 262144), (29, 2048 * 3 + 8)])
+def test_second_order_dma_kernel(ctx_dma_all, ctx_no_dma, k, rows):
+    """17 .. 64 index rows per half, one output, even row count: S S^T and T T^T from gram_dma_kernel against numpy,
+    against exactly rounded sums, against the kernel it replaced, and bit for bit run to run."""
+    import math
+    rng = np.random.RandomState(k * 31 + rows)
+    blocks = 1.0 + rng.randn(2 * k + 2, rows, 1)
+    C, D = blocks[2:2 + k, :, 0], blocks[2 + k:, :, 0]
+    S, T = C + D, C - D
+    got = []
+    for c in (ctx_dma_all, ctx_dma_all, ctx_no_dma):
+        f = c.upload_blocks(blocks)
+        gram = c.alloc(8 * 2 * k * k)
+        c.reduce_second_order(f, rows, k, 1, gram)
+        got.append(c.download(gram, (2, k, k)))
+        f.free()
+        gram.free()
+    G = got[0]
+    assert np.array_equal(G.view(np.uint64), got[1].view(np.uint64)), "not the same bits run to run"
+    scale = np.abs(S @ S.T).max()
+    np.testing.assert_allclose(G[0], S @ S.T, rtol=1e-12, atol=1e-12 * scale)
+    np.testing.assert_allclose(G[1], T @ T.T, rtol=1e-12, atol=1e-12 * scale)
+    np.testing.assert_allclose(G, got[2], rtol=1e-12, atol=1e-12 * scale)
+    assert np.array_equal(G[0], G[0].T) and np.array_equal(G[1], G[1].T)
+    for (i, j) in ((0, 0), (k - 1, 0), (k // 2, k - 1), (k - 1, k - 1), (15, 16), (31, 32)):
+        if i >= k or j >= k:
+            continue
+        for M, X in ((G[0], S), (G[1], T)):
+            want = math.fsum((X[i] * X[j]).tolist())
+            assert abs(M[i, j] - want) <= 1e-13 * scale, (i, j)
+
+
 @pytest.mark.parametrize("k,rows,l", [(6, 1000, 1), (32, 5000, 1), (16, 200000, 1), (3, 5, 1), (12, 100003, 1),
                                       (1, 17, 1), (25, 4096, 1), (40, 3000, 1), (5, 700, 2), (33, 2, 1), (64, 4099, 1),
                                       (65, 777, 1), (128, 10000, 1), (129, 2050, 1), (200, 333, 1), (48, 65536, 1),

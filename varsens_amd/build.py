@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvarsens_hip.so")
-SOURCES = ["vs_host.cpp", "vs_api.hip", "vs_generate.hip", "vs_scan.hip", "vs_scan_g.hip", "vs_scan_poly.hip", "vs_scan_lin.hip", "vs_scan_gram.hip", "vs_scan_gram8.hip", "vs_scan_gram8_g.hip", "vs_scan_gram8_poly.hip", "vs_scan_gram8_lin.hip", "vs_scan_gram4.hip", "vs_scan_gramm_g.hip", "vs_scan_gramm_poly.hip", "vs_scan_gramm_lin.hip", "vs_reduce.hip", "vs_values.hip", "vs_second.hip", "vs_gram_st.hip", "vs_comm.hip", "vs_rtc.hip"]
+SOURCES = ["vs_host.cpp", "vs_api.hip", "vs_generate.hip", "vs_scan.hip", "vs_scan_g.hip", "vs_scan_poly.hip", "vs_scan_lin.hip", "vs_scan_gram.hip", "vs_scan_gram8.hip", "vs_scan_gram8_g.hip", "vs_scan_gram8_poly.hip", "vs_scan_gram8_lin.hip", "vs_scan_gram4.hip", "vs_scan_gramm_g.hip", "vs_scan_gramm_poly.hip", "vs_scan_gramm_lin.hip", "vs_reduce.hip", "vs_values.hip", "vs_second.hip", "vs_gram_st.hip", "vs_gram_dma.hip", "vs_comm.hip", "vs_rtc.hip"]
 # device sources hiprtc needs at run time, embedded into the library as C++ raw strings
 EMBED = {"vs_device_gen.h": "vs_rtc_embed_gen.inc", "vs_device_scan.h": "vs_rtc_embed_scan.inc",
          "vs_rtc_kernel.h": "vs_rtc_embed_kernel.inc", "vs_rtc_kernel_sep.h": "vs_rtc_embed_kernel_sep.inc"}

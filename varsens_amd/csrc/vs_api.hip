@@ -105,6 +105,7 @@ extern "C" int vs_context_create(int device, vs_context** out) {
         t.gram_wgs_per_cu = (int)knob("VS_GRAM_WGS_PER_CU", t.gram_wgs_per_cu, 0, 8);
         t.gram_wide = (int)knob("VS_GRAM_WIDE", t.gram_wide, 0, 1);
         t.gram_st = (int)knob("VS_GRAM_ST", t.gram_st, 0, 1);
+        t.gram_dma = (int)knob("VS_GRAM_DMA", t.gram_dma, 0, 2);
         t.reduce_both = (int)knob("VS_REDUCE_BOTH", t.reduce_both, 0, 1);
         t.copy_threads = (int)knob("VS_COPY_THREADS", t.copy_threads, 1, 16);
         t.f_shift = (int)knob("VS_F_SHIFT", t.f_shift, VS_F_SHIFT_MIN, 40);

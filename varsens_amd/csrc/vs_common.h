@@ -41,6 +41,7 @@ struct vs_tuning {
     int gram_wgs_per_cu = 0;     // VS_GRAM_WGS_PER_CU (0 = by shape)
     int gram_st = 1;             // VS_GRAM_ST=0: 33..128 index rows per half keep the [C; D] macro kernel
     int gram_wide = 1;           // VS_GRAM_WIDE=0: keep gram_diag_wave_kernel for 33..64 index rows
+    int gram_dma = 1;            // VS_GRAM_DMA=0: 33..64 index rows per half stay on gram_st_kernel (tests compare the two); 2: gram_dma_kernel also for 17..32
     int reduce_both = 1;         // VS_REDUCE_BOTH=0: never take the combined first+second-order kernel
     int fused_both_wide = 1;     // VS_FUSED_BOTH_WIDE=0: no fused evaluate + both-orders kernel beyond 32 columns; 2 (with
                                  // VS_TUNING=1, tools/fused_multi_sweep.sh): also the several-output shapes measured slower

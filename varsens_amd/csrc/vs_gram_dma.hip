@@ -1,0 +1,254 @@
+// sens_2 / sens_2n sums for 33 .. 64 index rows per half, one output, even row count, no NaN mask
+// (varsens/saltelli.py:612-619): S S^T and T T^T of S = C + D, T = C - D on the fp64 matrix cores, operands brought in
+// by LDS-DMA in whole 128-byte lines, every wave on its own -- no workgroup barrier in the loop (round 5).
+//
+// Why (tools/gram_direct.hip, profiles/r05/gram_direct.txt).  gram_st_kernel<4, ..> (vs_gram_st.hip) stood at
+// 0.94-0.96 ms for k = 64, n = 2^22 -- 0.58 of HBM, matrix pipe busy 0.63 -- through three rounds of work on its
+// pipeline; its eight waves share one tile per stage and meet at a barrier every 40 MFMAs, each holding five of the 20
+// accumulator tiles, so every fragment is read from LDS by all of them.  Measured this round:
+//  * a wave that keeps ALL 20 tiles (160 VGPRs) and is fed from registers runs the MFMA + add loop at 0.57-0.59 ms (the
+//    pipe's 0.55 at 2.4 GHz): the matrix side has no problem at this shape;
+//  * what a wave-wide 16-byte load delivers from the row-blocked f-values depends on whether it fetches WHOLE LINES:
+//    16 planes x 64 B per instruction (the MFMA fragment layout itself, with or without neighbouring lanes contiguous)
+//    streams at 4.1-4.2 TB/s, 8 planes x 128 B at 6.8, 4 planes x 256 B at 6.1-6.2 -- so the operands cannot go straight
+//    into fragment registers; they have to be transposed on the way, and a register-staged transposition (load, add,
+//    ds_write, ds_read) does not fit beside 160 accumulator registers;
+//  * LDS-DMA (global_load_lds_dwordx4) needs no registers at all.  The LDS side of an LDS-DMA is lane-linear, so the
+//    image is [c, d][64 index rows][16 sample rows] with 128-byte rows and NO padding; the fragment reads are made
+//    conflict-free by storing the 16-byte chunk r of row u at chunk position r ^ ((u >> 1) & 7) -- applied on the
+//    SOURCE address of the DMA.  A ds_read_b128 lane group is {i = 0-3, 12-15 at chunk q} + {i = 4-11 at chunk q + 1}
+//    (MI355X_MICROARCH.md, LDS): with this swizzle its 16 lanes meet 16 different 16-byte slots of the bank row.
+// The kernel: one workgroup of eight waves per CU (two per SIMD, 246 VGPRs, no spills), persistent.  A wave takes units
+// of 16 sample rows (unit index = wave + 8 (workgroup + grid * visit): neighbouring waves read neighbouring lines), DMAs
+// the unit into its PRIVATE 16 KiB image (sixteen pieces of 8 planes x 128 B), reads the fragments of 8 sample rows at a
+// time (ds_read_b128: two MFMA steps per read), forms s = c + d, t = c - d from the fragments (8 v_add_f64 per step of
+// 20 MFMAs) and starts the DMA of its next unit as soon as the last fragments of this one are in registers; its partner
+// on the SIMD multiplies meanwhile.  Sums are formed in a fixed order (wave after wave through LDS at the end): the
+// same bits run to run, and whatever the row-block size of the layout.
+// Measured (k = 64, n = 2^22, prototype): 0.66-0.69 ms = 6.3-6.5 TB/s = 0.80 of HBM and 0.81 of the matrix pipe at
+// once, shader clock 2.25-2.35 GHz; the loop without its DMA 0.59 ms, the DMA stream alone 0.63.
+// Rows of the image past K are never written (their pieces are skipped, clamped lanes re-read row K - 1): whatever
+// they hold ends up in rows and columns >= K of the tiles, which the fold never reads.
+// A shard whose row count is not a multiple of 16 ends in a partial unit: the wave whose turn it is loads it straight
+// into the fragment layout with guarded loads (zeros past the last row).
+#include "vs_second.h"
+
+namespace {
+
+// NBL live 16-row blocks per half: 3, 4 (K = 33 .. 64): images of 64 rows per half, eight waves per CU (two per SIMD);
+// 2 (K = 17 .. 32): images of 32 rows per half, sixteen waves per CU (four per SIMD, 6 tiles per wave: HBM-bound)
+constexpr int dma_rows(int nbl) { return nbl <= 2 ? 32 : 64; }          // image rows per half = SB of the partial
+constexpr int dma_waves(int nbl) { return nbl <= 2 ? 16 : 8; }
+constexpr int dma_img(int nbl) { return 2 * dma_rows(nbl) * 16; }        // doubles per unit image: [c, d][rows][16]
+constexpr size_t dma_lds_bytes(int nbl) { return sizeof(double) * dma_waves(nbl) * dma_img(nbl); }   // 128 KiB
+
+typedef __attribute__((address_space(3))) void* vs_lds_ptr;
+typedef const __attribute__((address_space(1))) void* vs_glb_ptr;
+
+// NBL: live 16-row blocks per half (2: K = 17 .. 32, 3: 33 .. 48, 4: 49 .. 64); FULLK: K == 16 NBL with NBL even (no
+// clamping of rows past K)
+template <int NBL, bool FULLK>
+__global__ void __launch_bounds__(64 * dma_waves(NBL))
+__attribute__((amdgpu_waves_per_eu(dma_waves(NBL) / 4, dma_waves(NBL) / 4)))
+gram_dma_kernel(vs_gram_args A) {
+    static_assert(NBL >= 2 && NBL <= 4, "17 .. 64 index rows per half");
+    static_assert(!FULLK || NBL == 4 || NBL == 2, "FULLK means K == 64 or K == 32");
+    constexpr int NT = NBL * (NBL + 1) / 2;   // upper-triangle tiles per product
+    constexpr int DMA_WAVES = dma_waves(NBL), DMA_IMG = dma_img(NBL), DMA_SB = dma_rows(NBL);
+    constexpr int SRC = DMA_SB * 16;          // doubles between the c rows and the d rows of an image
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* const img = lds + wave * DMA_IMG;
+    const int K = A.K;
+    const uint64_t rows = A.rows;
+    const uint64_t units = rows >> 4;
+    uint32_t G = A.slab_wgs;
+    asm volatile("" : "+s"(G));   // kept in a scalar register (cf. gram_st_kernel)
+    const uint64_t stride = (uint64_t)G * DMA_WAVES;
+
+    // DMA side: lane = 8 p + r' brings plane 8 g + p of piece g, source chunk r' ^ sw(row) to chunk position r'
+    const int p = lane >> 3;
+    const uint32_t chA = (uint32_t)((lane & 7) ^ (p >> 1)), chB = chA ^ 4u;   // pieces with g even / odd
+    // fragment side: lane = i + 16 q reads chunk 4 h + q (sample rows 8 h + 2 q, + 1) of row 16 I + i
+    const int li = lane & 15, q = lane >> 4, sw = (li >> 1) & 7;
+    const uint32_t fr0 = (uint32_t)(li * 16 + 2 * (q ^ sw)), fr1 = (uint32_t)(li * 16 + 2 * ((4 + q) ^ sw));
+
+    vs_d4 accS[NT], accT[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) accS[t] = accT[t] = (vs_d4){0.0, 0.0, 0.0, 0.0};
+    vs_d2 F[2][2][NBL];   // [half of the unit][c, d][block]
+
+    // Source addresses: per unit two per-lane bases (chunk positions of even and odd pieces), per piece a wave-uniform
+    // plane offset (scalar arithmetic).  K < 64: the one piece that straddles K has its own bases (lanes past row K - 1
+    // re-read row K - 1: any mapped address will do, the fold never reads what comes of them).
+    auto dma = [&](uint64_t unit) {
+        VS2_FTILE(unit << 4);
+        const double* const lb = fb + (uint64_t)p * fp;
+        const double* const lbA = lb + 2 * chA;
+        const double* const lbB = lb + 2 * chB;
+        const int pc = p < ((K - 1) & 7) ? p : ((K - 1) & 7);
+        const double* const lc = FULLK ? lb : fb + (uint64_t)pc * fp;
+        const double* const lcA = lc + 2 * chA;
+        const double* const lcB = lc + 2 * chB;
+#pragma unroll
+        for (int src = 0; src < 2; ++src)
+#pragma unroll
+            for (int g = 0; g < 2 * NBL; ++g) {
+                if (!FULLK && 8 * g >= K) continue;              // wave-uniform: the piece is all padding
+                const bool part = !FULLK && 8 * g + 8 > K;       // wave-uniform: the piece straddles K
+                const uint64_t so = (uint64_t)(2 + src * K + 8 * g) * fp;
+                const double* gp = ((g & 1) ? (part ? lcB : lbB) : (part ? lcA : lbA)) + so;
+                __builtin_amdgcn_global_load_lds((vs_glb_ptr)gp, (vs_lds_ptr)(img + src * SRC + g * 128), 16, 0, 2 /* nt */);
+            }
+    };
+    auto read = [&](const int h) {
+        const double* rd = img + (h ? fr1 : fr0);
+#pragma unroll
+        for (int src = 0; src < 2; ++src)
+#pragma unroll
+            for (int I = 0; I < NBL; ++I) F[h][src][I] = *(const vs_d2*)(rd + src * SRC + I * 256);
+    };
+    auto step = [&](const int h, const int e) {
+        double s[NBL], t[NBL];
+#pragma unroll
+        for (int I = 0; I < NBL; ++I) {
+            const double c = F[h][0][I][e], d = F[h][1][I][e];
+            s[I] = c + d;
+            t[I] = c - d;
+        }
+        int idx = 0;
+#pragma unroll
+        for (int I = 0; I < NBL; ++I)
+#pragma unroll
+            for (int J = I; J < NBL; ++J) {
+                accS[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(s[I], s[J], accS[idx], 0, 0, 0);
+                accT[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[I], t[J], accT[idx], 0, 0, 0);
+                ++idx;
+            }
+    };
+#define DMA_PIN() __builtin_amdgcn_sched_barrier(0)
+    // The compiler does not know that an LDS-DMA writes what the fragment reads read: both waits are explicit, and the
+    // "memory" clobber keeps the reads and the DMAs on their side of them.
+#define DMA_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define DMA_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+    uint64_t u = (uint64_t)blockIdx.x * DMA_WAVES + wave;
+    if (u < units) {
+        dma(u);
+        DMA_LANDED();
+        read(0);
+    }
+    for (; u < units; u += stride) {
+        const uint64_t un = u + stride < units ? u + stride : u;   // the last unit of a wave fetches itself again (unused)
+        read(1);
+        DMA_PIN();
+        step(0, 0);
+        DMA_PIN();
+        step(0, 1);
+        DMA_PIN();
+        DMA_READS_DONE();   // every fragment of this unit is in registers: the image is free
+        dma(un);
+        step(1, 0);
+        DMA_PIN();
+        DMA_LANDED();
+        read(0);
+        DMA_PIN();
+        step(1, 1);
+        DMA_PIN();
+    }
+    // partial unit at the end of the shard: the wave whose turn it would be (exactly one leaves the loop at u == units)
+    if ((rows & 15) != 0 && u == units) {
+        DMA_READS_DONE();
+        VS2_FTILE(units << 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint64_t r = (units << 4) + 2 * (4 * h + q);   // rows is even: r and r + 1 are both inside or both outside
+            const bool in = r < rows;
+#pragma unroll
+            for (int src = 0; src < 2; ++src)
+#pragma unroll
+                for (int I = 0; I < NBL; ++I) {
+                    const int uu = 16 * I + li < K ? 16 * I + li : K - 1;
+                    const double* gp = fb + (uint64_t)(2 + src * K + uu) * fp + 2 * (4 * h + q);
+                    F[h][src][I] = in ? __builtin_nontemporal_load((const vs_d2*)gp) : (vs_d2){0.0, 0.0};
+                }
+        }
+        step(0, 0);
+        step(0, 1);
+        step(1, 0);
+        step(1, 1);
+    }
+#undef DMA_PIN
+#undef DMA_LANDED
+#undef DMA_READS_DONE
+
+    // the workgroup's sum in the partial's own layout [S S^T, T T^T][64][64], wave after wave
+    __syncthreads();
+    double* red = lds;
+    int lane_e = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_e));   // rebuilt here: nothing of it is carried through the loop
+    for (int w = 0; w < DMA_WAVES; ++w) {
+        if (wave == w) {
+            int idx = 0;
+#pragma unroll
+            for (int I = 0; I < NBL; ++I)
+#pragma unroll
+                for (int J = I; J < NBL; ++J) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int row = 16 * I + (lane_e >> 4) + 4 * v, col = 16 * J + (lane_e & 15);   // f64 C/D layout
+                        double* ps = red + row * DMA_SB + col;
+                        double* pt = ps + DMA_SB * DMA_SB;
+                        *ps = (w ? *ps : 0.0) + accS[idx][v];
+                        *pt = (w ? *pt : 0.0) + accT[idx][v];
+                    }
+                    ++idx;
+                }
+        }
+        __syncthreads();
+    }
+    // upper 16-blocks only: the fold never reads the mirror blocks
+    double* out = A.partials + (size_t)blockIdx.x * 2 * DMA_SB * DMA_SB;
+    for (int e = threadIdx.x; e < 2 * DMA_SB * DMA_SB; e += 64 * DMA_WAVES) {
+        const int rr = (e / DMA_SB) % DMA_SB, cc = e % DMA_SB;
+        if ((cc >> 4) >= (rr >> 4) && (rr >> 4) < NBL && (cc >> 4) < NBL) out[e] = red[e];   // (NBL = 3: SB = 64)
+    }
+}
+
+}  // namespace
+
+#define VS_DMA_INSTANCES(X) X(2, false) X(2, true) X(3, false) X(4, false) X(4, true)
+
+int vs_gram_dma_prepare(vs_context* ctx) {
+    (void)ctx;
+#define VS_DMA_SET(NL, FK)                                                                                     \
+    VS_HIP(hipFuncSetAttribute((const void*)gram_dma_kernel<NL, FK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)dma_lds_bytes(NL)));
+    VS_DMA_INSTANCES(VS_DMA_SET)
+#undef VS_DMA_SET
+    return VS_OK;
+}
+
+// A.K = k in 17 .. 64, A.l == 1, A.rows even, A.f 16-byte aligned (the caller checks); `workgroups` <= CUs.
+// Partials: one per workgroup, [S S^T, T T^T][SB][SB] with SB = 64 (K > 32) or 32, upper 16-blocks
+// (vs_gram_fold_args::st == 2, super == SB).
+int vs_gram_dma_launch(vs_context* ctx, const vs_gram_args& A, unsigned workgroups) {
+    VS_REQUIRE(A.K > 16 && A.K <= 64 && A.l == 1 && A.K == A.k, "gram_dma_kernel takes 17 .. 64 index rows, one output");
+    VS_REQUIRE(A.rows % 2 == 0 && ((uintptr_t)A.f & 15) == 0, "gram_dma_kernel needs an even row count and 16-byte alignment");
+    VS_REQUIRE(A.slab_wgs == workgroups && workgroups >= 1, "slab_wgs must be the grid size");
+    const dim3 grid(workgroups);
+    const int nbl = (A.K + 15) / 16;
+    const bool full = A.K == 64 || A.K == 32;
+    bool launched = false;
+#define VS_DMA_LAUNCH(NL, FK)                                                                                  \
+    if (!launched && nbl == NL && full == FK) {                                                                \
+        hipLaunchKernelGGL((gram_dma_kernel<NL, FK>), grid, dim3(64 * dma_waves(NL)), dma_lds_bytes(NL), ctx->stream, A); \
+        launched = true;                                                                                       \
+    }
+    VS_DMA_INSTANCES(VS_DMA_LAUNCH)
+#undef VS_DMA_LAUNCH
+    if (!launched) return vs_fail(VS_ERR_STATE, "no gram_dma_kernel instance for K=%d", A.K);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}

@@ -41,3 +41,8 @@ struct vs_gram_args {
 // vs_gram_st.hip: the S/T kernel for 33 .. 128 index rows per half (one output, even row count, no mask)
 int vs_gram_st_prepare(vs_context* ctx);
 int vs_gram_st_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, unsigned workgroups);
+
+// vs_gram_dma.hip: 33 .. 64 index rows per half, one output, even row count, no mask, second order alone: every wave
+// on its own image, filled by LDS-DMA in whole lines (round 5)
+int vs_gram_dma_prepare(vs_context* ctx);
+int vs_gram_dma_launch(vs_context* ctx, const vs_gram_args& A, unsigned workgroups);

@@ -1487,6 +1487,8 @@ static int gram_raise_lds_limits(vs_context* ctx) {
 #undef VS2_SET_WIDE
     int rc_st = vs_gram_st_prepare(ctx);
     if (rc_st) return rc_st;
+    rc_st = vs_gram_dma_prepare(ctx);
+    if (rc_st) return rc_st;
     ctx->gram_lds_raised = true;
     return VS_OK;
 }
@@ -1539,6 +1541,13 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const uint64_t units = macro ? (nchunks + 3) / 4 : nchunks;   // the macro kernel walks groups of 4 chunks
     const uint32_t slab_wgs = (uint32_t)(units < want ? units : want);
     const bool st_new = st128 || half_st;   // the unmasked pass runs on gram_st_kernel (any number of outputs)
+    // ... or, second order alone with one output and 33 .. 64 index rows, on gram_dma_kernel (vs_gram_dma.hip)
+    const bool dma = half_st && !with_first && l == 1 && ctx->tune.gram_dma != 0;
+    // ... and, as a measurement knob only (VS_GRAM_DMA=2), 17 .. 32 index rows (sixteen waves per CU on images of 32 rows
+    // per half; partials [S S^T, T T^T][32][32]): HBM-bound there and level with gram_diag_wide_kernel -- k = 32, n = 2^22:
+    // 0.338-0.348 against 0.332-0.398 ms, k = 24: 0.275 against 0.255 (profiles/r05/gram_dma_ab.txt) -- so not the default
+    const bool dma32 = !macro && K > 16 && l == 1 && aligned && !with_first && ctx->tune.gram_dma == 2;
+    const uint32_t dma32_wgs = (uint32_t)(nchunks < (uint64_t)cus ? nchunks : (uint64_t)cus);
     const uint32_t st_wgs = (uint32_t)(units < (uint64_t)cus ? units : (uint64_t)cus);   // one per CU (160 KiB of LDS)
     // the wide wave-private kernel (32 sample rows per unit, two workgroups per CU) takes the unmasked pass of
     // one-output problems with 33..64 index rows
@@ -1620,7 +1629,11 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
         }
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
-            if (half_st && st_new && !masked) {
+            if (half_st && st_new && !masked && dma) {
+                A.slab_wgs = F.P = st_wgs;   // one partial per workgroup
+                rc = vs_gram_dma_launch(ctx, A, st_wgs);
+                if (rc) return rc;
+            } else if (half_st && st_new && !masked) {
                 A.slab_wgs = st_wgs;
                 F.P = pslots_new;
                 rc = vs_gram_st_launch(ctx, A, with_first, st_wgs);
@@ -1661,6 +1674,10 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
                 VS2_MACRO_INSTANCES(VS2_LAUNCH_MACRO)
 #undef VS2_LAUNCH_MACRO
                 if (!launched) return vs_fail(VS_ERR_STATE, "no Gram kernel for this case");   // with_first is never masked
+            } else if (dma32 && !masked) {
+                A.slab_wgs = F.P = dma32_wgs;
+                rc = vs_gram_dma_launch(ctx, A, dma32_wgs);
+                if (rc) return rc;
             } else if (wide && !masked) {
                 const size_t lds_x = sizeof(double) * (size_t)(nb_wave == 3 ? VS2_WIDE_LDS(3, false) : VS2_WIDE_LDS(4, false));
                 A.slab_wgs = F.P = wide_wgs;
@@ -1707,7 +1724,16 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
         F.masked = masked ? 1 : 0;
         {
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_FOLD);
-            hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)(width / 64)), dim3(VS2_FOLD_THREADS), 0, ctx->stream, F);
+            vs_gram_fold_args Fp = F;
+            size_t fold_width = width;
+            if (dma32 && !masked) {   // gram_dma_kernel's partials at 17 .. 32 index rows: two tiles of 32 x 32
+                Fp.st = 2;
+                Fp.super = 32;
+                Fp.nsuper = 1;
+                Fp.npairs = 2;
+                fold_width = 2 * 32 * 32;
+            }
+            hipLaunchKernelGGL(gram_fold_kernel, dim3((unsigned)(fold_width / 64)), dim3(VS2_FOLD_THREADS), 0, ctx->stream, Fp);
         }
         VS_HIP(hipGetLastError());
     }
