@@ -643,6 +643,28 @@ def test_second_order_dma_kernel(ctx_dma_all, ctx_no_dma, k, rows):
         for M, X in ((G[0], S), (G[1], T)):
             want = math.fsum((X[i] * X[j]).tolist())
             assert abs(M[i, j] - want) <= 1e-13 * scale, (i, j)
+    # both orders in one call: from 33 index rows on the same kernel carries the first-order dot products (lane u owns
+    # index row u) where they fit -- 33 .. 48 rows and 64; the record against the first-order kernel's and exact sums
+    from varsens_amd import _native
+    nacc = _native.acc_len(k, 1, 1)
+    f = ctx_dma_all.upload_blocks(blocks)
+    acc1, acc2, g2 = ctx_dma_all.alloc(8 * nacc), ctx_dma_all.alloc(8 * nacc), ctx_dma_all.alloc(8 * 2 * k * k)
+    ctx_dma_all.reduce_first_order(f, rows, k, 1, acc1)
+    ctx_dma_all.reduce_first_second_order(f, rows, k, 1, acc2, g2)
+    a1, a2 = ctx_dma_all.download(acc1, (nacc,)), ctx_dma_all.download(acc2, (nacc,))
+    G2 = ctx_dma_all.download(g2, (2, k, k))
+    for b in (f, acc1, acc2, g2):
+        b.free()
+    assert np.array_equal(a1[:4], a2[:4])
+    per = _native.acc_per_output(k)
+    r1, r2 = a1[_native.ACC_HEADER:_native.ACC_HEADER + per], a2[_native.ACC_HEADER:_native.ACC_HEADER + per]
+    np.testing.assert_allclose(r2, r1, rtol=2e-13, atol=1e-13 * np.abs(r1).max())
+    a, b = blocks[0, :, 0], blocks[1, :, 0]
+    for j in (0, k // 2, k - 1):
+        for got, want in ((r2[3 + j], math.fsum((a * C[j]).tolist())), (r2[3 + k + j], math.fsum((b * D[j]).tolist())),
+                          (r2[3 + 2 * k + j], math.fsum((a * D[j]).tolist())), (r2[3 + 3 * k + j], math.fsum((b * C[j]).tolist()))):
+            assert abs(got - want) <= 1e-13 * max(abs(want), np.abs(r1).max() * 1e-3), j
+    np.testing.assert_allclose(G2, G, rtol=1e-12, atol=1e-12 * scale)
 
 
 @pytest.mark.parametrize("k,rows,l", [(6, 1000, 1), (32, 5000, 1), (16, 200000, 1), (3, 5, 1), (12, 100003, 1),

@@ -27,8 +27,8 @@
 // same bits run to run, and whatever the row-block size of the layout.
 // Measured (k = 64, n = 2^22, prototype): 0.66-0.69 ms = 6.3-6.5 TB/s = 0.80 of HBM and 0.81 of the matrix pipe at
 // once, shader clock 2.25-2.35 GHz; the loop without its DMA 0.59 ms, the DMA stream alone 0.63.
-// Rows of the image past K are never written (their pieces are skipped, clamped lanes re-read row K - 1): whatever
-// they hold ends up in rows and columns >= K of the tiles, which the fold never reads.
+// Rows of the image past K are never written (their pieces are skipped; a piece that would straddle K is moved back to
+// end at row K - 1): whatever they hold ends up in rows and columns >= K of the tiles, which the fold never reads.
 // A shard whose row count is not a multiple of 16 ends in a partial unit: the wave whose turn it is loads it straight
 // into the fragment layout with guarded loads (zeros past the last row).
 #include "vs_second.h"
@@ -39,23 +39,47 @@ namespace {
 // 2 (K = 17 .. 32): images of 32 rows per half, sixteen waves per CU (four per SIMD, 6 tiles per wave: HBM-bound)
 constexpr int dma_rows(int nbl) { return nbl <= 2 ? 32 : 64; }          // image rows per half = SB of the partial
 constexpr int dma_waves(int nbl) { return nbl <= 2 ? 16 : 8; }
-constexpr int dma_img(int nbl) { return 2 * dma_rows(nbl) * 16; }        // doubles per unit image: [c, d][rows][16]
-constexpr size_t dma_lds_bytes(int nbl) { return sizeof(double) * dma_waves(nbl) * dma_img(nbl); }   // 128 KiB
+// doubles per unit image: [c, d][rows][16], FIRST: + [a, b][16] (fM_1 and fM_2 of the unit's sample rows)
+constexpr int dma_img(int nbl, bool first) { return 2 * dma_rows(nbl) * 16 + (first ? 32 : 0); }
+constexpr size_t dma_lds_bytes(int nbl, bool first) { return sizeof(double) * dma_waves(nbl) * dma_img(nbl, first); }   // 128 KiB (+ 2 KiB)
 
 typedef __attribute__((address_space(3))) void* vs_lds_ptr;
 typedef const __attribute__((address_space(1))) void* vs_glb_ptr;
 
 // NBL: live 16-row blocks per half (2: K = 17 .. 32, 3: 33 .. 48, 4: 49 .. 64); FULLK: K == 16 NBL with NBL even (no
 // clamping of rows past K)
-template <int NBL, bool FULLK>
+// FIRST (vs_reduce_first_second_order, 33 .. 64 index rows): the dot products a.c_u, a.d_u, b.c_u, b.d_u of the first-order
+// record (a = fM_1, b = fM_2: varsens/saltelli.py:591-596) ride along.  They do not fit beside 160 accumulator registers
+// in the MFMA fragment layout (16 more accumulators per lane); here LANE u OWNS INDEX ROW u: it reads its own row of c and
+// of d from the image (the swizzle makes those reads conflict-free too: a ds_read_b128 lane group holds rows with eight
+// different (u >> 1) & 7, each twice with opposite u & 1) and a, b of the unit from a 17th piece of the DMA (every lane
+// the same address: a broadcast), 64 v_fma_f64 per unit into FOUR accumulators per lane, a chunk of two sample rows at a
+// time between the MFMAs of the unit's first two steps (16 VGPRs in flight).  To make room the fragments of one half-unit
+// live in registers at a time (32 instead of 64: the reads of the next half go out right after the adds that consumed the
+// last one, ahead of that step's 20 MFMAs).  The five scalar sums come from first_head_kernel, as for gram_st_kernel.
+template <int NBL, bool FULLK, bool FIRST>
 __global__ void __launch_bounds__(64 * dma_waves(NBL))
 __attribute__((amdgpu_waves_per_eu(dma_waves(NBL) / 4, dma_waves(NBL) / 4)))
 gram_dma_kernel(vs_gram_args A) {
     static_assert(NBL >= 2 && NBL <= 4, "17 .. 64 index rows per half");
     static_assert(!FULLK || NBL == 4 || NBL == 2, "FULLK means K == 64 or K == 32");
+    static_assert(!FIRST || NBL >= 3, "up to 32 index rows the wave-private kernels of vs_second.hip carry the first-order sums");
+    // (49 .. 63 index rows with the first-order sums: 11 registers short, the piece that ends at row K - 1 brings its own
+    // lane constants -- that shape stays on gram_st_kernel)
+    static_assert(!FIRST || NBL == 3 || FULLK, "FIRST: 33 .. 48 index rows, or 64");
     constexpr int NT = NBL * (NBL + 1) / 2;   // upper-triangle tiles per product
-    constexpr int DMA_WAVES = dma_waves(NBL), DMA_IMG = dma_img(NBL), DMA_SB = dma_rows(NBL);
+    constexpr int DMA_WAVES = dma_waves(NBL), DMA_IMG = dma_img(NBL, FIRST), DMA_SB = dma_rows(NBL);
     constexpr int SRC = DMA_SB * 16;          // doubles between the c rows and the d rows of an image
+    constexpr int AB = 2 * SRC;               // FIRST: a at [AB, AB + 16), b at [AB + 16, AB + 32)
+    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) {
+        // this kernel opens the call: reset the counters the two folds use (cf. gram_st_kernel)
+        uint32_t* c = const_cast<uint32_t*>(A.counters);
+        c[0] = 0;
+        c[1] = 0xffffffffu;
+        c[2] = 0;
+        c[3] = 0;
+        c[4] = 0;
+    }
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -77,55 +101,30 @@ gram_dma_kernel(vs_gram_args A) {
     vs_d4 accS[NT], accT[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) accS[t] = accT[t] = (vs_d4){0.0, 0.0, 0.0, 0.0};
-    vs_d2 F[2][2][NBL];   // [half of the unit][c, d][block]
 
-    // Source addresses: per unit two per-lane bases (chunk positions of even and odd pieces), per piece a wave-uniform
-    // plane offset (scalar arithmetic).  K < 64: the one piece that straddles K has its own bases (lanes past row K - 1
-    // re-read row K - 1: any mapped address will do, the fold never reads what comes of them).
+    // Source addresses: per unit one per-lane base (plane p of a piece), per piece a wave-uniform plane offset (scalar
+    // arithmetic) and the lane's chunk.  K not a multiple of 8: the piece that would straddle K brings rows K - 8 .. K - 1
+    // instead (into their own places in the image, over what the piece before it wrote there: the same values) -- no lane
+    // ever reads a plane past d_{K-1}, which in the last row block would be past the end of the buffer.
+    const uint32_t chC = (uint32_t)((lane & 7) ^ (((K - 8 + p) >> 1) & 7));
     auto dma = [&](uint64_t unit) {
         VS2_FTILE(unit << 4);
         const double* const lb = fb + (uint64_t)p * fp;
-        const double* const lbA = lb + 2 * chA;
-        const double* const lbB = lb + 2 * chB;
-        const int pc = p < ((K - 1) & 7) ? p : ((K - 1) & 7);
-        const double* const lc = FULLK ? lb : fb + (uint64_t)pc * fp;
-        const double* const lcA = lc + 2 * chA;
-        const double* const lcB = lc + 2 * chB;
 #pragma unroll
         for (int src = 0; src < 2; ++src)
 #pragma unroll
             for (int g = 0; g < 2 * NBL; ++g) {
                 if (!FULLK && 8 * g >= K) continue;              // wave-uniform: the piece is all padding
-                const bool part = !FULLK && 8 * g + 8 > K;       // wave-uniform: the piece straddles K
-                const uint64_t so = (uint64_t)(2 + src * K + 8 * g) * fp;
-                const double* gp = ((g & 1) ? (part ? lcB : lbB) : (part ? lcA : lbA)) + so;
-                __builtin_amdgcn_global_load_lds((vs_glb_ptr)gp, (vs_lds_ptr)(img + src * SRC + g * 128), 16, 0, 2 /* nt */);
+                const bool part = !FULLK && 8 * g + 8 > K;       // wave-uniform: the piece would straddle K
+                const int urow = part ? K - 8 : 8 * g;
+                const uint32_t ch = part ? chC : (g & 1) ? chB : chA;
+                const double* gp = lb + (uint64_t)(2 + src * K + urow) * fp + 2 * ch;
+                __builtin_amdgcn_global_load_lds((vs_glb_ptr)gp, (vs_lds_ptr)(img + src * SRC + urow * 16), 16, 0, 2 /* nt */);
             }
-    };
-    auto read = [&](const int h) {
-        const double* rd = img + (h ? fr1 : fr0);
-#pragma unroll
-        for (int src = 0; src < 2; ++src)
-#pragma unroll
-            for (int I = 0; I < NBL; ++I) F[h][src][I] = *(const vs_d2*)(rd + src * SRC + I * 256);
-    };
-    auto step = [&](const int h, const int e) {
-        double s[NBL], t[NBL];
-#pragma unroll
-        for (int I = 0; I < NBL; ++I) {
-            const double c = F[h][0][I][e], d = F[h][1][I][e];
-            s[I] = c + d;
-            t[I] = c - d;
+        if (FIRST && lane < 16) {   // planes 0 (a) and 1 (b): lanes 0-7 and 8-15, chunk lane & 7
+            const double* gp = fb + (uint64_t)(lane >> 3) * fp + 2 * (lane & 7);
+            __builtin_amdgcn_global_load_lds((vs_glb_ptr)gp, (vs_lds_ptr)(img + AB), 16, 0, 2 /* nt */);
         }
-        int idx = 0;
-#pragma unroll
-        for (int I = 0; I < NBL; ++I)
-#pragma unroll
-            for (int J = I; J < NBL; ++J) {
-                accS[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(s[I], s[J], accS[idx], 0, 0, 0);
-                accT[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[I], t[J], accT[idx], 0, 0, 0);
-                ++idx;
-            }
     };
 #define DMA_PIN() __builtin_amdgcn_sched_barrier(0)
     // The compiler does not know that an LDS-DMA writes what the fragment reads read: both waits are explicit, and the
@@ -134,50 +133,134 @@ gram_dma_kernel(vs_gram_args A) {
 #define DMA_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
     uint64_t u = (uint64_t)blockIdx.x * DMA_WAVES + wave;
-    if (u < units) {
-        dma(u);
-        DMA_LANDED();
-        read(0);
-    }
-    for (; u < units; u += stride) {
-        const uint64_t un = u + stride < units ? u + stride : u;   // the last unit of a wave fetches itself again (unused)
-        read(1);
-        DMA_PIN();
-        step(0, 0);
-        DMA_PIN();
-        step(0, 1);
-        DMA_PIN();
-        DMA_READS_DONE();   // every fragment of this unit is in registers: the image is free
-        dma(un);
-        step(1, 0);
-        DMA_PIN();
-        DMA_LANDED();
-        read(0);
-        DMA_PIN();
-        step(1, 1);
-        DMA_PIN();
-    }
-    // partial unit at the end of the shard: the wave whose turn it would be (exactly one leaves the loop at u == units)
-    if ((rows & 15) != 0 && u == units) {
-        DMA_READS_DONE();
-        VS2_FTILE(units << 4);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint64_t r = (units << 4) + 2 * (4 * h + q);   // rows is even: r and r + 1 are both inside or both outside
-            const bool in = r < rows;
+    // FIRST: the row-owner sums of lane u = lane
+    double ac = 0.0, ad = 0.0, bc = 0.0, bd = 0.0;
+    {
+        const int rsw = (lane >> 1) & 7;
+        const double* const own = img + lane * 16;
+        // chunk r (sample rows 2 r, 2 r + 1 of the unit) of this lane's rows of c and d, and of a and b
+        struct ro_regs {
+            vs_d2 c, d, a, b;
+        };
+        auto ro_read = [&](const int r, ro_regs& R) {
+            const double* pc = own + 2 * (r ^ rsw);
+            R.c = *(const vs_d2*)pc;
+            R.d = *(const vs_d2*)(pc + SRC);
+            R.a = *(const vs_d2*)(img + AB + 2 * r);
+            R.b = *(const vs_d2*)(img + AB + 16 + 2 * r);
+        };
+        auto ro_fma = [&](const ro_regs& R) {
+            ac = fma(R.a[0], R.c[0], ac);
+            ad = fma(R.a[0], R.d[0], ad);
+            bc = fma(R.b[0], R.c[0], bc);
+            bd = fma(R.b[0], R.d[0], bd);
+            ac = fma(R.a[1], R.c[1], ac);
+            ad = fma(R.a[1], R.d[1], ad);
+            bc = fma(R.b[1], R.c[1], bc);
+            bd = fma(R.b[1], R.d[1], bd);
+            // sched_barrier pins the machine schedule only: left alone the optimiser sinks all 64 fmas of a unit behind its
+            // last read and keeps eight chunks alive (292 spilled registers).  The sums pass through here, so the fmas of
+            // this chunk are done before the next chunk is read; the clobber keeps the reads on their side.
+            asm volatile("" : "+v"(ac), "+v"(ad), "+v"(bc), "+v"(bd) : : "memory");
+        };
+        vs_d2 H[2][NBL];   // the fragments of ONE half-unit: [c, d][block]
+        auto readh = [&](const int h) {
+            const double* rd = img + (h ? fr1 : fr0);
 #pragma unroll
             for (int src = 0; src < 2; ++src)
 #pragma unroll
-                for (int I = 0; I < NBL; ++I) {
-                    const int uu = 16 * I + li < K ? 16 * I + li : K - 1;
-                    const double* gp = fb + (uint64_t)(2 + src * K + uu) * fp + 2 * (4 * h + q);
-                    F[h][src][I] = in ? __builtin_nontemporal_load((const vs_d2*)gp) : (vs_d2){0.0, 0.0};
+                for (int I = 0; I < NBL; ++I) H[src][I] = *(const vs_d2*)(rd + src * SRC + I * 256);
+        };
+        // one MFMA step on element e of H.  act: what follows the adds (which are the last readers of element 1):
+        // 1: the fragments of the unit's second half, 2: wait for the next unit's DMA, then its first half.
+        // r0 >= 0: the row-owner chunks r0 .. r0 + 3, a chunk's reads NT / 4 tile pairs ahead of its 8 fmas.
+        auto step1 = [&](const int e, const int act, const int r0) {
+            double s[NBL], t[NBL];
+#pragma unroll
+            for (int I = 0; I < NBL; ++I) {
+                const double c = H[0][I][e], d = H[1][I][e];
+                s[I] = c + d;
+                t[I] = c - d;
+            }
+            DMA_PIN();
+            if (act == 1) readh(1);
+            if (act == 2) {
+                DMA_LANDED();
+                readh(0);
+            }
+            ro_regs R;
+            if (r0 >= 0) ro_read(r0, R);
+            DMA_PIN();
+            int idx = 0, chunk = 0;
+#pragma unroll
+            for (int I = 0; I < NBL; ++I)
+#pragma unroll
+                for (int J = I; J < NBL; ++J) {
+                    accS[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(s[I], s[J], accS[idx], 0, 0, 0);
+                    accT[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[I], t[J], accT[idx], 0, 0, 0);
+                    ++idx;
+                    if (r0 >= 0 && chunk < 3 && idx == (NT * (chunk + 1)) / 4) {
+                        DMA_PIN();
+                        ro_fma(R);
+                        ++chunk;
+                        ro_read(r0 + chunk, R);
+                        DMA_PIN();
+                    }
                 }
+            if (r0 >= 0) {
+                DMA_PIN();
+                ro_fma(R);
+            }
+        };
+        if (u < units) {
+            dma(u);
+            DMA_LANDED();
+            readh(0);
         }
-        step(0, 0);
-        step(0, 1);
-        step(1, 0);
-        step(1, 1);
+        for (; u < units; u += stride) {
+            const uint64_t un = u + stride < units ? u + stride : u;
+            DMA_PIN();
+            step1(0, 0, FIRST ? 0 : -1);
+            DMA_PIN();
+            step1(1, 1, FIRST ? 4 : -1);
+            DMA_PIN();
+            DMA_READS_DONE();   // fragments and row-owner chunks of this unit are in registers: the image is free
+            dma(un);
+            step1(0, 0, -1);
+            DMA_PIN();
+            step1(1, 2, -1);
+            DMA_PIN();
+        }
+        if ((rows & 15) != 0 && u == units) {
+            DMA_READS_DONE();
+            VS2_FTILE(units << 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint64_t r = (units << 4) + 2 * (4 * h + q);
+                const bool in = r < rows;
+#pragma unroll
+                for (int src = 0; src < 2; ++src)
+#pragma unroll
+                    for (int I = 0; I < NBL; ++I) {
+                        const int uu = 16 * I + li < K ? 16 * I + li : K - 1;
+                        const double* gp = fb + (uint64_t)(2 + src * K + uu) * fp + 2 * (4 * h + q);
+                        H[src][I] = in ? __builtin_nontemporal_load((const vs_d2*)gp) : (vs_d2){0.0, 0.0};
+                    }
+                step1(0, 0, -1);
+                step1(1, 0, -1);
+            }
+            // the row-owner sums of the partial unit, straight from memory
+            const int uo = lane < K ? lane : K - 1;
+            for (int r = 0; FIRST && r < 8; ++r) {
+                if ((units << 4) + 2 * r >= rows) break;
+                ro_regs R;
+                R.c = *(const vs_d2*)(fb + (uint64_t)(2 + uo) * fp + 2 * r);
+                R.d = *(const vs_d2*)(fb + (uint64_t)(2 + K + uo) * fp + 2 * r);
+                R.a = *(const vs_d2*)(fb + 2 * r);
+                R.b = *(const vs_d2*)(fb + fp + 2 * r);
+                ro_fma(R);
+            }
+        }
     }
 #undef DMA_PIN
 #undef DMA_LANDED
@@ -205,8 +288,30 @@ gram_dma_kernel(vs_gram_args A) {
                     }
                     ++idx;
                 }
+            if (FIRST) {   // [a.c, b.d, a.d, b.c][64] behind the tiles: the order of the record's slots
+                double* fs = red + 2 * DMA_SB * DMA_SB + lane_e;
+                fs[0] = (w ? fs[0] : 0.0) + ac;
+                fs[64] = (w ? fs[64] : 0.0) + bd;
+                fs[128] = (w ? fs[128] : 0.0) + ad;
+                fs[192] = (w ? fs[192] : 0.0) + bc;
+            }
         }
         __syncthreads();
+    }
+    if (FIRST) {
+        // one record per workgroup: head (zeros: first_head_kernel's records carry the five scalar sums), ac[k], bd[k], ad[k], bc[k]
+        const int k = A.k;
+        const size_t plen = VS_PLEN(k);
+        double* rec = A.first_partials + (size_t)blockIdx.x * plen;
+        const double* fs = red + 2 * DMA_SB * DMA_SB;
+        for (size_t e = threadIdx.x; e < plen; e += 64 * DMA_WAVES) {
+            double v = 0.0;
+            if (e >= VS_P_HEAD) {
+                const int slot = (int)((e - VS_P_HEAD) / k), j = (int)((e - VS_P_HEAD) % k);
+                v = fs[slot * 64 + j];
+            }
+            rec[e] = v;
+        }
     }
     // upper 16-blocks only: the fold never reads the mirror blocks
     double* out = A.partials + (size_t)blockIdx.x * 2 * DMA_SB * DMA_SB;
@@ -218,32 +323,39 @@ gram_dma_kernel(vs_gram_args A) {
 
 }  // namespace
 
-#define VS_DMA_INSTANCES(X) X(2, false) X(2, true) X(3, false) X(4, false) X(4, true)
+#define VS_DMA_INSTANCES(X) \
+    X(2, false, false) X(2, true, false) X(3, false, false) X(4, false, false) X(4, true, false) \
+    X(3, false, true) X(4, true, true)
 
 int vs_gram_dma_prepare(vs_context* ctx) {
     (void)ctx;
-#define VS_DMA_SET(NL, FK)                                                                                     \
-    VS_HIP(hipFuncSetAttribute((const void*)gram_dma_kernel<NL, FK>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                               (int)dma_lds_bytes(NL)));
+#define VS_DMA_SET(NL, FK, FI)                                                                                     \
+    VS_HIP(hipFuncSetAttribute((const void*)gram_dma_kernel<NL, FK, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)dma_lds_bytes(NL, FI)));
     VS_DMA_INSTANCES(VS_DMA_SET)
 #undef VS_DMA_SET
     return VS_OK;
 }
 
+bool vs_gram_dma_takes_first(int K) { return (K > 32 && K <= 48) || K == 64; }
+
 // A.K = k in 17 .. 64, A.l == 1, A.rows even, A.f 16-byte aligned (the caller checks); `workgroups` <= CUs.
 // Partials: one per workgroup, [S S^T, T T^T][SB][SB] with SB = 64 (K > 32) or 32, upper 16-blocks
 // (vs_gram_fold_args::st == 2, super == SB).
-int vs_gram_dma_launch(vs_context* ctx, const vs_gram_args& A, unsigned workgroups) {
+// with_first (K > 32): also one first-order record per workgroup at A.first_partials (dot products; head zero).
+int vs_gram_dma_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, unsigned workgroups) {
     VS_REQUIRE(A.K > 16 && A.K <= 64 && A.l == 1 && A.K == A.k, "gram_dma_kernel takes 17 .. 64 index rows, one output");
+    VS_REQUIRE(!with_first || (vs_gram_dma_takes_first(A.K) && A.first_partials),
+               "gram_dma_kernel carries the first-order sums at 33 .. 48 and at 64 index rows");
     VS_REQUIRE(A.rows % 2 == 0 && ((uintptr_t)A.f & 15) == 0, "gram_dma_kernel needs an even row count and 16-byte alignment");
     VS_REQUIRE(A.slab_wgs == workgroups && workgroups >= 1, "slab_wgs must be the grid size");
     const dim3 grid(workgroups);
     const int nbl = (A.K + 15) / 16;
     const bool full = A.K == 64 || A.K == 32;
     bool launched = false;
-#define VS_DMA_LAUNCH(NL, FK)                                                                                  \
-    if (!launched && nbl == NL && full == FK) {                                                                \
-        hipLaunchKernelGGL((gram_dma_kernel<NL, FK>), grid, dim3(64 * dma_waves(NL)), dma_lds_bytes(NL), ctx->stream, A); \
+#define VS_DMA_LAUNCH(NL, FK, FI)                                                                              \
+    if (!launched && nbl == NL && full == FK && with_first == FI) {                                            \
+        hipLaunchKernelGGL((gram_dma_kernel<NL, FK, FI>), grid, dim3(64 * dma_waves(NL)), dma_lds_bytes(NL, FI), ctx->stream, A); \
         launched = true;                                                                                       \
     }
     VS_DMA_INSTANCES(VS_DMA_LAUNCH)

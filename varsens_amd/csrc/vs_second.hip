@@ -1542,7 +1542,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const uint32_t slab_wgs = (uint32_t)(units < want ? units : want);
     const bool st_new = st128 || half_st;   // the unmasked pass runs on gram_st_kernel (any number of outputs)
     // ... or, second order alone with one output and 33 .. 64 index rows, on gram_dma_kernel (vs_gram_dma.hip)
-    const bool dma = half_st && !with_first && l == 1 && ctx->tune.gram_dma != 0;
+    const bool dma = half_st && l == 1 && ctx->tune.gram_dma != 0 && (!with_first || vs_gram_dma_takes_first(K));   // with_first: it carries the dot products too
     // ... and, as a measurement knob only (VS_GRAM_DMA=2), 17 .. 32 index rows (sixteen waves per CU on images of 32 rows
     // per half; partials [S S^T, T T^T][32][32]): HBM-bound there and level with gram_diag_wide_kernel -- k = 32, n = 2^22:
     // 0.338-0.348 against 0.332-0.398 ms, k = 24: 0.275 against 0.255 (profiles/r05/gram_dma_ab.txt) -- so not the default
@@ -1561,7 +1561,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const size_t plen = VS_PLEN(k);
     const uint32_t pslots_old = half_st ? 2 * slab_wgs : slab_wgs;   // partials per pair: the older kernels (masked pass)
     const uint32_t pslots_new = half_st ? 2 * st_wgs : st_wgs;        //   gram_st_kernel
-    const uint32_t pslots = (st_new && with_first) ? pslots_new : pslots_old;   // first-order records per pair
+    const uint32_t pslots = (dma && with_first) ? st_wgs : (st_new && with_first) ? pslots_new : pslots_old;   // first-order records per pair
     const uint32_t P_diag = with_first ? pslots * (uint32_t)nsuper : 0;                         // macro kernels' records
     const uint32_t P_head = with_first ? (uint32_t)((rows + 4095) / 4096 < (uint64_t)cus ? (rows + 4095) / 4096 : cus) : 0;
     const uint32_t P_first = P_diag + P_head;                                                   // + first_head_kernel's
@@ -1631,7 +1631,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
             vs_launch_scope scope(ctx, VS_KERNEL_SECOND_ORDER);
             if (half_st && st_new && !masked && dma) {
                 A.slab_wgs = F.P = st_wgs;   // one partial per workgroup
-                rc = vs_gram_dma_launch(ctx, A, st_wgs);
+                rc = vs_gram_dma_launch(ctx, A, with_first, st_wgs);
                 if (rc) return rc;
             } else if (half_st && st_new && !masked) {
                 A.slab_wgs = st_wgs;
@@ -1676,7 +1676,7 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
                 if (!launched) return vs_fail(VS_ERR_STATE, "no Gram kernel for this case");   // with_first is never masked
             } else if (dma32 && !masked) {
                 A.slab_wgs = F.P = dma32_wgs;
-                rc = vs_gram_dma_launch(ctx, A, dma32_wgs);
+                rc = vs_gram_dma_launch(ctx, A, false, dma32_wgs);
                 if (rc) return rc;
             } else if (wide && !masked) {
                 const size_t lds_x = sizeof(double) * (size_t)(nb_wave == 3 ? VS2_WIDE_LDS(3, false) : VS2_WIDE_LDS(4, false));
