@@ -239,6 +239,50 @@ def host_callable_route(ctx, k, log2n, cpu=True, second_order=True):
     return out
 
 
+def second_order_at(ctx, k, log2n, reps=10):
+    """Second order (and both orders in one call) at another shape than the headline's, on f-values evaluated here: the
+    33 .. 64 index rows of gram_dma_kernel (csrc/vs_gram_dma.hip), where HBM stream and matrix pipe weigh the same."""
+    from varsens_amd import _native
+    from varsens_amd.saltelli import seed1_permutation
+    n = 1 << log2n
+    design = ctx.design_create(_native.GEN_HALTON, k, n, 1 + 20 * k, _native.SCALE_IDENTITY, None, None, seed1_permutation(n))
+    objective = ctx.objective_create(_native.OBJ_LINEAR, k, 1, np.arange(1, k + 1, dtype=float))
+    f = ctx.alloc(8 * 2 * (k + 1) * n)
+    ctx.eval(design, objective, 0, n, f)
+    gram, acc = ctx.alloc(8 * _native.gram_len(k)), ctx.alloc(8 * _native.acc_len(k, 1, 1))
+    for _ in range(10):   # a dozen ms: the launch is power-bound and the first ones after another phase run slower
+        ctx.reduce_second_order(f, n, k, 1, gram)
+    ctx.sync()
+    ctx.profile_begin(8 * reps)
+    for _ in range(reps):
+        ctx.reduce_second_order(f, n, k, 1, gram)
+    so = [ms for name, ms in ctx.profile_end() if name == "second_order"]
+    for _ in range(3):
+        ctx.reduce_first_second_order(f, n, k, 1, acc, gram)
+    ctx.sync()
+    ctx.profile_begin(32 * reps)
+    for _ in range(reps):
+        ctx.reduce_first_second_order(f, n, k, 1, acc, gram)
+    recs = ctx.profile_end()
+    for b in (f, gram, acc):
+        b.free()
+    ms = float(np.median(so))
+    nbl = (k + 15) // 16
+    flops = nbl * (nbl + 1) * (n / 4.0) * (2 * 16 * 16 * 4)
+    gbytes = 16.0 * k * n / 1e9
+    return {"k": k, "n": n, "kernel": "gram_dma_kernel" if 32 < k <= 64 else "see DESIGN.md 4.3",
+            "avg_launch_ms": ms, "min_launch_ms": float(min(so)),
+            "hbm": {"achieved": gbytes / (ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbytes / (ms * 1e-3) / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 16 * k * n},
+            "mfma": {"achieved": flops / (ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "flops_per_launch": flops},
+            "both_orders_one_call_kernels_ms": sum(m for _, m in recs) / reps,
+            "both_orders_gram_kernel_ms": float(np.median([m for name, m in recs if name == "second_order"])),
+            "note": "HIP events around the launches, median of %d; at this shape the two roofs coincide (0.54 ms of HBM "
+                    "at 8 TB/s, 0.55 ms of fp64 MFMA at 2.4 GHz) and the launch is power-bound: the shader clock "
+                    "settles at 1.95-2.05 GHz under full-entropy operands (DESIGN.md 4.3)" % reps}
+
+
 def spawn_ranks(world, argv=None, script=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process (the
     reference's fan-out is a PBS array job, varsens/cluster/accre-submit.sh:27).  The parent never imports the
@@ -715,6 +759,9 @@ def main():
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
             cpu, _ = cpu_baseline(k, blocks, n_small, cores)
             line["cpu_baseline"] = cpu
+        if world == 1 and not args.no_host_routes and not args.no_cpu_baseline:
+            # (kept out of the profiling passes, which run with both flags: one more evaluation kernel instance)
+            line["second_order_k64"] = second_order_at(ctx, 64, 22)
         if world == 1 and not args.no_host_routes:
             # the two routes with an opaque model, whole API calls by the wall clock (k = 32; n = 2^20 with 1 and 3
             # outputs; a numpy-vectorised model at n = 2^18), each beside the oracle's CPU path on the same data
