@@ -667,6 +667,34 @@ def test_second_order_dma_kernel(ctx_dma_all, ctx_no_dma, k, rows):
     np.testing.assert_allclose(G2, G, rtol=1e-12, atol=1e-12 * scale)
 
 
+# ... with several outputs (index row u = column * l + output lives in plane output * (2k + 2) + 2 + column): 33 .. 64 rows
+@pytest.mark.parametrize("k,l,rows", [(17, 2, 34), (20, 3, 1000), (11, 4, 4096), (16, 4, 62), (13, 3, 3000), (32, 2, 65598),
+                                      (9, 7, 2050), (21, 3, 4110), (8, 8, 30), (12, 5, 131078), (16, 3, 48), (7, 9, 100),
+                                      (2, 17, 66), (1, 64, 2064), (1, 33, 16), (5, 11, 2), (19, 2, 2048 * 3 + 6)])
+def test_second_order_dma_kernel_several_outputs(ctx, ctx_no_dma, k, l, rows):
+    rng = np.random.RandomState(k * 131 + l * 17 + rows)
+    blocks = 1.0 + rng.randn(2 * k + 2, rows, l)
+    K = k * l
+    C = blocks[2:2 + k].transpose(0, 2, 1).reshape(K, rows)
+    D = blocks[2 + k:].transpose(0, 2, 1).reshape(K, rows)
+    S, T = C + D, C - D
+    got = []
+    for c in (ctx, ctx, ctx_no_dma):
+        f = c.upload_blocks(blocks)
+        gram = c.alloc(8 * 2 * K * K)
+        c.reduce_second_order(f, rows, k, l, gram)
+        got.append(c.download(gram, (2, K, K)))
+        f.free()
+        gram.free()
+    G = got[0]
+    assert np.array_equal(G.view(np.uint64), got[1].view(np.uint64)), "not the same bits run to run"
+    scale = np.abs(S @ S.T).max()
+    np.testing.assert_allclose(G[0], S @ S.T, rtol=1e-12, atol=1e-12 * scale)
+    np.testing.assert_allclose(G[1], T @ T.T, rtol=1e-12, atol=1e-12 * scale)
+    np.testing.assert_allclose(G, got[2], rtol=1e-12, atol=1e-12 * scale)
+    assert np.array_equal(G[0], G[0].T) and np.array_equal(G[1], G[1].T)
+
+
 @pytest.mark.parametrize("k,rows,l", [(6, 1000, 1), (32, 5000, 1), (16, 200000, 1), (3, 5, 1), (12, 100003, 1),
                                       (1, 17, 1), (25, 4096, 1), (40, 3000, 1), (5, 700, 2), (33, 2, 1), (64, 4099, 1),
                                       (65, 777, 1), (128, 10000, 1), (129, 2050, 1), (200, 333, 1), (48, 65536, 1),

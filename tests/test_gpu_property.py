@@ -71,7 +71,7 @@ def test_reduction_any_shape(k, rows, l, seed, offset):
     f.free(); acc.free()
 
 
-GRAM_K = st.one_of(st.integers(13, 34), st.sampled_from([40, 48, 63, 64, 65, 100, 127, 128, 129, 130]))
+GRAM_K = st.one_of(st.integers(13, 34), st.integers(33, 64), st.sampled_from([40, 48, 63, 64, 65, 100, 127, 128, 129, 130]))
 
 
 @settings(**dict(COMMON, max_examples=_SOAK or 100))

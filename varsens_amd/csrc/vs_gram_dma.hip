@@ -57,7 +57,10 @@ typedef const __attribute__((address_space(1))) void* vs_glb_ptr;
 // time between the MFMAs of the unit's first two steps (16 VGPRs in flight).  To make room the fragments of one half-unit
 // live in registers at a time (32 instead of 64: the reads of the next half go out right after the adds that consumed the
 // last one, ahead of that step's 20 MFMAs).  The five scalar sums come from first_head_kernel, as for gram_st_kernel.
-template <int NBL, bool FULLK, bool FIRST>
+// ONE: one output (index row u is plane 2 + u for c_u, 2 + K + u for d_u: a wave-uniform plane offset per piece); otherwise
+// index row u = j l + o lives in plane o (2k + 2) + 2 + j (+ k for d): the lane works its plane out per piece (u / l by a
+// multiplication: exact for u < 64)
+template <int NBL, bool FULLK, bool FIRST, bool ONE>
 __global__ void __launch_bounds__(64 * dma_waves(NBL))
 __attribute__((amdgpu_waves_per_eu(dma_waves(NBL) / 4, dma_waves(NBL) / 4)))
 gram_dma_kernel(vs_gram_args A) {
@@ -67,6 +70,7 @@ gram_dma_kernel(vs_gram_args A) {
     // (49 .. 63 index rows with the first-order sums: 11 registers short, the piece that ends at row K - 1 brings its own
     // lane constants -- that shape stays on gram_st_kernel)
     static_assert(!FIRST || NBL == 3 || FULLK, "FIRST: 33 .. 48 index rows, or 64");
+    static_assert(ONE || !FIRST, "the first-order sums ride along for one output only");
     constexpr int NT = NBL * (NBL + 1) / 2;   // upper-triangle tiles per product
     constexpr int DMA_WAVES = dma_waves(NBL), DMA_IMG = dma_img(NBL, FIRST), DMA_SB = dma_rows(NBL);
     constexpr int SRC = DMA_SB * 16;          // doubles between the c rows and the d rows of an image
@@ -107,9 +111,14 @@ gram_dma_kernel(vs_gram_args A) {
     // instead (into their own places in the image, over what the piece before it wrote there: the same values) -- no lane
     // ever reads a plane past d_{K-1}, which in the last row block would be past the end of the buffer.
     const uint32_t chC = (uint32_t)((lane & 7) ^ (((K - 8 + p) >> 1) & 7));
+    const uint32_t ldiv = (65536u + (uint32_t)A.l - 1u) / (uint32_t)A.l;   // (u * ldiv) >> 16 == u / l for u < 64
     auto dma = [&](uint64_t unit) {
         VS2_FTILE(unit << 4);
         const double* const lb = fb + (uint64_t)p * fp;
+        // several outputs: the lane's planes are worked out per piece and unit -- left loop-invariant they would live in
+        // sixteen registers between the units (an opaque copy of p keeps the optimiser from hoisting them)
+        int pv = p;
+        if (!ONE) asm volatile("" : "+v"(pv));
 #pragma unroll
         for (int src = 0; src < 2; ++src)
 #pragma unroll
@@ -118,7 +127,14 @@ gram_dma_kernel(vs_gram_args A) {
                 const bool part = !FULLK && 8 * g + 8 > K;       // wave-uniform: the piece would straddle K
                 const int urow = part ? K - 8 : 8 * g;
                 const uint32_t ch = part ? chC : (g & 1) ? chB : chA;
-                const double* gp = lb + (uint64_t)(2 + src * K + urow) * fp + 2 * ch;
+                const double* gp;
+                if (ONE) {
+                    gp = lb + (uint64_t)(2 + src * K + urow) * fp + 2 * ch;
+                } else {
+                    const uint32_t uu = (uint32_t)(urow + pv);         // < K: no piece reaches past row K - 1
+                    const uint32_t jj = (uu * ldiv) >> 16, oo = uu - jj * (uint32_t)A.l;
+                    gp = fb + (uint64_t)(oo * (2u * (uint32_t)A.k + 2u) + 2u + jj + (uint32_t)(src * A.k)) * fp + 2 * ch;
+                }
                 __builtin_amdgcn_global_load_lds((vs_glb_ptr)gp, (vs_lds_ptr)(img + src * SRC + urow * 16), 16, 0, 2 /* nt */);
             }
         if (FIRST && lane < 16) {   // planes 0 (a) and 1 (b): lanes 0-7 and 8-15, chunk lane & 7
@@ -242,8 +258,10 @@ gram_dma_kernel(vs_gram_args A) {
                 for (int src = 0; src < 2; ++src)
 #pragma unroll
                     for (int I = 0; I < NBL; ++I) {
-                        const int uu = 16 * I + li < K ? 16 * I + li : K - 1;
-                        const double* gp = fb + (uint64_t)(2 + src * K + uu) * fp + 2 * (4 * h + q);
+                        const uint32_t uu = (uint32_t)(16 * I + li < K ? 16 * I + li : K - 1);
+                        const uint32_t jj = (uu * ldiv) >> 16, oo = uu - jj * (uint32_t)A.l;   // one output: jj = uu, oo = 0
+                        const double* gp = fb + (uint64_t)(oo * (2u * (uint32_t)A.k + 2u) + 2u + jj + (uint32_t)(src * A.k)) * fp +
+                                           2 * (4 * h + q);
                         H[src][I] = in ? __builtin_nontemporal_load((const vs_d2*)gp) : (vs_d2){0.0, 0.0};
                     }
                 step1(0, 0, -1);
@@ -324,13 +342,14 @@ gram_dma_kernel(vs_gram_args A) {
 }  // namespace
 
 #define VS_DMA_INSTANCES(X) \
-    X(2, false, false) X(2, true, false) X(3, false, false) X(4, false, false) X(4, true, false) \
-    X(3, false, true) X(4, true, true)
+    X(2, false, false, true) X(2, true, false, true) X(3, false, false, true) X(4, false, false, true) X(4, true, false, true) \
+    X(3, false, true, true) X(4, true, true, true) \
+    X(3, false, false, false) X(4, false, false, false) X(4, true, false, false)
 
 int vs_gram_dma_prepare(vs_context* ctx) {
     (void)ctx;
-#define VS_DMA_SET(NL, FK, FI)                                                                                     \
-    VS_HIP(hipFuncSetAttribute((const void*)gram_dma_kernel<NL, FK, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+#define VS_DMA_SET(NL, FK, FI, ON)                                                                                 \
+    VS_HIP(hipFuncSetAttribute((const void*)gram_dma_kernel<NL, FK, FI, ON>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                (int)dma_lds_bytes(NL, FI)));
     VS_DMA_INSTANCES(VS_DMA_SET)
 #undef VS_DMA_SET
@@ -339,12 +358,13 @@ int vs_gram_dma_prepare(vs_context* ctx) {
 
 bool vs_gram_dma_takes_first(int K) { return (K > 32 && K <= 48) || K == 64; }
 
-// A.K = k in 17 .. 64, A.l == 1, A.rows even, A.f 16-byte aligned (the caller checks); `workgroups` <= CUs.
+// A.K = k l in 17 .. 64 (several outputs: 33 .. 64), A.rows even, A.f 16-byte aligned (the caller checks); `workgroups` <= CUs.
 // Partials: one per workgroup, [S S^T, T T^T][SB][SB] with SB = 64 (K > 32) or 32, upper 16-blocks
 // (vs_gram_fold_args::st == 2, super == SB).
 // with_first (K > 32): also one first-order record per workgroup at A.first_partials (dot products; head zero).
 int vs_gram_dma_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, unsigned workgroups) {
-    VS_REQUIRE(A.K > 16 && A.K <= 64 && A.l == 1 && A.K == A.k, "gram_dma_kernel takes 17 .. 64 index rows, one output");
+    VS_REQUIRE(A.K > 16 && A.K <= 64 && A.l >= 1 && A.K == A.k * A.l, "gram_dma_kernel takes 17 .. 64 index rows");
+    VS_REQUIRE(A.l == 1 || (A.K > 32 && !with_first), "several outputs: 33 .. 64 index rows, second order alone");
     VS_REQUIRE(!with_first || (vs_gram_dma_takes_first(A.K) && A.first_partials),
                "gram_dma_kernel carries the first-order sums at 33 .. 48 and at 64 index rows");
     VS_REQUIRE(A.rows % 2 == 0 && ((uintptr_t)A.f & 15) == 0, "gram_dma_kernel needs an even row count and 16-byte alignment");
@@ -352,10 +372,11 @@ int vs_gram_dma_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, 
     const dim3 grid(workgroups);
     const int nbl = (A.K + 15) / 16;
     const bool full = A.K == 64 || A.K == 32;
+    const bool one = A.l == 1;
     bool launched = false;
-#define VS_DMA_LAUNCH(NL, FK, FI)                                                                              \
-    if (!launched && nbl == NL && full == FK && with_first == FI) {                                            \
-        hipLaunchKernelGGL((gram_dma_kernel<NL, FK, FI>), grid, dim3(64 * dma_waves(NL)), dma_lds_bytes(NL, FI), ctx->stream, A); \
+#define VS_DMA_LAUNCH(NL, FK, FI, ON)                                                                          \
+    if (!launched && nbl == NL && full == FK && with_first == FI && one == ON) {                               \
+        hipLaunchKernelGGL((gram_dma_kernel<NL, FK, FI, ON>), grid, dim3(64 * dma_waves(NL)), dma_lds_bytes(NL, FI), ctx->stream, A); \
         launched = true;                                                                                       \
     }
     VS_DMA_INSTANCES(VS_DMA_LAUNCH)

@@ -1542,7 +1542,8 @@ static int second_order_impl(vs_context* ctx, const double* f_dev, uint64_t rows
     const uint32_t slab_wgs = (uint32_t)(units < want ? units : want);
     const bool st_new = st128 || half_st;   // the unmasked pass runs on gram_st_kernel (any number of outputs)
     // ... or, second order alone with one output and 33 .. 64 index rows, on gram_dma_kernel (vs_gram_dma.hip)
-    const bool dma = half_st && l == 1 && ctx->tune.gram_dma != 0 && (!with_first || vs_gram_dma_takes_first(K));   // with_first: it carries the dot products too
+    // (one output: with the first-order dot products on board where they fit; several outputs: second order alone)
+    const bool dma = half_st && ctx->tune.gram_dma != 0 && (!with_first || (l == 1 && vs_gram_dma_takes_first(K)));
     // ... and, as a measurement knob only (VS_GRAM_DMA=2), 17 .. 32 index rows (sixteen waves per CU on images of 32 rows
     // per half; partials [S S^T, T T^T][32][32]): HBM-bound there and level with gram_diag_wide_kernel -- k = 32, n = 2^22:
     // 0.338-0.348 against 0.332-0.398 ms, k = 24: 0.275 against 0.255 (profiles/r05/gram_dma_ab.txt) -- so not the default
