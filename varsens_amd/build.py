@@ -125,9 +125,11 @@ def build(force=False, verbose=True):
         cflags = [f for f in FLAGS if f != "-shared"] + os.environ.get("VS_EXTRA_CFLAGS", "").split()
         build_id = source_id()
 
+        again = [False]   # a second round: only what an edit during the first one made stale, and vs_host.o for the id
+
         def compile_one(src):
             obj = os.path.join(objdir, src.replace(".hip", ".o").replace(".cpp", ".o"))
-            if force or _deps_newer(obj):
+            if (force and not again[0]) or _deps_newer(obj) or (again[0] and src == "vs_host.cpp"):
                 cmd = [hipcc] + cflags + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", obj]
                 if src == "vs_host.cpp":    # vs_build_id()
                     cmd.insert(1, '-DVS_BUILD_ID="%s"' % build_id)
@@ -138,6 +140,16 @@ def build(force=False, verbose=True):
 
         with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
             objs = list(pool.map(compile_one, SOURCES))
+        # A source edited while the objects were being compiled would leave vs_build_id() naming sources the library was
+        # not (wholly) built from: go round again -- the objects older than the edit and vs_host.o with the new id
+        for _ in range(3):
+            now = source_id()
+            if now == build_id:
+                break
+            build_id = now
+            again[0] = True
+            with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
+                objs = list(pool.map(compile_one, SOURCES))
         tmp = OUT + ".tmp.%d" % os.getpid()
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-L/opt/rocm/lib", "-lhiprtc"]
         if verbose:
