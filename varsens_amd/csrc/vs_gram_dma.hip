@@ -56,7 +56,8 @@ typedef const __attribute__((address_space(1))) void* vs_glb_ptr;
 // the same address: a broadcast), 64 v_fma_f64 per unit into FOUR accumulators per lane, a chunk of two sample rows at a
 // time between the MFMAs of the unit's first two steps (16 VGPRs in flight).  To make room the fragments of one half-unit
 // live in registers at a time (32 instead of 64: the reads of the next half go out right after the adds that consumed the
-// last one, ahead of that step's 20 MFMAs).  The five scalar sums come from first_head_kernel, as for gram_st_kernel.
+// last one, ahead of that step's 20 MFMAs), and the DMA side's lane constants are rebuilt per unit.  The five scalar sums
+// come from first_head_kernel, as for gram_st_kernel.
 // ONE: one output (index row u is plane 2 + u for c_u, 2 + K + u for d_u: a wave-uniform plane offset per piece); otherwise
 // index row u = j l + o lives in plane o (2k + 2) + 2 + j (+ k for d): the lane works its plane out per piece (u / l by a
 // multiplication: exact for u < 64)
@@ -67,9 +68,6 @@ gram_dma_kernel(vs_gram_args A) {
     static_assert(NBL >= 2 && NBL <= 4, "17 .. 64 index rows per half");
     static_assert(!FULLK || NBL == 4 || NBL == 2, "FULLK means K == 64 or K == 32");
     static_assert(!FIRST || NBL >= 3, "up to 32 index rows the wave-private kernels of vs_second.hip carry the first-order sums");
-    // (49 .. 63 index rows with the first-order sums: 11 registers short, the piece that ends at row K - 1 brings its own
-    // lane constants -- that shape stays on gram_st_kernel)
-    static_assert(!FIRST || NBL == 3 || FULLK, "FIRST: 33 .. 48 index rows, or 64");
     static_assert(ONE || !FIRST, "the first-order sums ride along for one output only");
     constexpr int NT = NBL * (NBL + 1) / 2;   // upper-triangle tiles per product
     constexpr int DMA_WAVES = dma_waves(NBL), DMA_IMG = dma_img(NBL, FIRST), DMA_SB = dma_rows(NBL);
@@ -96,8 +94,8 @@ gram_dma_kernel(vs_gram_args A) {
     const uint64_t stride = (uint64_t)G * DMA_WAVES;
 
     // DMA side: lane = 8 p + r' brings plane 8 g + p of piece g, source chunk r' ^ sw(row) to chunk position r'
-    const int p = lane >> 3;
-    const uint32_t chA = (uint32_t)((lane & 7) ^ (p >> 1)), chB = chA ^ 4u;   // pieces with g even / odd
+    // (p and the chunk constants are rebuilt inside dma() from an opaque copy of the lane index: a handful of integer
+    // instructions per unit instead of four registers carried through the MFMA steps)
     // fragment side: lane = i + 16 q reads chunk 4 h + q (sample rows 8 h + 2 q, + 1) of row 16 I + i
     const int li = lane & 15, q = lane >> 4, sw = (li >> 1) & 7;
     const uint32_t fr0 = (uint32_t)(li * 16 + 2 * (q ^ sw)), fr1 = (uint32_t)(li * 16 + 2 * ((4 + q) ^ sw));
@@ -110,15 +108,18 @@ gram_dma_kernel(vs_gram_args A) {
     // arithmetic) and the lane's chunk.  K not a multiple of 8: the piece that would straddle K brings rows K - 8 .. K - 1
     // instead (into their own places in the image, over what the piece before it wrote there: the same values) -- no lane
     // ever reads a plane past d_{K-1}, which in the last row block would be past the end of the buffer.
-    const uint32_t chC = (uint32_t)((lane & 7) ^ (((K - 8 + p) >> 1) & 7));
     const uint32_t ldiv = (65536u + (uint32_t)A.l - 1u) / (uint32_t)A.l;   // (u * ldiv) >> 16 == u / l for u < 64
     auto dma = [&](uint64_t unit) {
         VS2_FTILE(unit << 4);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // not loop-invariant as far as the compiler can tell
+        const int p = ln >> 3;
+        const uint32_t chA = (uint32_t)((ln & 7) ^ (p >> 1)), chB = chA ^ 4u;   // pieces with g even / odd
+        const uint32_t chC = (uint32_t)((ln & 7) ^ (((K - 8 + p) >> 1) & 7));   // the piece that ends at row K - 1
         const double* const lb = fb + (uint64_t)p * fp;
         // several outputs: the lane's planes are worked out per piece and unit -- left loop-invariant they would live in
         // sixteen registers between the units (an opaque copy of p keeps the optimiser from hoisting them)
-        int pv = p;
-        if (!ONE) asm volatile("" : "+v"(pv));
+        const int pv = p;
 #pragma unroll
         for (int src = 0; src < 2; ++src)
 #pragma unroll
@@ -137,8 +138,8 @@ gram_dma_kernel(vs_gram_args A) {
                 }
                 __builtin_amdgcn_global_load_lds((vs_glb_ptr)gp, (vs_lds_ptr)(img + src * SRC + urow * 16), 16, 0, 2 /* nt */);
             }
-        if (FIRST && lane < 16) {   // planes 0 (a) and 1 (b): lanes 0-7 and 8-15, chunk lane & 7
-            const double* gp = fb + (uint64_t)(lane >> 3) * fp + 2 * (lane & 7);
+        if (FIRST && ln < 16) {   // planes 0 (a) and 1 (b): lanes 0-7 and 8-15, chunk lane & 7
+            const double* gp = fb + (uint64_t)(ln >> 3) * fp + 2 * (ln & 7);
             __builtin_amdgcn_global_load_lds((vs_glb_ptr)gp, (vs_lds_ptr)(img + AB), 16, 0, 2 /* nt */);
         }
     };
@@ -343,7 +344,7 @@ gram_dma_kernel(vs_gram_args A) {
 
 #define VS_DMA_INSTANCES(X) \
     X(2, false, false, true) X(2, true, false, true) X(3, false, false, true) X(4, false, false, true) X(4, true, false, true) \
-    X(3, false, true, true) X(4, true, true, true) \
+    X(3, false, true, true) X(4, false, true, true) X(4, true, true, true) \
     X(3, false, false, false) X(4, false, false, false) X(4, true, false, false)
 
 int vs_gram_dma_prepare(vs_context* ctx) {
@@ -356,7 +357,7 @@ int vs_gram_dma_prepare(vs_context* ctx) {
     return VS_OK;
 }
 
-bool vs_gram_dma_takes_first(int K) { return (K > 32 && K <= 48) || K == 64; }
+bool vs_gram_dma_takes_first(int K) { return K > 32 && K <= 64; }
 
 // A.K = k l in 17 .. 64 (several outputs: 33 .. 64), A.rows even, A.f 16-byte aligned (the caller checks); `workgroups` <= CUs.
 // Partials: one per workgroup, [S S^T, T T^T][SB][SB] with SB = 64 (K > 32) or 32, upper 16-blocks
@@ -366,7 +367,7 @@ int vs_gram_dma_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, 
     VS_REQUIRE(A.K > 16 && A.K <= 64 && A.l >= 1 && A.K == A.k * A.l, "gram_dma_kernel takes 17 .. 64 index rows");
     VS_REQUIRE(A.l == 1 || (A.K > 32 && !with_first), "several outputs: 33 .. 64 index rows, second order alone");
     VS_REQUIRE(!with_first || (vs_gram_dma_takes_first(A.K) && A.first_partials),
-               "gram_dma_kernel carries the first-order sums at 33 .. 48 and at 64 index rows");
+               "gram_dma_kernel carries the first-order sums at 33 .. 64 index rows");
     VS_REQUIRE(A.rows % 2 == 0 && ((uintptr_t)A.f & 15) == 0, "gram_dma_kernel needs an even row count and 16-byte alignment");
     VS_REQUIRE(A.slab_wgs == workgroups && workgroups >= 1, "slab_wgs must be the grid size");
     const dim3 grid(workgroups);

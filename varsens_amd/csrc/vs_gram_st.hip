@@ -46,8 +46,8 @@
 // LDS writes, the time is the same 1.0 ms.  The HBM stream itself takes the matrix pipe's throughput (clock 2.11
 // instead of 2.28 GHz, and a lower busy fraction at that clock).
 // Round 5: with one output the NB = 4 shapes run on gram_dma_kernel (vs_gram_dma.hip: no shared tile, every wave on its
-// own LDS-DMA image, 0.80-0.82 ms at k = 64); what stays here at NB = 4: several outputs, and 49 .. 63 index rows with
-// the first-order sums on board.
+// own LDS-DMA image, 0.80-0.82 ms at k = 64), several outputs included; the NB = 4 instances here are what VS_GRAM_DMA=0
+// selects (tests compare the two).
 #include "vs_second.h"
 
 namespace {

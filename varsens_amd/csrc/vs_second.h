@@ -46,4 +46,4 @@ int vs_gram_st_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, u
 // on its own image, filled by LDS-DMA in whole lines (round 5)
 int vs_gram_dma_prepare(vs_context* ctx);
 int vs_gram_dma_launch(vs_context* ctx, const vs_gram_args& A, bool with_first, unsigned workgroups);
-bool vs_gram_dma_takes_first(int K);   // the shapes whose first-order sums it can carry (33 .. 48 and 64 index rows)
+bool vs_gram_dma_takes_first(int K);   // the shapes whose first-order sums it can carry (33 .. 64 index rows)
