@@ -398,6 +398,198 @@ static float run_dma(const double* f, uint64_t rows, int fshift, uint32_t G, dou
     return best;
 }
 
+
+static void host_layout_index_fwd(uint64_t rows, int fshift, uint64_t P, uint64_t plane, uint64_t r, uint64_t& idx) {
+    const uint64_t rb = (r >> fshift) << fshift;
+    const uint64_t left = rows - rb;
+    const uint64_t pitch = left < ((uint64_t)1 << fshift) ? left : ((uint64_t)1 << fshift);
+    idx = rb * P + plane * pitch + (r - rb);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same idea at 128 index rows per half (BASELINE configs[4]), where a wave cannot own all 72 tiles: a workgroup of FOUR
+// waves shares an LDS-DMA image (32 KiB per unit of 16 sample rows, two images per workgroup), TWO such workgroups per CU
+// -- the two waves of a SIMD belong to different workgroups, so one workgroup's barrier (one per unit of 72 MFMAs per
+// wave) does not stop the SIMD.  Waves 0, 1 take S S^T (block rows {0, 7, 1, 6} and {2, 5, 3, 4}: 18 tiles each), waves
+// 2, 3 the same of T T^T; a wave forms only what it multiplies (s = c + d or t = c - d: one v_fma_f64 with a sign).
+// Timing prototype for the question "what would gram_st_kernel<8, ..> gain from this structure": TIMING leaves the tiles
+// in registers (one value per lane is written), VALIDATE adds them into a global matrix with atomics.
+constexpr int K2 = 128, NB2 = 8;
+
+template <int ROLE, bool VALIDATE>
+__device__ __forceinline__ void dma128_body(const double* __restrict__ f, uint64_t rows, int fshift, uint32_t G,
+                                            double* __restrict__ result, double* lds, const int wave, const double sgn) {
+    constexpr int FIRSTB = ROLE == 0 ? 0 : 2;          // lowest block this role reads
+    constexpr int ROWS[4] = {ROLE == 0 ? 0 : 2, ROLE == 0 ? 7 : 5, ROLE == 0 ? 1 : 3, ROLE == 0 ? 6 : 4};
+    const int lane = threadIdx.x & 63;
+    const uint64_t P = 2 * K2 + 2;
+    const uint64_t units = rows >> 4;
+    const int li = lane & 15, q = lane >> 4, sw = (li >> 1) & 7;
+    const uint32_t fr0 = (uint32_t)(li * 16 + 2 * (q ^ sw)), fr1 = (uint32_t)(li * 16 + 2 * ((4 + q) ^ sw));
+    d4 acc[18];
+#pragma unroll
+    for (int t = 0; t < 18; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    d2 H[2][NB2];   // [c, d][block] of one half-unit
+
+    auto dma = [&](uint64_t unit, double* img) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int p = ln >> 3;
+        const uint32_t chA = (uint32_t)((ln & 7) ^ (p >> 1)), chB = chA ^ 4u;
+        const uint64_t r0 = unit << 4;
+        const uint64_t rb = (r0 >> fshift) << fshift;
+        const uint64_t left = rows - rb;
+        const uint64_t pitch = left < ((uint64_t)1 << fshift) ? left : ((uint64_t)1 << fshift);
+        const int src = wave >> 1, g0 = 8 * (wave & 1);
+        const double* lb = f + rb * P + (r0 - rb) + (uint64_t)(2 + src * K2 + p) * pitch;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const double* gp = lb + (uint64_t)(8 * (g0 + g)) * pitch + 2 * ((g & 1) ? chB : chA);
+            __builtin_amdgcn_global_load_lds((glb_ptr)gp, (lds_ptr)(img + src * 2048 + (g0 + g) * 128), 16, 0, 2);
+        }
+    };
+    auto readh = [&](const int h, const double* img) {
+        const double* rd = img + (h ? fr1 : fr0);
+#pragma unroll
+        for (int src = 0; src < 2; ++src)
+#pragma unroll
+            for (int I = FIRSTB; I < NB2; ++I) H[src][I] = *(const d2*)(rd + src * 2048 + I * 256);
+    };
+    auto step = [&](const int e) {
+        double s[NB2];
+#pragma unroll
+        for (int I = FIRSTB; I < NB2; ++I) s[I] = fma(H[1][I][e], sgn, H[0][I][e]);
+        PIN();
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int J = ROWS[r]; J < NB2; ++J) {
+                acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(s[ROWS[r]], s[J], acc[idx], 0, 0, 0);
+                ++idx;
+            }
+    };
+    double* const img0 = lds;
+    uint64_t u = blockIdx.x;
+    int b = 0;
+    if (u < units) dma(u, img0);
+    for (; u < units; u += G) {
+        const uint64_t un = u + G < units ? u + G : u;
+        double* const cur = img0 + b * 4096;
+        double* const nxt = img0 + (b ^ 1) * 4096;
+        __syncthreads();          // own DMA landed (vmcnt(0)), everybody's, and everybody is done with the other image
+        dma(un, nxt);
+        readh(0, cur);
+        PIN();
+        step(0);
+        PIN();
+        step(1);
+        PIN();
+        readh(1, cur);
+        PIN();
+        step(0);
+        PIN();
+        step(1);
+        PIN();
+        b ^= 1;
+    }
+    if (VALIDATE) {
+        double* M = result + (sgn > 0.0 ? 0 : K2 * K2);
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int J = ROWS[r]; J < NB2; ++J) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    atomicAdd(&M[(16 * ROWS[r] + (lane >> 4) + 4 * v) * K2 + 16 * J + (lane & 15)], acc[idx][v]);
+                ++idx;
+            }
+    } else {
+        double x = 0.0;
+#pragma unroll
+        for (int t = 0; t < 18; ++t) x += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+        result[(size_t)blockIdx.x * 256 + threadIdx.x] = x;
+    }
+}
+
+template <bool VALIDATE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gram_dma128(const double* __restrict__ f, uint64_t rows, int fshift, uint32_t G, double* __restrict__ result) {
+    extern __shared__ double lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double sgn = wave < 2 ? 1.0 : -1.0;
+    if (wave & 1) dma128_body<1, VALIDATE>(f, rows, fshift, G, result, lds, wave, sgn);
+    else dma128_body<0, VALIDATE>(f, rows, fshift, G, result, lds, wave, sgn);
+}
+
+static int run_dma128(int log2rows, int fshift, int bits) {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const uint32_t G = 2 * prop.multiProcessorCount;
+    const uint64_t P = 2 * K2 + 2;
+    double *f, *result;
+    CK(hipFuncSetAttribute((const void*)gram_dma128<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CK(hipFuncSetAttribute((const void*)gram_dma128<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    {   // correctness, small shard with a short last row block
+        const uint64_t rows = 3 * 2048 + 16 * 21;
+        CK(hipMalloc(&f, rows * P * 8));
+        CK(hipMalloc(&result, 2 * K2 * K2 * 8));
+        CK(hipMemset(result, 0, 2 * K2 * K2 * 8));
+        hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, f, rows * P, 52);
+        hipLaunchKernelGGL((gram_dma128<true>), dim3(G), dim3(256), 65536, 0, f, rows, fshift, G, result);
+        CK(hipDeviceSynchronize());
+        std::vector<double> hf(rows * P), got(2 * K2 * K2);
+        CK(hipMemcpy(hf.data(), f, hf.size() * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(got.data(), result, got.size() * 8, hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int a = 0; a < K2; a += 5)
+            for (int b = a; b < K2; b += 3) {
+                if ((b >> 4) < (a >> 4)) continue;
+                long double ss = 0, tt = 0;
+                for (uint64_t r = 0; r < rows; ++r) {
+                    uint64_t ia, ib, ja, jb;
+                    host_layout_index_fwd(rows, fshift, P, 2 + a, r, ia);
+                    host_layout_index_fwd(rows, fshift, P, 2 + K2 + a, r, ja);
+                    host_layout_index_fwd(rows, fshift, P, 2 + b, r, ib);
+                    host_layout_index_fwd(rows, fshift, P, 2 + K2 + b, r, jb);
+                    ss += (long double)(hf[ia] + hf[ja]) * (hf[ib] + hf[jb]);
+                    tt += (long double)(hf[ia] - hf[ja]) * (hf[ib] - hf[jb]);
+                }
+                worst = fmax(worst, fabs(got[a * K2 + b] - (double)ss) / fabs((double)ss));
+                worst = fmax(worst, fabs(got[K2 * K2 + a * K2 + b] - (double)tt) / fabs((double)ss));
+            }
+        printf("k = 128 candidate, correctness (rows = %llu): max rel err %.3e %s\n", (unsigned long long)rows, worst,
+               worst < 1e-12 ? "OK" : "WRONG");
+        CK(hipFree(f));
+        CK(hipFree(result));
+        if (!(worst < 1e-12)) return 2;
+    }
+    const uint64_t rows = (uint64_t)1 << log2rows;
+    CK(hipMalloc(&f, rows * P * 8));
+    CK(hipMalloc(&result, (size_t)G * 256 * 8));
+    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, f, rows * P, bits);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    const int reps = 8;
+    for (int r = 0; r < reps + 2; ++r) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((gram_dma128<false>), dim3(G), dim3(256), 65536, 0, f, rows, fshift, G, result);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double gflop = 72.0 * 2048.0 * (rows / 4) / 1e9, gb = 2.0 * K2 * rows * 8 / 1e9;
+    printf("k = 128, rows = 2^%d, %d mantissa bits: best %.3f ms, mean %.3f ms = %.1f TFLOP/s (%.3f of 78.6), %.2f TB/s\n",
+           log2rows, bits, best, sum / reps, gflop / best, gflop / best / 78.6, gb / best);
+    return 0;
+}
+
 static void host_layout_index(uint64_t rows, int fshift, uint64_t P, uint64_t plane, uint64_t r, uint64_t& idx) {
     const uint64_t rb = (r >> fshift) << fshift;
     const uint64_t left = rows - rb;
@@ -430,6 +622,9 @@ static float run(const double* f, uint64_t rows, int fshift, uint32_t G, double*
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'k') {   // ./gd k128 [log2rows=24] [fshift=11] [bits=52]
+        return run_dma128(argc > 2 ? atoi(argv[2]) : 24, argc > 3 ? atoi(argv[3]) : 11, argc > 4 ? atoi(argv[4]) : 52);
+    }
     const int log2rows = argc > 1 ? atoi(argv[1]) : 22;
     const int fshift = argc > 2 ? atoi(argv[2]) : 11;
     const int bits = argc > 3 ? atoi(argv[3]) : 52;
