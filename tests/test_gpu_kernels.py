@@ -644,7 +644,7 @@ def test_second_order_dma_kernel(ctx_dma_all, ctx_no_dma, k, rows):
             want = math.fsum((X[i] * X[j]).tolist())
             assert abs(M[i, j] - want) <= 1e-13 * scale, (i, j)
     # both orders in one call: from 33 index rows on the same kernel carries the first-order dot products (lane u owns
-    # index row u) where they fit -- 33 .. 48 rows and 64; the record against the first-order kernel's and exact sums
+    # index row u); the record against the first-order kernel's and exact sums
     from varsens_amd import _native
     nacc = _native.acc_len(k, 1, 1)
     f = ctx_dma_all.upload_blocks(blocks)
