@@ -138,6 +138,31 @@ def test_three_outputs_with_nans_against_the_oracle(vs, n, capsys):
     numpy.testing.assert_allclose(v2.sens_2[:, :2, :, :2], R["sens_2"][:, :2, :, :2], rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("k,l,n", [(40, 1, 2064), (56, 1, 4110), (64, 1, 2048 * 2 + 40), (33, 1, 50), (20, 3, 1000), (16, 4, 2050),
+                                   (48, 1, 30000)])
+def test_mid_sized_designs_against_the_oracle(vs, k, l, n):
+    """Call stack (c) at 33 .. 64 index rows (csrc/vs_gram_dma.hip: one output -- both orders in one kernel, the first-order
+    dot products by row-owner lanes; several outputs -- second order alone beside the first-order kernel): values from a
+    model that ran elsewhere -> Objective(k, n, objective_vals=v) -> Varsens(o), every result of varsens/saltelli.py:572-622
+    against the oracle's load_objective + compute_varsens on the same values."""
+    rng = numpy.random.default_rng(k * 1000 + l * 10 + n)
+    N = 2 * n * (k + 1)
+    # a linear model with interactions: values with structure in every index row, not noise around zero
+    base = rng.standard_normal((2 * k + 2, n, 1))
+    vals = (3.0 + base + 0.25 * rng.standard_normal((2 * k + 2, n, l)) * numpy.arange(1, l + 1)).reshape(N, l)
+    o = vs.Objective(k, n, objective_vals=vals, verbose=False)
+    v = vs.Varsens(o, verbose=False)
+    want = orc.load_objective(vals, k, n)
+    R = orc.compute_varsens(*want[:4], n)
+    for name in ("E_2", "var_y", "U_j", "U_nj"):
+        numpy.testing.assert_allclose(getattr(v, name), R[name], rtol=1e-12)
+    scale = numpy.abs(R["sens_2"]).max()
+    for name in ("sens", "sens_t"):
+        numpy.testing.assert_allclose(getattr(v, name), R[name], rtol=1e-10, atol=1e-12)
+    for name in ("sens_2", "sens_2n"):
+        numpy.testing.assert_allclose(getattr(v, name), R[name], rtol=1e-9, atol=1e-11 * max(1.0, scale))
+
+
 def test_load_divides_per_output_and_falls_back_for_other_shapes(vs):
     """Objective.load(..., scaling=s): a scalar and one divisor per output are divided on the device, anything else
     numpy can broadcast against (N, l) on the host -- the values are the reference's x / scaling in every case"""
