@@ -296,7 +296,9 @@ def test_hot_kernels_do_not_spill():
     assert len(rows) > 400, "the report lost kernels: %d" % len(rows)
     names = " ".join(r["kernel"] for r in rows)
     for must in ("reduce_first_kernel", "scan_kernel<3, 8, 4, true", "scan_gram_kernel", "scan_gramn_kernel",
-                 "gram_st_kernel<8, 8, true, true, true>", "gram_diag_wide_kernel", "fold_first_kernel"):
+                 "gram_st_kernel<8, 8, true, true, true>", "gram_diag_wide_kernel", "fold_first_kernel",
+                 "gram_dma_kernel<4, true, false, true>", "gram_dma_kernel<4, true, true, true>",
+                 "gram_dma_kernel<4, false, true, true>", "gram_dma_kernel<3, false, false, false>"):
         assert must in names, must
     bad = []
     for r in rows:
@@ -306,6 +308,22 @@ def test_hot_kernels_do_not_spill():
             bad.append("%s: %d spilled VGPRs, %d B scratch (allowed %d)" % (r["kernel"], r["vgpr_spill"],
                                                                            r["scratch_bytes"], limit))
     assert not bad, "\n".join(bad)
+
+
+def test_roofline_table_reads_the_committed_summaries():
+    """tools/roofline_table.py over profiles/r05: every row it knows finds its kernel in the committed rocprofv3 summary,
+    and the north-star row says what the bench line says (the reduction kernel within 0.85 .. 0.92 of the HBM peak)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_table.py"), os.path.join(ROOT, "profiles", "r05")],
+                         stdout=subprocess.PIPE, text=True, check=True).stdout
+    rows = [line for line in out.splitlines() if line.startswith("| ") and not line.startswith("| kernel") and not line.startswith("|---")]
+    assert len(rows) == 16, len(rows)
+    north = [r for r in rows if "north star" in r][0].split("|")
+    assert 0.85 <= float(north[6]) <= 0.92, north
+    dma = [r for r in rows if r.startswith("| second order (gram_dma_kernel)")][0].split("|")
+    before = [r for r in rows if "before gram_dma_kernel" in r][0].split("|")
+    assert float(dma[3].split()[0]) < float(before[3].split()[0])
 
 
 def test_host_entry_points_under_sanitizers():
